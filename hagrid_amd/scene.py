@@ -1,0 +1,204 @@
+"""Synthetic scenes and ray buffers.
+
+Everything is generated from a counter-based 64-bit integer PRNG (splitmix64 finaliser keyed by
+``seed + (index + 1) * golden``), so any machine produces identical bits and any slice of a buffer
+can be generated independently (rank ``r`` of a multi-GPU run generates only its own rays).
+No libm, no ``numpy.random``.
+
+Layouts follow the reference PODs:
+  Tri  = 12 x f32: v0.xyz, n.x, e1.xyz, n.y, e2.xyz, n.z   (prims.h:13-25, main.cpp:259-267)
+  Ray  =  8 x f32: org.xyz, tmin, dir.xyz, tmax           (ray.h:9-20)
+  Hit  = {i32 id, f32 t, f32 u, f32 v}                     (ray.h:22-33)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HIT_DTYPE = np.dtype([("id", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+CELL_DTYPE = np.dtype([("min", "<i4", 3), ("begin", "<i4"), ("max", "<i4", 3), ("end", "<i4")])
+SMALL_CELL_DTYPE = np.dtype([("min", "<u2", 3), ("max", "<u2", 3), ("begin", "<i4")])
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+SCENE_SEED_BASE = 0x48414752494400  # + N          
+RAY_SEED_BASE = 0x52415953          # + config #
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * _M1
+    z = (z ^ (z >> np.uint64(27))) * _M2
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed: int, index: np.ndarray) -> np.ndarray:
+    """float32 in [0,1): (splitmix64(seed, index) >> 40) * 2^-24."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (index.astype(np.uint64) + np.uint64(1)) * _GOLDEN
+        z = _mix(z)
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+def _cross(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    # vec.h:104-109 in float32, no fused ops
+    return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1],
+                     a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2],
+                     a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], axis=1).astype(np.float32)
+
+
+def tris_from_vertices(v0: np.ndarray, v1: np.ndarray, v2: np.ndarray) -> np.ndarray:
+    """Pack triangles exactly like main.cpp:259-267: e1 = v0 - v1, e2 = v2 - v0, n = cross(e1, e2)."""
+    v0 = v0.astype(np.float32); v1 = v1.astype(np.float32); v2 = v2.astype(np.float32)
+    e1 = v0 - v1
+    e2 = v2 - v0
+    n = _cross(e1, e2)
+    out = np.empty((v0.shape[0], 12), dtype=np.float32)
+    out[:, 0:3] = v0; out[:, 3] = n[:, 0]
+    out[:, 4:7] = e1; out[:, 7] = n[:, 1]
+    out[:, 8:11] = e2; out[:, 11] = n[:, 2]
+    return out
+
+
+def make_soup(num_tris: int, seed: int | None = None, first: int = 0, count: int | None = None) -> np.ndarray:
+    """Scene "soup-N": c ~ U[0,1)^3, a, b ~ U[-s, s]^3, s = N^(-1/3); v0 = c, v1 = c + a, v2 = c + b."""
+    if seed is None:
+        seed = SCENE_SEED_BASE + num_tris
+    if count is None:
+        count = num_tris - first
+    s = np.float32(float(num_tris) ** (-1.0 / 3.0))
+    idx = (np.arange(first, first + count, dtype=np.uint64)[:, None] * np.uint64(9)
+           + np.arange(9, dtype=np.uint64)[None, :])
+    u = uniform01(seed, idx)
+    c = u[:, 0:3]
+    a = (np.float32(2.0) * u[:, 3:6] - np.float32(1.0)) * s
+    b = (np.float32(2.0) * u[:, 6:9] - np.float32(1.0)) * s
+    return tris_from_vertices(c, c + a, c + b)
+
+
+def tris_bbox(tris: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Scene bounding box over the three vertices (prims.h:27-31)."""
+    v0 = tris[:, 0:3]; v1 = v0 - tris[:, 4:7]; v2 = v0 + tris[:, 8:11]
+    lo = np.minimum(v0, np.minimum(v1, v2)).min(axis=0)
+    hi = np.maximum(v0, np.maximum(v1, v2)).max(axis=0)
+    return lo.astype(np.float32), hi.astype(np.float32)
+
+
+def make_rays_incoherent(bbox_min, bbox_max, num_rays: int, seed: int, first: int = 0,
+                         tmin: float = 0.0, tmax: float = float(FLT_MAX)) -> np.ndarray:
+    """org ~ U(bbox); dir rejection-sampled from U[-1,1]^3 with 0.01 < |d|^2 <= 1, un-normalised."""
+    lo = np.asarray(bbox_min, dtype=np.float32); hi = np.asarray(bbox_max, dtype=np.float32)
+    ids = np.arange(first, first + num_rays, dtype=np.uint64)
+    rays = np.empty((num_rays, 8), dtype=np.float32)
+    uo = uniform01(seed, ids[:, None] * np.uint64(3) + np.arange(3, dtype=np.uint64)[None, :])
+    rays[:, 0:3] = lo + uo * (hi - lo)
+    rays[:, 3] = np.float32(tmin)
+    rays[:, 7] = np.float32(tmax)
+    todo = np.arange(num_rays)
+    dseed = seed ^ 0x6469720000000000
+    for attempt in range(64):
+        if todo.size == 0:
+            break
+        base = (ids[todo] * np.uint64(64) + np.uint64(attempt)) * np.uint64(3)
+        u = uniform01(dseed, base[:, None] + np.arange(3, dtype=np.uint64)[None, :])
+        d = np.float32(2.0) * u - np.float32(1.0)
+        l2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        ok = (l2 > np.float32(0.01)) & (l2 <= np.float32(1.0))
+        rays[todo[ok], 4:7] = d[ok]
+        todo = todo[~ok]
+    if todo.size:
+        rays[todo, 4:7] = np.float32([0.0, 0.0, 1.0])
+    return rays
+
+
+def camera(bbox_min, bbox_max, eye_dist: float = 0.8, fov: float = 60.0, ratio: float = 1.0):
+    """gen_camera (main.cpp:42-50) looking down +z at the bbox centre from eye_dist * diagonal away."""
+    lo = np.asarray(bbox_min, dtype=np.float32); hi = np.asarray(bbox_max, dtype=np.float32)
+    ext = hi - lo
+    diag = np.float32(np.sqrt(np.float32(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2])))
+    center = np.float32(0.5) * (hi + lo)
+    eye = (center + np.float32([0.0, 0.0, -1.0]) * np.float32(eye_dist) * diag).astype(np.float32)
+    up0 = np.float32([0.0, 1.0, 0.0])
+
+    def norm(v):
+        return (v * (np.float32(1.0) / np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))))).astype(np.float32)
+
+    def cross(a, b):
+        return np.float32([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
+
+    f = np.float32(np.tan(np.pi * fov / 360.0))
+    cdir = norm(center - eye)
+    right = norm(cross(cdir, up0)) * np.float32(f * np.float32(ratio))
+    up = norm(cross(right, cdir)) * f
+    return eye, cdir, right.astype(np.float32), up.astype(np.float32), diag
+
+
+def make_rays_primary(bbox_min, bbox_max, width: int, height: int, first: int = 0, count: int | None = None,
+                      eye_dist: float = 0.8, fov: float = 60.0) -> np.ndarray:
+    """gen_rays (main.cpp:52-66): pixel (x, y) -> dir = cam.dir + right*kx + up*ky, tmax = clip = |extents|."""
+    eye, cdir, right, up, diag = camera(bbox_min, bbox_max, eye_dist, fov, width / float(height))
+    if count is None:
+        count = width * height - first
+    pid = np.arange(first, first + count, dtype=np.int64)
+    x = (pid % width).astype(np.float32); y = (pid // width).astype(np.float32)
+    kx = np.float32(2.0) * x / np.float32(width) - np.float32(1.0)
+    ky = np.float32(1.0) - np.float32(2.0) * y / np.float32(height)
+    rays = np.empty((count, 8), dtype=np.float32)
+    rays[:, 0:3] = eye
+    rays[:, 3] = np.float32(0.0)
+    rays[:, 4:7] = cdir[None, :] + right[None, :] * kx[:, None] + up[None, :] * ky[:, None]
+    rays[:, 7] = diag
+    return rays
+
+
+def make_rays_bounce(tris: np.ndarray, rays: np.ndarray, hits: np.ndarray, bbox_min, bbox_max, seed: int,
+                     first: int = 0) -> np.ndarray:
+    """Diffuse-bounce rays (BASELINE config 5): from each hit, org = p + 1e-4 * n, cosine-weighted
+    direction about the ray-facing normal from two PRNG floats keyed by the ray index; misses are
+    re-drawn as incoherent rays."""
+    n_rays = rays.shape[0]
+    hid = hits["id"]
+    out = make_rays_incoherent(bbox_min, bbox_max, n_rays, seed ^ 0x6D69737300000000, first)
+    hit_mask = hid >= 0
+    if not hit_mask.any():
+        return out
+    r = rays[hit_mask]; t = hits["t"][hit_mask]
+    tri = tris[hid[hit_mask]]
+    p = r[:, 0:3] + r[:, 4:7] * t[:, None]
+    n = np.stack([tri[:, 3], tri[:, 7], tri[:, 11]], axis=1)
+    ln = np.sqrt(np.maximum((n * n).sum(axis=1), np.float32(1e-30))).astype(np.float32)
+    n = n / ln[:, None]
+    facing = (n * r[:, 4:7]).sum(axis=1) > 0
+    n[facing] = -n[facing]
+    ids = np.arange(first, first + n_rays, dtype=np.uint64)[hit_mask]
+    u = uniform01(seed, ids[:, None] * np.uint64(2) + np.arange(2, dtype=np.uint64)[None, :])
+    # cosine-weighted hemisphere via a polynomial-free construction: disk point by rejection-free
+    # concentric mapping would need trig; use (r, phi) with sqrt only and a rational unit circle
+    # parametrisation phi -> ((1-s^2)/(1+s^2), 2s/(1+s^2)), s in [-1,1), mirrored by the second bit.
+    s = np.float32(2.0) * u[:, 1] - np.float32(1.0)
+    half = (ids & np.uint64(1)).astype(np.float32) * np.float32(2.0) - np.float32(1.0)
+    cx = (np.float32(1.0) - s * s) / (np.float32(1.0) + s * s) * half
+    cy = np.float32(2.0) * s / (np.float32(1.0) + s * s)
+    rad = np.sqrt(u[:, 0]).astype(np.float32)
+    dx = rad * cx; dy = rad * cy
+    dz = np.sqrt(np.maximum(np.float32(1.0) - u[:, 0], np.float32(0.0))).astype(np.float32)
+    # orthonormal basis (Frisvad-free, branch on the dominant axis)
+    a = np.where((np.abs(n[:, 0]) > np.float32(0.5))[:, None], np.float32([0.0, 1.0, 0.0])[None, :], np.float32([1.0, 0.0, 0.0])[None, :]).astype(np.float32)
+    tx = _cross(a, n)
+    tx = tx / np.sqrt((tx * tx).sum(axis=1)).astype(np.float32)[:, None]
+    ty = _cross(n, tx)
+    d = tx * dx[:, None] + ty * dy[:, None] + n * dz[:, None]
+    b = np.empty((r.shape[0], 8), dtype=np.float32)
+    b[:, 0:3] = p + np.float32(1e-4) * n
+    b[:, 3] = np.float32(0.0)
+    b[:, 4:7] = d
+    b[:, 7] = FLT_MAX
+    out[hit_mask] = b
+    return out.astype(np.float32)
+
+
+def shard_range(num_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous ray range of rank ``rank``: [g*n/G, (g+1)*n/G)."""
+    return (num_items * rank) // world, (num_items * (rank + 1)) // world

@@ -1,0 +1,210 @@
+"""The CPU oracle against the golden vectors produced by the reference's own headers
+(tests/golden/make_golden.py), bit for bit.  No GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hagrid_amd import scene
+from oracle import oracle as O
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "l0_kat.npz"))
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_scalars(kat):
+    L = O.lib()
+    got = np.float32([L.orc_safe_rcp(float(v)) for v in kat["rcp_in"]])
+    assert (bits(got) == bits(kat["rcp_out"])).all()
+    got = np.float32([L.orc_prodsign(float(a), float(b)) for a, b in zip(kat["prodsign_x"], kat["prodsign_y"])])
+    assert (bits(got) == bits(kat["prodsign_out"])).all()
+    got = np.int32([L.orc_ilog2_i32(int(v)) for v in kat["ilog2_in"]])
+    assert (got == kat["ilog2_out"]).all()
+    got = np.uint32([L.orc_make_entry(int(a), int(b)) for a, b in zip(kat["entry_log_dim"], kat["entry_begin"])])
+    assert (got == kat["entry_out"]).all()
+    # documented bit layout: log_dim | begin << 2 (grid.h:12-20)
+    assert L.orc_make_entry(3, 5) == 0x17
+
+
+def test_tri_bbox(kat):
+    tris = kat["tris"]
+    out = np.zeros((1, 8), dtype=np.float32)
+    for i in range(0, tris.shape[0], 7):
+        O.lib().orc_tri_bbox(p(tris[i:i + 1]), p(out))
+        assert (bits(out) == bits(kat["tri_bbox"][i:i + 1])).all()
+
+
+def test_intersect_prim_ray(kat):
+    tris, rays, tid = kat["tris"], kat["ipr_rays"], kat["ipr_tid"]
+    n = rays.shape[0]
+    ret = np.zeros(n, dtype=np.int32); hid = np.zeros(n, dtype=np.int32); ht = np.zeros(n, dtype=np.float32)
+    for i in range(n):
+        h = np.array([(-1, rays[i, 7], 0, 0)], dtype=O.HIT_DTYPE)
+        ret[i] = O.lib().orc_intersect_prim_ray(p(tris[tid[i]:tid[i] + 1]), p(rays[i:i + 1]), int(tid[i]), p(h))
+        hid[i] = h["id"][0]; ht[i] = h["t"][0]
+    assert (ret == kat["ipr_ret"]).all()
+    assert (hid == kat["ipr_hit_id"]).all()
+    assert (bits(ht) == bits(kat["ipr_hit_t"])).all()
+    assert 0.2 < ret.mean() < 0.95  # the vectors exercise both outcomes
+
+
+def test_intersect_prim_cell(kat):
+    tris, boxes, tid = kat["tris"], kat["ipc_boxes"], kat["ipc_tid"]
+    ret = np.int32([O.lib().orc_intersect_prim_cell(p(tris[t:t + 1]), p(boxes[i:i + 1])) for i, t in enumerate(tid)])
+    assert (ret == kat["ipc_ret"]).all()
+    assert 0.05 < ret.mean() < 0.95
+
+
+def test_compute_range(kat):
+    dims, gbb, obb = kat["range_dims"], kat["range_grid_bb"], kat["range_obj_bb"]
+    out = np.zeros((dims.shape[0], 6), dtype=np.int32)
+    for i in range(dims.shape[0]):
+        O.lib().orc_compute_range(p(dims[i:i + 1]), p(gbb[i:i + 1]), p(obb[i:i + 1]), p(out[i:i + 1]))
+    assert (out == kat["range_out"]).all()
+
+
+def test_compute_grid_dims(kat):
+    """The reference calls libm cbrtf (grid.h:99); the oracle uses the deterministic cbrt shared with
+    the HIP side (difference D5).  They must agree on every golden input."""
+    bbs, nprims, dens = kat["gd_bb"], kat["gd_nprims"], kat["gd_density"]
+    out = np.zeros((bbs.shape[0], 3), dtype=np.int32)
+    for i in range(bbs.shape[0]):
+        O.lib().orc_compute_grid_dims(p(bbs[i:i + 1]), int(nprims[i]), float(dens[i]), p(out[i:i + 1]))
+    assert (out == kat["gd_out"]).all()
+
+
+def test_cbrt_is_correctly_rounded():
+    x = (scene.uniform01(77, np.arange(20000, dtype=np.uint64)).astype(np.float64) * 12 - 4)
+    x = np.float32(10.0 ** x)
+    got = np.float32([O.lib().orc_cbrtf(float(v)) for v in x])
+    want = np.cbrt(x.astype(np.float64)).astype(np.float32)
+    assert (bits(got) == bits(want)).all()
+    assert O.lib().orc_cbrtf(0.0) == 0.0 and O.lib().orc_cbrtf(-8.0) == -2.0 and O.lib().orc_cbrtf(27.0) == 3.0
+
+
+@pytest.mark.parametrize("tag", ["octree", "flat"])
+def test_lookup_entry(kat, tag):
+    ent, vox = kat[f"lk_{tag}_entries"], kat[f"lk_{tag}_voxels"]
+    shift, td = int(kat[f"lk_{tag}_shift"]), kat[f"lk_{tag}_dims"]
+    got = np.uint32([O.lib().orc_lookup_entry(p(ent), shift, p(td), p(vox[i:i + 1]), None) for i in range(vox.shape[0])])
+    assert (got == kat[f"lk_{tag}_out"]).all()
+
+
+def test_foreach_ref_semantics(kat):
+    """grid.h:118-140: Cell lists are [begin, end), SmallCell lists end at the -1 sentinel and the
+    returned count includes it; the oracle's traversal counters follow the same convention."""
+    refs = kat["fe_refs"]
+    for i in range(4):
+        b, e = int(kat["fe_cell_begin"][i]), int(kat["fe_cell_end"][i])
+        r = kat["fe_cell_out"][i]
+        assert r[0] == e - b
+        assert list(r[1:1 + max(e - b, 0)]) == list(refs[b:e])
+        sb = int(kat["fe_small_begin"][i]); r = kat["fe_small_out"][i]
+        if sb < 0:
+            assert r[0] == 0
+        else:
+            k = sb
+            while refs[k] >= 0:
+                k += 1
+            assert r[0] == k - sb + 1 and list(r[1:1 + k - sb]) == list(refs[sb:k])
+
+
+# ---- BASELINE config 1: every stage of the oracle pipeline reproduces the reference-arithmetic brute force
+
+
+@pytest.fixture(scope="module")
+def config1(golden_dir):
+    g = np.load(os.path.join(golden_dir, "config1_hits.npz"))
+    tris = scene.make_soup(10000)
+    lo, hi = scene.tris_bbox(tris)
+    rays = scene.make_rays_incoherent(lo, hi, 65536, scene.RAY_SEED_BASE + 1)
+    assert np.uint32(np.bitwise_xor.reduce(tris.view(np.uint32).ravel())) == g["tris_crc"]
+    assert np.uint32(np.bitwise_xor.reduce(rays.view(np.uint32).ravel())) == g["rays_crc"]
+    return tris, rays, g["id"], g["t"]
+
+
+def test_oracle_brute_force_matches_reference(config1):
+    tris, rays, gid, gt = config1
+    h = O.brute_force(tris, rays[:8192], nthreads=8)
+    assert (h["id"] == gid[:8192]).all() and (bits(h["t"]) == bits(gt[:8192])).all()
+
+
+def test_oracle_pipeline_matches_brute_force(config1):
+    tris, rays, gid, gt = config1
+    G = O.Grid.build(tris)
+    stages = [("build", lambda: None), ("merge", lambda: G.merge(0.995)), ("flatten", G.flatten),
+              ("expand", lambda: G.expand(tris, 3)), ("compress", G.compress)]
+    prev_cells = None
+    for name, fn in stages:
+        fn()
+        rc, msg = G.check(tris, 1 if name in ("build", "expand", "compress") else 0)
+        assert rc == 0, f"{name}: {msg}"
+        h, st = G.traverse(tris, rays, nthreads=8)
+        assert (h["id"] == gid).all(), name
+        assert (bits(h["t"]) == bits(gt)).all(), name
+        assert st["rays"] == rays.shape[0] and st["hits"] == int((gid >= 0).sum())
+        if name == "merge":
+            assert G.num_cells < prev_cells
+        prev_cells = G.num_cells
+    assert G.summary()["compressed"]
+
+
+def test_oracle_steps_equal_cells_plus_refs(config1):
+    """traverse.cu:80: steps = sum(1 + nrefs) = visited cells + tested refs (the byte formula's counts)."""
+    tris, rays, _, _ = config1
+    G = O.Grid.full(tris)
+    h, st, steps = G.traverse(tris, rays[:4096], want_steps=True)
+    assert int(steps.sum()) == st["cells"] + st["refs"]
+
+
+def test_grid_regression_pins_config1(config1):
+    """Oracle's own structural numbers (NOT reference-pinned; see DESIGN.md 'parity unpinned')."""
+    tris = config1[0]
+    G = O.Grid.build(tris)
+    assert G.dims == (10, 10, 10) and G.shift == 3
+    assert (G.num_cells, G.num_refs, G.num_entries) == (57329, 68032, 65376)
+    G.merge(0.995)
+    assert (G.num_cells, G.num_refs) == (34686, 51367)
+    G.flatten()
+    assert G.num_entries == 61072 and G.offsets == [1000, 61072]
+
+
+def test_edge_cases():
+    # a single triangle, and a pair of far-apart triangles (mostly empty grid)
+    one = scene.tris_from_vertices(np.float32([[0, 0, 0]]), np.float32([[1, 0, 0]]), np.float32([[0, 1, 0.5]]))
+    two = scene.tris_from_vertices(np.float32([[0, 0, 0], [5, 5, 5]]), np.float32([[1, 0, 0], [6, 5, 5]]), np.float32([[0, 1, 0], [5, 6, 5.5]]))
+    for tris in (one, two):
+        G = O.Grid.full(tris)
+        rc, msg = G.check(tris, 2)
+        assert rc == 0, msg
+        lo, hi = scene.tris_bbox(tris)
+        rays = scene.make_rays_incoherent(lo - 0.5, hi + 0.5, 4096, 99)
+        h, _ = G.traverse(tris, rays)
+        bf = O.brute_force(tris, rays)
+        assert (h["id"] == bf["id"]).all() and (bits(h["t"]) == bits(bf["t"])).all()
+    # zero rays
+    h, st = G.traverse(tris, np.zeros((0, 8), dtype=np.float32))
+    assert h.shape[0] == 0 and st["rays"] == 0
+
+
+def test_primary_rays_with_zero_components():
+    tris = scene.make_soup(3000)
+    lo, hi = scene.tris_bbox(tris)
+    rays = scene.make_rays_primary(lo, hi, 128, 128)
+    assert (rays[:, 4] == 0).any() and (rays[:, 5] == 0).any()   # centre column / row (main.cpp:55-57)
+    G = O.Grid.full(tris)
+    h, _ = G.traverse(tris, rays)
+    bf = O.brute_force(tris, rays, nthreads=8)
+    assert (h["id"] == bf["id"]).all() and (bits(h["t"]) == bits(bf["t"])).all()
+    assert (h["id"] >= 0).mean() > 0.25
