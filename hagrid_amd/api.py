@@ -1,0 +1,272 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference's C++ API so that tests read like
+the reference's own call sequence (main.cpp:471-506, :535, :410-425):
+
+    mem  = MemManager(keep=True)                        # mem_manager.h:34-119
+    tris = mem.upload(host_tris)                        # mem.alloc<Tri> + copy<HST_TO_DEV>
+    grid = Grid()
+    build_grid(mem, tris, n, grid, 0.12, 2.4)           # build.h:17
+    merge_grid(mem, grid, 0.995)                        # build.h:20
+    flatten_grid(mem, grid)                             # build.h:25
+    expand_grid(mem, grid, tris, 3)                     # build.h:28
+    compress_grid(mem, grid)                            # build.h:31 (bool)
+    setup_traversal(grid)                               # traverse.h:11
+    traverse_grid(grid, tris, rays, hits, num_rays)     # traverse.h:14
+    ms = profile(lambda: traverse_grid(...))            # common.h:15
+
+Device buffers are plain integer addresses (what the C ABI takes).  Errors raise HagridError carrying the
+"file(line): message" text -- the reference prints that text and abort()s (common.h:103-108).
+There is no CPU path here: without the compiled library and a GPU every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import GridPOD, HagridError, TraversalStats
+from .scene import CELL_DTYPE, HIT_DTYPE, SMALL_CELL_DTYPE
+
+_current = None  # the most recently created MemManager (profile / setup_traversal take no manager)
+
+
+def _check(mem: "MemManager", rc: int, what: str) -> int:
+    if rc < 0:
+        msg = _lib.load().hagrid_last_error(mem._ctx)
+        raise HagridError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+class MemManager:
+    """Buffer pool on one GPU (reference: MemManager, mem_manager.h:34-119).  `keep` retains freed
+    buffers between builds (README.md:52-54 recommends it for build benchmarks)."""
+
+    def __init__(self, keep: bool = False, device: int | None = None):
+        global _current
+        L = _lib.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        rc = L.hagrid_ctx_create(C.byref(h), int(device), 1 if keep else 0)
+        if rc != 0 or not h:
+            raise HagridError(f"hagrid_ctx_create(device={device}) failed ({rc}): no usable gfx950 device")
+        self._L = L
+        self._ctx = h
+        self.device = int(device)
+        _current = self
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.hagrid_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream: int | None):
+        """Enqueue all further work on a hipStream_t given as an integer (e.g. torch's cuda_stream)."""
+        _check(self, self._L.hagrid_ctx_set_stream(self._ctx, C.c_void_p(stream or 0)), "set_stream")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(128); cus = C.c_int(); mem = C.c_int64()
+        _check(self, self._L.hagrid_device_info(self._ctx, name, 128, C.byref(cus), C.byref(mem)), "device_info")
+        return {"arch": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}
+
+    # -- alloc / free / copy / zero / one ------------------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        p = self._L.hagrid_mem_alloc(self._ctx, int(nbytes))
+        if not p:
+            raise HagridError("alloc failed: " + self._L.hagrid_last_error(self._ctx).decode())
+        return int(p)
+
+    def free(self, ptr: int | None):
+        if ptr:
+            _check(self, self._L.hagrid_mem_free(self._ctx, C.c_void_p(ptr)), "free")
+
+    def copy_h2d(self, dst: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        _check(self, self._L.hagrid_mem_copy_h2d(self._ctx, C.c_void_p(dst), src.ctypes.data_as(C.c_void_p), src.nbytes), "copy h2d")
+
+    def copy_d2h(self, dst: np.ndarray, src: int):
+        assert dst.flags["C_CONTIGUOUS"]
+        _check(self, self._L.hagrid_mem_copy_d2h(self._ctx, dst.ctypes.data_as(C.c_void_p), C.c_void_p(src), dst.nbytes), "copy d2h")
+
+    def copy_d2d(self, dst: int, src: int, nbytes: int):
+        _check(self, self._L.hagrid_mem_copy_d2d(self._ctx, C.c_void_p(dst), C.c_void_p(src), int(nbytes)), "copy d2d")
+
+    def zero(self, ptr: int, nbytes: int):
+        _check(self, self._L.hagrid_mem_zero(self._ctx, C.c_void_p(ptr), int(nbytes)), "zero")
+
+    def one(self, ptr: int, nbytes: int):
+        _check(self, self._L.hagrid_mem_one(self._ctx, C.c_void_p(ptr), int(nbytes)), "one")
+
+    def usage(self) -> int:
+        return int(self._L.hagrid_mem_usage(self._ctx))
+
+    def max_usage(self) -> int:
+        return int(self._L.hagrid_mem_max_usage(self._ctx))
+
+    def debug_slots(self):
+        self._L.hagrid_mem_debug_slots(self._ctx)
+
+    # -- conveniences ----------------------------------------------------------------------------------
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(max(arr.nbytes, 4))
+        if arr.nbytes:
+            self.copy_h2d(p, arr)
+        return p
+
+    def download(self, ptr: int, dtype, count: int) -> np.ndarray:
+        out = np.empty(int(count), dtype=dtype)
+        if out.nbytes:
+            self.copy_d2h(out, ptr)
+        return out
+
+
+class Grid:
+    """The reference's `struct Grid` (grid.h:48-62); device pointers are integers."""
+
+    def __init__(self):
+        self.pod = GridPOD()
+        self.mem: MemManager | None = None
+
+    entries = property(lambda s: s.pod.entries or 0)
+    ref_ids = property(lambda s: s.pod.ref_ids or 0)
+    cells = property(lambda s: s.pod.cells or 0)
+    small_cells = property(lambda s: s.pod.small_cells or 0)
+    dims = property(lambda s: tuple(s.pod.dims))
+    shift = property(lambda s: int(s.pod.shift))
+    num_cells = property(lambda s: int(s.pod.num_cells))
+    num_entries = property(lambda s: int(s.pod.num_entries))
+    num_refs = property(lambda s: int(s.pod.num_refs))
+    offsets = property(lambda s: [int(s.pod.offsets[i]) for i in range(s.pod.num_offsets)])
+    bbox_min = property(lambda s: np.array(list(s.pod.bbox_min), dtype=np.float32))
+    bbox_max = property(lambda s: np.array(list(s.pod.bbox_max), dtype=np.float32))
+
+    def summary(self) -> dict:
+        return {"dims": self.dims, "shift": self.shift, "num_cells": self.num_cells, "num_refs": self.num_refs,
+                "num_entries": self.num_entries, "offsets": self.offsets, "compressed": bool(self.small_cells)}
+
+    def free(self, mem: MemManager | None = None):
+        """mem.free(grid.entries / cells / ref_ids [/ small_cells]) as main.cpp:496-498 does."""
+        mem = mem or self.mem
+        for f in ("entries", "cells", "ref_ids", "small_cells"):
+            p = getattr(self.pod, f)
+            if p:
+                mem.free(p)
+                setattr(self.pod, f, None)
+
+    def download(self, mem: MemManager | None = None) -> dict:
+        mem = mem or self.mem
+        d = {"entries": mem.download(self.entries, np.uint32, self.num_entries),
+             "ref_ids": mem.download(self.ref_ids, np.int32, self.num_refs),
+             "cells": mem.download(self.cells, CELL_DTYPE, self.num_cells) if self.cells else None,
+             "small_cells": mem.download(self.small_cells, SMALL_CELL_DTYPE, self.num_cells) if self.small_cells else None}
+        d.update(bbox_min=self.bbox_min, bbox_max=self.bbox_max, dims=self.dims, shift=self.shift, offsets=self.offsets)
+        return d
+
+    @staticmethod
+    def upload(mem: MemManager, entries, ref_ids, cells, small_cells, bbox_min, bbox_max, dims, shift, offsets) -> "Grid":
+        """Assemble a device grid from host arrays (fixtures, the broadcast blob of dist.py)."""
+        g = Grid(); g.mem = mem
+        g.pod.entries = mem.upload(np.ascontiguousarray(entries, dtype=np.uint32))
+        g.pod.ref_ids = mem.upload(np.ascontiguousarray(ref_ids, dtype=np.int32))
+        n_cells = 0
+        if cells is not None:
+            g.pod.cells = mem.upload(cells); n_cells = len(cells)
+        if small_cells is not None:
+            g.pod.small_cells = mem.upload(small_cells); n_cells = len(small_cells)
+        for i in range(3):
+            g.pod.bbox_min[i] = float(bbox_min[i]); g.pod.bbox_max[i] = float(bbox_max[i]); g.pod.dims[i] = int(dims[i])
+        g.pod.num_cells = n_cells; g.pod.num_entries = len(entries); g.pod.num_refs = len(ref_ids)
+        g.pod.shift = int(shift); g.pod.num_offsets = len(offsets)
+        for i, o in enumerate(offsets):
+            g.pod.offsets[i] = int(o)
+        return g
+
+
+# ---- build.h -----------------------------------------------------------------------------------------
+
+def build_grid(mem: MemManager, tris: int, num_tris: int, grid: Grid, top_density: float, snd_density: float):
+    grid.mem = mem
+    _check(mem, mem._L.hagrid_build_grid(mem._ctx, C.c_void_p(tris), int(num_tris), C.byref(grid.pod), top_density, snd_density), "build_grid")
+
+
+def merge_grid(mem: MemManager, grid: Grid, alpha: float):
+    _check(mem, mem._L.hagrid_merge_grid(mem._ctx, C.byref(grid.pod), alpha), "merge_grid")
+
+
+def flatten_grid(mem: MemManager, grid: Grid):
+    _check(mem, mem._L.hagrid_flatten_grid(mem._ctx, C.byref(grid.pod)), "flatten_grid")
+
+
+def expand_grid(mem: MemManager, grid: Grid, tris: int, iters: int):
+    _check(mem, mem._L.hagrid_expand_grid(mem._ctx, C.byref(grid.pod), C.c_void_p(tris), int(iters)), "expand_grid")
+
+
+def compress_grid(mem: MemManager, grid: Grid) -> bool:
+    return _check(mem, mem._L.hagrid_compress_grid(mem._ctx, C.byref(grid.pod)), "compress_grid") == 1
+
+
+def build_all(mem: MemManager, tris: int, num_tris: int, top_density=0.12, snd_density=2.4, alpha=0.995,
+              exp_iters=3, compress=False, grid: Grid | None = None) -> Grid:
+    """The construction sequence of main.cpp:500-506."""
+    grid = grid or Grid()
+    build_grid(mem, tris, num_tris, grid, top_density, snd_density)
+    merge_grid(mem, grid, alpha)
+    flatten_grid(mem, grid)
+    expand_grid(mem, grid, tris, exp_iters)
+    if compress:
+        compress_grid(mem, grid)
+    return grid
+
+
+# ---- traverse.h ---------------------------------------------------------------------------------------
+
+def setup_traversal(grid: Grid):
+    mem = grid.mem or _current
+    _check(mem, mem._L.hagrid_setup_traversal(mem._ctx, C.byref(grid.pod)), "setup_traversal")
+
+
+def traverse_grid(grid: Grid, tris: int, rays: int, hits: int, num_rays: int):
+    mem = grid.mem or _current
+    _check(mem, mem._L.hagrid_traverse_grid(mem._ctx, C.byref(grid.pod), C.c_void_p(tris), C.c_void_p(rays), C.c_void_p(hits), int(num_rays)), "traverse_grid")
+
+
+def traverse_grid_stats(grid: Grid, tris: int, rays: int, hits: int, num_rays: int, steps: int = 0) -> dict:
+    mem = grid.mem or _current
+    st = TraversalStats()
+    _check(mem, mem._L.hagrid_traverse_grid_stats(mem._ctx, C.byref(grid.pod), C.c_void_p(tris), C.c_void_p(rays), C.c_void_p(hits),
+                                                  int(num_rays), C.c_void_p(steps), C.byref(st)), "traverse_grid_stats")
+    return st.as_dict()
+
+
+def profile(fn, mem: MemManager | None = None) -> float:
+    """Milliseconds between two events on the manager's stream around fn() (profile.cu:5-18)."""
+    mem = mem or _current
+    _check(mem, mem._L.hagrid_profile_begin(mem._ctx), "profile")
+    fn()
+    ms = mem._L.hagrid_profile_end(mem._ctx)
+    if ms < 0:
+        raise HagridError("profile failed")
+    return float(ms)
+
+
+def algorithmic_bytes(stats: dict, compressed: bool) -> dict:
+    """DESIGN.md / BASELINE.md section 4: bytes the algorithm must touch for a batch, from exact counters."""
+    s_cell = 16 if compressed else 32
+    walk = 4 * stats["entry_words"] + s_cell * stats["cells"]
+    total = 48 * stats["rays"] + walk + 52 * stats["refs"] + 4 * stats["sentinels"]
+    return {"B_ray": int(total), "B_walk": int(walk)}
+
+
+__all__ = ["MemManager", "Grid", "build_grid", "merge_grid", "flatten_grid", "expand_grid", "compress_grid", "build_all",
+           "setup_traversal", "traverse_grid", "traverse_grid_stats", "profile", "algorithmic_bytes", "HagridError",
+           "HIT_DTYPE", "CELL_DTYPE", "SMALL_CELL_DTYPE"]

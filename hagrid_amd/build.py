@@ -1,0 +1,69 @@
+"""Builds hagrid_amd/libhagrid_amd.so in-tree: every csrc/*.hip is compiled for gfx950 with hipcc and
+the objects are linked WITHOUT naming a HIP runtime, so the library binds to whichever libamdhip64 the
+process already holds (PyTorch's when loaded from Python, /opt/rocm's when linked into a C++ program).
+
+Floating-point policy: no contraction, no fast-math, correctly rounded divide/sqrt -- the
+kernels must agree bit for bit with the CPU oracle.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "obj")
+LIB = os.path.join(HERE, "libhagrid_amd.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-DHOST=__host__", "-DDEVICE=__device__",
+    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True)
+    hdrs.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not _newer(o, [s] + hdrs):
+            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not _newer(LIB, objs):
+        run(["g++", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

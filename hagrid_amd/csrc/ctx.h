@@ -1,0 +1,79 @@
+// ctx.h -- internal state behind the C ABI (include/hagrid_amd.h).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hagrid_amd.h"
+
+namespace hagrid_impl {
+
+struct Slot {
+    void* ptr = nullptr;
+    size_t size = 0;
+    bool in_use = false;
+};
+
+} // namespace hagrid_impl
+
+struct hagrid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool keep = false;
+    int num_cus = 0;
+
+    // buffer pool (MemManager backend)
+    std::vector<hagrid_impl::Slot> slots;
+    std::unordered_map<void*, int> tracker;
+    size_t usage = 0, max_usage = 0;
+
+    // profile()
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    // pinned mailbox for scalar read-backs (build passes) -- 256 ints
+    int* mailbox = nullptr;
+    // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
+    int* dscratch = nullptr;
+
+    std::string err;
+};
+
+namespace hagrid_impl {
+
+inline int fail(hagrid_ctx* ctx, int code, const char* file, int line, const char* msg) {
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s(%d): %s", file, line, msg);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HG_FAIL(ctx, code, msg) return ::hagrid_impl::fail((ctx), (code), __FILE__, __LINE__, (msg))
+#define HG_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return ::hagrid_impl::fail((ctx), HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e_)); \
+    } while (0)
+#define HG_TRY(expr)                                                                              \
+    do {                                                                                          \
+        int rc_ = (expr);                                                                         \
+        if (rc_ < 0) return rc_;                                                                  \
+    } while (0)
+
+// pool access for the passes (typed convenience over hagrid_mem_alloc)
+template <typename T>
+inline T* pool_alloc(hagrid_ctx* ctx, size_t n) {
+    return static_cast<T*>(hagrid_mem_alloc(ctx, (n ? n : 1) * sizeof(T)));
+}
+
+// Reads `count` ints from device memory into host memory after draining the stream.
+int read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes);
+
+inline int grid_blocks(long long n, int block) { return (int)((n + block - 1) / block); }
+
+} // namespace hagrid_impl

@@ -1,0 +1,207 @@
+// ctx.hip -- context, buffer pool (MemManager backend) and the event timer behind the C ABI.
+//
+// Reference interfaces replaced: MemManager's out-of-line members (mem_manager.h:106-112,
+// mem_manager.cu:6-75: alloc_slot, free_slot, copy_*, zero_dev, one_dev, debug_slots) and
+// profile() (profile.cu:5-18).
+#include "ctx.h"
+
+#include <algorithm>
+#include <cstring>
+#include <iostream>
+
+using namespace hagrid_impl;
+
+extern "C" int hagrid_abi_version(void) { return HAGRID_ABI_VERSION; }
+
+extern "C" int hagrid_ctx_create(hagrid_ctx** out, int device, int keep) {
+    if (!out) return HAGRID_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return HAGRID_ENODEV;
+    hagrid_ctx* ctx = new hagrid_ctx();
+    ctx->device = device;
+    ctx->keep = keep != 0;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return HAGRID_ENODEV; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return HAGRID_ENODEV; }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->mailbox, 256 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&ctx->dscratch, 256 * sizeof(int)) != hipSuccess) {
+        hagrid_ctx_destroy(ctx);
+        return HAGRID_EHIP;
+    }
+    *out = ctx;
+    return HAGRID_OK;
+}
+
+extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->slots)
+        if (s.ptr) (void)hipFree(s.ptr);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+    delete ctx;
+}
+
+extern "C" int hagrid_ctx_set_stream(hagrid_ctx* ctx, void* stream) {
+    if (!ctx) return HAGRID_EINVAL;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return HAGRID_OK;
+}
+
+extern "C" const char* hagrid_last_error(const hagrid_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int hagrid_device_info(const hagrid_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem) {
+    if (!ctx) return HAGRID_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return HAGRID_EHIP;
+    if (name && name_len > 0) { strncpy(name, prop.gcnArchName, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem) *total_mem = (int64_t)prop.totalGlobalMem;
+    return HAGRID_OK;
+}
+
+// ---- buffer pool ---------------------------------------------------------------------------------
+// Contract of the reference's MemManager: alloc re-uses a free slot when possible, free(nullptr) is a
+// no-op, a pointer not obtained from alloc is an error, keep mode retains freed buffers, usage() /
+// max_usage() count bytes held from the device allocator.  Policy here: the smallest free slot that
+// fits; otherwise the largest free slot is re-grown; otherwise a new slot.
+
+static void release_slot_memory(hagrid_ctx* ctx, Slot& s) {
+    if (s.ptr) (void)hipFree(s.ptr);
+    ctx->usage -= s.size;
+    s.ptr = nullptr;
+    s.size = 0;
+}
+
+extern "C" void* hagrid_mem_alloc(hagrid_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    if (bytes == 0) bytes = 4;
+    bytes = (bytes + 255) & ~size_t(255);
+    int fit = -1, biggest = -1, empty = -1;
+    for (int i = 0, n = (int)ctx->slots.size(); i < n; i++) {
+        const Slot& s = ctx->slots[i];
+        if (s.in_use) continue;
+        if (!s.ptr) { if (empty < 0) empty = i; continue; }
+        if (s.size >= bytes && (fit < 0 || s.size < ctx->slots[fit].size)) fit = i;
+        if (biggest < 0 || s.size > ctx->slots[biggest].size) biggest = i;
+    }
+    int idx = fit;
+    // a fitting slot more than 4x too large is left for a bigger request unless nothing else is free
+    if (idx >= 0 && ctx->slots[idx].size > 4 * bytes && ctx->slots[idx].size > (size_t(64) << 20)) idx = -1;
+    if (idx < 0) {
+        idx = fit < 0 ? (biggest >= 0 && ctx->keep ? biggest : empty) : empty;
+        if (idx < 0) { idx = (int)ctx->slots.size(); ctx->slots.emplace_back(); }
+        Slot& s = ctx->slots[idx];
+        if (s.ptr) release_slot_memory(ctx, s);
+        void* p = nullptr;
+        (void)hipSetDevice(ctx->device);
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            // give back every cached buffer and retry once
+            for (auto& t : ctx->slots) if (!t.in_use && t.ptr) release_slot_memory(ctx, t);
+            if (hipMalloc(&p, bytes) != hipSuccess) { fail(ctx, HAGRID_ENOMEM, __FILE__, __LINE__, "hipMalloc failed"); return nullptr; }
+        }
+        s.ptr = p; s.size = bytes;
+        ctx->usage += bytes;
+        ctx->max_usage = std::max(ctx->max_usage, ctx->usage);
+    }
+    Slot& s = ctx->slots[idx];
+    s.in_use = true;
+    ctx->tracker[s.ptr] = idx;
+    return s.ptr;
+}
+
+extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!ptr) return HAGRID_OK;
+    auto it = ctx->tracker.find(ptr);
+    if (it == ctx->tracker.end()) HG_FAIL(ctx, HAGRID_EINVAL, "free of a pointer that does not come from this MemManager");
+    Slot& s = ctx->slots[it->second];
+    ctx->tracker.erase(it);
+    s.in_use = false;
+    if (!ctx->keep) {
+        // buffers may still be read by work queued on the stream
+        HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        release_slot_memory(ctx, s);
+    }
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_mem_copy_h2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" int hagrid_mem_copy_d2h(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" int hagrid_mem_copy_d2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" int hagrid_mem_zero(hagrid_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" int hagrid_mem_one(hagrid_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ctx) return HAGRID_EINVAL;
+    if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipMemsetAsync(ptr, 0xFF, bytes, ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" size_t hagrid_mem_usage(const hagrid_ctx* ctx) { return ctx ? ctx->usage : 0; }
+extern "C" size_t hagrid_mem_max_usage(const hagrid_ctx* ctx) { return ctx ? ctx->max_usage : 0; }
+
+extern "C" void hagrid_mem_debug_slots(const hagrid_ctx* ctx) {
+    if (!ctx) return;
+    size_t total = 0;
+    std::cout << "SLOTS: " << std::endl;
+    for (const auto& s : ctx->slots) {
+        std::cout << "[" << (s.in_use ? 'X' : ' ') << "] " << (double)s.size / (1024.0 * 1024.0) << "MB" << std::endl;
+        total += s.size;
+    }
+    std::cout << (double)total / (1024.0 * 1024.0) << "MB total" << std::endl;
+}
+
+// ---- profile ---------------------------------------------------------------------------------------
+
+extern "C" int hagrid_profile_begin(hagrid_ctx* ctx) {
+    if (!ctx) return HAGRID_EINVAL;
+    HG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    return HAGRID_OK;
+}
+extern "C" float hagrid_profile_end(hagrid_ctx* ctx) {
+    if (!ctx) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(ctx->ev_end) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int hagrid_impl::read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes) {
+    if (bytes <= 256 * sizeof(int)) {
+        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(hptr, ctx->mailbox, bytes);
+    } else {
+        HG_HIP(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return HAGRID_OK;
+}

@@ -1,0 +1,118 @@
+"""ctypes loader for libhagrid_amd.so (the C ABI declared in include/hagrid_amd.h).
+
+The library is linked without a HIP runtime of its own: it binds to the libamdhip64 the process already
+holds.  From Python that is PyTorch's copy (PyTorch is the plumbing for device memory, streams and
+torch.distributed), which is promoted to the global symbol scope before the library is opened.
+
+There is NO fallback: if the library is missing or cannot be loaded, every product entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhagrid_amd.so")
+MAX_LEVELS = 32
+
+OK, EINVAL, EHIP, ENOMEM, ERANGE, ENODEV = 0, -1, -2, -3, -4, -5
+
+
+class HagridError(RuntimeError):
+    pass
+
+
+class GridPOD(C.Structure):
+    """struct hagrid_grid (include/hagrid_amd.h) == the reference's Grid (grid.h:48-62) as a POD."""
+    _fields_ = [("entries", C.c_void_p), ("ref_ids", C.c_void_p), ("cells", C.c_void_p), ("small_cells", C.c_void_p),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("dims", C.c_int32 * 3),
+                ("num_cells", C.c_int32), ("num_entries", C.c_int32), ("num_refs", C.c_int32), ("shift", C.c_int32),
+                ("num_offsets", C.c_int32), ("offsets", C.c_int32 * MAX_LEVELS)]
+
+
+class TraversalStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("rays", "rays_hit_grid", "cells", "entry_words", "refs", "sentinels", "hits")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "hagrid_abi_version": (_i32, []),
+    "hagrid_ctx_create": (_i32, [C.POINTER(_vp), _i32, _i32]),
+    "hagrid_ctx_destroy": (None, [_vp]),
+    "hagrid_ctx_set_stream": (_i32, [_vp, _vp]),
+    "hagrid_last_error": (C.c_char_p, [_vp]),
+    "hagrid_device_info": (_i32, [_vp, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
+    "hagrid_mem_alloc": (_vp, [_vp, _sz]),
+    "hagrid_mem_free": (_i32, [_vp, _vp]),
+    "hagrid_mem_copy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "hagrid_mem_copy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+    "hagrid_mem_copy_d2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "hagrid_mem_zero": (_i32, [_vp, _vp, _sz]),
+    "hagrid_mem_one": (_i32, [_vp, _vp, _sz]),
+    "hagrid_mem_usage": (_sz, [_vp]),
+    "hagrid_mem_max_usage": (_sz, [_vp]),
+    "hagrid_mem_debug_slots": (None, [_vp]),
+    "hagrid_profile_begin": (_i32, [_vp]),
+    "hagrid_profile_end": (_f32, [_vp]),
+    "hagrid_build_grid": (_i32, [_vp, _vp, _i32, C.POINTER(GridPOD), _f32, _f32]),
+    "hagrid_merge_grid": (_i32, [_vp, C.POINTER(GridPOD), _f32]),
+    "hagrid_flatten_grid": (_i32, [_vp, C.POINTER(GridPOD)]),
+    "hagrid_expand_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _i32]),
+    "hagrid_compress_grid": (_i32, [_vp, C.POINTER(GridPOD)]),
+    "hagrid_setup_traversal": (_i32, [_vp, C.POINTER(GridPOD)]),
+    "hagrid_traverse_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32]),
+    "hagrid_traverse_grid_stats": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, _vp, C.POINTER(TraversalStats)]),
+    "hagrid_kat_intersect_prim_ray": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "hagrid_kat_intersect_prim_cell": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "hagrid_kat_compute_range": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "hagrid_kat_compute_grid_dims": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "hagrid_kat_lookup_entry": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+}
+
+_lib = None
+
+
+def _preload_hip_runtime() -> None:
+    """Make the process' HIP runtime visible to libhagrid_amd.so (which names none itself)."""
+    candidates = []
+    try:
+        import torch  # noqa: F401  (PyTorch's bundled runtime; must be the one and only in the process)
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    last = None
+    for c in candidates:
+        try:
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return
+        except OSError as e:  # try the next location
+            last = e
+    raise HagridError(f"no HIP runtime (libamdhip64.so) could be loaded: {last}")
+
+
+def load() -> C.CDLL:
+    """Loads the library (once) and declares every signature.  Raises HagridError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HagridError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or python hagrid_amd/build.py).  There is no CPU fallback.")
+    _preload_hip_runtime()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HagridError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hagrid_abi_version() != 1:
+        raise HagridError("ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,147 @@
+/*
+ * hagrid_amd.h -- C ABI of libhagrid_amd.so, the MI355X (gfx950) implementation of Hagrid's
+ * irregular-grid construction and ray-traversal hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no torch types.  Every entry
+ * point names the reference interface it stands behind (paths relative to the reference's src/).  The
+ * C++ API of the reference (build.h / traverse.h / mem_manager.h / profile) is provided on top of this
+ * file as header-only shims in include/hagrid/ -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returning int returns HAGRID_OK (0) or a negative HAGRID_E* code;
+ *     hagrid_last_error(ctx) then holds "file(line): message" (the text the reference prints before
+ *     abort(), common.h:103-108).  Nothing aborts behind the ABI; the C++ shims abort like the reference.
+ *   - All Tri / Ray / Hit / grid array pointers are DEVICE pointers.  Grid arrays produced by the build
+ *     passes come from the context's buffer pool and are released with hagrid_mem_free (main.cpp:496-498).
+ *   - All work is enqueued on the context's HIP stream (default: the null stream, like the reference's
+ *     <<<...>>> launches).  Build passes synchronise with the host where they need sizes; traversal is
+ *     asynchronous.
+ *   - One host thread per context.  Contexts are independent (the reference keeps per-TU __constant__
+ *     state and therefore allows one grid per process: traverse.cu:7-12; here the traversal constants
+ *     live in the context / the grid descriptor).
+ */
+#ifndef HAGRID_AMD_H
+#define HAGRID_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAGRID_ABI_VERSION 1
+#define HAGRID_MAX_LEVELS 32
+
+enum {
+    HAGRID_OK = 0,
+    HAGRID_EINVAL = -1,   /* bad argument */
+    HAGRID_EHIP = -2,     /* a HIP runtime call failed */
+    HAGRID_ENOMEM = -3,   /* device allocation failed */
+    HAGRID_ERANGE = -4,   /* a count does not fit the 30-bit entry / 31-bit index space */
+    HAGRID_ENODEV = -5    /* no usable gfx950 device */
+};
+
+typedef struct hagrid_ctx hagrid_ctx;
+
+/* Grid descriptor: the reference's `struct Grid` (grid.h:48-62) as a POD.  std::vector<int> offsets
+ * becomes a fixed array + count. */
+typedef struct hagrid_grid {
+    void* entries;        /* uint32 words, log_dim | begin << 2     (grid.h:12-20) */
+    void* ref_ids;        /* int32                                  (grid.h:50)    */
+    void* cells;          /* 32-byte Cell records, NULL if compressed (grid.h:23-33) */
+    void* small_cells;    /* 16-byte SmallCell records or NULL      (grid.h:36-45) */
+    float bbox_min[3];
+    float bbox_max[3];
+    int32_t dims[3];      /* top-level resolution */
+    int32_t num_cells;
+    int32_t num_entries;
+    int32_t num_refs;
+    int32_t shift;
+    int32_t num_offsets;
+    int32_t offsets[HAGRID_MAX_LEVELS];
+} hagrid_grid;
+
+/* Per-batch traversal counters (exact integers; the algorithmic-bytes formula of DESIGN.md). */
+typedef struct hagrid_traversal_stats {
+    int64_t rays, rays_hit_grid, cells, entry_words, refs, sentinels, hits;
+} hagrid_traversal_stats;
+
+/* ---- context ----------------------------------------------------------------------------------- */
+
+int hagrid_abi_version(void);
+
+/* Creates a context on HIP device `device`.  keep != 0 is MemManager's keep mode (mem_manager.h:40-42):
+ * freed buffers stay allocated for reuse by later builds. */
+int hagrid_ctx_create(hagrid_ctx** out, int device, int keep);
+void hagrid_ctx_destroy(hagrid_ctx* ctx);
+/* Launch all further work on `stream` (a hipStream_t; NULL = null stream). */
+int hagrid_ctx_set_stream(hagrid_ctx* ctx, void* stream);
+const char* hagrid_last_error(const hagrid_ctx* ctx);
+/* Name / compute-unit count / memory of the context's device (diagnostics, bench records). */
+int hagrid_device_info(const hagrid_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem);
+
+/* ---- MemManager backend (mem_manager.h:34-119, mem_manager.cu:6-75) -------------------------------- */
+/* alloc<T>(n) -> hagrid_mem_alloc(n * sizeof(T)): best-fit reuse of a free slot, else hipMalloc. */
+void* hagrid_mem_alloc(hagrid_ctx* ctx, size_t bytes);
+/* free(ptr): NULL is a no-op; an untracked pointer is an error (the reference asserts). */
+int hagrid_mem_free(hagrid_ctx* ctx, void* ptr);
+/* copy<HST_TO_DEV | DEV_TO_HST | DEV_TO_DEV>; blocking like cudaMemcpy. */
+int hagrid_mem_copy_h2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes);
+int hagrid_mem_copy_d2h(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes);
+int hagrid_mem_copy_d2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* zero() / one() (memset 0x00 / 0xFF). */
+int hagrid_mem_zero(hagrid_ctx* ctx, void* ptr, size_t bytes);
+int hagrid_mem_one(hagrid_ctx* ctx, void* ptr, size_t bytes);
+size_t hagrid_mem_usage(const hagrid_ctx* ctx);
+size_t hagrid_mem_max_usage(const hagrid_ctx* ctx);
+/* debug_slots(): prints the slot table to stdout. */
+void hagrid_mem_debug_slots(const hagrid_ctx* ctx);
+
+/* ---- profile (common.h:15, profile.cu:5-18) ------------------------------------------------------- */
+/* Event pair on the context's stream around arbitrary host code; end returns the elapsed ms. */
+int hagrid_profile_begin(hagrid_ctx* ctx);
+float hagrid_profile_end(hagrid_ctx* ctx);
+
+/* ---- construction (build.h:17-31) ------------------------------------------------------------------ */
+/* build_grid (build.cu:718-760).  tris: 48-byte Tri records on the device.  grid is overwritten. */
+int hagrid_build_grid(hagrid_ctx* ctx, const void* tris, int num_tris, hagrid_grid* grid,
+                      float top_density, float snd_density);
+/* merge_grid (merge.cu:331-377) */
+int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha);
+/* flatten_grid (flatten.cu:109-175) */
+int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid);
+/* expand_grid (expand.cu:199-225) */
+int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris, int iters);
+/* compress_grid (compress.cu:38-63): returns 1 when compressed, 0 when the virtual resolution does not
+ * fit 16 bits (grid untouched), negative on error. */
+int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
+
+/* ---- traversal (traverse.h:11-14) ------------------------------------------------------------------- */
+/* setup_traversal (traverse.cu:97-109): derives and stores the traversal constants of `grid`. */
+int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
+/* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
+ * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
+int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
+                         const void* rays, void* hits, int num_rays);
+/* Same traversal, additionally: steps[i] (device int32, may be NULL) = the reference's per-ray step
+ * count (traverse.cu:80,93), and *stats (host, may be NULL) = batch totals.  Synchronous. */
+int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
+                               const void* rays, void* hits, int num_rays,
+                               void* steps, hagrid_traversal_stats* stats);
+
+/* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */
+/* Each evaluates the named device function for n inputs (host arrays in, host arrays out). */
+int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
+                                  int n, int32_t* ret, int32_t* hit_id, float* hit_t);
+int hagrid_kat_intersect_prim_cell(hagrid_ctx* ctx, const void* tris, const void* boxes, const int32_t* tri_index,
+                                   int n, int32_t* ret);
+int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* grid_bb, const void* obj_bb, int n, int32_t* out6);
+int hagrid_kat_compute_grid_dims(hagrid_ctx* ctx, const void* bb, const int32_t* num_prims, const float* density, int n, int32_t* out3);
+int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_entries, int shift, const int32_t* top_dims3,
+                            const int32_t* voxels3, int n, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAGRID_AMD_H */

@@ -1,0 +1,155 @@
+"""GPU parity of the traversal kernels against the CPU oracle (bit-exact ids AND t), through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hagrid_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def mem():
+    from hagrid_amd import api
+    m = api.MemManager(keep=True)
+    yield m
+    m.close()
+
+
+def upload_oracle_grid(mem, G):
+    from hagrid_amd import api
+    return api.Grid.upload(mem, G.entries, G.ref_ids, G.cells, G.small_cells, G.bbox_min, G.bbox_max, G.dims, G.shift, G.offsets)
+
+
+def gpu_traverse(mem, grid, d_tris, rays, stats=False):
+    from hagrid_amd import api
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(max(16 * n, 16))
+    api.setup_traversal(grid)
+    st = None
+    if stats:
+        d_steps = mem.alloc(max(4 * n, 4))
+        st = api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n, d_steps)
+        steps = mem.download(d_steps, np.int32, n); mem.free(d_steps)
+    else:
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+    hits = mem.download(d_hits, api.HIT_DTYPE, n)
+    mem.free(d_rays); mem.free(d_hits)
+    return (hits, st, steps) if stats else hits
+
+
+def test_l0_device_functions_match_golden(mem, golden_dir):
+    """The DEVICE versions of the L0 functions against the reference-header golden vectors."""
+    kat = np.load(os.path.join(golden_dir, "l0_kat.npz"))
+    L, ctx = mem._L, mem._ctx
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tris = np.ascontiguousarray(kat["tris"])
+    n = kat["ipr_rays"].shape[0]
+    ret = np.zeros(n, np.int32); hid = np.zeros(n, np.int32); ht = np.zeros(n, np.float32)
+    tid = np.ascontiguousarray(kat["ipr_tid"]); rays = np.ascontiguousarray(kat["ipr_rays"])
+    assert L.hagrid_kat_intersect_prim_ray(ctx, p(tris), p(rays), p(tid), n, p(ret), p(hid), p(ht)) == 0
+    assert (ret == kat["ipr_ret"]).all() and (hid == kat["ipr_hit_id"]).all() and (bits(ht) == bits(kat["ipr_hit_t"])).all()
+    n = kat["ipc_boxes"].shape[0]
+    ret = np.zeros(n, np.int32); tid = np.ascontiguousarray(kat["ipc_tid"]); boxes = np.ascontiguousarray(kat["ipc_boxes"])
+    assert L.hagrid_kat_intersect_prim_cell(ctx, p(tris), p(boxes), p(tid), n, p(ret)) == 0
+    assert (ret == kat["ipc_ret"]).all()
+    n = kat["range_dims"].shape[0]; out = np.zeros((n, 6), np.int32)
+    a, b, c = (np.ascontiguousarray(kat[k]) for k in ("range_dims", "range_grid_bb", "range_obj_bb"))
+    assert L.hagrid_kat_compute_range(ctx, p(a), p(b), p(c), n, p(out)) == 0
+    assert (out == kat["range_out"]).all()
+    n = kat["gd_bb"].shape[0]; out = np.zeros((n, 3), np.int32)
+    a, b, c = (np.ascontiguousarray(kat[k]) for k in ("gd_bb", "gd_nprims", "gd_density"))
+    assert L.hagrid_kat_compute_grid_dims(ctx, p(a), p(b), p(c), n, p(out)) == 0
+    assert (out == kat["gd_out"]).all()
+    for tag in ("octree", "flat"):
+        ent = np.ascontiguousarray(kat[f"lk_{tag}_entries"]); vox = np.ascontiguousarray(kat[f"lk_{tag}_voxels"])
+        td = np.ascontiguousarray(kat[f"lk_{tag}_dims"]); out = np.zeros(vox.shape[0], np.uint32)
+        assert L.hagrid_kat_lookup_entry(ctx, p(ent), ent.shape[0], int(kat[f"lk_{tag}_shift"]), p(td), p(vox), vox.shape[0], p(out)) == 0
+        assert (out == kat[f"lk_{tag}_out"]).all()
+
+
+@pytest.mark.parametrize("stage", ["build", "merge", "flatten", "expand", "compress"])
+def test_traverse_config1_every_stage(mem, golden_dir, stage):
+    """BASELINE config 1 (soup-10k, 64k incoherent rays): GPU hits == oracle hits == reference brute force."""
+    from oracle import oracle as O
+    g = np.load(os.path.join(golden_dir, "config1_hits.npz"))
+    tris = scene.make_soup(10000)
+    lo, hi = scene.tris_bbox(tris)
+    rays = scene.make_rays_incoherent(lo, hi, 65536, scene.RAY_SEED_BASE + 1)
+    G = O.Grid.build(tris)
+    order = ["build", "merge", "flatten", "expand", "compress"]
+    for s in order[1:order.index(stage) + 1]:
+        {"merge": lambda: G.merge(0.995), "flatten": G.flatten, "expand": lambda: G.expand(tris, 3), "compress": G.compress}[s]()
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    hits, st, steps = gpu_traverse(mem, grid, d_tris, rays, stats=True)
+    oh, ost, osteps = G.traverse(tris, rays, want_steps=True)
+    assert (hits["id"] == oh["id"]).all() and (bits(hits["t"]) == bits(oh["t"])).all()
+    assert (hits["id"] == g["id"]).all() and (bits(hits["t"]) == bits(g["t"])).all()
+    assert (hits["u"] == 0).all() and (hits["v"] == 0).all()
+    assert st == ost, (st, ost)
+    assert (steps == osteps).all()
+    # the plain (non-stats) kernel gives the same hits
+    h2 = gpu_traverse(mem, grid, d_tris, rays)
+    assert (h2["id"] == hits["id"]).all() and (bits(h2["t"]) == bits(hits["t"])).all()
+    grid.free(); mem.free(d_tris)
+
+
+def test_traverse_primary_rays_and_edge_cases(mem):
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(30000)
+    G = O.Grid.full(tris)
+    rays = scene.make_rays_primary(G.bbox_min, G.bbox_max, 256, 256)
+    assert (rays[:, 4] == 0).any()
+    # rays that miss the grid, rays starting inside, tmin/tmax windows, a degenerate zero direction
+    extra = scene.make_rays_incoherent(G.bbox_min - 2, G.bbox_max + 2, 8192, 5)
+    extra[:2048, 3] = 0.3; extra[1024:4096, 7] = 0.6
+    extra[0, 4:7] = 0.0
+    rays = np.concatenate([rays, extra]).astype(np.float32)
+    d_tris = mem.upload(tris)
+    for compressed in (False, True):
+        if compressed:
+            assert G.compress()
+        grid = upload_oracle_grid(mem, G)
+        hits = gpu_traverse(mem, grid, d_tris, rays)
+        oh, _ = G.traverse(tris, rays, nthreads=8)
+        assert (hits["id"] == oh["id"]).all() and (bits(hits["t"]) == bits(oh["t"])).all()
+        # zero rays: a no-op
+        api.traverse_grid(grid, d_tris, 0, 0, 0)
+        grid.free()
+    mem.free(d_tris)
+
+
+def test_traverse_rejects_incomplete_grid(mem):
+    from hagrid_amd import api
+    g = api.Grid(); g.mem = mem
+    with pytest.raises(api.HagridError):
+        api.traverse_grid(g, 0, 0, 0, 16)
+
+
+def test_mem_manager_contract(mem):
+    from hagrid_amd import api
+    m = api.MemManager(keep=False)
+    a = m.alloc(1000); b = m.alloc(1 << 20)
+    assert m.usage() >= 1000 + (1 << 20) and m.max_usage() >= m.usage()
+    x = np.arange(250, dtype=np.int32)
+    m.copy_h2d(a, x)
+    assert (m.download(a, np.int32, 250) == x).all()
+    m.one(a, 1000); assert (m.download(a, np.int32, 250) == -1).all()
+    m.zero(a, 1000); assert (m.download(a, np.int32, 250) == 0).all()
+    m.free(a); m.free(b); m.free(None)
+    assert m.usage() == 0
+    with pytest.raises(api.HagridError):
+        m.free(12345678)
+    peak = m.max_usage()
+    assert peak >= (1 << 20)
+    ms = api.profile(lambda: None, m)
+    assert ms >= 0
+    m.close()
