@@ -1,0 +1,543 @@
+// build.hip -- hagrid_build_grid: construction of the initial (octree-structured) irregular grid on gfx950.
+//
+// Replaces the reference's build.cu (build :718-758, first_build_iter :470-525, build_iter :527-619,
+// concat_levels :621-716 and their 20 kernels) and the CUB calls behind them (parallel.cuh).  The result
+// -- entries, cells, ref_ids, dims, bbox, shift, offsets -- is bit-identical to the CPU oracle's.
+//
+// How it differs from the reference's pipeline (not a port):
+//  * Only the ORDER OF CELLS is part of the result; the final reference list of a cell is the ascending
+//    list of primitive ids.  So references never go through ordered scans, a flagged partition or a radix
+//    sort: kept and split references are appended with one atomic per wavefront (wave_append), per-cell
+//    reference counts are accumulated with atomics while the levels are built, the final scatter uses a
+//    per-cell cursor, and each (short) list is sorted in place.  Ordered scans run over cells only.
+//  * Per level there is ONE host round trip (new cells, children, kept) instead of four; the bounding box,
+//    the reference count and the shift cost two more; concat costs one.
+//  * Per-primitive bounding boxes are recomputed from the 48-byte triangle instead of being stored.
+//  * The top-level cell a reference sits in is known from its index, so the SAT filter (filter_refs,
+//    build.cu:139-157) is fused into the emission kernel.
+#include "ctx.h"
+#include "wave_prims.h"
+
+#include "hagrid/grid.h"
+#include "hagrid/prims.h"
+
+#include <vector>
+
+using namespace hagrid;
+using namespace hagrid_impl;
+
+namespace {
+
+struct BuildK {              // build.cu:37-40 (__constant__ there, kernel argument here)
+    ivec3 dims;              // top-level resolution
+    int shift;
+    vec3 bmin, bmax;         // enlarged grid box
+    vec3 cell_size;          // extents / (dims << shift)
+};
+
+__device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) {
+    const float4* p = tris + 3 * size_t(i);
+    const float4 a = p[0], b = p[1], c = p[2];
+    return Tri(vec3(a.x, a.y, a.z), a.w, vec3(b.x, b.y, b.z), b.w, vec3(c.x, c.y, c.z), c.w);
+}
+__device__ __forceinline__ void store_cell(Cell* cells, int i, ivec3 lo, int begin, ivec3 hi, int end) {
+    int4* p = reinterpret_cast<int4*>(cells) + 2 * size_t(i);
+    p[0] = make_int4(lo.x, lo.y, lo.z, begin);
+    p[1] = make_int4(hi.x, hi.y, hi.z, end);
+}
+__device__ __forceinline__ ivec3 load_cell_min(const Cell* cells, int i) {
+    const int4 a = reinterpret_cast<const int4*>(cells)[2 * size_t(i)];
+    return ivec3(a.x, a.y, a.z);
+}
+__device__ __forceinline__ BBox cell_world_box(const BuildK& k, ivec3 lo, ivec3 hi) {   // build.cu:150-151
+    return BBox(k.bmin + vec3(lo) * k.cell_size, k.bmin + vec3(hi) * k.cell_size);
+}
+
+// ---- scene bounding box (compute_bboxes + DeviceReduce, build.cu:725-727) ----------------------------
+// one partial box per workgroup, then a single workgroup folds the partials
+__global__ void __launch_bounds__(kBlock) bbox_partials(const float4* __restrict__ tris, int n, float* __restrict__ partials) {
+    __shared__ float lds[kWaves][6];
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const BBox b = load_tri(tris, i).bbox();
+        lo[0] = min(lo[0], b.min.x); lo[1] = min(lo[1], b.min.y); lo[2] = min(lo[2], b.min.z);
+        hi[0] = max(hi[0], b.max.x); hi[1] = max(hi[1], b.max.y); hi[2] = max(hi[2], b.max.z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { lo[c] = wave_min_f(lo[c]); hi[c] = wave_max_f(hi[c]); }
+    if (lane_id() == 0) for (int c = 0; c < 3; c++) { lds[wave_id()][c] = lo[c]; lds[wave_id()][3 + c] = hi[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = lds[0][threadIdx.x];
+        for (int w = 1; w < kWaves; w++) v = threadIdx.x < 3 ? min(v, lds[w][threadIdx.x]) : max(v, lds[w][threadIdx.x]);
+        partials[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void __launch_bounds__(kBlock) bbox_final(const float* __restrict__ partials, int num, float* __restrict__ out) {
+    __shared__ float lds[kWaves][6];
+    float v[6] = { FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = threadIdx.x; i < num; i += kBlock)
+        for (int c = 0; c < 6; c++) v[c] = c < 3 ? min(v[c], partials[i * 6 + c]) : max(v[c], partials[i * 6 + c]);
+#pragma unroll
+    for (int c = 0; c < 6; c++) v[c] = c < 3 ? wave_min_f(v[c]) : wave_max_f(v[c]);
+    if (lane_id() == 0) for (int c = 0; c < 6; c++) lds[wave_id()][c] = v[c];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = lds[0][threadIdx.x];
+        for (int w = 1; w < kWaves; w++) r = threadIdx.x < 3 ? min(r, lds[w][threadIdx.x]) : max(r, lds[w][threadIdx.x]);
+        out[threadIdx.x] = r;
+    }
+}
+
+// ---- top level -----------------------------------------------------------------------------------------
+// count_new_refs (build.cu:57-66) + count_refs_per_cell (build.cu:246-253, counted BEFORE the SAT filter)
+__global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restrict__ tris, int n, BuildK k,
+                                                         int* __restrict__ counts, int* __restrict__ refs_per_cell) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const BBox gb(k.bmin, k.bmax);
+    const Range r = compute_range(k.dims, gb, load_tri(tris, i).bbox());
+    counts[i] = max(0, r.size());
+    for (int z = r.lz; z <= r.hz; z++)
+        for (int y = r.ly; y <= r.hy; y++)
+            for (int x = r.lx; x <= r.hx; x++)
+                atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+}
+
+// compute_log_dims (build.cu:256-270) + the max reduction of build.cu:508
+__global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ refs_per_cell, int num_top, BuildK k, float snd_density,
+                                                       int* __restrict__ log_dims, int* __restrict__ max_out) {
+    __shared__ int lds[kWaves];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    int ld = 0;
+    if (i < num_top) {
+        const vec3 ext = BBox(k.bmin, k.bmax).extents() / vec3(k.dims);
+        const ivec3 d = compute_grid_dims(BBox(vec3(0, 0, 0), ext), refs_per_cell[i], snd_density);
+        const int max_dim = max(d.x, max(d.y, d.z));
+        ld = 31 - __clz(max_dim);
+        ld = (1 << ld) < max_dim ? ld + 1 : ld;
+        log_dims[i] = ld;
+    }
+    ld = wave_max(ld);
+    if (lane_id() == 0) lds[wave_id()] = ld;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = lds[0];
+        for (int w = 1; w < kWaves; w++) m = max(m, lds[w]);
+        if (m > 0) atomicMax(max_out, m);
+    }
+}
+
+// emit_new_refs (build.cu:69-136) + filter_refs (build.cu:139-157): every (primitive, top cell) pair of the
+// primitive's cell range, with -1/-1 where the triangle misses the cell
+__global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
+                                                        int* __restrict__ ref_ids, int* __restrict__ cell_ids) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Tri tri = load_tri(tris, i);
+    const Range r = compute_range(k.dims, BBox(k.bmin, k.bmax), tri.bbox());
+    if (r.size() <= 0) return;
+    int cur = start_emit[i];
+    const int inc = 1 << k.shift;
+    for (int z = r.lz; z <= r.hz; z++)
+        for (int y = r.ly; y <= r.hy; y++)
+            for (int x = r.lx; x <= r.hx; x++) {
+                const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
+                const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
+                ref_ids[cur] = hit ? i : -1;
+                cell_ids[cur] = hit ? x + k.dims.x * (y + k.dims.y * z) : -1;
+                cur++;
+            }
+}
+
+// emit_top_cells (build.cu:332-351)
+__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= num_top) return;
+    const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
+    const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
+    store_cell(cells, id, lo, 0, lo + ivec3(1 << k.shift), 0);
+}
+
+// ---- one subdivision level -----------------------------------------------------------------------------
+// compute_dims (build.cu:286-302) with update_log_dims (:273-278) folded in as max(0, log_dim0 - level)
+__global__ void __launch_bounds__(kBlock) mark_split_cells(const int* __restrict__ cell_ids, int num_refs, const Cell* __restrict__ cells,
+                                                           const int* __restrict__ log_dims, int level, BuildK k, uint32_t* __restrict__ entries) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_refs) return;
+    const int c = cell_ids[i];
+    if (c < 0) return;
+    const ivec3 m = load_cell_min(cells, c);
+    const int top = (m.x >> k.shift) + k.dims.x * ((m.y >> k.shift) + k.dims.y * (m.z >> k.shift));
+    if (log_dims[top] - level > 0) entries[c] = 1u;   // make_entry(1, 0); same value from every writer
+}
+
+// scan functors: 8 children per split cell (build.cu:557-559), then update_entries (build.cu:317-329)
+struct ChildCountIn {
+    const uint32_t* entries;
+    __device__ int operator()(int i) const { return (entries[i] & 3u) ? 8 : 0; }
+};
+struct UpdateEntriesOut {
+    uint32_t* entries;
+    __device__ void operator()(int i, int start) const {
+        const uint32_t ld = entries[i] & 3u;
+        entries[i] = ld | (uint32_t(ld ? start : i) << 2);
+    }
+};
+
+// compute_split_masks (build.cu:160-216)
+__device__ __forceinline__ int split_mask(const BuildK& k, ivec3 lo, ivec3 hi, const Tri& tri) {
+    const vec3 cmin = k.bmin + k.cell_size * vec3(lo);
+    const vec3 cmax = k.bmin + k.cell_size * vec3(hi);
+    const vec3 mid = (cmin + cmax) * 0.5f;
+    int mask = 0xFF;
+    const BBox rb = tri.bbox();
+    if (rb.min.x > cmax.x || rb.max.x < cmin.x) mask = 0;
+    if (rb.min.x > mid.x) mask &= 0xAA;
+    if (rb.max.x < mid.x) mask &= 0x55;
+    if (rb.min.y > cmax.y || rb.max.y < cmin.y) mask = 0;
+    if (rb.min.y > mid.y) mask &= 0xCC;
+    if (rb.max.y < mid.y) mask &= 0x33;
+    if (rb.min.z > cmax.z || rb.max.z < cmin.z) mask = 0;
+    if (rb.min.z > mid.z) mask &= 0xF0;
+    if (rb.max.z < mid.z) mask &= 0x0F;
+    int todo = mask;
+    while (todo) {
+        const int i = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const BBox b(vec3(i & 1 ? mid.x : cmin.x, i & 2 ? mid.y : cmin.y, i & 4 ? mid.z : cmin.z),
+                     vec3(i & 1 ? cmax.x : mid.x, i & 2 ? cmax.y : mid.y, i & 4 ? cmax.z : mid.z));
+        if (!intersect_prim_cell(tri, b)) mask &= ~(1 << i);
+    }
+    return mask;
+}
+
+// mark_kept_refs (build.cu:305-314) + compute_split_masks + the popcount reduction of build.cu:597, and the
+// per-cell reference count that replaces the final sort's histogram.  totals[0] += children, totals[1] += kept.
+__global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
+                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells,
+                                                        const uint32_t* __restrict__ entries, BuildK k,
+                                                        unsigned char* __restrict__ masks, int* __restrict__ cell_counts, int* __restrict__ totals) {
+    __shared__ int lds[kWaves];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    int children = 0, kept = 0;
+    if (i < num_refs) {
+        const int c = cell_ids[i];
+        int m = 0;
+        if (c >= 0) {
+            if ((entries[c] & 3u) == 0) {
+                kept = 1;
+                atomicAdd(cell_counts + c, 1);
+            } else {
+                const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
+                const int4 a = p[0], b = p[1];
+                m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref_ids[i]));
+                children = __popc(m);
+            }
+        }
+        masks[i] = (unsigned char)m;
+    }
+    children = block_sum(children, lds);
+    kept = block_sum(kept, lds);
+    if (threadIdx.x == 0) {
+        if (children) atomicAdd(totals + 0, children);
+        if (kept) atomicAdd(totals + 1, kept);
+    }
+}
+
+// split_refs (build.cu:219-243); slots come from one atomic per wavefront, order is irrelevant
+__global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
+                                                          const unsigned char* __restrict__ masks, const uint32_t* __restrict__ entries,
+                                                          int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    int m = i < num_refs ? masks[i] : 0;
+    int pos = wave_append(__popc(m), cursor);
+    if (m) {
+        const int ref = ref_ids[i];
+        const int begin = int(entries[cell_ids[i]] >> 2);
+        while (m) {
+            const int child = __ffs(m) - 1;
+            m &= m - 1;
+            new_ref_ids[pos] = ref;
+            new_cell_ids[pos] = begin + child;
+            pos++;
+        }
+    }
+}
+
+// emit_new_cells (build.cu:354-383): 8 cells x 32 B = 256 contiguous bytes per split cell
+__global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, int num_cells,
+                                                           Cell* __restrict__ new_cells) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int id = t >> 3, child = t & 7;     // 8 lanes per parent: each lane stores one child
+    if (id >= num_cells) return;
+    const uint32_t e = entries[id];
+    if ((e & 3u) == 0) return;
+    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
+    const int4 a = p[0], b = p[1];
+    const int inc = (b.x - a.x) >> 1;
+    const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
+    store_cell(new_cells, int(e >> 2) + child, lo, 0, lo + ivec3(inc), 0);
+}
+
+// ---- concatenation ---------------------------------------------------------------------------------------
+// leaf flag + kept-reference count per cell, scanned over all levels in cell order
+struct LeafIn {
+    const uint32_t* entries; const int* cell_counts;
+    __device__ Int2 operator()(int i) const {
+        const bool leaf = (entries[i] & 3u) == 0;
+        return Int2{ leaf ? 1 : 0, leaf ? cell_counts[i] : 0 };
+    }
+};
+struct LeafOut {
+    int* start_cell; int* ref_begin;
+    __device__ void operator()(int i, Int2 v) const { start_cell[i] = v.a; ref_begin[i] = v.b; }
+};
+
+// copy_cells (build.cu:407-419) + copy_entries (:422-440) + compute_cell_ranges (:453-468)
+__global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, const int* __restrict__ cell_counts,
+                                                       const int* __restrict__ start_cell, const int* __restrict__ ref_begin, int num_cells,
+                                                       int level_off, Cell* __restrict__ out_cells, uint32_t* __restrict__ out_entries) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_cells) return;
+    const uint32_t e = entries[i];
+    if ((e & 3u) == 0) {
+        const int dst = start_cell[i], cnt = cell_counts[i], rb = ref_begin[i];
+        const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+        const int4 a = p[0], b = p[1];
+        store_cell(out_cells, dst, ivec3(a.x, a.y, a.z), cnt ? rb : 0, ivec3(b.x, b.y, b.z), cnt ? rb + cnt : 0);
+        out_entries[level_off + i] = uint32_t(dst) << 2;
+    } else {
+        out_entries[level_off + i] = (e & 3u) | (((e >> 2) + uint32_t(level_off + num_cells)) << 2);
+    }
+}
+
+// copy_refs + remap_refs + the scatter half of the sort (build.cu:634-647, :681, :691): slot from a per-cell cursor
+__global__ void __launch_bounds__(kBlock) scatter_kept_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
+                                                            const uint32_t* __restrict__ entries, int* __restrict__ cell_counts,
+                                                            const int* __restrict__ ref_begin, int* __restrict__ out_refs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_refs) return;
+    const int c = cell_ids[i];
+    if (c < 0 || (entries[c] & 3u) != 0) return;
+    const int slot = atomicSub(cell_counts + c, 1) - 1;
+    out_refs[ref_begin[c] + slot] = ref_ids[i];
+}
+
+} // namespace
+
+namespace {
+
+struct PlainIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
+struct PlainOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
+
+// Puts every cell's reference list in ascending order (the canonical order: primitive ids within a cell
+// are distinct).  Lists are short -- a handful of references -- so each lane sorts its own cell in place:
+// insertion sort, preceded by Shell passes for the rare long list.
+__global__ void __launch_bounds__(kBlock) sort_cell_refs(const Cell* __restrict__ cells, int num_cells, int* __restrict__ refs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_cells) return;
+    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+    const int begin = p[0].w, n = p[1].w - begin;
+    if (n < 2) return;
+    int* r = refs + begin;
+    if (n > 24) {
+        const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
+        for (int g = 0; g < 8; g++) {
+            const int gap = gaps[g];
+            for (int a = gap; a < n; a++) {
+                const int v = r[a];
+                int b = a - gap;
+                while (b >= 0 && r[b] > v) { r[b + gap] = r[b]; b -= gap; }
+                r[b + gap] = v;
+            }
+        }
+    }
+    for (int a = 1; a < n; a++) {
+        const int v = r[a];
+        int b = a - 1;
+        while (b >= 0 && r[b] > v) { r[b + 1] = r[b]; b--; }
+        r[b + 1] = v;
+    }
+}
+
+struct Level {
+    int* ref_ids = nullptr; int* cell_ids = nullptr; int num_refs = 0;
+    Cell* cells = nullptr; uint32_t* entries = nullptr; int num_cells = 0;
+    int* cell_counts = nullptr;                 // kept references per cell
+    int* start_cell = nullptr; int* ref_begin = nullptr;
+};
+
+struct Temps {           // pool buffers released on every exit path
+    hagrid_ctx* ctx;
+    std::vector<void*> ptrs;
+    explicit Temps(hagrid_ctx* c) : ctx(c) {}
+    template <typename T> T* get(size_t n) { T* p = pool_alloc<T>(ctx, n); if (p) ptrs.push_back(p); return p; }
+    void drop(void* p) { for (auto& q : ptrs) if (q == p) { hagrid_mem_free(ctx, p); q = nullptr; } }
+    ~Temps() { for (void* p : ptrs) if (p) hagrid_mem_free(ctx, p); }
+};
+
+} // namespace
+
+extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tris, hagrid_grid* grid,
+                                 float top_density, float snd_density) {
+    if (!ctx || !grid) return HAGRID_EINVAL;
+    if (!tris_v || num_tris <= 0) HG_FAIL(ctx, HAGRID_EINVAL, "build_grid: no triangles");
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    const float4* tris = static_cast<const float4*>(tris_v);
+    hipStream_t st = ctx->stream;
+    Temps tmp(ctx);
+    int* dsc = ctx->dscratch;                       // device scalars
+    HG_HIP(ctx, hipMemsetAsync(dsc, 0, 256 * sizeof(int), st));
+
+    // ---- scene box, top-level resolution (build.cu:725-740) ----
+    const int bb_blocks = std::min(grid_blocks(num_tris, kBlock), 1024);
+    float* bb_part = tmp.get<float>(size_t(bb_blocks) * 6 + 8);
+    if (!bb_part) return HAGRID_ENOMEM;
+    float* bb_out = bb_part + size_t(bb_blocks) * 6;
+    bbox_partials<<<bb_blocks, kBlock, 0, st>>>(tris, num_tris, bb_part);
+    bbox_final<<<1, kBlock, 0, st>>>(bb_part, bb_blocks, bb_out);
+    float hb[6];
+    HG_TRY(read_back(ctx, bb_out, hb, sizeof(hb)));
+    BBox gb(vec3(hb[0], hb[1], hb[2]), vec3(hb[3], hb[4], hb[5]));
+    ivec3 dims = compute_grid_dims(gb, num_tris, top_density);
+    dims.x += dims.x & 1; dims.y += dims.y & 1; dims.z += dims.z & 1;      // even: 8-entry blocks stay 32 B aligned
+    const vec3 ext = gb.extents();
+    gb.min -= ext * 0.001f;
+    gb.max += ext * 0.001f;
+    const long long num_top_ll = (long long)dims.x * dims.y * dims.z;
+    if (num_top_ll > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: top-level grid too large");
+    const int num_top = int(num_top_ll);
+
+    BuildK k;
+    k.dims = dims; k.shift = 0; k.bmin = gb.min; k.bmax = gb.max; k.cell_size = vec3(0.0f);
+
+    // ---- reference counts, per-cell depth, shift (first_build_iter, build.cu:470-512) ----
+    int* counts = tmp.get<int>(size_t(num_tris));
+    int* start_emit = tmp.get<int>(size_t(num_tris));
+    int* refs_per_cell = tmp.get<int>(size_t(num_top));
+    int* log_dims = tmp.get<int>(size_t(num_top));
+    int* partials = tmp.get<int>(2 * size_t(scan_num_tiles(std::max(num_tris, num_top)) + 1));
+    if (!counts || !start_emit || !refs_per_cell || !log_dims || !partials) return HAGRID_ENOMEM;
+    HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
+    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, refs_per_cell);
+    device_scan<int>(st, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0);
+    top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1);
+    int h2[2];
+    HG_TRY(read_back(ctx, dsc, h2, sizeof(h2)));
+    const int R0 = h2[0], shift = h2[1];
+    if (R0 < 0 || R0 > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many top-level references");
+    if (shift >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
+    k.shift = shift;
+    k.cell_size = gb.extents() / vec3(dims << shift);
+    tmp.drop(counts); tmp.drop(refs_per_cell);
+
+    std::vector<Level> levels;
+    {
+        Level L;
+        L.num_refs = R0; L.num_cells = num_top;
+        L.ref_ids = tmp.get<int>(size_t(R0)); L.cell_ids = tmp.get<int>(size_t(R0));
+        L.cells = tmp.get<Cell>(size_t(num_top)); L.entries = tmp.get<uint32_t>(size_t(num_top) + 1);
+        L.cell_counts = tmp.get<int>(size_t(num_top));
+        L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
+        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
+        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids);
+        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k);
+        HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
+        HG_HIP(ctx, hipMemsetAsync(L.cell_counts, 0, size_t(num_top) * sizeof(int), st));
+        levels.push_back(L);
+    }
+    tmp.drop(start_emit);
+
+    // ---- subdivision, one level per iteration (build_iter, build.cu:527-619) ----
+    for (int level = 0;; level++) {
+        Level& L = levels.back();
+        int* tot = dsc + 8 + 4 * level;              // {new cells, children, kept}; zeroed above
+        int* part = tmp.get<int>(size_t(scan_num_tiles(L.num_cells)) + 1);
+        unsigned char* masks = tmp.get<unsigned char>(size_t(L.num_refs) + 1);
+        if (!part || !masks) return HAGRID_ENOMEM;
+        if (L.num_refs > 0)
+            mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries);
+        device_scan<int>(st, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0);
+        if (L.num_refs > 0)
+            classify_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
+                                                                               masks, L.cell_counts, tot + 1);
+        int h3[3];
+        HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
+        const int num_new_cells = h3[0], num_children = h3[1];
+        tmp.drop(part);
+        if (num_new_cells == 0) { tmp.drop(masks); break; }              // build.cu:583-587
+        if (num_new_cells < 0 || num_children < 0 || num_children > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: level too large");
+        if ((int)levels.size() >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
+
+        Level N;
+        N.num_refs = num_children; N.num_cells = num_new_cells;
+        N.ref_ids = tmp.get<int>(size_t(num_children)); N.cell_ids = tmp.get<int>(size_t(num_children));
+        N.cells = tmp.get<Cell>(size_t(num_new_cells)); N.entries = tmp.get<uint32_t>(size_t(num_new_cells) + 1);
+        N.cell_counts = tmp.get<int>(size_t(num_new_cells));
+        N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
+        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
+        HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
+        HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
+        int* cursor = tot + 3;                                              // zeroed above
+        emit_child_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
+                                                                             N.ref_ids, N.cell_ids, cursor);
+        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells);
+        tmp.drop(masks);
+        levels.push_back(N);
+    }
+    tmp.drop(log_dims);
+
+    // ---- concat_levels (build.cu:621-716) ----
+    const int num_levels = (int)levels.size();
+    long long total_cells_ll = 0;
+    int max_cells = 0;
+    for (auto& L : levels) { total_cells_ll += L.num_cells; max_cells = std::max(max_cells, L.num_cells); }
+    if (total_cells_ll > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many voxel map entries");
+    const int total_cells = int(total_cells_ll);
+    Int2* part2 = tmp.get<Int2>(size_t(scan_num_tiles(max_cells)) + 1);
+    Int2* carry = reinterpret_cast<Int2*>(dsc + 128);      // one Int2 per level, chained on the device
+    if (!part2) return HAGRID_ENOMEM;
+    for (int l = 0; l < num_levels; l++) {
+        Level& L = levels[l];
+        device_scan<Int2>(st, LeafIn{L.entries, L.cell_counts}, LeafOut{L.start_cell, L.ref_begin}, L.num_cells, part2,
+                          l ? carry + (l - 1) : (const Int2*)nullptr, carry + l);
+    }
+    int hf[2];
+    HG_TRY(read_back(ctx, carry + (num_levels - 1), hf, sizeof(hf)));
+    const int new_total_cells = hf[0], total_refs = hf[1];
+    if (new_total_cells <= 0 || total_refs < 0) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: inconsistent totals");
+
+    Cell* out_cells = pool_alloc<Cell>(ctx, size_t(new_total_cells));
+    uint32_t* out_entries = pool_alloc<uint32_t>(ctx, size_t(total_cells));
+    int* out_refs = pool_alloc<int>(ctx, size_t(total_refs));
+    if (!out_cells || !out_entries || !out_refs) {
+        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
+        return HAGRID_ENOMEM;
+    }
+    for (int l = 0, off = 0; l < num_levels; off += levels[l].num_cells, l++) {
+        Level& L = levels[l];
+        concat_level<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.cell_counts, L.start_cell, L.ref_begin,
+                                                                          L.num_cells, off, out_cells, out_entries);
+        if (L.num_refs > 0)
+            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.entries, L.cell_counts,
+                                                                                  L.ref_begin, out_refs);
+    }
+    sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs);
+    HG_HIP(ctx, hipGetLastError());
+    HG_HIP(ctx, hipStreamSynchronize(st));      // temporaries are released below
+
+    memset(grid, 0, sizeof(*grid));
+    grid->entries = out_entries; grid->ref_ids = out_refs; grid->cells = out_cells; grid->small_cells = nullptr;
+    grid->bbox_min[0] = gb.min.x; grid->bbox_min[1] = gb.min.y; grid->bbox_min[2] = gb.min.z;
+    grid->bbox_max[0] = gb.max.x; grid->bbox_max[1] = gb.max.y; grid->bbox_max[2] = gb.max.z;
+    grid->dims[0] = dims.x; grid->dims[1] = dims.y; grid->dims[2] = dims.z;
+    grid->num_cells = new_total_cells; grid->num_entries = total_cells; grid->num_refs = total_refs;
+    grid->shift = shift;                         // the cell-coordinate shift
+    grid->num_offsets = shift + 1;
+    for (int i = 0, off = 0; i <= shift; i++) {  // build.cu:711-715, padded when the deepest level is empty
+        if (i < num_levels) off += levels[i].num_cells;
+        grid->offsets[i] = off;
+    }
+    return HAGRID_OK;
+}

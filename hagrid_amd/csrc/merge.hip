@@ -1,0 +1,265 @@
+// merge.hip -- hagrid_merge_grid: SAH-guided merging of neighbouring cells on gfx950.
+//
+// Replaces the reference's merge.cu: merge_grid (:331-377), merge_iteration<axis> (:292-329) and the kernels
+// compute_merge_counts (:91-142), compute_cell_flags (:145-170), compute_ref_counts (:173-186), merge (:189-278),
+// remap_entries (:281-290).  Results are bit-identical to the CPU oracle's.
+//
+// Differences in structure: the axis is a kernel argument (one kernel instead of three instantiations); the two
+// scans of an iteration (cells kept, references kept) run as ONE scan over int pairs with the per-cell count
+// computed inside the scan's input functor (compute_ref_counts disappears); one host round trip per
+// axis-iteration; the reference's warp-cooperative copy of unmerged runs (written for 32-lane warps,
+// merge.cu:245-270) is replaced by per-cell copies -- lists hold one to two references on average.
+#include "ctx.h"
+#include "wave_prims.h"
+
+#include "hagrid/grid.h"
+
+using namespace hagrid;
+using namespace hagrid_impl;
+
+namespace {
+
+struct MergeK {          // merge.cu:17-19
+    ivec3 dims;          // virtual resolution
+    ivec3 top;           // top-level resolution
+    vec3 cell_size;
+    int shift;
+};
+
+struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
+
+__device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
+    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+    const int4 a = p[0], b = p[1];
+    CellRec c; c.lo = ivec3(a.x, a.y, a.z); c.begin = a.w; c.hi = ivec3(b.x, b.y, b.z); c.end = b.w;
+    return c;
+}
+__device__ __forceinline__ void store_cell(Cell* cells, int i, ivec3 lo, int begin, ivec3 hi, int end) {
+    int4* p = reinterpret_cast<int4*>(cells) + 2 * size_t(i);
+    p[0] = make_int4(lo.x, lo.y, lo.z, begin);
+    p[1] = make_int4(hi.x, hi.y, hi.z, end);
+}
+__device__ __forceinline__ int comp(const ivec3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+__device__ __forceinline__ float comp(const vec3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// merge.cu:21-31
+__device__ __forceinline__ bool aligned(int axis, const CellRec& c1, const CellRec& c2) {
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+    return comp(c1.hi, axis) == comp(c2.lo, axis) &&
+           comp(c1.lo, a1) == comp(c2.lo, a1) && comp(c1.lo, a2) == comp(c2.lo, a2) &&
+           comp(c1.hi, a1) == comp(c2.hi, a1) && comp(c1.hi, a2) == comp(c2.hi, a2);
+}
+// merge.cu:34-39
+__device__ __forceinline__ bool merge_allowed(const MergeK& k, int empty_mask, int pos) {
+    const int top_level_mask = (1 << k.shift) - 1;
+    const int is_shifted = (pos >> k.shift) & empty_mask;
+    const bool is_top_level = !(pos & top_level_mask);
+    return !is_shifted || !is_top_level;
+}
+// merge.cu:42-47
+__device__ __forceinline__ ivec3 next_cell_pos(int axis, const ivec3& lo, const ivec3& hi) {
+    return ivec3(axis == 0 ? hi.x : lo.x, axis == 1 ? hi.y : lo.y, axis == 2 ? hi.z : lo.z);
+}
+// merge.cu:58-69
+__device__ __forceinline__ int count_union(const int* __restrict__ p0, int c0, const int* __restrict__ p1, int c1) {
+    int i = 0, j = 0, c = 0;
+    while ((i < c0) & (j < c1)) {
+        const int a = p0[i], b = p1[j];
+        i += (a <= b); j += (a >= b); c++;
+    }
+    return c + (c1 - j) + (c0 - i);
+}
+// merge.cu:72-88
+__device__ __forceinline__ void merge_refs(const int* __restrict__ p0, int c0, const int* __restrict__ p1, int c1, int* __restrict__ q) {
+    int i = 0, j = 0;
+    while (i < c0 && j < c1) {
+        const int a = p0[i], b = p1[j];
+        *(q++) = (a < b) ? a : b;
+        i += (a <= b); j += (a >= b);
+    }
+    int kk = i < c0 ? i : j;
+    const int c = i < c0 ? c0 : c1;
+    const int* p = i < c0 ? p0 : p1;
+    while (kk < c) *(q++) = p[kk++];
+}
+
+// compute_merge_counts (merge.cu:91-142)
+__global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
+                                                              const int* __restrict__ refs, int* __restrict__ merge_counts,
+                                                              int* __restrict__ nexts, int* __restrict__ prevs, int empty_mask, int num_cells) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= num_cells) return;
+    const float unit_cost = 1.0f;
+    const CellRec c1 = load_cell(cells, id);
+    const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
+    int count = -(c1.end - c1.begin + 1);
+    int next_id = -1;
+    if (merge_allowed(k, empty_mask, comp(c1.lo, axis)) && comp(np, axis) < comp(k.dims, axis)) {
+        next_id = int(lookup_entry(entries, k.shift, k.top, np));
+        const CellRec c2 = load_cell(cells, next_id);
+        if (aligned(axis, c1, c2)) {
+            const vec3 e1 = vec3(c1.hi - c1.lo) * k.cell_size;
+            const vec3 e2 = vec3(c2.hi - c2.lo) * k.cell_size;
+            const float a1 = e1.x * (e1.y + e1.z) + e1.y * e1.z;
+            const float a2 = e2.x * (e2.y + e2.z) + e2.y * e2.z;
+            const float a = a1 + a2 - comp(e1, (axis + 1) % 3) * comp(e1, (axis + 2) % 3);
+            const int n1 = c1.end - c1.begin, n2 = c2.end - c2.begin;
+            const float cc1 = a1 * (n1 + unit_cost), cc2 = a2 * (n2 + unit_cost);
+            if (a * (max(n1, n2) + unit_cost) <= cc1 + cc2) {
+                const int n = count_union(refs + c1.begin, n1, refs + c2.begin, n2);
+                const float c = a * (n + unit_cost);
+                if (c <= cc1 + cc2) count = n;
+            }
+        }
+    }
+    merge_counts[id] = count;
+    next_id = count >= 0 ? next_id : -1;
+    nexts[id] = next_id;
+    if (next_id >= 0) prevs[next_id] = id;      // at most one predecessor can be aligned with a cell
+}
+
+// compute_cell_flags (merge.cu:145-170): chain heads mark every second cell of their chain as residue
+__global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ prevs,
+                                                            int* __restrict__ cell_flags, int num_cells) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= num_cells) return;
+    if (prevs[id] < 0) {
+        int next_id = nexts[id];
+        cell_flags[id] = 1;
+        int count = 1;
+        while (next_id >= 0) {
+            cell_flags[next_id] = (count & 1) ? 0 : 1;
+            next_id = nexts[next_id];
+            count++;
+        }
+    }
+}
+
+// scans of merge.cu:310-311 fused; compute_ref_counts (merge.cu:173-186) folded into the input
+struct KeepIn {
+    const int* cell_flags; const int* merge_counts;
+    __device__ Int2 operator()(int i) const {
+        const int f = cell_flags[i];
+        const int m = merge_counts[i];
+        return Int2{ f ? 1 : 0, f ? (m >= 0 ? m : -(m + 1)) : 0 };
+    }
+};
+struct KeepOut {
+    int* cell_scan; int* ref_scan;
+    __device__ void operator()(int i, Int2 v) const { cell_scan[i] = v.a; ref_scan[i] = v.b; }
+};
+
+// merge (merge.cu:189-278)
+__global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
+                                                       const int* __restrict__ refs, const int* __restrict__ cell_flags,
+                                                       const int* __restrict__ cell_scan, const int* __restrict__ ref_scan,
+                                                       const int* __restrict__ merge_counts, int* __restrict__ new_cell_ids,
+                                                       Cell* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= num_cells || !cell_flags[id]) return;
+    const int new_id = cell_scan[id];
+    const CellRec cell = load_cell(cells, id);
+    const int mc = merge_counts[id];
+    const int nb = ref_scan[id];
+    new_cell_ids[id] = new_id;
+    const int n1 = cell.end - cell.begin;
+    if (mc >= 0) {
+        const int next_id = int(lookup_entry(entries, k.shift, k.top, next_cell_pos(axis, cell.lo, cell.hi)));
+        const CellRec nc = load_cell(cells, next_id);
+        new_cell_ids[next_id] = new_id;
+        store_cell(new_cells, new_id, min(nc.lo, cell.lo), nb, max(nc.hi, cell.hi), nb + mc);
+        if (nc.begin < nc.end) {
+            merge_refs(refs + cell.begin, n1, refs + nc.begin, nc.end - nc.begin, new_refs + nb);
+            return;
+        }
+    } else {
+        store_cell(new_cells, new_id, cell.lo, nb, cell.hi, nb + n1);
+    }
+    for (int i = 0; i < n1; i++) new_refs[nb + i] = refs[cell.begin + i];
+}
+
+// remap_entries (merge.cu:281-290)
+__global__ void __launch_bounds__(kBlock) remap_entries_kernel(uint32_t* __restrict__ entries, const int* __restrict__ new_cell_ids, int num_entries) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= num_entries) return;
+    const uint32_t e = entries[id];
+    if ((e & 3u) == 0) entries[id] = uint32_t(new_cell_ids[e >> 2]) << 2;
+}
+
+} // namespace
+
+extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha) {
+    if (!ctx || !grid) return HAGRID_EINVAL;
+    if (!grid->cells || !grid->entries || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "merge_grid: incomplete (or compressed) grid");
+    if (!(alpha > 0)) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    MergeK k;
+    k.top = ivec3(grid->dims[0], grid->dims[1], grid->dims[2]);
+    k.dims = k.top << grid->shift;
+    k.shift = grid->shift;
+    k.cell_size = (vec3(grid->bbox_max[0], grid->bbox_max[1], grid->bbox_max[2]) - vec3(grid->bbox_min[0], grid->bbox_min[1], grid->bbox_min[2])) / vec3(k.dims);
+
+    // buffers sized for the un-merged grid (merge.cu:334-347); cells and refs ping-pong with grid arrays
+    const size_t nc0 = size_t(grid->num_cells), nr0 = size_t(grid->num_refs);
+    Cell* cells_b = pool_alloc<Cell>(ctx, nc0);
+    int* refs_b = pool_alloc<int>(ctx, nr0);
+    int* merge_counts = pool_alloc<int>(ctx, nc0 + 1);
+    int* nexts = pool_alloc<int>(ctx, nc0 + 1);
+    int* prevs = pool_alloc<int>(ctx, nc0 + 1);
+    int* cell_flags = pool_alloc<int>(ctx, nc0 + 1);
+    int* cell_scan = pool_alloc<int>(ctx, nc0 + 1);
+    int* ref_scan = pool_alloc<int>(ctx, nc0 + 1);
+    Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(grid->num_cells)) + 1);
+    Int2* total = reinterpret_cast<Int2*>(ctx->dscratch);
+    auto release = [&]() {
+        hagrid_mem_free(ctx, merge_counts); hagrid_mem_free(ctx, nexts); hagrid_mem_free(ctx, prevs); hagrid_mem_free(ctx, cell_flags);
+        hagrid_mem_free(ctx, cell_scan); hagrid_mem_free(ctx, ref_scan); hagrid_mem_free(ctx, partials);
+    };
+    if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !cell_scan || !ref_scan || !partials) {
+        release(); hagrid_mem_free(ctx, cells_b); hagrid_mem_free(ctx, refs_b);
+        return HAGRID_ENOMEM;
+    }
+
+    Cell* cells = static_cast<Cell*>(grid->cells);
+    int* refs = static_cast<int*>(grid->ref_ids);
+    uint32_t* entries = static_cast<uint32_t*>(grid->entries);
+    int num_cells = grid->num_cells, num_refs = grid->num_refs;
+    const int num_entries = grid->num_entries;
+
+    int rc = HAGRID_OK;
+    int prev_num_cells = 0, iter = 0;
+    do {                                                                   // merge.cu:357-367
+        prev_num_cells = num_cells;
+        const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
+        for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
+            const int blocks = grid_blocks(num_cells, kBlock);
+            (void)hipMemsetAsync(prevs, 0xFF, size_t(num_cells) * sizeof(int), st);
+            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells);
+            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells);
+            device_scan<Int2>(st, KeepIn{cell_flags, merge_counts}, KeepOut{cell_scan, ref_scan}, num_cells, partials, (const Int2*)nullptr, total);
+            merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
+                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells);
+            remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries);
+            int h[2];
+            rc = read_back(ctx, total, h, sizeof(h));
+            if (rc != HAGRID_OK) break;
+            std::swap(cells, cells_b);
+            std::swap(refs, refs_b);
+            num_cells = h[0]; num_refs = h[1];
+        }
+        iter++;
+    } while (rc == HAGRID_OK && num_cells < alpha * prev_num_cells);
+
+    if (rc == HAGRID_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e));
+    }
+    release();
+    hagrid_mem_free(ctx, cells_b);       // whichever buffers are not the live ones (merge.cu:375-376)
+    hagrid_mem_free(ctx, refs_b);
+    grid->cells = cells; grid->ref_ids = refs;
+    grid->num_cells = num_cells; grid->num_refs = num_refs;
+    return rc;
+}

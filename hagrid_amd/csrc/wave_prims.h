@@ -1,0 +1,195 @@
+// wave_prims.h -- hand-written wave64 / workgroup primitives for the construction passes.
+//
+// These replace the reference's CUB wrappers (src/parallel.cuh:12-89: DeviceScan::ExclusiveSum,
+// DeviceReduce::Reduce, DevicePartition::Flagged, DeviceRadixSort::SortPairs):
+//
+//   * device_scan<V>(...)        ordered exclusive scan with a fused input functor and a fused output
+//                                functor (the TransformInputIterator + follow-up kernel pairs of
+//                                build.cu:557-560, :597, flatten.cu:136), chained on the device through a
+//                                carry word so consecutive scans need no host round trip;
+//   * wave_append / block_sum    unordered compaction: one atomicAdd per wavefront (ballot / prefix over
+//                                64 lanes), used wherever only the SET of items matters;
+//   * block_reduce_*             shuffle reductions.
+//
+// Workgroups are 256 threads = 4 wavefronts of 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hagrid_impl {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kScanItems = 8;                        // items per thread in device_scan
+constexpr int kScanTile = kBlock * kScanItems;       // items per workgroup
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- value types for scans: int and a pair of ints ---------------------------------------------------
+struct Int2 { int a, b; };   // trivial: lives in __shared__ arrays
+__host__ __device__ inline Int2 operator+(Int2 x, Int2 y) { return Int2{x.a + y.a, x.b + y.b}; }
+__host__ __device__ inline int zero_of(int) { return 0; }
+__host__ __device__ inline Int2 zero_of(Int2) { return Int2{0, 0}; }
+
+__device__ __forceinline__ int shfl_up_v(int v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ Int2 shfl_up_v(Int2 v, int d) { return Int2{__shfl_up(v.a, d, 64), __shfl_up(v.b, d, 64)}; }
+__device__ __forceinline__ int shfl_v(int v, int l) { return __shfl(v, l, 64); }
+__device__ __forceinline__ Int2 shfl_v(Int2 v, int l) { return Int2{__shfl(v.a, l, 64), __shfl(v.b, l, 64)}; }
+
+/// Inclusive prefix sum over the 64 lanes of a wavefront (Hillis-Steele on register shuffles).
+template <typename V>
+__device__ __forceinline__ V wave_inclusive_scan(V v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V o = shfl_up_v(v, d);
+        if (l >= d) v = v + o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { float o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { float o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+/// Sum over the workgroup; result valid in every thread.  `lds` holds kWaves ints.
+__device__ __forceinline__ int block_sum(int v, int* lds) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) lds[wave_id()] = v;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) r += lds[w];
+    return r;
+}
+
+/// Unordered append: every lane asks for `n` consecutive slots of a global array whose fill count is
+/// *counter; returns the lane's first slot.  One atomic per wavefront.
+__device__ __forceinline__ int wave_append(int n, int* counter) {
+    const int incl = wave_inclusive_scan(n);
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane_id() == 63 && total > 0) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
+// ---- ordered device-wide exclusive scan ------------------------------------------------------------
+// out(i, exclusive_prefix(i) + carry) for i < n, where in(i) supplies the values.  Reduce-then-scan:
+//   scan_partials : one partial sum per workgroup tile
+//   scan_spine    : a single workgroup scans the partials (adds *carry_in), publishes the grand total
+//   scan_apply    : each workgroup rescans its tile with its offset and calls out()
+// The spine writes total_out[0] = carry + sum, which the next scan may take as its carry_in: chains of
+// scans (one per grid level) run back to back without the host.
+
+template <typename V, typename In>
+__global__ void __launch_bounds__(kBlock) scan_partials(In in, int n, V* partials) {
+    __shared__ V lds[kWaves];
+    const int base = blockIdx.x * kScanTile;
+    V s = zero_of(V());
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        const int i = base + j * kBlock + threadIdx.x;
+        if (i < n) s = s + in(i);
+    }
+    s = wave_inclusive_scan(s);
+    if (lane_id() == 63) lds[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        V t = lds[0];
+        for (int w = 1; w < kWaves; w++) t = t + lds[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+template <typename V>
+__global__ void __launch_bounds__(kBlock) scan_spine(V* partials, int num_partials, const V* carry_in, V* total_out) {
+    __shared__ V lds[kWaves];
+    __shared__ V running;
+    if (threadIdx.x == 0) running = carry_in ? *carry_in : zero_of(V());
+    __syncthreads();
+    for (int base = 0; base < num_partials; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const V v = i < num_partials ? partials[i] : zero_of(V());
+        const V incl = wave_inclusive_scan(v);
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        V excl = running;
+        for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
+        const V prev = shfl_up_v(incl, 1);
+        if (lane_id() > 0) excl = excl + prev;
+        if (i < num_partials) partials[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            V t = running;
+            for (int w = 0; w < kWaves; w++) t = t + lds[w];
+            running = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = running;
+}
+
+template <typename V, typename In, typename Out>
+__global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, const V* partials) {
+    __shared__ V lds[kWaves];
+    __shared__ V running;
+    if (threadIdx.x == 0) running = partials[blockIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * kScanTile;
+#pragma unroll 1
+    for (int j = 0; j < kScanItems; j++) {
+        const int i = base + j * kBlock + threadIdx.x;
+        if (base + j * kBlock >= n) break;
+        const V v = i < n ? in(i) : zero_of(V());
+        const V incl = wave_inclusive_scan(v);
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        V excl = running;
+        for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
+        const V prev = shfl_up_v(incl, 1);
+        if (lane_id() > 0) excl = excl + prev;
+        if (i < n) out(i, excl);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            V t = running;
+            for (int w = 0; w < kWaves; w++) t = t + lds[w];
+            running = t;
+        }
+        __syncthreads();
+    }
+}
+
+inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
+
+/// Launches the three scan kernels.  `partials` must hold scan_num_tiles(n) values of V.
+/// n == 0 still runs the spine so that total_out = carry.
+template <typename V, typename In, typename Out>
+inline void device_scan(hipStream_t stream, In in, Out out, int n, V* partials, const V* carry_in, V* total_out) {
+    const int tiles = scan_num_tiles(n);
+    if (tiles > 0) scan_partials<V, In><<<tiles, kBlock, 0, stream>>>(in, n, partials);
+    scan_spine<V><<<1, kBlock, 0, stream>>>(partials, tiles, carry_in, total_out);
+    if (tiles > 0) scan_apply<V, In, Out><<<tiles, kBlock, 0, stream>>>(in, out, n, partials);
+}
+
+} // namespace hagrid_impl

@@ -27,8 +27,8 @@
 namespace hagrid {
 
 /// Milliseconds elapsed on the device while f runs (reference: common.h:15, profile.cu:5-18).
-/// Implemented in hagrid/mem_manager.h on top of hagrid_profile_begin/end.
-float profile(std::function<void()> f);
+/// Defined inline in hagrid/mem_manager.h on top of hagrid_profile_begin/end.
+inline float profile(std::function<void()> f);
 
 /// Smallest q with q * j >= i (reference: common.h:18-20).
 HOST DEVICE inline int round_div(int i, int j) { return (i + j - 1) / j; }
@@ -83,7 +83,6 @@ HOST DEVICE inline float det_cbrtf(float v) {
     uint64_t i = as<uint64_t>(x);
     i = i / 3 + 0x2A9F7893782DA1CEull;
     double y = as<double>(i);
-#pragma unroll
     for (int k = 0; k < 6; k++) {
         double y2 = y * y;
         y = y - (y2 * y - x) / (3.0 * y2);

@@ -1,0 +1,29 @@
+// hagrid/traverse.h -- ray traversal with the reference's signatures (src/traverse.h:11-14), as
+// header-only shims over the C ABI.  Work goes to the current MemManager's context (the reference keeps
+// the equivalent state in per-process __constant__ symbols, traverse.cu:7-12).
+#ifndef HAGRID_TRAVERSE_H
+#define HAGRID_TRAVERSE_H
+
+#include "build.h"
+#include "grid.h"
+#include "vec.h"
+#include "prims.h"
+
+namespace hagrid {
+
+/// Validates the grid and derives its traversal constants.
+inline void setup_traversal(const Grid& grid) {
+    hagrid_grid p = detail::to_pod(grid);
+    detail::check(detail::current_ctx(), hagrid_setup_traversal(detail::current_ctx(), &p));
+}
+
+/// Nearest hit per ray: hits[i].id = primitive id or -1, hits[i].t = distance.  Asynchronous on the
+/// context's stream, like a kernel launch.
+inline void traverse_grid(const Grid& grid, const Tri* tris, const Ray* rays, Hit* hits, int num_rays) {
+    hagrid_grid p = detail::to_pod(grid);
+    detail::check(detail::current_ctx(), hagrid_traverse_grid(detail::current_ctx(), &p, tris, rays, hits, num_rays));
+}
+
+} // namespace hagrid
+
+#endif // HAGRID_TRAVERSE_H

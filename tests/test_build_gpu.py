@@ -1,0 +1,144 @@
+"""GPU parity of the construction passes against the CPU oracle: after every pass the device grid
+(entries, cells, ref_ids, dims, bbox, shift, offsets, counts) must equal the oracle's bit for bit."""
+import numpy as np
+import pytest
+
+from hagrid_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mem():
+    from hagrid_amd import api
+    m = api.MemManager(keep=True)
+    yield m
+    m.close()
+
+
+def assert_same_grid(dev: dict, G, stage: str):
+    assert tuple(dev["dims"]) == tuple(G.dims), stage
+    assert dev["shift"] == G.shift, stage
+    assert list(dev["offsets"]) == list(G.offsets), (stage, dev["offsets"], G.offsets)
+    assert (dev["bbox_min"].view(np.uint32) == G.bbox_min.view(np.uint32)).all(), stage
+    assert (dev["bbox_max"].view(np.uint32) == G.bbox_max.view(np.uint32)).all(), stage
+    assert dev["entries"].shape == G.entries.shape and (dev["entries"] == G.entries).all(), stage
+    if G.cells is not None:
+        assert dev["cells"] is not None and dev["cells"].shape == G.cells.shape, stage
+        for f in ("min", "max", "begin", "end"):
+            assert (dev["cells"][f] == G.cells[f]).all(), (stage, f)
+    else:
+        assert dev["small_cells"] is not None and dev["small_cells"].shape == G.small_cells.shape, stage
+        for f in ("min", "max", "begin"):
+            assert (dev["small_cells"][f] == G.small_cells[f]).all(), (stage, f)
+    assert dev["ref_ids"].shape == G.ref_ids.shape and (dev["ref_ids"] == G.ref_ids).all(), stage
+
+
+def run_stages(mem, tris, td=0.12, sd=2.4, alpha=0.995, exp=3, compress=True):
+    from hagrid_amd import api
+    from oracle import oracle as O
+    d_tris = mem.upload(tris)
+    n = tris.shape[0]
+    grid = api.Grid()
+    api.build_grid(mem, d_tris, n, grid, td, sd)
+    G = O.Grid.build(tris, td, sd)
+    assert_same_grid(grid.download(), G, "build")
+    api.merge_grid(mem, grid, alpha); G.merge(alpha)
+    assert_same_grid(grid.download(), G, "merge")
+    api.flatten_grid(mem, grid); G.flatten()
+    assert_same_grid(grid.download(), G, "flatten")
+    api.expand_grid(mem, grid, d_tris, exp); G.expand(tris, exp)
+    assert_same_grid(grid.download(), G, "expand")
+    if compress:
+        ok = api.compress_grid(mem, grid)
+        assert ok == G.compress()
+        assert_same_grid(grid.download(), G, "compress")
+    return grid, G, d_tris
+
+
+def test_build_config1_every_stage(mem):
+    """BASELINE config 1: soup-10k, defaults."""
+    tris = scene.make_soup(10000)
+    grid, G, d_tris = run_stages(mem, tris)
+    assert grid.summary() == G.summary()
+    grid.free(); mem.free(d_tris)
+
+
+@pytest.mark.parametrize("n,td,sd", [(1, 0.12, 2.4), (2, 0.12, 2.4), (37, 0.12, 2.4), (3000, 0.15, 3.0), (50000, 0.12, 2.4), (20000, 0.5, 8.0)])
+def test_build_sizes_and_densities(mem, n, td, sd):
+    tris = scene.make_soup(n, seed=1234 + n)
+    grid, G, d_tris = run_stages(mem, tris, td, sd)
+    grid.free(); mem.free(d_tris)
+
+
+def test_build_clustered_scene_long_lists(mem):
+    """Teapot-in-a-stadium: a dense cluster (long per-cell lists, deep levels) inside a sparse soup."""
+    big = scene.make_soup(2000, seed=7)
+    small = scene.make_soup(6000, seed=8).copy()
+    small[:, 0:3] = small[:, 0:3] * np.float32(0.01) + np.float32(0.4)      # v0 into a 1 % box
+    small[:, 4:7] *= np.float32(0.002); small[:, 8:11] *= np.float32(0.002)   # tiny edges
+    e1, e2 = small[:, 4:7], small[:, 8:11]
+    nrm = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2], e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
+    small[:, 3] = nrm[:, 0]; small[:, 7] = nrm[:, 1]; small[:, 11] = nrm[:, 2]
+    tris = np.concatenate([big, small]).astype(np.float32)
+    grid, G, d_tris = run_stages(mem, tris)
+    grid.free(); mem.free(d_tris)
+
+
+def test_build_then_traverse_matches_reference_bruteforce(mem, golden_dir):
+    """End to end on the GPU only (build + traverse), against the reference-arithmetic brute force."""
+    import os
+    from hagrid_amd import api
+    g = np.load(os.path.join(golden_dir, "config1_hits.npz"))
+    tris = scene.make_soup(10000)
+    lo, hi = scene.tris_bbox(tris)
+    rays = scene.make_rays_incoherent(lo, hi, 65536, scene.RAY_SEED_BASE + 1)
+    d_tris = mem.upload(tris)
+    for compress in (False, True):
+        grid = api.build_all(mem, d_tris, tris.shape[0], compress=compress)
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+        api.setup_traversal(grid)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+        hits = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+        assert (hits["id"] == g["id"]).all()
+        assert (hits["t"].view(np.uint32) == g["t"].view(np.uint32)).all()
+        mem.free(d_rays); mem.free(d_hits); grid.free()
+    mem.free(d_tris)
+
+
+def test_rebuild_in_keep_mode_is_stable(mem):
+    """main.cpp:481-508: repeated builds with freed grid arrays give identical grids; pool does not grow."""
+    from hagrid_amd import api
+    tris = scene.make_soup(20000)
+    d_tris = mem.upload(tris)
+    ref = None; usage = []
+    for it in range(3):
+        grid = api.build_all(mem, d_tris, tris.shape[0])
+        d = grid.download()
+        if ref is None:
+            ref = d
+        else:
+            assert (d["entries"] == ref["entries"]).all() and (d["ref_ids"] == ref["ref_ids"]).all()
+            assert d["cells"].tobytes() == ref["cells"].tobytes()
+        grid.free()
+        usage.append(mem.usage())
+    assert usage[2] <= usage[1] * 1.05
+    mem.free(d_tris)
+
+
+def test_compress_refuses_fine_grids(mem):
+    from hagrid_amd import api
+    tris = scene.make_soup(64)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    grid.pod.shift = 15                                       # pretend: dims << 15 >= 65536
+    cells_before = grid.cells
+    assert api.compress_grid(mem, grid) is False and grid.cells == cells_before and not grid.small_cells
+    grid.pod.shift = 0
+    mem.free(d_tris)
+
+
+def test_build_rejects_bad_input(mem):
+    from hagrid_amd import api
+    with pytest.raises(api.HagridError):
+        api.build_grid(mem, 0, 0, api.Grid(), 0.12, 2.4)
