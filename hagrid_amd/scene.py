@@ -136,13 +136,17 @@ def camera(bbox_min, bbox_max, eye_dist: float = 0.8, fov: float = 60.0, ratio: 
 
 
 def make_rays_primary(bbox_min, bbox_max, width: int, height: int, first: int = 0, count: int | None = None,
-                      eye_dist: float = 0.8, fov: float = 60.0) -> np.ndarray:
-    """gen_rays (main.cpp:52-66): pixel (x, y) -> dir = cam.dir + right*kx + up*ky, tmax = clip = |extents|."""
+                      eye_dist: float = 0.8, fov: float = 60.0, sample: int = 0, num_samples: int = 1) -> np.ndarray:
+    """gen_rays (main.cpp:52-66): pixel (x, y) -> dir = cam.dir + right*kx + up*ky, tmax = clip = |extents|.
+    sample / num_samples shifts the pixel by a sub-pixel offset in x (sample 0 of 1 = the reference's rays):
+    the weak-scaling batches of a multi-GPU run are the N sub-pixel samples of the same camera."""
     eye, cdir, right, up, diag = camera(bbox_min, bbox_max, eye_dist, fov, width / float(height))
     if count is None:
         count = width * height - first
     pid = np.arange(first, first + count, dtype=np.int64)
     x = (pid % width).astype(np.float32); y = (pid // width).astype(np.float32)
+    if sample:
+        x = x + np.float32(sample) / np.float32(num_samples)
     kx = np.float32(2.0) * x / np.float32(width) - np.float32(1.0)
     ky = np.float32(1.0) - np.float32(2.0) * y / np.float32(height)
     rays = np.empty((count, 8), dtype=np.float32)
