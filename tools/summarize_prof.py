@@ -1,0 +1,43 @@
+"""Condenses rocprofv3 CSV output of one gpu_round into (a) a per-kernel stats table and (b) the HBM traffic
+of the traversal kernel per launch (FETCH_SIZE / WRITE_SIZE are in KiB: MI355X_MICROARCH.md, HBM section;
+on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads, so a x2-corrected figure is given
+next to the raw one)."""
+import csv, glob, json, os, sys
+out = sys.argv[1]
+
+def find(pattern):
+    r = glob.glob(os.path.join(out, pattern), recursive=True)
+    return r[0] if r else None
+
+stats = find("prof/**/*kernel_stats.csv")
+if stats:
+    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    rows = list(csv.DictReader(open(stats)))
+    for r in rows[:40]:
+        print(f'{r.get("Name","")[:70]:70s} calls {r.get("Calls","")} total_ns {r.get("TotalDurationNs","")} avg_ns {r.get("AverageNs","")} pct {r.get("Percentage","")}')
+
+def pmc(dirname, counter):
+    f = find(f"{dirname}/**/*counter_collection.csv")
+    if not f:
+        return None
+    tot = 0.0; n = 0
+    for r in csv.DictReader(open(f)):
+        if "traverse_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+            tot += float(r["Counter_Value"]); n += 1
+    return (tot / n, n) if n else None
+
+res = {}
+for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", "TCC_HIT_sum"), ("pmc_l2", "TCC_MISS_sum")):
+    v = pmc(d, c)
+    if v:
+        res[c] = {"avg_per_launch": v[0], "launches": v[1]}
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    f = res["FETCH_SIZE"]["avg_per_launch"] * 1024; w = res["WRITE_SIZE"]["avg_per_launch"] * 1024
+    res["hbm_bytes_per_launch_raw"] = f + w
+    res["hbm_bytes_per_launch"] = 2 * f + w          # gfx950 FETCH_SIZE correction
+if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res:
+    h = res["TCC_HIT_sum"]["avg_per_launch"]; m = res["TCC_MISS_sum"]["avg_per_launch"]
+    res["l2_hit_rate"] = h / (h + m) if h + m else None
+print("== traversal kernel PMC ==")
+print(json.dumps(res, indent=1))
+json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
