@@ -11,6 +11,8 @@
 // moved as 16-byte vector accesses.  See DESIGN.md for the algorithmic-byte accounting.
 #include "ctx.h"
 
+#include <cstdlib>
+
 #include "hagrid/grid.h"
 #include "hagrid/prims.h"
 #include "hagrid/ray.h"
@@ -169,6 +171,261 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
     }
 }
 
+
+// ---- v2: latency-oriented kernel ---------------------------------------------------------------------------------
+// A 1M-ray batch is bound by the critical path of its longest rays (hundreds of cell steps, each a chain of
+// dependent loads: top entry -> sub entry -> cell -> ref id -> triangle), not by throughput.  v2 shortens that chain:
+//   * the NEXT cell's voxel-map walk and cell load are issued before the current cell's triangles are tested
+//     (they are independent of the tests; if the ray terminates in this cell the loads are simply dropped);
+//   * the top-level entry is kept in a register while the ray stays inside the same top-level cell;
+//   * loads are issued unconditionally with clamped addresses so that independent chains overlap instead of
+//     being serialised by divergent branches;
+//   * one wavefront per workgroup (a finished wave frees its slot at once) and an XCD-aware block -> ray-range map:
+//     consecutive ray ranges run on the same XCD, so each of the 8 private L2s caches one band of the scene.
+// Same arithmetic per ray as v1 (and the oracle): identical hits.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// streaming (read-once / write-once) accesses for rays and hits: keep them out of the way of the grid in L2
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float x, float y, float z, float w) {
+    f32x4 v; v.x = x; v.y = y; v.z = z; v.w = w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
+
+template <bool SMALL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) traverse_kernel_v2(const TraverseArgs a) {
+    int b = blockIdx.x;
+    {   // bijective remap: blocks are dispatched round-robin over the 8 XCDs
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int id = b * BLOCK + threadIdx.x;
+    if (id >= a.num_rays) return;
+
+    const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
+    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    const float tmin = r0.w, tmax = r1.w;
+    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+    const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+
+    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+
+    Hit hit(-1, tmax, 0.0f, 0.0f);
+
+    if (!(tstart > tend)) {
+        const vec3 fv = (tstart * dir + org - gmin) * ginv;
+        int vx = min(max(int(fv.x), 0), a.dims_x - 1);
+        int vy = min(max(int(fv.y), 0), a.dims_y - 1);
+        int vz = min(max(int(fv.z), 0), a.dims_z - 1);
+
+        auto walk = [&](uint32_t w, int x, int y, int z) -> uint32_t {   // sub-levels of the voxel map
+            int depth = 0;
+            while (w & 3u) {
+                const int k = int(w & 3u);
+                depth += k;
+                const int s = a.shift - depth, m = (1 << k) - 1;
+                w = a.entries[(w >> 2) + ((x >> s) & m) + ((((y >> s) & m) + (((z >> s) & m) << k)) << k)];
+            }
+            return w;
+        };
+
+        int top_idx = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
+        uint32_t topw = a.entries[top_idx];
+        CellBox c = load_cell_box<SMALL>(a.cells, walk(topw, vx, vy, vz) >> 2);
+
+        for (;;) {
+            const int cx = px ? c.hx : c.lx, cy = py ? c.hy : c.ly, cz = pz ? c.hz : c.lz;
+            const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+            const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+            const vec3 ev = (texit * dir + org - gmin) * ginv;
+            const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
+            const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
+            const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+            vx = px ? max(nx, vx) : min(nx, vx);
+            vy = py ? max(ny, vy) : min(ny, vy);
+            vz = pz ? max(nz, vz) : min(nz, vz);
+            const bool outside = (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
+
+            // first reference of this cell and the next cell's top entry: two independent loads in flight
+            const int begin = c.begin;
+            const bool nonempty = SMALL ? begin >= 0 : begin < c.end;
+            int cur = nonempty ? begin : 0;
+            int ref = a.refs[cur];
+            cur++;
+            if (!nonempty) ref = -1;
+            const int ntop = outside ? top_idx : (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
+            if (ntop != top_idx) { topw = a.entries[ntop]; top_idx = ntop; }
+            // next cell: walk + load, overlapping the triangle tests below
+            const CellBox nc = load_cell_box<SMALL>(a.cells, walk(topw, vx, vy, vz) >> 2);
+
+            while (ref >= 0) {
+                const int next = SMALL ? a.refs[cur] : (cur < c.end ? a.refs[cur] : -1);
+                cur++;
+                intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                ref = next;
+            }
+            if (hit.t <= texit || outside) break;
+            c = nc;
+        }
+    }
+    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
+}
+
+
+// ---- v3: persistent wavefronts, lane refill, vote-scheduled phases -------------------------------------------------
+// Profile of v1/v2 on the 1M-ray batch (profiles/): the SIMDs issue ~80 % of the time while only ~19 % of the lanes
+// of an issued VALU instruction are live -- the kernel is instruction-issue bound and 4 of 5 lanes idle, because (a) a
+// wave lives as long as its longest ray and (b) inside a cell step every lane waits for the lane with the longest
+// reference list.  v3 attacks lane utilisation, the thing that costs twice as much on 64-wide waves as on the
+// reference's 32-wide warps:
+//   * wavefronts are persistent; a lane whose ray is finished takes the next ray from a global cursor (one atomic
+//     per refill, issued when at least kRefillAt lanes are free);
+//   * a ray is a small state machine -- it wants either a CELL step (voxel-map walk + cell load + exit plane) or ONE
+//     TRIANGLE test -- and each iteration the wave votes (ballot + popcount, scalar) and runs the phase most lanes
+//     are waiting for, so an issued instruction always has at least half of the ray-carrying lanes live;
+//   * the next reference id is fetched one test ahead, next to the triangle loads.
+// Every ray performs exactly the operation sequence of v1 / the oracle, so hits are identical.
+constexpr int kRefillAt = 12;
+constexpr int kBands = 8;           // one ray band + cursor per XCD (private L2 each)
+
+template <bool SMALL>
+__global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, int* __restrict__ band_cursors, int chunk, int both_phases) {
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+
+    // wave-uniform ray supply: a local pool [pool_next, pool_end) refilled in chunks from the band cursors.
+    // Workgroups are dispatched round-robin over the XCDs, so (blockIdx & 7) is the wave's home band: rays of one
+    // band -- one slab of the image for primary rays -- stay on one XCD and its L2.  Empty bands are skipped.
+    const int band_len = (a.num_rays + kBands - 1) / kBands;
+    int band = blockIdx.x & (kBands - 1), bands_left = kBands;
+    int pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+
+    int ray_id = -1;                // -1: the lane carries no ray
+    vec3 org(0.0f), dir(0.0f), inv_dir(0.0f);
+    float tmin = 0.0f, hit_t = 0.0f, texit = 0.0f;
+    int hit_id = -1;
+    int vx = 0, vy = 0, vz = 0;
+    int ref = -1, cur = 0, end = 0; // pending reference (prefetched id), its index, list end (Cell variant)
+    bool outside = false;
+
+    for (;;) {
+        const bool has_ray = ray_id >= 0;
+        const bool want_tri = has_ray && ref >= 0;
+        const unsigned long long m_free = __ballot(!has_ray);
+        const int n_free = __popcll(m_free);
+        if (n_free == 64 && exhausted) break;
+
+        // ---- refill ---------------------------------------------------------------------------------------------
+        if (!exhausted && (n_free >= kRefillAt)) {
+            while (pool_next >= pool_end && !exhausted) {          // fetch a chunk: one atomic per `chunk` rays
+                int base = 0;
+                if (threadIdx.x == 0) base = atomicAdd(band_cursors + band, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int band_end = min((band + 1) * band_len, a.num_rays);
+                const int first = band * band_len + base;
+                if (first < band_end) { pool_next = first; pool_end = min(first + chunk, band_end); }
+                else { band = (band + 1) & (kBands - 1); if (--bands_left == 0) exhausted = true; }
+            }
+            const int take = min(n_free, pool_end - pool_next);
+            if (!has_ray) {
+                const int rank = __builtin_amdgcn_mbcnt_hi(unsigned(m_free >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m_free), 0));
+                if (rank < take) {
+                    const int id = pool_next + rank;
+                    const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
+                    org = vec3(r0.x, r0.y, r0.z); dir = vec3(r1.x, r1.y, r1.z);
+                    tmin = r0.w;
+                    const float tmax = r1.w;
+                    inv_dir = vec3(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+                    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+                    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+                    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+                    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+                    if (tstart > tend) {
+                        nt_store4(a.hits + id, __int_as_float(-1), tmax, 0.0f, 0.0f);     // misses the grid
+                    } else {
+                        const vec3 fv = (tstart * dir + org - gmin) * ginv;
+                        vx = min(max(int(fv.x), 0), a.dims_x - 1);
+                        vy = min(max(int(fv.y), 0), a.dims_y - 1);
+                        vz = min(max(int(fv.z), 0), a.dims_z - 1);
+                        hit_t = tmax; hit_id = -1; ref = -1;
+                        ray_id = id;
+                    }
+                }
+            }
+            pool_next += take;
+            continue;
+        }
+
+        // ---- phase vote ---------------------------------------------------------------------------------------------
+        // Throughput mode (rays still available): run only the phase most lanes wait for, so issued instructions are
+        // well filled.  Tail mode (no rays left to take): every lane advances every iteration -- the batch now ends
+        // when its longest ray ends, and that ray must not wait for votes.
+        const int n_tri = __popcll(__ballot(want_tri));
+        const int n_cell = 64 - n_free - n_tri;
+        const bool all = exhausted || both_phases;
+        const bool run_cell = n_cell > 0 && (all || n_cell > n_tri);
+        const bool run_tri = n_tri > 0 && (all || !run_cell);
+        bool finished = false;
+
+        if (run_cell) {
+            if (has_ray && !want_tri) {
+                uint32_t w = a.entries[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
+                int depth = 0;
+                while (w & 3u) {
+                    const int k = int(w & 3u);
+                    depth += k;
+                    const int s = a.shift - depth, m = (1 << k) - 1;
+                    w = a.entries[(w >> 2) + ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << k)) << k)];
+                }
+                const CellBox c = load_cell_box<SMALL>(a.cells, w >> 2);
+                const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+                const int cx = px ? c.hx : c.lx, cy = py ? c.hy : c.ly, cz = pz ? c.hz : c.lz;
+                const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+                texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+                const vec3 ev = (texit * dir + org - gmin) * ginv;
+                const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
+                const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
+                const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+                vx = px ? max(nx, vx) : min(nx, vx);
+                vy = py ? max(ny, vy) : min(ny, vy);
+                vz = pz ? max(nz, vz) : min(nz, vz);
+                outside = (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
+                cur = c.begin; end = c.end;
+                const bool nonempty = SMALL ? c.begin >= 0 : c.begin < c.end;
+                ref = nonempty ? a.refs[c.begin] : -1;
+                finished = ref < 0 && (hit_t <= texit || outside);
+            }
+        }
+        if (run_tri) {
+            // one test per lane that was waiting for one at the vote (a lane that just finished its cell step and
+            // found references starts testing in the next iteration)
+            if (want_tri) {
+                int next;
+                if (SMALL) next = a.refs[cur + 1];
+                else next = cur + 1 < end ? a.refs[cur + 1] : -1;
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit_t), ref, h);
+                hit_id = h.id; hit_t = h.t;
+                cur++;
+                ref = next;
+                finished = ref < 0 && (hit_t <= texit || outside);
+            }
+        }
+        if (finished) {
+            nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+            ray_id = -1; ref = -1;
+        }
+    }
+}
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -210,9 +467,36 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
-    const int blocks = grid_blocks(num_rays, 256);
-    if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
-    else                   traverse_kernel<false, false><<<blocks, 256, 0, ctx->stream>>>(a);
+    // Kernel choice.  Small batches (a few rays per resident lane) end when their longest ray ends: the latency-
+    // oriented v2 wins.  Large batches are throughput-bound: the persistent, vote-scheduled v3 wins (measured
+    // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
+    // HAGRID_TRAVERSE_VARIANT (1 = plain reference-shaped kernel, 2, 3) overrides for experiments.
+    const char* venv = getenv("HAGRID_TRAVERSE_VARIANT");
+    const long long lanes = (long long)ctx->num_cus * 32 * 64;
+    const int variant = venv ? atoi(venv) : (num_rays >= 24 * lanes ? 3 : 2);
+    if (variant == 1) {
+        const int blocks = grid_blocks(num_rays, 256);
+        if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
+        else                   traverse_kernel<false, false><<<blocks, 256, 0, ctx->stream>>>(a);
+    } else if (variant == 2) {
+        const int blocks = grid_blocks(num_rays, 64);
+        if (grid->small_cells) traverse_kernel_v2<true, 64><<<blocks, 64, 0, ctx->stream>>>(a);
+        else                   traverse_kernel_v2<false, 64><<<blocks, 64, 0, ctx->stream>>>(a);
+    } else {
+        const char* wenv = getenv("HAGRID_WAVES_PER_CU");
+        const int waves_per_cu = wenv ? atoi(wenv) : 32;
+        const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * waves_per_cu);
+        // rays per cursor atomic: a few chunks per wave for balance, at least one wave-load, at most 1024
+        const char* cenv = getenv("HAGRID_CHUNK");
+        int chunk = cenv ? atoi(cenv) : (num_rays / (blocks * 4));
+        chunk = std::max(64, std::min(1024, (chunk + 63) & ~63));
+        const char* benv = getenv("HAGRID_BOTH");
+        const int both = benv ? atoi(benv) : 0;
+        int* cursors = ctx->dscratch + 240;                  // 8 band cursors
+        HG_HIP(ctx, hipMemsetAsync(cursors, 0, 8 * sizeof(int), ctx->stream));
+        if (grid->small_cells) traverse_kernel_v3<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both);
+        else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both);
+    }
     HG_HIP(ctx, hipGetLastError());
     return HAGRID_OK;
 }

@@ -1,0 +1,33 @@
+"""DEV TOOL: in-process interleaved A/B of traversal kernel variants on the GPU-built 1M grid.
+usage: python tools/dev_ab_traverse.py 1,2 [rounds]"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hagrid_amd import api, scene
+
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2").split(",")]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+N = int(os.environ.get("N", 1000000))
+mem = api.MemManager(keep=True)
+tris = scene.make_soup(N); d_tris = mem.upload(tris)
+grid = api.build_all(mem, d_tris, N, compress=bool(int(os.environ.get("COMPRESS", "0"))))
+sets = {"primary1M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
+        "incoh1M": scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4),
+        "primary16M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096)}
+for name, rays in sets.items():
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    ref = None; times = {v: [] for v in variants}
+    for r in range(rounds + 1):
+        for v in variants:
+            os.environ["HAGRID_TRAVERSE_VARIANT"] = str(v)
+            ms = api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n))
+            if r: times[v].append(ms)
+            if r == 1:
+                h = mem.download(d_hits, api.HIT_DTYPE, n)
+                if ref is None: ref = h
+                else: assert (h["id"] == ref["id"]).all() and (h["t"].view(np.uint32) == ref["t"].view(np.uint32)).all(), f"variant {v} differs"
+    for v in variants:
+        t = sorted(times[v])
+        print(json.dumps({"rays": name, "variant": v, "ms_med": round(t[len(t) // 2], 4), "ms_min": round(t[0], 4), "mrays_med": round(n / t[len(t) // 2] / 1e3, 1)}), flush=True)
+    mem.free(d_rays); mem.free(d_hits)

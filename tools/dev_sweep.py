@@ -1,0 +1,27 @@
+"""DEV TOOL: traversal variants x batch sizes (primary rays of growing images, incoherent)."""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hagrid_amd import api, scene
+mem = api.MemManager(keep=True)
+N = 1000000
+tris = scene.make_soup(N); d_tris = mem.upload(tris)
+grid = api.build_all(mem, d_tris, N)
+configs = [dict(v=1), dict(v=2), dict(v=3), dict(v=3, BOTH=1), dict(v=3, BOTH=1, WAVES=16), dict(v=3, WAVES=16)]
+if len(sys.argv) > 1:
+    configs = [json.loads(a) for a in sys.argv[1:]]
+for kind, sizes in (("primary", [(1024, 1024), (2048, 1024), (2048, 2048), (4096, 2048), (4096, 4096)]), ("incoherent", [(1 << 20, 1), (1 << 22, 1), (1 << 24, 1)])):
+    for w, h in sizes:
+        rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, w, h) if kind == "primary" else scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, w, scene.RAY_SEED_BASE + 4)
+        n = rays.shape[0]; d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+        row = {"rays": kind, "n": n}
+        for c in configs:
+            os.environ["HAGRID_TRAVERSE_VARIANT"] = str(c["v"])
+            os.environ["HAGRID_BOTH"] = str(c.get("BOTH", 0)); os.environ["HAGRID_WAVES_PER_CU"] = str(c.get("WAVES", 32))
+            if "CHUNK" in c: os.environ["HAGRID_CHUNK"] = str(c["CHUNK"])
+            else: os.environ.pop("HAGRID_CHUNK", None)
+            for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(7))
+            row["|".join(f"{k}{v}" for k, v in c.items())] = round(n / t[3] / 1e3, 0)
+        print(json.dumps(row), flush=True)
+        mem.free(d_rays); mem.free(d_hits)
