@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--build-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     import torch
@@ -64,17 +66,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    mem = api.MemManager(keep=True, device=local_rank)
+    mem = api.MemManager(keep=True, device=device)
     info = mem.device_info()
 
     # ---- scene + grid: built on rank 0, broadcast once -------------------------------------------------------------
@@ -182,7 +188,7 @@ def main():
             sample = int(min(n_rays, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
             t0 = time.perf_counter(); oh, _ = G.traverse(tris_h, rays[:sample], nthreads=cores); t_cpu = time.perf_counter() - t0
             reps = 1
-            while t_cpu < 0.5 * args.cpu_seconds and reps < 64:        # the whole batch is too small: repeat it
+            while t_cpu < 0.5 * args.cpu_seconds and reps < 512:        # the whole batch is too small: repeat it
                 t0 = time.perf_counter(); G.traverse(tris_h, rays[:sample], nthreads=cores); t_cpu += time.perf_counter() - t0; reps += 1
             same_id = bool((hits["id"][:sample] == oh["id"]).all())
             same_t = bool((hits["t"][:sample].view(np.uint32) == oh["t"].view(np.uint32)).all())
