@@ -219,20 +219,21 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
                                                         const uint32_t* __restrict__ entries, BuildK k,
                                                         unsigned char* __restrict__ masks, int* __restrict__ cell_counts, int* __restrict__ totals) {
     __shared__ int lds[kWaves];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     int children = 0, kept = 0;
-    if (i < num_refs) {
+    // grid-stride: the two totals cost one atomic pair per workgroup (a same-word atomic per 256 references
+    // would run into the ~88 atomics/us ceiling of a single L2 word)
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < num_refs; i += gridDim.x * kBlock) {
         const int c = cell_ids[i];
         int m = 0;
         if (c >= 0) {
             if ((entries[c] & 3u) == 0) {
-                kept = 1;
+                kept++;
                 atomicAdd(cell_counts + c, 1);
             } else {
                 const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
                 const int4 a = p[0], b = p[1];
                 m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref_ids[i]));
-                children = __popc(m);
+                children += __popc(m);
             }
         }
         masks[i] = (unsigned char)m;
@@ -245,23 +246,50 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
     }
 }
 
-// split_refs (build.cu:219-243); slots come from one atomic per wavefront, order is irrelevant
+// split_refs (build.cu:219-243).  Output order is irrelevant (see the header), so slots are handed out per TILE of
+// 2048 references: block-wide prefix over the per-thread child counts, one atomic per tile.
+constexpr int kEmitItems = 8;
 __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
                                                           const unsigned char* __restrict__ masks, const uint32_t* __restrict__ entries,
                                                           int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    int m = i < num_refs ? masks[i] : 0;
-    int pos = wave_append(__popc(m), cursor);
-    if (m) {
-        const int ref = ref_ids[i];
-        const int begin = int(entries[cell_ids[i]] >> 2);
-        while (m) {
-            const int child = __ffs(m) - 1;
-            m &= m - 1;
-            new_ref_ids[pos] = ref;
-            new_cell_ids[pos] = begin + child;
-            pos++;
+    __shared__ int lds[kWaves];
+    __shared__ int tile_base;
+    const int tile_size = kBlock * kEmitItems;
+    for (int base = blockIdx.x * tile_size; base < num_refs; base += gridDim.x * tile_size) {
+        int m[kEmitItems];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kEmitItems; j++) {
+            const int i = base + j * kBlock + threadIdx.x;
+            m[j] = i < num_refs ? masks[i] : 0;
+            cnt += __popc(m[j]);
         }
+        const int incl = wave_inclusive_scan(cnt);
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        int off = incl - cnt, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) off += lds[w]; total += lds[w]; }
+        if (threadIdx.x == 0) tile_base = total ? atomicAdd(cursor, total) : 0;
+        __syncthreads();
+        int pos = tile_base + off;
+#pragma unroll
+        for (int j = 0; j < kEmitItems; j++) {
+            int mm = m[j];
+            if (mm) {
+                const int i = base + j * kBlock + threadIdx.x;
+                const int ref = ref_ids[i];
+                const int begin = int(entries[cell_ids[i]] >> 2);
+                while (mm) {
+                    const int child = __ffs(mm) - 1;
+                    mm &= mm - 1;
+                    new_ref_ids[pos] = ref;
+                    new_cell_ids[pos] = begin + child;
+                    pos++;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -460,7 +488,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
             mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries);
         device_scan<int>(st, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0);
         if (L.num_refs > 0)
-            classify_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
+            classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
                                                                                masks, L.cell_counts, tot + 1);
         int h3[3];
         HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
@@ -480,7 +508,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
-        emit_child_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
+        emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
                                                                              N.ref_ids, N.cell_ids, cursor);
         emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells);
         tmp.drop(masks);

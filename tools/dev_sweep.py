@@ -10,7 +10,10 @@ grid = api.build_all(mem, d_tris, N)
 configs = [dict(v=1), dict(v=2), dict(v=3), dict(v=3, BOTH=1), dict(v=3, BOTH=1, WAVES=16), dict(v=3, WAVES=16)]
 if len(sys.argv) > 1:
     configs = [json.loads(a) for a in sys.argv[1:]]
-for kind, sizes in (("primary", [(1024, 1024), (2048, 1024), (2048, 2048), (4096, 2048), (4096, 4096)]), ("incoherent", [(1 << 20, 1), (1 << 22, 1), (1 << 24, 1)])):
+SIZES = (("primary", [(1024, 1024), (2048, 2048), (4096, 4096)]), ("incoherent", [(1 << 20, 1), (1 << 22, 1), (1 << 24, 1)]))
+if os.environ.get("SWEEP") == "small":
+    SIZES = (("primary", [(1024, 1024), (2048, 2048)]),)
+for kind, sizes in SIZES:
     for w, h in sizes:
         rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, w, h) if kind == "primary" else scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, w, scene.RAY_SEED_BASE + 4)
         n = rays.shape[0]; d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
