@@ -292,11 +292,17 @@ __global__ void __launch_bounds__(BLOCK) traverse_kernel_v2(const TraverseArgs a
 //     are waiting for, so an issued instruction always has at least half of the ray-carrying lanes live;
 //   * the next reference id is fetched one test ahead, next to the triangle loads.
 // Every ray performs exactly the operation sequence of v1 / the oracle, so hits are identical.
+//
+// Why this is the LARGE-batch kernel only: a persistent wave is always full, so every lock-step iteration costs the
+// slowest of 64 busy lanes for the whole life of a long ray, whereas a v2 wave thins out and lets its longest ray
+// finish at its own pace.  A batch of a few rays per lane ends when its longest rays end and is 2.7x slower here
+// (measured: 1M primary rays 0.40 ms with v2, 1.1 ms with any persistent variant -- also with v2's cell step inside
+// the persistent loop, with deferred stores, with any refill threshold or chunk size; profiles/dev_r1_variant_sweep.txt).
 constexpr int kRefillAt = 12;
 constexpr int kBands = 8;           // one ray band + cursor per XCD (private L2 each)
 
 template <bool SMALL>
-__global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, int* __restrict__ band_cursors, int chunk, int both_phases) {
+__global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, int* __restrict__ band_cursors, int chunk, int both_phases, int refill_at) {
     const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
     const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
 
@@ -309,6 +315,7 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
     bool exhausted = false;
 
     int ray_id = -1;                // -1: the lane carries no ray
+    bool done = false;              // the lane's ray is finished, its result waits in registers for the next refill
     vec3 org(0.0f), dir(0.0f), inv_dir(0.0f);
     float tmin = 0.0f, hit_t = 0.0f, texit = 0.0f;
     int hit_id = -1;
@@ -317,14 +324,15 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
     bool outside = false;
 
     for (;;) {
-        const bool has_ray = ray_id >= 0;
+        const bool has_ray = ray_id >= 0 && !done;
         const bool want_tri = has_ray && ref >= 0;
         const unsigned long long m_free = __ballot(!has_ray);
         const int n_free = __popcll(m_free);
         if (n_free == 64 && exhausted) break;
 
-        // ---- refill ---------------------------------------------------------------------------------------------
-        if (!exhausted && (n_free >= kRefillAt)) {
+        // ---- refill (finished lanes first write their results: stores count against vmcnt on gfx9-family
+        // hardware, so a store inside the stepping loop would make every following load-wait pay its latency) ---------------------------------------------------------------------------------------------
+        if (!exhausted && (n_free >= refill_at)) {
             while (pool_next >= pool_end && !exhausted) {          // fetch a chunk: one atomic per `chunk` rays
                 int base = 0;
                 if (threadIdx.x == 0) base = atomicAdd(band_cursors + band, chunk);
@@ -335,6 +343,7 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
                 else { band = (band + 1) & (kBands - 1); if (--bands_left == 0) exhausted = true; }
             }
             const int take = min(n_free, pool_end - pool_next);
+            if (done) { nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f); done = false; ray_id = -1; }
             if (!has_ray) {
                 const int rank = __builtin_amdgcn_mbcnt_hi(unsigned(m_free >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m_free), 0));
                 if (rank < take) {
@@ -419,12 +428,11 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
                 finished = ref < 0 && (hit_t <= texit || outside);
             }
         }
-        if (finished) {
-            nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-            ray_id = -1; ref = -1;
-        }
+        if (finished) { done = true; ref = -1; }
     }
+    if (done) nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
 }
+
 
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
@@ -492,10 +500,12 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         chunk = std::max(64, std::min(1024, (chunk + 63) & ~63));
         const char* benv = getenv("HAGRID_BOTH");
         const int both = benv ? atoi(benv) : 0;
+        const char* renv = getenv("HAGRID_REFILL");
+        const int refill_at = renv ? atoi(renv) : kRefillAt;
         int* cursors = ctx->dscratch + 240;                  // 8 band cursors
         HG_HIP(ctx, hipMemsetAsync(cursors, 0, 8 * sizeof(int), ctx->stream));
-        if (grid->small_cells) traverse_kernel_v3<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both);
-        else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both);
+        if (grid->small_cells) traverse_kernel_v3<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
+        else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
     }
     HG_HIP(ctx, hipGetLastError());
     return HAGRID_OK;

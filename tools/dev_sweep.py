@@ -21,6 +21,7 @@ for kind, sizes in SIZES:
         for c in configs:
             os.environ["HAGRID_TRAVERSE_VARIANT"] = str(c["v"])
             os.environ["HAGRID_BOTH"] = str(c.get("BOTH", 0)); os.environ["HAGRID_WAVES_PER_CU"] = str(c.get("WAVES", 32))
+            os.environ["HAGRID_REFILL"] = str(c.get("REFILL", 12))
             if "CHUNK" in c: os.environ["HAGRID_CHUNK"] = str(c["CHUNK"])
             else: os.environ.pop("HAGRID_CHUNK", None)
             for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
