@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--build-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 for primary rays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
     args = ap.parse_args()
@@ -114,6 +115,8 @@ def main():
         rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, n_rays, scene.RAY_SEED_BASE + 4, first=rank * n_rays)
     d_rays = mem.upload(rays)
     d_hits = mem.alloc(16 * n_rays)
+    bin_rays = (1 if args.rays == "incoherent" else 0) if args.bin_rays is None else args.bin_rays
+    mem.set_ray_binning(bin_rays)
     api.setup_traversal(grid)
 
     # exact algorithmic byte counters of this batch (outside the timed region)
@@ -164,7 +167,7 @@ def main():
             "config": {"workload": f"soup-{n_tris} triangles, {args.rays} rays {args.width}x{args.height} per GPU"
                                    f" (BASELINE.json configs[1]), td {args.top_density} sd {args.snd_density} alpha {args.alpha} exp {args.expansion}"
                                    + (" compress" if args.compress else ""),
-                       "rays_per_gpu": n_rays, "triangles": n_tris, "parallelism": f"ray-sharded x{world}, grid broadcast once",
+                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "parallelism": f"ray-sharded x{world}, grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),
             "grid_broadcast_ms": round(t_bcast, 3),

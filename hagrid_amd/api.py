@@ -73,6 +73,10 @@ class MemManager:
         """Enqueue all further work on a hipStream_t given as an integer (e.g. torch's cuda_stream)."""
         _check(self, self._L.hagrid_ctx_set_stream(self._ctx, C.c_void_p(stream or 0)), "set_stream")
 
+    def set_ray_binning(self, mode: int):
+        """Extension: 1 = bin each ray batch by grid-entry position before traversal (for incoherent batches)."""
+        _check(self, self._L.hagrid_set_ray_binning(self._ctx, int(mode)), "set_ray_binning")
+
     def device_info(self) -> dict:
         name = C.create_string_buffer(128); cus = C.c_int(); mem = C.c_int64()
         _check(self, self._L.hagrid_device_info(self._ctx, name, 128, C.byref(cus), C.byref(mem)), "device_info")

@@ -39,6 +39,9 @@ struct hagrid_ctx {
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
 
+    // traversal options (hagrid_set_ray_binning)
+    int ray_binning = 0;
+
     std::string err;
 };
 

@@ -10,6 +10,7 @@
 // grids / contexts can traverse concurrently.  Ray and hit records are 32 B / 16 B per lane and are
 // moved as 16-byte vector accesses.  See DESIGN.md for the algorithmic-byte accounting.
 #include "ctx.h"
+#include "wave_prims.h"
 
 #include <cstdlib>
 
@@ -31,6 +32,7 @@ struct TraverseArgs {
     float4* __restrict__ hits;
     int* __restrict__ steps;                 // optional per-ray step counter
     unsigned long long* __restrict__ stats;  // optional 7 batch counters
+    const int* __restrict__ perm;            // optional traversal order (ray binning): slot i processes ray perm[i]
     int num_rays;
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
@@ -201,8 +203,9 @@ __global__ void __launch_bounds__(BLOCK) traverse_kernel_v2(const TraverseArgs a
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int id = b * BLOCK + threadIdx.x;
-    if (id >= a.num_rays) return;
+    const int slot = b * BLOCK + threadIdx.x;
+    if (slot >= a.num_rays) return;
+    const int id = a.perm ? a.perm[slot] : slot;
 
     const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
     const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
@@ -434,6 +437,75 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
 }
 
 
+
+// ---- ray binning (extension; north_star: "ray packets sorted ... to tame divergence") ----------------------------------
+// A batch without spatial order (random origins and directions) makes every load of a wavefront touch 64 unrelated cache
+// lines.  Measured on MI355X (tools/dev_sort_potential.py): ordering such a batch by a coarse Morton key of the ray's
+// position -- 8 x 8 x 8 bins are enough, the direction octant does not matter -- lifts traversal from 1.0 to 2.3-2.6
+// Grays/s.  So the device does a counting sort on 512 bins, not a general sort:
+//   ray_bin_count   : key = Morton3(entry point of the ray into the grid box, 3 bits per axis); per-workgroup histogram in
+//                     LDS, written to table[bin][workgroup]
+//   device_scan     : exclusive scan of the table in (bin, workgroup) order = first slot of every (bin, workgroup) run
+//   ray_bin_scatter : slot = run start + rank inside the run (LDS atomic), perm[slot] = ray index
+// The order inside a bin is irrelevant.  No global atomics; one extra 4-byte word per ray.
+constexpr int kBinBits = 3;
+constexpr int kBins = 1 << (3 * kBinBits);
+constexpr int kBinItems = 16;                       // rays per thread
+constexpr int kBinTile = kBlock * kBinItems;        // rays per workgroup
+
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {   // 3 bits -> every third bit
+    return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4);
+}
+
+__device__ __forceinline__ int ray_bin_key(const TraverseArgs& a, int id) {
+    const float4 r0 = a.rays[2 * size_t(id)], r1 = a.rays[2 * size_t(id) + 1];
+    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+    const vec3 t0 = min(ta, tb);
+    float ts = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), r0.w);
+    if (!(ts == ts) || ts > 3.0e38f || ts < -3.0e38f) ts = 0.0f;
+    const vec3 p = (ts * dir + org - gmin) / (gmax - gmin) * float(1 << kBinBits);
+    const int m = (1 << kBinBits) - 1;
+    const int x = min(max(int(detail::fmin2(detail::fmax2(p.x, 0.0f), float(m))), 0), m);
+    const int y = min(max(int(detail::fmin2(detail::fmax2(p.y, 0.0f), float(m))), 0), m);
+    const int z = min(max(int(detail::fmin2(detail::fmax2(p.z, 0.0f), float(m))), 0), m);
+    return int(spread3(uint32_t(x)) | (spread3(uint32_t(y)) << 1) | (spread3(uint32_t(z)) << 2));
+}
+
+__global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, unsigned short* __restrict__ keys, int* __restrict__ table) {
+    __shared__ int hist[kBins];
+    for (int i = threadIdx.x; i < kBins; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kBinTile;
+    for (int j = 0; j < kBinItems; j++) {
+        const int id = base + j * kBlock + threadIdx.x;
+        if (id < a.num_rays) {
+            const int k = ray_bin_key(a, id);
+            keys[id] = (unsigned short)k;
+            atomicAdd(&hist[k], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBins; i += kBlock) table[size_t(i) * gridDim.x + blockIdx.x] = hist[i];
+}
+
+__global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* __restrict__ keys, const int* __restrict__ table_scan,
+                                                          int num_rays, int* __restrict__ perm) {
+    __shared__ int cursor[kBins];
+    for (int i = threadIdx.x; i < kBins; i += kBlock) cursor[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * kBinTile;
+    for (int j = 0; j < kBinItems; j++) {
+        const int id = base + j * kBlock + threadIdx.x;
+        if (id < num_rays) perm[atomicAdd(&cursor[keys[id]], 1)] = id;
+    }
+}
+
+struct TableIn { const int* t; __device__ int operator()(int i) const { return t[i]; } };
+struct TableOut { int* t; __device__ void operator()(int i, int s) const { t[i] = s; } };
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -450,7 +522,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.tris = static_cast<const float4*>(tris);
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
-    a.steps = nullptr; a.stats = nullptr;
+    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr;
     a.num_rays = num_rays; a.shift = g->shift;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
@@ -475,13 +547,34 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
+    int* perm = nullptr;
+    unsigned short* bin_keys = nullptr;
+    int* bin_table = nullptr;
+    int* bin_partials = nullptr;
+    if (ctx->ray_binning && num_rays > kBinTile) {
+        const int tiles = grid_blocks(num_rays, kBinTile);
+        const int table_n = kBins * tiles;
+        perm = pool_alloc<int>(ctx, size_t(num_rays));
+        bin_keys = pool_alloc<unsigned short>(ctx, size_t(num_rays));
+        bin_table = pool_alloc<int>(ctx, size_t(table_n));
+        bin_partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(table_n)) + 1);
+        if (!perm || !bin_keys || !bin_table || !bin_partials) {
+            hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
+            return HAGRID_ENOMEM;
+        }
+        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table);
+        device_scan<int>(ctx->stream, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
+        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm);
+        a.perm = perm;
+    }
     // Kernel choice.  Small batches (a few rays per resident lane) end when their longest ray ends: the latency-
     // oriented v2 wins.  Large batches are throughput-bound: the persistent, vote-scheduled v3 wins (measured
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
     // HAGRID_TRAVERSE_VARIANT (1 = plain reference-shaped kernel, 2, 3) overrides for experiments.
     const char* venv = getenv("HAGRID_TRAVERSE_VARIANT");
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
-    const int variant = venv ? atoi(venv) : (num_rays >= 24 * lanes ? 3 : 2);
+    int variant = venv ? atoi(venv) : (num_rays >= 24 * lanes ? 3 : 2);
+    if (perm) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
     if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -508,6 +601,17 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
     }
     HG_HIP(ctx, hipGetLastError());
+    if (perm) {
+        // the pool hands these buffers to nobody else before the kernels above are done: in keep mode free() only marks
+        // the slot (work of one context is stream-ordered), without keep mode free() synchronises the stream first
+        hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
+    }
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) return HAGRID_EINVAL;
+    ctx->ray_binning = mode;
     return HAGRID_OK;
 }
 

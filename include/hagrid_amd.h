@@ -130,6 +130,13 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
                                const void* rays, void* hits, int num_rays,
                                void* steps, hagrid_traversal_stats* stats);
 
+/* Extension (no reference counterpart): spatial binning of the ray batch before traversal.  mode 0 (default): rays
+ * are traversed in buffer order, as the reference does.  mode 1: each hagrid_traverse_grid call first bins the rays by
+ * the position where they enter the grid (512 Morton-ordered bins, counting sort on the device) and traverses them in
+ * bin order; hits are written to the rays' original slots, results are identical.  Pays for batches without spatial
+ * order (random origins / directions: ~2.3x); costs a few percent on batches that are already coherent. */
+int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
+
 /* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */
 /* Each evaluates the named device function for n inputs (host arrays in, host arrays out). */
 int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,

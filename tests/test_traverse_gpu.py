@@ -153,3 +153,34 @@ def test_mem_manager_contract(mem):
     ms = api.profile(lambda: None, m)
     assert ms >= 0
     m.close()
+
+
+def test_ray_binning_gives_identical_hits(mem):
+    """Extension hagrid_set_ray_binning: same hits in the same slots, for unordered and for ordered batches."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(60000)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    batches = [scene.make_rays_incoherent(G.bbox_min - 0.3, G.bbox_max + 0.3, 300001, 21),      # some start outside / miss
+               scene.make_rays_primary(G.bbox_min, G.bbox_max, 512, 384),                          # one shared origin
+               scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 5000, 22)]                       # below one tile: not binned
+    batches[0][:100, 4:7] = 0.0                                                                     # degenerate directions
+    try:
+        for rays in batches:
+            mem.set_ray_binning(0)
+            plain = gpu_traverse(mem, grid, d_tris, rays)
+            mem.set_ray_binning(1)
+            binned = gpu_traverse(mem, grid, d_tris, rays)
+            assert (plain["id"] == binned["id"]).all() and (bits(plain["t"]) == bits(binned["t"])).all()
+        oh, _ = G.traverse(tris, batches[0], nthreads=8)
+        assert (binned["id"] == plain["id"]).all()
+        mem.set_ray_binning(1)
+        b0 = gpu_traverse(mem, grid, d_tris, batches[0])
+        assert (b0["id"] == oh["id"]).all() and (bits(b0["t"]) == bits(oh["t"])).all()
+    finally:
+        mem.set_ray_binning(0)
+    with pytest.raises(api.HagridError):
+        mem.set_ray_binning(7)
+    grid.free(); mem.free(d_tris)
