@@ -197,7 +197,7 @@ __device__ __forceinline__ void nt_store4(float4* p, float x, float y, float z, 
 }
 
 template <bool SMALL, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) traverse_kernel_v2(const TraverseArgs a) {
+__global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
     int b = blockIdx.x;
     {   // bijective remap: blocks are dispatched round-robin over the 8 XCDs
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
