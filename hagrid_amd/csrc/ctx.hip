@@ -135,6 +135,7 @@ extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
 extern "C" int hagrid_mem_copy_h2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HAGRID_OK;
@@ -142,6 +143,7 @@ extern "C" int hagrid_mem_copy_h2d(hagrid_ctx* ctx, void* dst, const void* src, 
 extern "C" int hagrid_mem_copy_d2h(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HAGRID_OK;
@@ -182,6 +184,7 @@ extern "C" void hagrid_mem_debug_slots(const hagrid_ctx* ctx) {
 
 extern "C" int hagrid_profile_begin(hagrid_ctx* ctx) {
     if (!ctx) return HAGRID_EINVAL;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     return HAGRID_OK;
 }

@@ -547,6 +547,7 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     int* perm = nullptr;
     unsigned short* bin_keys = nullptr;
     int* bin_table = nullptr;
@@ -623,6 +624,7 @@ extern "C" int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* gr
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (stats) memset(stats, 0, sizeof(*stats));
     if (num_rays == 0) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long* dstats = nullptr;
     if (stats) {
         dstats = pool_alloc<unsigned long long>(ctx, 8);

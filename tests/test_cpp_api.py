@@ -119,3 +119,71 @@ def test_cpp_program_through_the_headers_on_gpu():
         sys.stdout.write(r.stdout)
         assert r.returncode == 0, r.stdout + r.stderr
         assert " 0 mismatches" in r.stdout
+
+
+def _build_cli(d):
+    import torch
+    hip_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    exe = os.path.join(d, "hagrid_cli")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DHOST=", "-DDEVICE=", "-I", INC, os.path.join(ROOT, "tools", "hagrid_cli.cpp"),
+                    "-o", exe, "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-L", hip_lib, "-lamdhip64",
+                    "-Wl,-rpath," + os.path.join(ROOT, "hagrid_amd"), "-Wl,-rpath," + hip_lib, "-Wl,--allow-shlib-undefined"], check=True)
+    return exe
+
+
+def test_cli_usage_and_option_errors_need_no_gpu():
+    with tempfile.TemporaryDirectory() as d:
+        exe = _build_cli(d)
+        r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+        assert r.returncode == 0 and "--top-density" in r.stdout and "--ray-file" in r.stdout and "--compress" in r.stdout
+        r = subprocess.run([exe, "--bogus", "x.obj"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Unknown argument: --bogus" in r.stderr
+        r = subprocess.run([exe, "-td"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Argument missing for: -td" in r.stderr
+        r = subprocess.run([exe, "-k"], capture_output=True, text=True)
+        assert r.returncode == 1 and "No model specified" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_obj_scene_and_ray_file_benchmark():
+    """OBJ scene + .rays file through the CLI; the intersection count equals the Python API's."""
+    import numpy as np
+    from hagrid_amd import api, scene
+    tris = scene.make_soup(5000)
+    v0 = tris[:, 0:3]; v1 = v0 - tris[:, 4:7]; v2 = v0 + tris[:, 8:11]
+    with tempfile.TemporaryDirectory() as d:
+        exe = _build_cli(d)
+        obj = os.path.join(d, "soup.obj")
+        with open(obj, "w") as f:
+            f.write("# soup\n")
+            for a, b, c in zip(v0, v1, v2):
+                for p in (a, b, c):
+                    f.write("v %r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+            for i in range(tris.shape[0]):
+                # mix absolute, v/vt/vn and negative (relative to the END of the vertex list) index forms
+                if i % 3 == 0: f.write(f"f {3*i+1} {3*i+2} {3*i+3}\n")
+                elif i % 3 == 1: f.write(f"f {3*i+1}/1/1 {3*i+2}/1/1 {3*i+3}/1/1\n")
+                else: f.write(f"f {3*i+1-3*5000-1} {3*i+2-3*5000-1} {3*i+3-3*5000-1}\n")
+        mem = api.MemManager(keep=True)
+        # the OBJ round trip re-derives e1, e2, n from printed vertices: build the reference result from the same vertices
+        t2 = scene.tris_from_vertices(v0, v1.astype(np.float32), v2.astype(np.float32))
+        d_tris = mem.upload(t2)
+        grid = api.build_all(mem, d_tris, t2.shape[0])
+        rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 50000, 5)
+        rays[:, 3] = 0.0; rays[:, 7] = scene.FLT_MAX
+        rfile = os.path.join(d, "soup.rays")
+        np.ascontiguousarray(rays[:, [0, 1, 2, 4, 5, 6]]).tofile(rfile)
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+        want = int((mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])["id"] >= 0).sum())
+        r = subprocess.run([exe, obj, "-r", rfile, "-n", "3", "-w", "1", "-k", "-nb", "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "5000 triangle(s)" in r.stdout and "Grid built in " in r.stdout and "Entering benchmark mode" in r.stdout
+        assert f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
+        assert f"{want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout and "# Median: " in r.stdout
+        # synthetic scene + compression + one traced frame written as an image
+        img = os.path.join(d, "frame.pgm")
+        r = subprocess.run([exe, "soup:20000", "-z", "-sx", "256", "-sy", "128", "-o", img], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "20000 triangle(s)" in r.stdout and "Tracing one 256x128 frame" in r.stdout
+        assert os.path.getsize(img) == len("P5\n256 128\n255\n") + 256 * 128
+        mem.close()

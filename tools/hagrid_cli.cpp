@@ -1,0 +1,270 @@
+// hagrid_cli -- command-line front-end over include/hagrid/*.h with the option names, defaults and output lines of
+// the reference's `hagrid` executable (src/main.cpp:113-244 options, :469 / :512-533 build report, :434-444 benchmark
+// report), minus the SDL viewer: without a ray file it traces ONE frame of primary rays (gen_camera / gen_rays formulas,
+// main.cpp:42-66) and can write it as a PGM depth image instead of opening a window.
+//
+// SURVEY.md 8(f) rows 1 and 2 ("next" rows): CLI parity and a Wavefront OBJ reader (vertices + faces, fan triangulation,
+// negative indices, v/vt/vn index forms), so that logs of the two binaries can be compared line by line.
+// Extension: a model name of the form soup:N generates the synthetic triangle soup of BASELINE.md instead of reading a file.
+//
+//   g++ -std=c++11 -O2 -DHOST= -DDEVICE= -Iinclude tools/hagrid_cli.cpp -o hagrid_cli -Lhagrid_amd -lhagrid_amd -lamdhip64
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "hagrid/build.h"
+#include "hagrid/mem_manager.h"
+#include "hagrid/traverse.h"
+
+using namespace hagrid;
+
+namespace {
+
+struct Options {
+    std::string scene, ray_file, out_image;
+    float top_density = 0.12f, snd_density = 2.4f, alpha = 0.995f;
+    int exp_iters = 3, width = 1024, height = 1024;
+    float clip = 0, fov = 60;
+    int build_iter = 1, build_warmup = 0, bench_iter = 1, bench_warmup = 0;
+    float tmin = 0, tmax = FLT_MAX;
+    bool keep_alive = false, compress = false, help = false;
+};
+
+enum Kind { FLAG, INT, FLOAT, STRING };
+struct OptDesc { const char* s; const char* l; Kind kind; void* dst; const char* text; };
+
+bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
+    table = {
+        {"-h", "--help", FLAG, &o.help, "Shows this message"},
+        {"-sx", "--width", INT, &o.width, "Sets the viewport width"},
+        {"-sy", "--height", INT, &o.height, "Sets the viewport height"},
+        {"-c", "--clip", FLOAT, &o.clip, "Sets the clipping distance"},
+        {"-f", "--fov", FLOAT, &o.fov, "Sets the field of view"},
+        {"-td", "--top-density", FLOAT, &o.top_density, "Sets the top-level density"},
+        {"-sd", "--snd-density", FLOAT, &o.snd_density, "Sets the second-level density"},
+        {"-a", "--alpha", FLOAT, &o.alpha, "Sets the cell merging threshold"},
+        {"-e", "--expansion", INT, &o.exp_iters, "Sets the number of expansion iterations"},
+        {"-nb", "--build-iter", INT, &o.build_iter, "Sets the number of build iterations"},
+        {"-wb", "--build-warmup", INT, &o.build_warmup, "Sets the number of warmup build iterations"},
+        {"-k", "--keep-alive", FLAG, &o.keep_alive, "Keep the buffers alive during construction"},
+        {"-z", "--compress", FLAG, &o.compress, "Compress the cells after construction"},
+        {"-r", "--ray-file", STRING, &o.ray_file, "Loads rays from a file and enters benchmark mode"},
+        {"-tmin", "--tmin", FLOAT, &o.tmin, "Sets the minimum distance along every ray"},
+        {"-tmax", "--tmax", FLOAT, &o.tmax, "Sets the maximum distance along every ray"},
+        {"-n", "--bench-iter", INT, &o.bench_iter, "Sets the number of benchmarking iterations"},
+        {"-w", "--bench-warmup", INT, &o.bench_warmup, "Sets the number of benchmarking warmup iterations"},
+        {"-o", "--out", STRING, &o.out_image, "(extension) writes the traced frame as a PGM depth image"},
+    };
+    bool have_scene = false;
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        if (a[0] != '-') {
+            if (have_scene) { std::cerr << "Cannot accept more than one model on the command line" << std::endl; return false; }
+            o.scene = a; have_scene = true;
+            continue;
+        }
+        const OptDesc* d = nullptr;
+        for (const auto& t : table) if (!strcmp(a, t.s) || !strcmp(a, t.l)) d = &t;
+        if (!d) { std::cerr << "Unknown argument: " << a << std::endl; return false; }
+        if (d->kind == FLAG) { *static_cast<bool*>(d->dst) = true; continue; }
+        if (i >= argc - 1 || (argv[i + 1][0] == '-' && d->kind == STRING)) { std::cerr << "Argument missing for: " << a << std::endl; return false; }
+        const char* v = argv[++i];
+        if (d->kind == INT) *static_cast<int*>(d->dst) = int(strtol(v, nullptr, 10));
+        else if (d->kind == FLOAT) *static_cast<float*>(d->dst) = strtof(v, nullptr);
+        else *static_cast<std::string*>(d->dst) = v;
+    }
+    if (!have_scene && !o.help) { std::cerr << "No model specified" << std::endl; return false; }
+    return true;
+}
+
+void usage(const std::vector<OptDesc>& table) {
+    std::cout << "Usage: hagrid [options] file\nOptions:\n";
+    for (const auto& t : table) printf("  %-7s %-15s %s\n", t.s, t.l, t.text);
+    std::cout << std::endl;
+}
+
+Tri make_tri(const vec3& v0, const vec3& v1, const vec3& v2) {     // packing of main.cpp:259-267
+    const vec3 e1 = v0 - v1, e2 = v2 - v0, n = cross(e1, e2);
+    return Tri(v0, n.x, e1, n.y, e2, n.z);
+}
+
+// Wavefront OBJ: "v x y z" and "f i[/t[/n]] ..." lines; polygons are triangulated as a fan around their first vertex
+// (what main.cpp:253-270 does with the loader's faces); negative indices count from the end.
+bool load_obj(const std::string& name, std::vector<Tri>& tris) {
+    std::ifstream in(name);
+    if (!in) return false;
+    std::vector<vec3> verts;
+    std::string line;
+    while (std::getline(in, line)) {
+        size_t p = line.find_first_not_of(" \t\r");
+        if (p == std::string::npos || line[p] == '#') continue;
+        if (line.compare(p, 2, "v ") == 0 || line.compare(p, 2, "v\t") == 0) {
+            std::istringstream ss(line.substr(p + 2));
+            vec3 v(0.0f);
+            ss >> v.x >> v.y >> v.z;
+            verts.push_back(v);
+        } else if (line.compare(p, 2, "f ") == 0 || line.compare(p, 2, "f\t") == 0) {
+            std::istringstream ss(line.substr(p + 2));
+            std::string tok;
+            std::vector<int> idx;
+            while (ss >> tok) {
+                long i = strtol(tok.c_str(), nullptr, 10);          // stops at '/'
+                if (i == 0) return false;
+                i = i < 0 ? long(verts.size()) + i : i - 1;
+                if (i < 0 || i >= long(verts.size())) return false;
+                idx.push_back(int(i));
+            }
+            for (size_t k = 1; k + 1 < idx.size(); k++) tris.push_back(make_tri(verts[idx[0]], verts[idx[k]], verts[idx[k + 1]]));
+        }
+    }
+    return !tris.empty();
+}
+
+uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+float uniform01(uint64_t seed, uint64_t i) { return float(mix64(seed + (i + 1) * 0x9E3779B97F4A7C15ull) >> 40) * (1.0f / 16777216.0f); }
+
+void make_soup(int n, std::vector<Tri>& tris) {     // hagrid_amd/scene.py:make_soup, same bits
+    const uint64_t seed = 0x48414752494400ull + uint64_t(n);
+    const float s = float(std::pow(double(n), -1.0 / 3.0));
+    tris.resize(size_t(n));
+    for (int i = 0; i < n; i++) {
+        float u[9];
+        for (int j = 0; j < 9; j++) u[j] = uniform01(seed, uint64_t(i) * 9 + j);
+        const vec3 c(u[0], u[1], u[2]);
+        const vec3 a = (2.0f * vec3(u[3], u[4], u[5]) - vec3(1.0f)) * s, b = (2.0f * vec3(u[6], u[7], u[8]) - vec3(1.0f)) * s;
+        tris[i] = make_tri(c, c + a, c + b);
+    }
+}
+
+bool load_rays(const std::string& name, std::vector<Ray>& rays, float tmin, float tmax) {   // main.cpp:277-300 format
+    std::ifstream in(name, std::ifstream::binary);
+    if (!in) return false;
+    in.seekg(0, std::ifstream::end);
+    const size_t count = size_t(in.tellg()) / (sizeof(float) * 6);
+    in.seekg(0);
+    std::vector<float> raw(count * 6);
+    in.read(reinterpret_cast<char*>(raw.data()), std::streamsize(raw.size() * sizeof(float)));
+    rays.resize(count);
+    for (size_t i = 0; i < count; i++)
+        rays[i] = Ray(vec3(raw[6 * i], raw[6 * i + 1], raw[6 * i + 2]), tmin, vec3(raw[6 * i + 3], raw[6 * i + 4], raw[6 * i + 5]), tmax);
+    return true;
+}
+
+void report_timings(std::vector<double> t, size_t rays_per_iter, int intr) {    // main.cpp:434-444
+    std::sort(t.begin(), t.end());
+    const double sum = std::accumulate(t.begin(), t.end(), 0.0);
+    std::cout << intr << " intersection(s)." << std::endl;
+    std::cout << sum << "ms for " << t.size() << " iteration(s)." << std::endl;
+    std::cout << rays_per_iter * t.size() / (1000.0 * sum) << " Mrays/sec." << std::endl;
+    std::cout << "# Average: " << sum / t.size() << " ms" << std::endl;
+    std::cout << "# Median: " << t[t.size() / 2] << " ms" << std::endl;
+    std::cout << "# Min: " << t.front() << " ms" << std::endl;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+    Options opts;
+    std::vector<OptDesc> table;
+    if (argc < 2) { parse(1, argv, opts, table); usage(table); return 1; }
+    if (!parse(argc, argv, opts, table)) return 1;
+    if (opts.help) { usage(table); return 0; }
+
+    std::vector<Tri> host_tris;
+    if (opts.scene.compare(0, 5, "soup:") == 0) make_soup(atoi(opts.scene.c_str() + 5), host_tris);
+    else if (!load_obj(opts.scene, host_tris)) {
+        std::cerr << "Scene cannot be loaded (file not present or contains errors)" << std::endl;
+        return 1;
+    }
+    std::cout << host_tris.size() << " triangle(s)" << std::endl;
+
+    MemManager mem(opts.keep_alive);
+    Tri* tris = mem.alloc<Tri>(host_tris.size());
+    mem.copy<Copy::HST_TO_DEV>(tris, host_tris.data(), host_tris.size());
+
+    Grid grid;
+    grid.entries = nullptr; grid.cells = nullptr; grid.ref_ids = nullptr; grid.small_cells = nullptr;
+    auto construct = [&] {
+        build_grid(mem, tris, int(host_tris.size()), grid, opts.top_density, opts.snd_density);
+        merge_grid(mem, grid, opts.alpha);
+        flatten_grid(mem, grid);
+        expand_grid(mem, grid, tris, opts.exp_iters);
+        if (opts.compress) compress_grid(mem, grid);
+    };
+    auto release = [&] {
+        mem.free(grid.entries); mem.free(grid.cells); mem.free(grid.ref_ids); mem.free(grid.small_cells);
+        grid.entries = nullptr; grid.cells = nullptr; grid.ref_ids = nullptr; grid.small_cells = nullptr;
+    };
+    for (int i = 0; i < opts.build_warmup; i++) { release(); construct(); }
+    double total_time = 0;
+    for (int i = 0; i < opts.build_iter; i++) { release(); total_time += profile(construct); }
+    if (opts.compress && !grid.small_cells) std::cerr << "Could not compress grid. Continuing with uncompressed structure." << std::endl;
+
+    const ivec3 dims = grid.dims << grid.shift;
+    std::cout << "Grid built in " << total_time / opts.build_iter << " ms (" << dims.x << "x" << dims.y << "x" << dims.z << ", "
+              << grid.num_cells << " cells, " << grid.num_refs << " references)" << std::endl;
+    const size_t cells_mem = size_t(grid.num_cells) * (grid.small_cells ? sizeof(SmallCell) : sizeof(Cell));
+    const size_t entries_mem = size_t(grid.num_entries) * sizeof(int), refs_mem = size_t(grid.num_refs) * sizeof(int);
+    const size_t tris_mem = host_tris.size() * sizeof(Tri);
+    const double mb = 1024.0 * 1024.0;
+    std::cout << "Total memory: " << (cells_mem + entries_mem + refs_mem + tris_mem) / mb << " MB" << std::endl;
+    std::cout << "Cells: " << cells_mem / mb << " MB" << std::endl;
+    std::cout << "Entries: " << entries_mem / mb << " MB" << std::endl;
+    std::cout << "References: " << refs_mem / mb << " MB" << std::endl;
+    std::cout << "Triangles: " << tris_mem / mb << " MB" << std::endl;
+    std::cout << "Peak usage: " << mem.max_usage() / mb << " MB" << std::endl;
+
+    setup_traversal(grid);
+    const float scene_size = length(grid.bbox.extents());
+    const vec3 center = grid.bbox.center();
+    if (opts.clip <= 0) opts.clip = scene_size;
+
+    std::vector<Ray> host_rays;
+    if (!opts.ray_file.empty()) {
+        std::cout << "Entering benchmark mode" << std::endl;
+        if (!load_rays(opts.ray_file, host_rays, opts.tmin, opts.tmax)) { std::cerr << "Cannot load ray file" << std::endl; return 1; }
+    } else {
+        // one frame from the viewer's start position (main.cpp:543-556: eye on the -z side of the scene, looking at its centre)
+        std::cout << "Tracing one " << opts.width << "x" << opts.height << " frame (no interactive viewer in this front-end)" << std::endl;
+        const vec3 eye = center - vec3(0, 0, 1) * scene_size, up(0, 1, 0);
+        const float f = tanf(float(M_PI) * opts.fov / 360.0f), ratio = float(opts.width) / float(opts.height);
+        const vec3 dir = normalize(center - eye), right = normalize(cross(dir, up)) * (f * ratio), cup = normalize(cross(right, dir)) * f;
+        host_rays.resize(size_t(opts.width) * opts.height);
+        for (int y = 0; y < opts.height; y++)
+            for (int x = 0; x < opts.width; x++) {
+                const float kx = 2 * x / float(opts.width) - 1, ky = 1 - 2 * y / float(opts.height);
+                host_rays[size_t(y) * opts.width + x] = Ray(eye, 0.0f, dir + right * kx + cup * ky, opts.clip);
+            }
+    }
+    Ray* rays = mem.alloc<Ray>(host_rays.size());
+    Hit* hits = mem.alloc<Hit>(host_rays.size());
+    mem.copy<Copy::HST_TO_DEV>(rays, host_rays.data(), host_rays.size());
+    for (int i = 0; i < opts.bench_warmup; i++) traverse_grid(grid, tris, rays, hits, int(host_rays.size()));
+    std::vector<double> timings;
+    for (int i = 0; i < std::max(opts.bench_iter, 1); i++)
+        timings.push_back(profile([&] { traverse_grid(grid, tris, rays, hits, int(host_rays.size())); }));
+    std::vector<Hit> host_hits(host_rays.size());
+    mem.copy<Copy::DEV_TO_HST>(host_hits.data(), hits, host_hits.size());
+    int intr = 0;
+    for (const auto& h : host_hits) intr += h.id >= 0;
+    report_timings(timings, host_rays.size(), intr);
+
+    if (!opts.out_image.empty() && opts.ray_file.empty()) {
+        std::ofstream img(opts.out_image, std::ofstream::binary);
+        img << "P5\n" << opts.width << " " << opts.height << "\n255\n";
+        for (const auto& h : host_hits) img.put(char(h.id >= 0 ? std::min(255.0f, 255.0f * h.t / opts.clip) : 255));
+    }
+    mem.free(rays); mem.free(hits); release(); mem.free(tris);
+    return 0;
+}
