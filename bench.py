@@ -174,7 +174,8 @@ def main():
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "traverse_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": "traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2",
+                         "kernel_ms": round(kernel_ms, 5),
                          "bytes_per_ray": round(ab["B_ray"] / n_rays, 1),
                          "walk_achieved": round(ab["B_walk"] / (kernel_ms * 1e6), 1),
                          "walk_frac": round(ab["B_walk"] / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4)},
