@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 for primary rays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, broadcast, all-reduce) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -69,15 +70,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     device = local_rank if args.device is None else args.device
     torch.cuda.set_device(device)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=args.backend)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -101,7 +105,7 @@ def main():
             times.append(api.profile(lambda: build(grid), mem))
         build_ms = float(np.mean(times))
         log(f"[bench] grid {grid.summary()} build_ms {build_ms:.2f} (min {min(times):.2f})")
-    if world > 1:
+    if multi:
         barrier(); t0 = time.perf_counter()
         grid, d_tris = hdist.broadcast_grid(mem, grid, d_tris, n_tris, src=0)
         barrier(); t_bcast = (time.perf_counter() - t0) * 1e3
@@ -134,7 +138,7 @@ def main():
     kernel_ms_total = mem._L.hagrid_profile_end(mem._ctx)                    # waits for the last launch
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_total = float(t[0]), float(t[1])
@@ -200,7 +204,7 @@ def main():
                                    "sample": f"first {sample} rays of the batch x{reps}, oracle traversal of the GPU-built grid, {cores} threads"}
             out["parity"] = {"rays_checked": sample, "ids_identical": same_id, "t_bit_identical": same_t}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -88,3 +88,14 @@ def test_broadcast_grid_and_sharded_traversal():
     for rank, b, e, hid, ht, *_ in res:
         assert (hid == want["id"][b:e]).all() and (ht.view(np.uint32) == want["t"][b:e].view(np.uint32)).all()
     mem.close()
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The RCCL code path (process group on backend nccl, barrier, grid broadcast, all-reduce) with world size 1."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--tris", "100000",
+           "--width", "512", "--height", "512", "--build-iter", "1", "--force-dist", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["grid_broadcast_ms"] >= 0
