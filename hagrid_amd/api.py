@@ -77,6 +77,10 @@ class MemManager:
         """Extension: 1 = bin each ray batch by grid-entry position before traversal (for incoherent batches)."""
         _check(self, self._L.hagrid_set_ray_binning(self._ctx, int(mode)), "set_ray_binning")
 
+    def set_option(self, key: str, value: int):
+        """Tuning knobs for experiments/tests (include/hagrid_amd.h: hagrid_set_option); results never depend on them."""
+        _check(self, self._L.hagrid_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+
     def device_info(self) -> dict:
         name = C.create_string_buffer(128); cus = C.c_int(); mem = C.c_int64()
         _check(self, self._L.hagrid_device_info(self._ctx, name, 128, C.byref(cus), C.byref(mem)), "device_info")

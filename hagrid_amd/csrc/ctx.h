@@ -39,8 +39,13 @@ struct hagrid_ctx {
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
 
-    // traversal options (hagrid_set_ray_binning)
+    // traversal options (hagrid_set_ray_binning, hagrid_set_option)
     int ray_binning = 0;
+    int opt_variant = 0;        // 0 = choose by batch size, 1 / 2 / 3 = force that kernel
+    int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
+    int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
+    int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
+    int opt_refill_at = 12;     // persistent kernel: free lanes that trigger a refill
 
     std::string err;
 };

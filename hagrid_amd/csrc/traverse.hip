@@ -13,6 +13,7 @@
 #include "wave_prims.h"
 
 #include <cstdlib>
+#include <cstring>
 
 #include "hagrid/grid.h"
 #include "hagrid/prims.h"
@@ -301,7 +302,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
 // finish at its own pace.  A batch of a few rays per lane ends when its longest rays end and is 2.7x slower here
 // (measured: 1M primary rays 0.40 ms with v2, 1.1 ms with any persistent variant -- also with v2's cell step inside
 // the persistent loop, with deferred stores, with any refill threshold or chunk size; profiles/dev_r1_variant_sweep.txt).
-constexpr int kRefillAt = 12;
 constexpr int kBands = 8;           // one ray band + cursor per XCD (private L2 each)
 
 template <bool SMALL>
@@ -568,13 +568,12 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm);
         a.perm = perm;
     }
-    // Kernel choice.  Small batches (a few rays per resident lane) end when their longest ray ends: the latency-
+    // Kernel choice.  Small batches (a few rays per resident lane) end when their longest rays end: the latency-
     // oriented v2 wins.  Large batches are throughput-bound: the persistent, vote-scheduled v3 wins (measured
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
-    // HAGRID_TRAVERSE_VARIANT (1 = plain reference-shaped kernel, 2, 3) overrides for experiments.
-    const char* venv = getenv("HAGRID_TRAVERSE_VARIANT");
+    // hagrid_set_option("traverse.variant", 1|2|3) forces a kernel (tests, experiments).
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
-    int variant = venv ? atoi(venv) : (num_rays >= 24 * lanes ? 3 : 2);
+    int variant = ctx->opt_variant ? ctx->opt_variant : (num_rays >= 24 * lanes ? 3 : 2);
     if (perm) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
     if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
@@ -585,17 +584,11 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         if (grid->small_cells) traverse_kernel_v2<true, 64><<<blocks, 64, 0, ctx->stream>>>(a);
         else                   traverse_kernel_v2<false, 64><<<blocks, 64, 0, ctx->stream>>>(a);
     } else {
-        const char* wenv = getenv("HAGRID_WAVES_PER_CU");
-        const int waves_per_cu = wenv ? atoi(wenv) : 32;
-        const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * waves_per_cu);
+        const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
         // rays per cursor atomic: a few chunks per wave for balance, at least one wave-load, at most 1024
-        const char* cenv = getenv("HAGRID_CHUNK");
-        int chunk = cenv ? atoi(cenv) : (num_rays / (blocks * 4));
+        int chunk = ctx->opt_chunk ? ctx->opt_chunk : (num_rays / (blocks * 4));
         chunk = std::max(64, std::min(1024, (chunk + 63) & ~63));
-        const char* benv = getenv("HAGRID_BOTH");
-        const int both = benv ? atoi(benv) : 0;
-        const char* renv = getenv("HAGRID_REFILL");
-        const int refill_at = renv ? atoi(renv) : kRefillAt;
+        const int both = ctx->opt_both_phases, refill_at = ctx->opt_refill_at;
         int* cursors = ctx->dscratch + 240;                  // 8 band cursors
         HG_HIP(ctx, hipMemsetAsync(cursors, 0, 8 * sizeof(int), ctx->stream));
         if (grid->small_cells) traverse_kernel_v3<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
@@ -608,6 +601,22 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
     }
     return HAGRID_OK;
+}
+
+extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return HAGRID_EINVAL;
+    struct { const char* name; int* dst; int lo, hi; } table[] = {
+        {"traverse.variant", &ctx->opt_variant, 0, 3},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
+        {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
+        {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},
+    };
+    for (auto& t : table)
+        if (!strcmp(key, t.name)) {
+            if (value < t.lo || value > t.hi) HG_FAIL(ctx, HAGRID_EINVAL, "set_option: value out of range");
+            *t.dst = value;
+            return HAGRID_OK;
+        }
+    HG_FAIL(ctx, HAGRID_EINVAL, "set_option: unknown key");
 }
 
 extern "C" int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode) {

@@ -137,6 +137,12 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
  * order (random origins / directions: ~2.3x); costs a few percent on batches that are already coherent. */
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
+/* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
+ * kernel by batch size, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled),
+ * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at".  Returns HAGRID_EINVAL for an
+ * unknown key or a value out of range.  Results never depend on these settings. */
+int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
+
 /* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */
 /* Each evaluates the named device function for n inputs (host arrays in, host arrays out). */
 int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,

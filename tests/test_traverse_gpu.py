@@ -184,3 +184,38 @@ def test_ray_binning_gives_identical_hits(mem):
     with pytest.raises(api.HagridError):
         mem.set_ray_binning(7)
     grid.free(); mem.free(d_tris)
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
+    """The three kernels (plain v1, latency-oriented v2, persistent vote-scheduled v3) and v3's tuning knobs: forced through
+    hagrid_set_option, each must reproduce the oracle bit for bit -- including batches that are not a multiple of the
+    wavefront size and batches smaller than the persistent grid."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(80000)
+    G = O.Grid.full(tris, compress=compressed)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 640, 480),
+                           scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 200003, 31)]).astype(np.float32)
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 3},
+                {"traverse.variant": 3, "traverse.both_phases": 1}, {"traverse.variant": 3, "traverse.refill_at": 1, "traverse.chunk": 64},
+                {"traverse.variant": 3, "traverse.refill_at": 64, "traverse.waves_per_cu": 2, "traverse.chunk": 1024}]
+    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 12, "traverse.chunk": 0, "traverse.waves_per_cu": 32}
+    try:
+        for st in settings:
+            for k, v in {**defaults, **st}.items():
+                mem.set_option(k, v)
+            for n in (rays.shape[0], 64, 63, 1, 4097):
+                got = gpu_traverse(mem, grid, d_tris, rays[:n])
+                assert (got["id"] == want["id"][:n]).all() and (bits(got["t"]) == bits(want["t"][:n])).all(), (st, n)
+    finally:
+        for k, v in defaults.items():
+            mem.set_option(k, v)
+    with pytest.raises(api.HagridError):
+        mem.set_option("traverse.variant", 9)
+    with pytest.raises(api.HagridError):
+        mem.set_option("no.such.key", 1)
+    grid.free(); mem.free(d_tris)

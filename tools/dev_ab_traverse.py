@@ -20,7 +20,7 @@ for name, rays in sets.items():
     ref = None; times = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
-            os.environ["HAGRID_TRAVERSE_VARIANT"] = str(v)
+            mem.set_option("traverse.variant", v)
             ms = api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n))
             if r: times[v].append(ms)
             if r == 1:

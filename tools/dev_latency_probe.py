@@ -14,7 +14,7 @@ api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n, d_steps)
 steps = mem.download(d_steps, np.int32, n)
 print("steps: mean", steps.mean(), "max", steps.max(), "p99.9", np.percentile(steps, 99.9))
 def timeit(ptr, cnt, variant, reps=7):
-    os.environ["HAGRID_TRAVERSE_VARIANT"] = str(variant)
+    mem.set_option("traverse.variant", variant)
     for _ in range(2): api.traverse_grid(grid, d_tris, ptr, d_hits, cnt)
     t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, ptr, d_hits, cnt)) for _ in range(reps))
     return t[len(t) // 2]

@@ -21,7 +21,7 @@ def keys(res_bits):
     octant = (rays[:, 4] < 0).astype(np.uint32) | ((rays[:, 5] < 0).astype(np.uint32) << 1) | ((rays[:, 6] < 0).astype(np.uint32) << 2)
     return m, octant
 def bench(r, variant):
-    os.environ["HAGRID_TRAVERSE_VARIANT"] = str(variant)
+    mem.set_option("traverse.variant", variant)
     d_rays = mem.upload(r); d_hits = mem.alloc(16 * n)
     for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
     t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(5))

@@ -19,11 +19,10 @@ for kind, sizes in SIZES:
         n = rays.shape[0]; d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
         row = {"rays": kind, "n": n}
         for c in configs:
-            os.environ["HAGRID_TRAVERSE_VARIANT"] = str(c["v"])
-            os.environ["HAGRID_BOTH"] = str(c.get("BOTH", 0)); os.environ["HAGRID_WAVES_PER_CU"] = str(c.get("WAVES", 32))
-            os.environ["HAGRID_REFILL"] = str(c.get("REFILL", 12))
-            if "CHUNK" in c: os.environ["HAGRID_CHUNK"] = str(c["CHUNK"])
-            else: os.environ.pop("HAGRID_CHUNK", None)
+            mem.set_option("traverse.variant", c["v"])
+            mem.set_option("traverse.both_phases", c.get("BOTH", 0)); mem.set_option("traverse.waves_per_cu", c.get("WAVES", 32))
+            mem.set_option("traverse.refill_at", c.get("REFILL", 12))
+            mem.set_option("traverse.chunk", c.get("CHUNK", 0))
             for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
             t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(7))
             row["|".join(f"{k}{v}" for k, v in c.items())] = round(n / t[3] / 1e3, 0)
