@@ -425,6 +425,8 @@ int orc_build_grid(const OTri* tris, int num_tris, OGrid* grid, float top_densit
         }
         free(L->ref_ids); free(L->cell_ids);
         L->ref_ids = nref; L->cell_ids = ncel; L->num_kept = num_kept;
+        if (getenv("ORC_VERBOSE"))
+            fprintf(stderr, "[oracle] level %d: cells %d refs %d kept %d new_cells %d\n", num_levels - 1, num_cells, num_refs, num_kept, num_new_cells);
         if (num_new_cells == 0) break;      /* build.cu:583-587 */
         if (num_levels >= ORC_MAX_LEVELS) return -2;
 
