@@ -90,18 +90,38 @@ __global__ void __launch_bounds__(kBlock) bbox_final(const float* __restrict__ p
 }
 
 // ---- top level -----------------------------------------------------------------------------------------
-// count_new_refs (build.cu:57-66) + count_refs_per_cell (build.cu:246-253, counted BEFORE the SAT filter)
+// count_new_refs (build.cu:57-66) + count_refs_per_cell (build.cu:246-253, counted BEFORE the SAT filter).
+// A primitive that covers many top-level cells (a ground plane) is handled by the whole wavefront: lanes stride
+// over its cell range -- the wave64 counterpart of the reference's 32-lane cooperative emission (build.cu:106-135).
+constexpr int kCoopCells = 64;
+
 __global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restrict__ tris, int n, BuildK k,
                                                          int* __restrict__ counts, int* __restrict__ refs_per_cell) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const BBox gb(k.bmin, k.bmax);
-    const Range r = compute_range(k.dims, gb, load_tri(tris, i).bbox());
-    counts[i] = max(0, r.size());
-    for (int z = r.lz; z <= r.hz; z++)
-        for (int y = r.ly; y <= r.hy; y++)
-            for (int x = r.lx; x <= r.hx; x++)
-                atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+    Range r(0, 0, 0, -1, -1, -1);
+    int size = 0;
+    if (i < n) {
+        r = compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox());
+        size = max(0, r.size());
+        counts[i] = size;
+    }
+    const bool coop = size >= kCoopCells;
+    if (size > 0 && !coop)
+        for (int z = r.lz; z <= r.hz; z++)
+            for (int y = r.ly; y <= r.hy; y++)
+                for (int x = r.lx; x <= r.hx; x++)
+                    atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
+        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1, total = __shfl(size, src, 64);
+        for (int c = lane_id(); c < total; c += 64) {
+            const int x = lx + c % sx, y = ly + (c / sx) % sy, z = lz + c / (sx * sy);
+            atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+        }
+    }
 }
 
 // compute_log_dims (build.cu:256-270) + the max reduction of build.cu:508
@@ -129,25 +149,47 @@ __global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ r
 }
 
 // emit_new_refs (build.cu:69-136) + filter_refs (build.cu:139-157): every (primitive, top cell) pair of the
-// primitive's cell range, with -1/-1 where the triangle misses the cell
+// primitive's cell range in x-fastest order, with -1/-1 where the triangle misses the cell.  Large ranges are spread
+// over the wavefront as in count_top_refs (slot = start + linear cell index, so the order is the serial one).
+__device__ __forceinline__ void emit_one_top_ref(const BuildK& k, const Tri& tri, int prim, int x, int y, int z, int slot,
+                                                 int* __restrict__ ref_ids, int* __restrict__ cell_ids) {
+    const int inc = 1 << k.shift;
+    const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
+    const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
+    ref_ids[slot] = hit ? prim : -1;
+    cell_ids[slot] = hit ? x + k.dims.x * (y + k.dims.y * z) : -1;
+}
+
 __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
                                                         int* __restrict__ ref_ids, int* __restrict__ cell_ids) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const Tri tri = load_tri(tris, i);
-    const Range r = compute_range(k.dims, BBox(k.bmin, k.bmax), tri.bbox());
-    if (r.size() <= 0) return;
-    int cur = start_emit[i];
-    const int inc = 1 << k.shift;
-    for (int z = r.lz; z <= r.hz; z++)
-        for (int y = r.ly; y <= r.hy; y++)
-            for (int x = r.lx; x <= r.hx; x++) {
-                const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
-                const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
-                ref_ids[cur] = hit ? i : -1;
-                cell_ids[cur] = hit ? x + k.dims.x * (y + k.dims.y * z) : -1;
-                cur++;
-            }
+    Range r(0, 0, 0, -1, -1, -1);
+    int size = 0, start = 0;
+    Tri tri;
+    if (i < n) {
+        tri = load_tri(tris, i);
+        r = compute_range(k.dims, BBox(k.bmin, k.bmax), tri.bbox());
+        size = max(0, r.size());
+        start = start_emit[i];
+    }
+    const bool coop = size >= kCoopCells;
+    if (size > 0 && !coop) {
+        int cur = start;
+        for (int z = r.lz; z <= r.hz; z++)
+            for (int y = r.ly; y <= r.hy; y++)
+                for (int x = r.lx; x <= r.hx; x++) emit_one_top_ref(k, tri, i, x, y, z, cur++, ref_ids, cell_ids);
+    }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int prim = __shfl(i, src, 64), first = __shfl(start, src, 64), total = __shfl(size, src, 64);
+        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
+        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
+        const Tri t = load_tri(tris, prim);                     // same address in every lane: one broadcast load
+        for (int c = lane_id(); c < total; c += 64)
+            emit_one_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), first + c, ref_ids, cell_ids);
+    }
 }
 
 // emit_top_cells (build.cu:332-351)

@@ -142,3 +142,30 @@ def test_build_rejects_bad_input(mem):
     from hagrid_amd import api
     with pytest.raises(api.HagridError):
         api.build_grid(mem, 0, 0, api.Grid(), 0.12, 2.4)
+
+
+def test_build_scene_with_huge_triangles(mem):
+    """Teapot-in-a-stadium: a soup standing on a ground plane and inside four walls whose triangles cover thousands of
+    top-level cells each (the wave-cooperative emission path, build.cu:106-135 in the reference)."""
+    soup = scene.make_soup(30000, seed=99)
+    lo, hi = np.float32([-2, -0.05, -2]), np.float32([3, 1.5, 3])
+    def quad(a, b, c, d):
+        a, b, c, d = (np.float32(v)[None, :] for v in (a, b, c, d))
+        return np.concatenate([scene.tris_from_vertices(a, b, c), scene.tris_from_vertices(a, c, d)])
+    walls = [quad([lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], lo[1], hi[2]], [lo[0], lo[1], hi[2]]),       # ground
+             quad([lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]]),
+             quad([lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]),
+             quad([lo[0], lo[1], lo[2]], [lo[0], lo[1], hi[2]], [lo[0], hi[1], hi[2]], [lo[0], hi[1], lo[2]]),
+             quad([hi[0], lo[1], lo[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [hi[0], hi[1], lo[2]]),
+             quad([lo[0], 0.4, lo[2]], [hi[0], 0.9, lo[2]], [hi[0], 0.2, hi[2]], [lo[0], 0.7, hi[2]])]               # a slanted sheet
+    tris = np.concatenate([soup] + walls).astype(np.float32)
+    grid, G, d_tris = run_stages(mem, tris)
+    rays = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 100000, 3)
+    from hagrid_amd import api
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+    hits = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    assert (hits["id"] == want["id"]).all() and (hits["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    assert (hits["id"] >= soup.shape[0]).mean() > 0.3          # the big triangles are what most rays hit
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
