@@ -9,6 +9,11 @@
 // computed inside the scan's input functor (compute_ref_counts disappears); one host round trip per
 // axis-iteration; the reference's warp-cooperative copy of unmerged runs (written for 32-lane warps,
 // merge.cu:245-270) is replaced by per-cell copies -- lists hold one to two references on average.
+//
+// Tried and rejected (round 1): merging in place (cells keep their index, absorbed cells become tombstones with a
+// redirect, merged lists bump-allocated by a chained scan, one compaction at the end).  Bit-identical, but slower:
+// 2.9 instead of 2.5 ms at 1M triangles, because every pass then runs over all 7.4M original slots while compacting
+// after each pass shrinks the population to 4.2M -- the compaction pays for itself.
 #include "ctx.h"
 #include "wave_prims.h"
 
