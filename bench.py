@@ -136,8 +136,9 @@ def main():
     for _ in range(args.steps):
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
     kernel_ms_total = mem._L.hagrid_profile_end(mem._ctx)                    # waits for the last launch
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0                                       # this rank's K steps; MAX over ranks below
     barrier()
-    elapsed = time.perf_counter() - t0
     if multi:
         t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
