@@ -169,3 +169,28 @@ def test_build_scene_with_huge_triangles(mem):
     assert (hits["id"] == want["id"]).all() and (hits["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
     assert (hits["id"] >= soup.shape[0]).mean() > 0.3          # the big triangles are what most rays hit
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
+def test_build_degenerate_inputs(mem):
+    """Coincident triangles (every cell they touch holds a list of thousands of references: the Shell-sort path of
+    sort_cell_refs and long union / subset loops) and zero-area triangles (no normal)."""
+    base = scene.make_soup(300, seed=5)
+    same = np.repeat(scene.make_soup(1, seed=6), 3000, axis=0)
+    flat = scene.tris_from_vertices(np.float32([[0.2, 0.2, 0.2], [0.5, 0.5, 0.5]]), np.float32([[0.4, 0.4, 0.4], [0.5, 0.5, 0.5]]),
+                                    np.float32([[0.3, 0.3, 0.3], [0.5, 0.5, 0.5]]))        # a segment and a point
+    tris = np.concatenate([base, same, flat]).astype(np.float32)
+    grid, G, d_tris = run_stages(mem, tris)
+    assert max(np.diff(np.stack([G.small_cells["begin"], np.roll(G.small_cells["begin"], -1)]), axis=0).max(), 1) > 0
+    from hagrid_amd import api
+    rays = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 50000, 8)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+    hits = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    assert (hits["id"] == want["id"]).all() and (hits["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    # of 3000 coincident triangles either the first tested wins (ascending lists -> the smallest id) or, for rays where
+    # abs_det * fl(t / abs_det) rounds above t, every later copy passes `abs_det * tmax > t` again and the last one wins
+    # (prims.h:281-283) -- the reference's arithmetic, reproduced bit for bit
+    dup = hits["id"][(hits["id"] >= 300) & (hits["id"] < 3300)]
+    assert dup.size > 0 and set(np.unique(dup)) <= {300, 3299}
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
