@@ -44,3 +44,17 @@ def test_no_gpu_means_loud_failure(built):
     from hagrid_amd import api
     with pytest.raises(api.HagridError):
         api.MemManager()
+
+
+def test_header_is_plain_c():
+    """include/hagrid_amd.h compiles as C99 (what a cgo / JNI / ctypes author needs) and a C user of the whole ABI links
+    against the library's exported names."""
+    import subprocess, tempfile
+    src = os.path.join(ROOT, "tests", "cpp", "c_abi_user.c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src], check=True)
+    with tempfile.TemporaryDirectory() as d:
+        obj = os.path.join(d, "u.o")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj], check=True)
+        undefined = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout
+        used = sorted(set(re.findall(r"\b(hagrid_[a-z0-9_]+)", undefined)))
+        assert len(used) >= 20 and set(used) <= set(declared_symbols())

@@ -187,3 +187,32 @@ def test_cli_obj_scene_and_ray_file_benchmark():
         assert r.returncode == 0 and "20000 triangle(s)" in r.stdout and "Tracing one 256x128 frame" in r.stdout
         assert os.path.getsize(img) == len("P5\n256 128\n255\n") + 256 * 128
         mem.close()
+
+
+@pytest.mark.gpu
+def test_plain_c_user_of_the_abi_on_gpu():
+    """tests/cpp/c_abi_user.c (C99, the whole ABI incl. binning and options) driven through ctypes: hits == Python API's."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from hagrid_amd import api, lib, scene
+    lib.load()                                                   # makes the HIP runtime + libhagrid_amd visible
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "libcuser.so")
+        subprocess.run(["gcc", "-std=c99", "-O1", "-fPIC", "-shared", "-I", INC, os.path.join(ROOT, "tests", "cpp", "c_abi_user.c"), "-o", so,
+                        "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-Wl,-rpath," + os.path.join(ROOT, "hagrid_amd"),
+                        "-Wl,--allow-shlib-undefined"], check=True)
+        U = C.CDLL(so)
+        tris = scene.make_soup(20000)
+        lo, hi = scene.tris_bbox(tris)
+        rays = scene.make_rays_incoherent(lo, hi, 30000, 12)
+        hits = np.zeros(rays.shape[0], dtype=api.HIT_DTYPE)
+        rc = U.run(tris.ctypes.data_as(C.c_void_p), tris.shape[0], rays.ctypes.data_as(C.c_void_p), rays.shape[0], hits.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        mem = api.MemManager(keep=True)
+        d_tris = mem.upload(tris); g = api.build_all(mem, d_tris, tris.shape[0])
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+        api.traverse_grid(g, d_tris, d_rays, d_hits, rays.shape[0])
+        want = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+        assert (hits["id"] == want["id"]).all() and (hits["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+        mem.close()
