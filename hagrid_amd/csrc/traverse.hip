@@ -586,7 +586,7 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     } else {
         const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
         // rays per cursor atomic: a few chunks per wave for balance, at least one wave-load, at most 1024
-        int chunk = ctx->opt_chunk ? ctx->opt_chunk : (num_rays / (blocks * 4));
+        int chunk = ctx->opt_chunk ? ctx->opt_chunk : (num_rays / (blocks * 2));
         chunk = std::max(64, std::min(1024, (chunk + 63) & ~63));
         const int both = ctx->opt_both_phases, refill_at = ctx->opt_refill_at;
         int* cursors = ctx->dscratch + 240;                  // 8 band cursors

@@ -203,7 +203,7 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
     settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 3},
                 {"traverse.variant": 3, "traverse.both_phases": 1}, {"traverse.variant": 3, "traverse.refill_at": 1, "traverse.chunk": 64},
                 {"traverse.variant": 3, "traverse.refill_at": 64, "traverse.waves_per_cu": 2, "traverse.chunk": 1024}]
-    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 12, "traverse.chunk": 0, "traverse.waves_per_cu": 32}
+    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 24, "traverse.chunk": 0, "traverse.waves_per_cu": 32}
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():
