@@ -821,6 +821,8 @@ static int is_subset(const int* p0, int c0, const int* p1, int c1) { /* expand.c
     return j == c1;
 }
 
+static long long g_walk_iters, g_walk_max;   /* ORC_VERBOSE statistics */
+
 /* expand.cu:60-143 */
 static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* entries, const int* refs,
                         const OCell* cells, const OCell* cell, int* continue_overlap) {
@@ -832,7 +834,9 @@ static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* 
     int k1, k2 = iget(k->dims, axis2);
     int i = iget(cell->min, axis1), j = iget(cell->min, axis2);
     int max_d = d;
+    long long iters = 0;
     for (;;) {
+        iters++;
         oivec3 np;
         int a = dir ? iget(cell->max, axis) : iget(cell->min, axis) - 1;
         if (axis == 0) np = iv3(a, i, j);
@@ -854,6 +858,7 @@ static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* 
             if (j >= iget(cell->max, axis2)) break;
         }
     }
+    g_walk_iters += iters; if (iters > g_walk_max) g_walk_max = iters;
     *continue_overlap |= d == max_d;
     return d;
 }
@@ -871,6 +876,12 @@ int orc_expand_grid(OGrid* grid, const OTri* tris, int iters) { /* expand.cu:199
     for (int it = 0; it < iters; it++) {
         for (int axis = 0; axis < 3; axis++) {                                   /* expand.cu:184-197 */
             const OCell* cells = grid->cells;
+            if (getenv("ORC_VERBOSE")) {
+                int flagged = 0;
+                for (int id = 0; id < n; id++) flagged += (flags[id] & (1 << axis)) != 0;
+                fprintf(stderr, "[oracle] expand iter %d axis %d: %d of %d cells processed; previous step: %lld face-walk iterations, longest %lld\n", it, axis, flagged, n, g_walk_iters, g_walk_max);
+                g_walk_iters = 0; g_walk_max = 0;
+            }
             for (int id = 0; id < n; id++) {                                      /* overlap_step expand.cu:145-182 */
                 if ((flags[id] & (1 << axis)) == 0) { new_cells[id] = cells[id]; continue; } /* D2 */
                 OCell cell = cells[id];
