@@ -45,6 +45,7 @@ struct hagrid_ctx {
     int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
     int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
     int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
+    int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
     std::string err;

@@ -2,20 +2,22 @@
 // is a subset of its own, on gfx950.
 //
 // Replaces the reference's expand.cu: expand (:199-223), expansion_iter (:184-197), overlap_step<axis> (:145-182),
-// find_overlap (:60-143), is_subset (:21-36), with subset_only = true (the reference's compiled setting, :159).
+// find_overlap (:60-143), is_subset (:21-36), compute_overlap (:39-57).  subset_only = true is the reference's compiled setting
+// (:159) and the default; the precise mode (subset_only = false) is selected with hagrid_set_option("expand.subset_only", 0).
 // Bit-identical to the CPU oracle.  Cells that are not processed in a step are copied through to the new
 // buffer (the reference leaves them stale, expand.cu:154-155,181 -- DESIGN.md D2).
 #include "ctx.h"
 #include "wave_prims.h"
 
 #include "hagrid/grid.h"
+#include "hagrid/prims.h"
 
 using namespace hagrid;
 using namespace hagrid_impl;
 
 namespace {
 
-struct ExpandK { ivec3 dims; ivec3 top; int shift; };   // expand.cu:5-9 (only what subset_only needs)
+struct ExpandK { ivec3 dims; ivec3 top; int shift; vec3 gmin, cell_size, grid_inv; };   // expand.cu:5-9
 struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
 
 __device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
@@ -40,9 +42,29 @@ __device__ __forceinline__ bool is_subset(const int* __restrict__ p0, int c0, co
     return j == c1;
 }
 
-// find_overlap (expand.cu:60-143)
+// compute_overlap (expand.cu:39-57): how far the cell may grow along `axis` before it would have to reference `prim`
 template <int axis, bool dir>
-__device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs,
+__device__ __forceinline__ int compute_overlap(const ExpandK& k, const Tri& prim, const CellRec& cell, const BBox& cb, int d) {
+    constexpr int axis1 = (axis + 1) % 3, axis2 = (axis + 2) % 3;
+    const BBox pb = prim.bbox();
+    if (get<axis1>(pb.min) <= get<axis1>(cb.max) && get<axis1>(pb.max) >= get<axis1>(cb.min) &&
+        get<axis2>(pb.min) <= get<axis2>(cb.max) && get<axis2>(pb.max) >= get<axis2>(cb.min)) {
+        const int prim_d = int(((dir ? get<axis>(pb.min) : get<axis>(pb.max)) - get<axis>(k.gmin)) * get<axis>(k.grid_inv));
+        d = dir ? min(d, prim_d - comp(cell.hi, axis)) : max(d, prim_d - comp(cell.lo, axis) + 1);
+        d = dir ? max(d, 0) : min(d, 0);
+    }
+    return d;
+}
+
+__device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) {
+    const float4* p = tris + 3 * size_t(i);
+    const float4 a = p[0], b = p[1], c = p[2];
+    return Tri(vec3(a.x, a.y, a.z), a.w, vec3(b.x, b.y, b.z), b.w, vec3(c.x, c.y, c.z), c.w);
+}
+
+// find_overlap (expand.cu:60-143)
+template <int axis, bool dir, bool SUBSET_ONLY>
+__device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
                                             const Cell* __restrict__ cells, const CellRec& cell, bool& continue_overlap) {
     constexpr int axis1 = (axis + 1) % 3, axis2 = (axis + 2) % 3;
     if (dir) { if (!(comp(cell.hi, axis) < comp(k.dims, axis))) return 0; }     // overlap_possible, expand.cu:12-18
@@ -57,7 +79,32 @@ __device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __res
         const CellRec next = load_cell(cells, int(lookup_entry(entries, k.shift, k.top, np)));
         max_d = dir ? min(max_d, comp(next.hi, axis) - comp(cell.hi, axis)) : max(max_d, comp(next.lo, axis) - comp(cell.lo, axis));
         d = dir ? min(d, max_d) : max(d, max_d);
-        if (!is_subset(refs + cell.begin, cell.end - cell.begin, refs + next.begin, next.end - next.begin)) { d = 0; break; }
+        if (SUBSET_ONLY) {
+            if (!is_subset(refs + cell.begin, cell.end - cell.begin, refs + next.begin, next.end - next.begin)) { d = 0; break; }
+        } else {
+            // expand.cu:96-127: references of the neighbour that the cell does not hold limit the growth
+            if (next.begin < next.end) {
+                const BBox cb(k.gmin + k.cell_size * vec3(cell.lo), k.gmin + k.cell_size * vec3(cell.hi));
+                int p1 = cell.begin, p2 = next.begin;
+                int ref2 = refs[p2];
+                for (;;) {
+                    while (p1 < cell.end) {
+                        const int ref1 = refs[p1];
+                        if (ref1 > ref2) break;
+                        if (ref1 == ref2) {
+                            if (++p2 >= next.end) break;
+                            ref2 = refs[p2];
+                        }
+                        p1++;
+                    }
+                    if (p2 >= next.end) break;
+                    d = compute_overlap<axis, dir>(k, load_tri(tris, ref2), cell, cb, d);
+                    if (d == 0 || ++p2 >= next.end) break;
+                    ref2 = refs[p2];
+                }
+            }
+            if (d == 0) break;
+        }
         const int k1 = comp(next.hi, axis1) - i;
         k2 = min(k2, comp(next.hi, axis2) - j);
         i += k1;
@@ -73,9 +120,9 @@ __device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __res
 }
 
 // overlap_step (expand.cu:145-182)
-template <int axis>
+template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
-                                                       const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
+                                                       const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                        int* __restrict__ cell_flags, int num_cells) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_cells) return;
@@ -89,8 +136,8 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
     }
     CellRec cell = load_cell(cells, id);
     bool flag = false;
-    const int ov1 = find_overlap<axis, false>(k, entries, refs, cells, cell, flag);
-    const int ov2 = find_overlap<axis, true>(k, entries, refs, cells, cell, flag);
+    const int ov1 = find_overlap<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    const int ov2 = find_overlap<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
     if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
     if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
     if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
@@ -101,9 +148,11 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
 
 } // namespace
 
-extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris, int iters) {
-    (void)tris;                                 // only the subset_only = false variant reads primitives
+extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris_v, int iters) {
     if (!ctx || !grid) return HAGRID_EINVAL;
+    const bool subset_only = ctx->opt_expand_subset_only != 0;      // the reference's compiled setting (expand.cu:159) is true
+    if (!subset_only && !tris_v && iters > 0) HG_FAIL(ctx, HAGRID_EINVAL, "expand_grid: the precise mode needs the triangles");
+    const float4* tris = static_cast<const float4*>(tris_v);
     if (iters <= 0) return HAGRID_OK;
     if (!grid->cells || !grid->entries || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "expand_grid: incomplete (or compressed) grid");
     HG_HIP(ctx, hipSetDevice(ctx->device));
@@ -112,6 +161,10 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     k.top = ivec3(grid->dims[0], grid->dims[1], grid->dims[2]);
     k.dims = k.top << grid->shift;
     k.shift = grid->shift;
+    {   // expand.cu:208-216
+        const vec3 lo(grid->bbox_min[0], grid->bbox_min[1], grid->bbox_min[2]), ext = vec3(grid->bbox_max[0], grid->bbox_max[1], grid->bbox_max[2]) - lo;
+        k.gmin = lo; k.cell_size = ext / vec3(k.dims); k.grid_inv = vec3(k.dims) / ext;
+    }
     const int n = grid->num_cells;
     Cell* cells = static_cast<Cell*>(grid->cells);
     Cell* other = pool_alloc<Cell>(ctx, size_t(n));
@@ -122,9 +175,15 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
     for (int it = 0; it < iters; it++) {                                               // expansion_iter, expand.cu:184-197
-        overlap_step<0><<<blocks, kBlock, 0, st>>>(k, entries, refs, cells, other, flags, n); std::swap(cells, other);
-        overlap_step<1><<<blocks, kBlock, 0, st>>>(k, entries, refs, cells, other, flags, n); std::swap(cells, other);
-        overlap_step<2><<<blocks, kBlock, 0, st>>>(k, entries, refs, cells, other, flags, n); std::swap(cells, other);
+        if (subset_only) {
+            overlap_step<0, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<1, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<2, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+        } else {
+            overlap_step<0, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<1, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<2, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+        }
     }
     hipError_t e = hipGetLastError();
     HG_HIP(ctx, hipStreamSynchronize(st));

@@ -608,7 +608,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
     struct { const char* name; int* dst; int lo, hi; } table[] = {
         {"traverse.variant", &ctx->opt_variant, 0, 3},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
-        {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},
+        {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {

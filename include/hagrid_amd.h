@@ -139,8 +139,10 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel by batch size, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled),
- * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at".  Returns HAGRID_EINVAL for an
- * unknown key or a value out of range.  Results never depend on these settings. */
+ * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at"; "expand.subset_only" (1 = the
+ * reference's compiled setting, default; 0 = the precise expansion of expand.cu:39-57,96-127 -- this one changes the grid,
+ * not the hits).  Returns HAGRID_EINVAL for an
+ * unknown key or a value out of range.  Hits never depend on these settings. */
 int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 
 /* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */

@@ -806,7 +806,7 @@ int orc_flatten_grid(OGrid* grid) {
 /* ------------------------------------------------------------------------------------------ */
 /* expand_grid: expand.cu:11-225 with subset_only = true (expand.cu:159) */
 
-typedef struct { oivec3 dims; int shift; oivec3 top; } ExpandConsts;
+typedef struct { oivec3 dims; int shift; oivec3 top; ovec3 gmin, cell_size, grid_inv; int subset_only; const OTri* tris; } ExpandConsts;
 
 static int is_subset(const int* p0, int c0, const int* p1, int c1) { /* expand.cu:21-36 */
     if (c1 > c0) return 0;
@@ -822,6 +822,19 @@ static int is_subset(const int* p0, int c0, const int* p1, int c1) { /* expand.c
 }
 
 static long long g_walk_iters, g_walk_max;   /* ORC_VERBOSE statistics */
+
+/* expand.cu:39-57: how far may `cell` grow along axis before it would have to reference `prim` */
+static int compute_overlap(int axis, int dir, const ExpandConsts* k, const OTri* prim, const OCell* cell, const OBBox* cb, int d) {
+    int axis1 = (axis + 1) % 3, axis2 = (axis + 2) % 3;
+    OBBox pb; orc_tri_bbox(prim, &pb);
+    if (fget(pb.min, axis1) <= fget(cb->max, axis1) && fget(pb.max, axis1) >= fget(cb->min, axis1) &&
+        fget(pb.min, axis2) <= fget(cb->max, axis2) && fget(pb.max, axis2) >= fget(cb->min, axis2)) {
+        int prim_d = (int)(((dir ? fget(pb.min, axis) : fget(pb.max, axis)) - fget(k->gmin, axis)) * fget(k->grid_inv, axis));
+        d = dir ? imin(d, prim_d - iget(cell->max, axis)) : imax(d, prim_d - iget(cell->min, axis) + 1);
+        d = dir ? imax(d, 0) : imin(d, 0);
+    }
+    return d;
+}
 
 /* expand.cu:60-143 */
 static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* entries, const int* refs,
@@ -847,7 +860,34 @@ static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* 
         max_d = dir ? imin(max_d, iget(next.max, axis) - iget(cell->max, axis))
                     : imax(max_d, iget(next.min, axis) - iget(cell->min, axis));
         d = dir ? imin(d, max_d) : imax(d, max_d);
-        if (!is_subset(refs + cell->begin, cell->end - cell->begin, refs + next.begin, next.end - next.begin)) { d = 0; break; }
+        if (k->subset_only) {
+            if (!is_subset(refs + cell->begin, cell->end - cell->begin, refs + next.begin, next.end - next.begin)) { d = 0; break; }
+        } else {
+            /* expand.cu:96-127: references of the neighbour that the cell does not hold limit the growth */
+            if (next.begin < next.end) {
+                OBBox cb;
+                cb.min = v3_add(k->gmin, v3_mul(k->cell_size, v3_from_i(cell->min)));
+                cb.max = v3_add(k->gmin, v3_mul(k->cell_size, v3_from_i(cell->max)));
+                int p1 = cell->begin, p2 = next.begin;
+                int ref2 = refs[p2];
+                for (;;) {
+                    while (p1 < cell->end) {
+                        int ref1 = refs[p1];
+                        if (ref1 > ref2) break;
+                        if (ref1 == ref2) {
+                            if (++p2 >= next.end) break;
+                            ref2 = refs[p2];
+                        }
+                        p1++;
+                    }
+                    if (p2 >= next.end) break;
+                    d = compute_overlap(axis, dir, k, &k->tris[ref2], cell, &cb, d);
+                    if (d == 0 || ++p2 >= next.end) break;
+                    ref2 = refs[p2];
+                }
+            }
+            if (d == 0) break;
+        }
         k1 = iget(next.max, axis1) - i;
         k2 = imin(k2, iget(next.max, axis2) - j);
         i += k1;
@@ -863,12 +903,20 @@ static int find_overlap(int axis, int dir, const ExpandConsts* k, const OEntry* 
     return d;
 }
 
-int orc_expand_grid(OGrid* grid, const OTri* tris, int iters) { /* expand.cu:199-225 */
-    (void)tris;
+int orc_expand_grid(OGrid* grid, const OTri* tris, int iters) { return orc_expand_grid_ex(grid, tris, iters, 1); }
+
+int orc_expand_grid_ex(OGrid* grid, const OTri* tris, int iters, int subset_only) { /* expand.cu:199-225 */
     if (iters == 0) return 0;
     ExpandConsts k;
     k.dims = iv3(grid->dims.x << grid->shift, grid->dims.y << grid->shift, grid->dims.z << grid->shift);
     k.shift = grid->shift; k.top = grid->dims;
+    k.subset_only = subset_only; k.tris = tris;
+    {   /* expand.cu:208-216 */
+        ovec3 ext = v3_sub(grid->bbox.max, grid->bbox.min);
+        k.gmin = grid->bbox.min;
+        k.cell_size = v3_div(ext, v3_from_i(k.dims));
+        k.grid_inv = v3_div(v3_from_i(k.dims), ext);
+    }
     int n = grid->num_cells;
     OCell* new_cells = (OCell*)xmalloc(sizeof(OCell) * (size_t)imax(n, 1));
     int* flags = (int*)xmalloc(sizeof(int) * (size_t)imax(n, 1));

@@ -94,7 +94,8 @@ void orc_grid_free(OGrid* g);
 int  orc_build_grid(const OTri* tris, int num_tris, OGrid* grid, float top_density, float snd_density);
 int  orc_merge_grid(OGrid* grid, float alpha);
 int  orc_flatten_grid(OGrid* grid);
-int  orc_expand_grid(OGrid* grid, const OTri* tris, int iters);
+int  orc_expand_grid(OGrid* grid, const OTri* tris, int iters);              /* subset_only = true, expand.cu:159 */
+int  orc_expand_grid_ex(OGrid* grid, const OTri* tris, int iters, int subset_only);   /* false: expand.cu:39-57,96-127 */
 int  orc_compress_grid(OGrid* grid);   /* 1 on success, 0 if dims do not fit 16 bits */
 
 /* traversal: hits[i].id = primitive id or -1 (decision SURVEY.md 8(b)); steps (optional) receives

@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         L.orc_merge_grid.restype = i32; L.orc_merge_grid.argtypes = [vp, f32]
         L.orc_flatten_grid.restype = i32; L.orc_flatten_grid.argtypes = [vp]
         L.orc_expand_grid.restype = i32; L.orc_expand_grid.argtypes = [vp, vp, i32]
+        L.orc_expand_grid_ex.restype = i32; L.orc_expand_grid_ex.argtypes = [vp, vp, i32, i32]
         L.orc_compress_grid.restype = i32; L.orc_compress_grid.argtypes = [vp]
         L.orc_traverse_grid.argtypes = [vp, vp, vp, vp, i64, vp, vp]
         L.orc_traverse_grid_mt.argtypes = [vp, vp, vp, vp, i64, i32, vp]
@@ -145,9 +146,9 @@ class Grid:
     def flatten(self):
         lib().orc_flatten_grid(C.byref(self.g)); return self
 
-    def expand(self, tris: np.ndarray, iters: int = 3):
+    def expand(self, tris: np.ndarray, iters: int = 3, subset_only: bool = True):
         tris = np.ascontiguousarray(tris, dtype=np.float32)
-        lib().orc_expand_grid(C.byref(self.g), _p(tris), iters); return self
+        lib().orc_expand_grid_ex(C.byref(self.g), _p(tris), iters, 1 if subset_only else 0); return self
 
     def compress(self) -> bool:
         return bool(lib().orc_compress_grid(C.byref(self.g)))

@@ -194,3 +194,29 @@ def test_build_degenerate_inputs(mem):
     dup = hits["id"][(hits["id"] >= 300) & (hits["id"] < 3300)]
     assert dup.size > 0 and set(np.unique(dup)) <= {300, 3299}
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
+def test_precise_expansion_matches_oracle(mem):
+    """expand with subset_only = false (compute_overlap, expand.cu:39-57,96-127), an option here."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(40000, seed=77)
+    d_tris = mem.upload(tris)
+    G = O.Grid.build(tris).merge(0.995).flatten().expand(tris, 3, subset_only=False)
+    Gd = O.Grid.build(tris).merge(0.995).flatten().expand(tris, 3)
+    assert G.cells.tobytes() != Gd.cells.tobytes()                 # the two modes really differ
+    try:
+        mem.set_option("expand.subset_only", 0)
+        grid = api.Grid()
+        api.build_grid(mem, d_tris, tris.shape[0], grid, 0.12, 2.4)
+        api.merge_grid(mem, grid, 0.995); api.flatten_grid(mem, grid); api.expand_grid(mem, grid, d_tris, 3)
+    finally:
+        mem.set_option("expand.subset_only", 1)
+    assert_same_grid(grid.download(), G, "precise expand")
+    rays = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 100000, 6)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+    hits = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+    bf = O.brute_force(tris, rays[:20000], nthreads=8)
+    assert (hits["id"][:20000] == bf["id"]).all() and (hits["t"][:20000].view(np.uint32) == bf["t"].view(np.uint32)).all()
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)

@@ -208,3 +208,16 @@ def test_primary_rays_with_zero_components():
     bf = O.brute_force(tris, rays, nthreads=8)
     assert (h["id"] == bf["id"]).all() and (bits(h["t"]) == bits(bf["t"])).all()
     assert (h["id"] >= 0).mean() > 0.25
+
+
+def test_precise_expansion_keeps_the_grid_valid(config1):
+    """expand.cu:39-57,96-127 (subset_only = false): a different, still valid grid -- same hits as the brute force."""
+    tris, rays, gid, gt = config1
+    G = O.Grid.build(tris).merge(0.995).flatten().expand(tris, 3, subset_only=False)
+    rc, msg = G.check(tris, 1)
+    assert rc == 0, msg
+    h, st = G.traverse(tris, rays, nthreads=8)
+    assert (h["id"] == gid).all() and (bits(h["t"]) == bits(gt)).all()
+    D = O.Grid.full(tris)
+    _, sd = D.traverse(tris, rays, nthreads=8)
+    assert st["cells"] <= sd["cells"]                    # grows cells at least as far as the subset rule
