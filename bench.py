@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--rays", choices=["primary", "incoherent"], default="primary")
+    ap.add_argument("--eye-dist", type=float, default=0.8, help="camera distance in scene diagonals (SURVEY proposed 1.5, where only ~17 %% of the pixels see the scene; DESIGN.md section 5)")
     ap.add_argument("--top-density", type=float, default=0.12)
     ap.add_argument("--snd-density", type=float, default=2.4)
     ap.add_argument("--alpha", type=float, default=0.995)
@@ -114,7 +115,7 @@ def main():
     # ---- this rank's ray batch ---------------------------------------------------------------------------------------
     n_rays = args.width * args.height
     if args.rays == "primary":
-        rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, args.width, args.height, sample=rank, num_samples=world)
+        rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, args.width, args.height, eye_dist=args.eye_dist, sample=rank, num_samples=world)
     else:
         rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, n_rays, scene.RAY_SEED_BASE + 4, first=rank * n_rays)
     d_rays = mem.upload(rays)
@@ -172,7 +173,7 @@ def main():
             "config": {"workload": f"soup-{n_tris} triangles, {args.rays} rays {args.width}x{args.height} per GPU"
                                    f" (BASELINE.json configs[1]), td {args.top_density} sd {args.snd_density} alpha {args.alpha} exp {args.expansion}"
                                    + (" compress" if args.compress else ""),
-                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "parallelism": f"ray-sharded x{world}, grid broadcast once",
+                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),
             "grid_broadcast_ms": round(t_bcast, 3),
