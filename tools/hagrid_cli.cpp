@@ -1,7 +1,7 @@
 // hagrid_cli -- command-line front-end over include/hagrid/*.h with the option names, defaults and output lines of
 // the reference's `hagrid` executable (src/main.cpp:113-244 options, :469 / :512-533 build report, :434-444 benchmark
-// report), minus the SDL viewer: without a ray file it traces ONE frame of primary rays (gen_camera / gen_rays formulas,
-// main.cpp:42-66) and can write it as a PGM depth image instead of opening a window.
+// report), minus the SDL viewer: without a ray file it traces ONE frame of primary rays -- the viewer's initial view, gen_camera / gen_rays formulas
+// (main.cpp:42-66, :572-598) -- and can write it as a PGM depth image instead of opening a window.
 //
 // SURVEY.md 8(f) rows 1 and 2 ("next" rows): CLI parity and a Wavefront OBJ reader (vertices + faces, fan triangulation,
 // negative indices, v/vt/vn index forms), so that logs of the two binaries can be compared line by line.
@@ -235,11 +235,11 @@ int main(int argc, char** argv) {
         std::cout << "Entering benchmark mode" << std::endl;
         if (!load_rays(opts.ray_file, host_rays, opts.tmin, opts.tmax)) { std::cerr << "Cannot load ray file" << std::endl; return 1; }
     } else {
-        // one frame from the viewer's start position (main.cpp:543-556: eye on the -z side of the scene, looking at its centre)
+        // one frame of the viewer's initial view (main.cpp:572-579, :592-598): eye at the scene centre, looking down +z
         std::cout << "Tracing one " << opts.width << "x" << opts.height << " frame (no interactive viewer in this front-end)" << std::endl;
-        const vec3 eye = center - vec3(0, 0, 1) * scene_size, up(0, 1, 0);
+        const vec3 eye = center, forward(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
         const float f = tanf(float(M_PI) * opts.fov / 360.0f), ratio = float(opts.width) / float(opts.height);
-        const vec3 dir = normalize(center - eye), right = normalize(cross(dir, up)) * (f * ratio), cup = normalize(cross(right, dir)) * f;
+        const vec3 dir = normalize((eye + forward * 100.0f) - eye), right = normalize(cross(dir, up)) * (f * ratio), cup = normalize(cross(right, dir)) * f;
         host_rays.resize(size_t(opts.width) * opts.height);
         for (int y = 0; y < opts.height; y++)
             for (int x = 0; x < opts.width; x++) {
