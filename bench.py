@@ -173,7 +173,7 @@ def main():
             "config": {"workload": f"soup-{n_tris} triangles, {args.rays} rays {args.width}x{args.height} per GPU"
                                    f" (BASELINE.json configs[1]), td {args.top_density} sd {args.snd_density} alpha {args.alpha} exp {args.expansion}"
                                    + (" compress" if args.compress else ""),
-                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
+                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)", "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),
             "grid_broadcast_ms": round(t_bcast, 3),

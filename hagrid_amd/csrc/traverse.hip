@@ -34,6 +34,10 @@ struct TraverseArgs {
     int* __restrict__ steps;                 // optional per-ray step counter
     unsigned long long* __restrict__ stats;  // optional 7 batch counters
     const int* __restrict__ perm;            // optional traversal order (ray binning): slot i processes ray perm[i]
+    const int* __restrict__ row_len;         // optional, device: row length found by detect_ray_rows (0 = none)
+    int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
+    int super_log2;                          // tile packets: tiles per super-tile edge, log2
+    int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
     int num_rays;
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
@@ -197,14 +201,108 @@ __device__ __forceinline__ void nt_store4(float4* p, float x, float y, float z, 
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
 
+// ---- tile packets ---------------------------------------------------------------------------------------------------
+// A batch of camera rays arrives in image order (gen_rays, main.cpp:55-66: ray y * w + x), so 64 consecutive rays are
+// a 64 x 1 pixel strip: the lanes of a wavefront fan out over 64 pixel columns and share few cells.  An 8 x 8 pixel
+// tile per wavefront keeps the packet compact in both image directions (the vector L1 serves fewer distinct lines per
+// load instruction), and listing the tiles along a Z curve inside super-tiles keeps neighbouring wavefronts -- and the
+// contiguous block range each XCD receives -- compact as well (L2).  Measured on MI355X, soup-1M, unchanged kernel,
+// rays reordered on the host (tools/dev_tile_order.py): 1024^2 rays 0.406 -> 0.355 ms, 4096^2 rays 3.36 -> 2.10 ms.
+// The ray buffer stays in the reference's order and every hit goes to its ray's slot: only the lane <-> ray assignment
+// changes, so results are identical.  The row length w comes from the caller ("traverse.image_width") or from
+// detect_ray_rows below; w must be a multiple of 8; rows beyond the last multiple of 8 and rays beyond the last full
+// row keep the identity assignment.
+__device__ __forceinline__ uint32_t compact1by1(uint32_t v) {   // even bits of v, packed
+    v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
+    return (v | (v >> 8)) & 0x0000ffffu;
+}
+
+// Blocks are dispatched round-robin over the 8 XCDs (private L2 each).  split: XCD x runs the x-th eighth of the logical
+// block range (bands of a batch in buffer order).  chunked: XCD x runs the logical chunks x, x + 8, x + 16, ... of
+// 2^k blocks each -- along the Z curve an aligned run of 4^j tiles is a compact square, so every L2 serves compact
+// squares while the 8 XCDs work side by side on neighbouring ones: an image whose cost is concentrated in one region
+// (scene in the middle, sky around it) still loads them evenly.
+__device__ __forceinline__ int xcd_split(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+__device__ __forceinline__ int xcd_chunked(int b, int nb, int chunk_log2) {
+    const int full = (nb >> (chunk_log2 + 3)) << (chunk_log2 + 3);       // blocks in complete groups of 8 chunks
+    if (b >= full) return full + xcd_split(b - full, nb - full);
+    const int xcd = b & 7, j = b >> 3;
+    return ((((j >> chunk_log2) << 3) + xcd) << chunk_log2) + (j & ((1 << chunk_log2) - 1));
+}
+
+__device__ __forceinline__ int tile_packet_row_len(const TraverseArgs& a) {      // 0: buffer order
+    const int w = a.row_len_hint > 0 ? a.row_len_hint : (a.row_len ? __builtin_amdgcn_readfirstlane(*a.row_len) : 0);
+    return (w < 8 || (w & 7) || a.num_rays / w < 8) ? 0 : w;
+}
+
+__device__ __forceinline__ int tile_packet_slot(const TraverseArgs& a, int w, int b, int lane) {
+    const int identity = b * 64 + lane;
+    if (!w) return identity;
+    const int tiles_x = w >> 3, tiles_y = (a.num_rays / w) >> 3;
+    if (b >= tiles_x * tiles_y) return identity;             // ragged rows at the bottom, rays past the last full row
+    const int S = 1 << a.super_log2;
+    const int band = b / (tiles_x * S), in_band = b - band * tiles_x * S;
+    const int hb = min(S, tiles_y - band * S);               // tile rows in this band of super-tiles
+    const int col = in_band / (S * hb), in_super = in_band - col * S * hb;
+    const int wc = min(S, tiles_x - col * S);                // tile columns in this super-tile
+    int tx, ty;
+    if (wc == S && hb == S) { tx = int(compact1by1(uint32_t(in_super))); ty = int(compact1by1(uint32_t(in_super) >> 1)); }
+    else                    { ty = in_super / wc; tx = in_super - ty * wc; }
+    const int px = ((col * S + tx) << 3) + (lane & 7), py = ((band * S + ty) << 3) + (lane >> 3);
+    return py * w + px;
+}
+
+// Row length of an image-ordered batch, or 0: the (origin, direction) of consecutive rays advances by a constant step
+// s = ray[1] - ray[0] along a row (perspective: the direction; orthographic: the origin) and jumps at a row break.
+// w = index of the first break; accepted if it is a multiple of 8, the second row starts with the same step and, when
+// there is a third row, ray 2w is a break too.  One workgroup; the answer stays on the device (no host round trip).
+// A wrong answer can only cost speed: any row length gives a valid lane <-> ray assignment.
+constexpr int kDetectBlock = 1024;
+constexpr int kDetectLimit = 1 << 16;
+
+__device__ __forceinline__ float ray_step_dev2(const float4* __restrict__ rays, int i, const float (&s)[6]) {
+    // squared distance between (ray[i+1] - ray[i]) and s over origin and direction
+    const float4 a0 = rays[2 * size_t(i)], a1 = rays[2 * size_t(i) + 1], b0 = rays[2 * size_t(i) + 2], b1 = rays[2 * size_t(i) + 3];
+    const float d[6] = {b0.x - a0.x - s[0], b0.y - a0.y - s[1], b0.z - a0.z - s[2], b1.x - a1.x - s[3], b1.y - a1.y - s[4], b1.z - a1.z - s[5]};
+    return d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+}
+
+__global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __restrict__ rays, int n, int* __restrict__ out) {
+    __shared__ int first_break;
+    if (threadIdx.x == 0) { first_break = 0x7fffffff; out[0] = 0; }
+    if (n < 128) return;
+    const float4 a0 = rays[0], a1 = rays[1], b0 = rays[2], b1 = rays[3];
+    const float s[6] = {b0.x - a0.x, b0.y - a0.y, b0.z - a0.z, b1.x - a1.x, b1.y - a1.y, b1.z - a1.z};
+    const float s2 = s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+    if (!(s2 > 0.0f) || !(s2 < 3.0e38f)) return;
+    const float tol = 0.25f * s2;
+    const int limit = min(n - 1, kDetectLimit);              // pairs (i, i + 1) with i < limit
+    __syncthreads();
+    for (int base = 1; base < limit; base += kDetectBlock) {
+        const int i = base + int(threadIdx.x);
+        if (i < limit && !(ray_step_dev2(rays, i, s) <= tol)) atomicMin(&first_break, i + 1);
+        __syncthreads();
+        const int found = first_break;
+        __syncthreads();
+        if (found != 0x7fffffff) break;
+    }
+    if (threadIdx.x == 0) {
+        const int w = first_break;
+        bool ok = w != 0x7fffffff && w >= 8 && (w & 7) == 0 && n / w >= 8;
+        if (ok) ok = ray_step_dev2(rays, w, s) <= tol;                                   // second row advances like the first
+        if (ok && n > 2 * w) ok = !(ray_step_dev2(rays, 2 * w - 1, s) <= tol);            // and ends where the first did
+        out[0] = ok ? w : 0;
+    }
+}
+
 template <bool SMALL, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
-    int b = blockIdx.x;
-    {   // bijective remap: blocks are dispatched round-robin over the 8 XCDs
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int slot = b * BLOCK + threadIdx.x;
+    const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
+    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
+    const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
     if (slot >= a.num_rays) return;
     const int id = a.perm ? a.perm[slot] : slot;
 
@@ -523,6 +621,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr;
+    a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.num_rays = num_rays; a.shift = g->shift;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
@@ -573,8 +672,28 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
     // hagrid_set_option("traverse.variant", 1|2|3) forces a kernel (tests, experiments).
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
-    int variant = ctx->opt_variant ? ctx->opt_variant : (num_rays >= 24 * lanes ? 3 : 2);
+    const bool large = num_rays >= 24 * lanes;
+    int variant = ctx->opt_variant ? ctx->opt_variant : (large ? 3 : 2);
     if (perm) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
+    // Tile packets (v2 only, not for binned batches): "traverse.image_width" > 0 gives the row length, 0 (default) looks
+    // for one on the device, -1 switches the feature off.  A small batch never waits for the answer (the kernel reads it
+    // from device memory); a large one reads it back, because an image-ordered batch is faster with v2 + tiles than with
+    // v3 (4096^2 rays: 2.10 vs 2.61 ms) and the kernel has to be chosen on the host.
+    if (!perm && ctx->opt_image_width >= 0 && (variant == 2 || (!ctx->opt_variant && large))) {
+        if (ctx->opt_image_width > 0) {
+            a.row_len_hint = ctx->opt_image_width;
+            if ((a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
+        } else {
+            int* row_len = ctx->dscratch + 232;
+            detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len);
+            a.row_len = row_len;
+            if (variant != 2) {
+                int w = 0;
+                HG_TRY(read_back(ctx, row_len, &w, sizeof(int)));
+                if (w > 0) variant = 2;
+            }
+        }
+    }
     if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -609,6 +728,8 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.variant", &ctx->opt_variant, 0, 3},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
+        {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {
@@ -694,6 +815,12 @@ __global__ void kat_lookup(const Entry* entries, int shift, ivec3 top, const int
     out[i] = lookup_entry(entries, shift, top, ivec3(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]));
 }
 
+__global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray assignment of v2, one wavefront per block
+    const int w = tile_packet_row_len(a);
+    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
+    out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
+}
+
 struct Staged {   // host array staged on the device through the pool
     hagrid_ctx* ctx; void* d = nullptr; size_t bytes;
     Staged(hagrid_ctx* c, const void* h, size_t b) : ctx(c), bytes(b) {
@@ -752,4 +879,25 @@ extern "C" int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries,
     kat_lookup<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Entry*)e.d, shift, ivec3(top_dims3[0], top_dims3[1], top_dims3[2]), (const int*)v.d, n, (uint32_t*)o.d);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(out);
+}
+
+extern "C" int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len) {
+    if (!ctx || !rays_dev || num_rays < 0 || !row_len) return HAGRID_EINVAL;
+    int* d = ctx->dscratch + 232;
+    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(static_cast<const float4*>(rays_dev), num_rays, d);
+    HG_HIP(ctx, hipGetLastError());
+    return read_back(ctx, d, row_len, sizeof(int));
+}
+
+extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots) {
+    if (!ctx || num_rays <= 0 || !slots || super_log2 < 0 || super_log2 > 8) return HAGRID_EINVAL;
+    const int blocks = grid_blocks(num_rays, 64);
+    TraverseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.num_rays = num_rays; a.row_len_hint = row_len; a.super_log2 = super_log2; a.xcd_chunk_log2 = xcd_chunk_log2;
+    Staged o(ctx, nullptr, size_t(blocks) * 64 * 4);
+    if (!o.d) return HAGRID_ENOMEM;
+    kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d);
+    HG_HIP(ctx, hipGetLastError());
+    return o.fetch(slots);
 }

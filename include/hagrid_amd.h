@@ -139,9 +139,14 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel by batch size, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled),
- * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at"; "expand.subset_only" (1 = the
- * reference's compiled setting, default; 0 = the precise expansion of expand.cu:39-57,96-127 -- this one changes the grid,
- * not the hits).  Returns HAGRID_EINVAL for an
+ * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
+ * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
+ * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
+ * looked for on the device at every call (constant (origin, direction) step along a row), > 0 = w given by the
+ * caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
+ * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
+ * "expand.subset_only" (1 = the reference's compiled setting, default; 0 = the precise expansion of
+ * expand.cu:39-57,96-127 -- this one changes the grid, not the hits).  Returns HAGRID_EINVAL for an
  * unknown key or a value out of range.  Hits never depend on these settings. */
 int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 
@@ -155,6 +160,11 @@ int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* 
 int hagrid_kat_compute_grid_dims(hagrid_ctx* ctx, const void* bb, const int32_t* num_prims, const float* density, int n, int32_t* out3);
 int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_entries, int shift, const int32_t* top_dims3,
                             const int32_t* voxels3, int n, uint32_t* out);
+/* Tile packets (see "traverse.image_width"): the row length the device finds for a ray buffer in device memory (0 = not
+ * image-ordered), and the ray slot every lane of every 64-lane block gets for a batch of num_rays rays with rows of
+ * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */
+int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len);
+int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
 
 #ifdef __cplusplus
 }

@@ -219,3 +219,82 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
     with pytest.raises(api.HagridError):
         mem.set_option("no.such.key", 1)
     grid.free(); mem.free(d_tris)
+
+
+def _tile_slots(mem, n, w, super_log2=5, chunked=6):
+    """slot of every lane, blocks in dispatch order"""
+    out = np.full(64 * ((n + 63) // 64), -1, np.int32)
+    assert mem._L.hagrid_kat_tile_slots(mem._ctx, n, w, super_log2, chunked, out.ctypes.data_as(C.c_void_p)) == 0
+    return out
+
+
+@pytest.mark.parametrize("n,w", [(1024 * 1024, 1024), (640 * 480, 640), (200 * 77 + 13, 200), (256 * 256, 256), (2048 * 24, 2048),
+                                 (72 * 72, 72), (4096 * 520, 4096), (1000, 0), (1000, 12), (64 * 9, 64), (4097, 8)])
+def test_tile_packets_assign_every_ray_to_exactly_one_lane(mem, n, w):
+    """The lane <-> ray assignment of the tile packets is a bijection for every batch size / row length / super-tile
+    size / XCD order (values >= n are idle lanes), and where it applies a wavefront really holds an 8 x 8 pixel tile."""
+    tiled = w >= 8 and w % 8 == 0 and (n // w) >= 8
+    for sl in (0, 2, 5):
+        for chunked in (-1, 0, 3, 10):
+            slots = _tile_slots(mem, n, w, sl, chunked)
+            live = slots[slots < n]
+            assert live.min() >= 0 and live.size == n and (np.sort(live) == np.arange(n)).all(), (n, w, sl, chunked)
+            t = slots.reshape(-1, 64)
+            x, y = (t % w, t // w) if tiled else (t, t)
+            is_tile = (x.max(axis=1) - x.min(axis=1) == 7) & (y.max(axis=1) - y.min(axis=1) == 7)
+            is_strip = (t == t[:, :1] + np.arange(64)).all(axis=1)
+            tiles = (w // 8) * ((n // w) // 8) if tiled else 0
+            assert is_tile.sum() >= tiles and (is_tile | is_strip).all() and is_strip.sum() >= t.shape[0] - tiles
+
+
+def test_row_length_detection(mem):
+    lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
+    def detect(rays):
+        d = mem.upload(np.ascontiguousarray(rays, np.float32)); w = C.c_int32(-1)
+        assert mem._L.hagrid_kat_detect_ray_rows(mem._ctx, C.c_void_p(d), rays.shape[0], C.byref(w)) == 0
+        mem.free(d)
+        return w.value
+    assert detect(scene.make_rays_primary(lo, hi, 1024, 512)) == 1024
+    assert detect(scene.make_rays_primary(lo, hi, 640, 480)) == 640
+    assert detect(scene.make_rays_primary(lo, hi, 4096, 16)) == 4096
+    assert detect(scene.make_rays_primary(lo, hi, 1000, 100, sample=3, num_samples=8)) == 1000
+    assert detect(scene.make_rays_primary(lo, hi, 1001, 100)) == 0                      # not a multiple of 8
+    assert detect(scene.make_rays_primary(lo, hi, 512, 4)) == 0                         # fewer than 8 rows
+    assert detect(scene.make_rays_primary(lo, hi, 64, 64)[:100]) == 0                   # tiny batch
+    assert detect(scene.make_rays_incoherent(lo, hi, 100000, 5)) == 0
+    prim = scene.make_rays_primary(lo, hi, 256, 256)
+    assert detect(np.concatenate([prim, scene.make_rays_incoherent(lo, hi, 1000, 6)])) == 256   # ragged tail is fine
+    same = np.repeat(prim[:1], 4096, axis=0)
+    assert detect(same) == 0                                                            # no step at all
+    # orthographic camera: one direction, the origin steps across the image plane
+    ys, xs = np.divmod(np.arange(320 * 200), 320)
+    ortho = np.zeros((320 * 200, 8), np.float32)
+    ortho[:, 0] = xs / 320.0; ortho[:, 1] = ys / 200.0; ortho[:, 2] = -1.0; ortho[:, 6] = 1.0; ortho[:, 7] = 10.0
+    assert detect(ortho) == 320
+    nan = prim.copy(); nan[1, 4] = np.nan
+    assert detect(nan) == 0
+
+
+def test_tile_packets_give_identical_hits(mem):
+    """Image-ordered batches through v2 with the row length detected on the device, given by the caller (right, wrong and
+    useless values) and switched off: always the oracle's hits, in the rays' own slots."""
+    from oracle import oracle as O
+    tris = scene.make_soup(60000)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    batches = {"640x480": scene.make_rays_primary(G.bbox_min, G.bbox_max, 640, 480),
+               "200x77+13": np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 200, 77), scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 13, 3)]),
+               "incoherent": scene.make_rays_incoherent(G.bbox_min - 0.1, G.bbox_max + 0.1, 70001, 9)}
+    try:
+        for name, rays in batches.items():
+            rays = np.ascontiguousarray(rays, np.float32)
+            want, _ = G.traverse(tris, rays, nthreads=8)
+            for width in (0, -1, 640, 200, 8, 24, 1 << 20, 333):
+                for sl in (5, 1):
+                    mem.set_option("traverse.image_width", width); mem.set_option("traverse.super_tile", sl)
+                    got = gpu_traverse(mem, grid, d_tris, rays)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (name, width, sl)
+    finally:
+        mem.set_option("traverse.image_width", 0); mem.set_option("traverse.super_tile", 5)
+    grid.free(); mem.free(d_tris)
