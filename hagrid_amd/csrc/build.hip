@@ -452,6 +452,7 @@ struct Temps {           // pool buffers released on every exit path
 extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tris, hagrid_grid* grid,
                                  float top_density, float snd_density) {
     if (!ctx || !grid) return HAGRID_EINVAL;
+    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     if (!tris_v || num_tris <= 0) HG_FAIL(ctx, HAGRID_EINVAL, "build_grid: no triangles");
     HG_HIP(ctx, hipSetDevice(ctx->device));
     const float4* tris = static_cast<const float4*>(tris_v);

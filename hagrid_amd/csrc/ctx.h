@@ -20,6 +20,21 @@ struct Slot {
 
 } // namespace hagrid_impl
 
+namespace hagrid_impl {
+
+// Traversal image (trav_image.hip): one per context, derived from the grid of the last hagrid_setup_traversal call.
+struct TravImageCache {
+    void* table = nullptr;          // uint2 per top-level cell
+    void* blocks = nullptr;         // 128-byte aligned blocks: local voxel map + 32-byte cell records
+    size_t block_bytes = 0;
+    bool valid = false;
+    // identity of the source grid
+    const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
+    int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0};
+};
+
+} // namespace hagrid_impl
+
 struct hagrid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -49,7 +64,10 @@ struct hagrid_ctx {
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_super_log2 = 5;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
+    int opt_image = 1;          // setup_traversal builds the traversal image (trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
+
+    hagrid_impl::TravImageCache image;
 
     std::string err;
 };
@@ -87,5 +105,12 @@ inline T* pool_alloc(hagrid_ctx* ctx, size_t n) {
 int read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes);
 
 inline int grid_blocks(long long n, int block) { return (int)((n + block - 1) / block); }
+
+// trav_image.hip
+int trav_image_build(hagrid_ctx* ctx, const hagrid_grid* grid);       // leaves the image invalid for grids it does not cover
+void trav_image_drop(hagrid_ctx* ctx);
+bool trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* grid);
+// a pool buffer is freed or overwritten: the image goes if it was derived from that buffer
+void trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, size_t bytes);
 
 } // namespace hagrid_impl

@@ -121,6 +121,8 @@ extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
     if (!ptr) return HAGRID_OK;
     auto it = ctx->tracker.find(ptr);
     if (it == ctx->tracker.end()) HG_FAIL(ctx, HAGRID_EINVAL, "free of a pointer that does not come from this MemManager");
+    trav_image_source_touched(ctx, ptr, 1);       // a traversal image derived from this buffer goes with it
+    it = ctx->tracker.find(ptr);
     Slot& s = ctx->slots[it->second];
     ctx->tracker.erase(it);
     s.in_use = false;
@@ -135,6 +137,7 @@ extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
 extern "C" int hagrid_mem_copy_h2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    trav_image_source_touched(ctx, dst, bytes);
     HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -151,18 +154,21 @@ extern "C" int hagrid_mem_copy_d2h(hagrid_ctx* ctx, void* dst, const void* src, 
 extern "C" int hagrid_mem_copy_d2d(hagrid_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    trav_image_source_touched(ctx, dst, bytes);
     HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return HAGRID_OK;
 }
 extern "C" int hagrid_mem_zero(hagrid_ctx* ctx, void* ptr, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    trav_image_source_touched(ctx, ptr, bytes);
     HG_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
     return HAGRID_OK;
 }
 extern "C" int hagrid_mem_one(hagrid_ctx* ctx, void* ptr, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
+    trav_image_source_touched(ctx, ptr, bytes);
     HG_HIP(ctx, hipMemsetAsync(ptr, 0xFF, bytes, ctx->stream));
     return HAGRID_OK;
 }

@@ -1,0 +1,255 @@
+// trav_image.hip -- the traversal image: the finished grid re-laid-out for the vector L1 of gfx950.
+//
+// No reference counterpart.  The reference traverses the construction format directly (traverse.cu:27-95): per cell
+// step a top-level entry, a second-level entry, a 32-byte cell, then per reference a 4-byte id and a 48-byte triangle,
+// each in a different region of memory.  On MI355X a divergent gather costs one 128-byte line fill of the vector L1
+// (64 B/clk/CU) however few bytes are used (tools/micro/l1_gather.hip: 2.4 CU-cycles per record for 4, 16 or 32
+// bytes), so what bounds the traversal is the number of distinct lines a ray touches, not its bytes.  The image puts
+// what a ray needs while it crosses one top-level cell into one contiguous, 128-byte aligned block:
+//
+//   table[T]  (uint2 per top-level cell)   x = block offset in 128-byte units
+//                                          y = depth d | wide << 2 | count << 8
+//   block     [ (2^d)^3 local slots, u8 (u16 if wide), padded to >= 32 B ]   only if d > 0
+//             [ count records of 32 bytes ]
+//   record    u16 lo.x lo.y lo.z hi.x hi.y hi.z | u32 n | the reference ids inline (unused = -1)          n <= 4
+//             u16 lo.x lo.y lo.z hi.x hi.y hi.z | u32 n | 1 << 31 | first reference index into ref_ids    n  > 4
+//             0 0 0 | 0xffffffff | entry index, depth of that entry                                        deep
+//
+// d is the deepest subdivision inside the top-level cell, capped at 3 (512 slots); a slot names one of the cells that
+// overlap the top-level cell (a cell spanning several top-level cells has a record in each), and a reference list of
+// up to four ids travels with its cell.  Where the construction format subdivides further than the block resolves, the
+// record is a `deep` link to the voxel-map entry at which the walk of the construction format continues for that step
+// (dense spots of very non-uniform scenes; everything else never touches the construction format).  A cell step is
+// then [table entry, only when the top-level cell changes] -> slot byte -> record, typically inside one or two lines
+// that neighbouring rays share, and the reference-id gather disappears for short lists.  Cell bounds, reference order
+// and every value the traversal arithmetic uses are copied unchanged: hits are identical to the traversal of the
+// construction format (tests/test_traverse_gpu.py).
+//
+// Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal state), owned by
+// the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids with a
+// virtual resolution below 65536 per axis; otherwise traversal reads the construction format.
+#include "ctx.h"
+#include "wave_prims.h"
+
+#include "hagrid/grid.h"
+
+using namespace hagrid;
+using namespace hagrid_impl;
+
+namespace {
+
+struct ImgK {
+    const uint32_t* __restrict__ entries;
+    const int4* __restrict__ cells;        // two int4 per cell
+    const int* __restrict__ refs;
+    int top_x, top_y, num_top;
+    int shift;
+};
+
+__host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
+    if (d == 0) return 0u;
+    const uint32_t b = (1u << (3 * d)) << (wide ? 1 : 0);
+    return b < 32u ? 32u : b;
+}
+
+// One wavefront per top-level cell.  D = min(shift, 3) is the finest resolution a block can have.
+// FILL = false: sizes[T] (128-byte units) and metas[T]; FILL = true: the block.
+template <int D, bool FILL>
+__global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restrict__ sizes, uint32_t* __restrict__ metas,
+                                                     const int* __restrict__ offsets, uint2* __restrict__ table, unsigned char* __restrict__ blocks) {
+    constexpr int SHIFT = D;                 // index arithmetic inside the block
+    constexpr int V = 1 << (3 * D), P = (V + 63) / 64, M = (1 << D) - 1;
+    __shared__ unsigned long long rep_mask[P];
+    __shared__ int rep_prefix[P];
+    __shared__ int ids[V];
+    const int T = blockIdx.x, lane = threadIdx.x;
+    const uint32_t topw = k.entries[T];
+    const int up = k.shift - D;              // block voxel -> finest-level voxel inside the top-level cell
+
+    // what every block voxel resolves to: a leaf cell (id >= 0) or, where the construction format subdivides beyond
+    // depth D, the entry at which its walk has to continue (id = -1 - entry index)
+    int cell[P], rep[P], dep[P];
+    int depth_max = 0;
+    #pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int f = p * 64 + lane;
+        cell[p] = -1; rep[p] = -1; dep[p] = 0;
+        if (f < V) {
+            const int rx = (f & M) << up, ry = ((f >> SHIFT) & M) << up, rz = (f >> (2 * SHIFT)) << up;
+            uint32_t w = topw;
+            int depth = 0, eidx = T;
+            while ((w & 3u) && depth + int(w & 3u) <= D) {
+                const int kk = int(w & 3u);
+                depth += kk;
+                const int s = k.shift - depth, m = (1 << kk) - 1;
+                eidx = int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk);
+                w = k.entries[eidx];
+            }
+            cell[p] = (w & 3u) ? -1 - eidx : int(w >> 2);
+            dep[p] = depth;
+            ids[f] = cell[p];
+            depth_max = max(depth_max, depth);
+        }
+    }
+    const int d = wave_max(depth_max);
+    const int sd = D - d;
+    __syncthreads();
+
+    // The voxels that name one cell form a box (the cell before expand_grid stretched its bounds; the voxel map is not
+    // touched by the expansion).  Its representative is the lowest corner of that box inside this block, found by walking
+    // the runs of equal ids down x, then y, then z.  Whatever the shape, the representative names the same cell as the
+    // voxel, so a region that is not a box only costs duplicate records.
+    int count = 0;
+    #pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int f = p * 64 + lane;
+        bool is_rep = false;
+        if (f < V) {
+            const int fx = f & M, fy = (f >> SHIFT) & M, fz = f >> (2 * SHIFT);
+            if (((fx | fy | fz) & ((1 << sd) - 1)) == 0) {                           // a voxel of depth d
+                const int step = 1 << sd, c = cell[p];
+                int x = fx, y = fy, z = fz;
+                while (x > 0 && ids[(x - step) + (y << SHIFT) + (z << (2 * SHIFT))] == c) x -= step;
+                while (y > 0 && ids[x + ((y - step) << SHIFT) + (z << (2 * SHIFT))] == c) y -= step;
+                while (z > 0 && ids[x + (y << SHIFT) + ((z - step) << (2 * SHIFT))] == c) z -= step;
+                rep[p] = x + (y << SHIFT) + (z << (2 * SHIFT));
+                is_rep = rep[p] == f;
+            }
+        }
+        const unsigned long long mask = __ballot(is_rep);
+        if (lane == 0) { rep_mask[p] = mask; rep_prefix[p] = count; }
+        count += __popcll(mask);
+    }
+    const bool wide = count > 255;
+    const uint32_t meta = uint32_t(d) | (wide ? 4u : 0u) | (uint32_t(count) << 8);
+    const uint32_t ebytes = slot_bytes(d, wide);
+    if (!FILL) {
+        if (lane == 0) { sizes[T] = int((ebytes + 32u * uint32_t(count) + 127u) >> 7); metas[T] = meta; }
+        return;
+    }
+    __syncthreads();
+    const uint32_t off = uint32_t(offsets[T]);
+    if (lane == 0) table[T] = make_uint2(off, meta);
+    unsigned char* base = blocks + size_t(off) * 128u;
+    #pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int f = p * 64 + lane;
+        if (f >= V || rep[p] < 0) continue;
+        const int g = rep[p];
+        const int slot = rep_prefix[g >> 6] + __popcll(rep_mask[g >> 6] & ((1ull << (g & 63)) - 1ull));
+        if (d > 0) {
+            const int fx = f & M, fy = (f >> SHIFT) & M, fz = f >> (2 * SHIFT);
+            const int idx = (fx >> sd) + (((fy >> sd) + ((fz >> sd) << d)) << d);
+            if (wide) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)slot;
+            else      base[idx] = (unsigned char)slot;
+        }
+        if (g == f && cell[p] < 0) {
+            uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
+            rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu);
+            rec[1] = make_uint4(uint32_t(-1 - cell[p]), uint32_t(dep[p]), 0u, 0u);
+        } else if (g == f) {
+            const int4 lo = k.cells[2 * size_t(cell[p])], hi = k.cells[2 * size_t(cell[p]) + 1];
+            const int begin = lo.w, n = hi.w - lo.w;
+            uint4 a, b;
+            a.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
+            a.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
+            a.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+            a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
+            if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }
+            else {
+                b.x = n > 0 ? uint32_t(k.refs[begin]) : ~0u;
+                b.y = n > 1 ? uint32_t(k.refs[begin + 1]) : ~0u;
+                b.z = n > 2 ? uint32_t(k.refs[begin + 2]) : ~0u;
+                b.w = n > 3 ? uint32_t(k.refs[begin + 3]) : ~0u;
+            }
+            uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
+            rec[0] = a; rec[1] = b;
+        }
+    }
+}
+
+struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
+struct SizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
+
+template <int D>
+int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
+    hipStream_t st = ctx->stream;
+    int* sizes = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
+    uint32_t* metas = pool_alloc<uint32_t>(ctx, size_t(k.num_top) + 1);   // lives until the fill pass re-derives it
+    int* partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(k.num_top)) + 1);
+    uint2* table = pool_alloc<uint2>(ctx, size_t(k.num_top));
+    auto release = [&]() { hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials); };
+    if (!sizes || !metas || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    int* total = ctx->dscratch + 224;
+    image_top_cell<D, false><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr);
+    device_scan<int>(st, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total);
+    int units = 0;
+    int rc = read_back(ctx, total, &units, sizeof(int));
+    if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
+    unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, size_t(units) * 128u));
+    if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    image_top_cell<D, true><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks);
+    hipError_t e = hipGetLastError();
+    release();
+    if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }
+    img.table = table; img.blocks = blocks; img.block_bytes = size_t(units) * 128u;
+    return HAGRID_OK;
+}
+
+} // namespace
+
+void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
+    TravImageCache& img = ctx->image;
+    void* t = img.table; void* b = img.blocks;
+    img = TravImageCache();
+    if (t) hagrid_mem_free(ctx, t);
+    if (b) hagrid_mem_free(ctx, b);
+}
+
+bool hagrid_impl::trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* g) {
+    const TravImageCache& img = ctx->image;
+    return img.valid && g->entries == img.entries && g->cells == img.cells && g->ref_ids == img.refs && !g->small_cells &&
+           g->num_cells == img.num_cells && g->num_entries == img.num_entries && g->num_refs == img.num_refs && g->shift == img.shift &&
+           g->dims[0] == img.dims[0] && g->dims[1] == img.dims[1] && g->dims[2] == img.dims[2];
+}
+
+void hagrid_impl::trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, size_t bytes) {
+    const TravImageCache& img = ctx->image;
+    if (!img.valid || !ptr) return;
+    const char* lo = static_cast<const char*>(ptr);
+    const char* hi = lo + (bytes ? bytes : 1);
+    auto overlaps = [&](const void* p, size_t n) { const char* q = static_cast<const char*>(p); return q < hi && lo < q + n; };
+    if (overlaps(img.entries, size_t(img.num_entries) * 4) || overlaps(img.cells, size_t(img.num_cells) * 32) || overlaps(img.refs, size_t(img.num_refs) * 4))
+        trav_image_drop(ctx);
+}
+
+int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
+    trav_image_drop(ctx);
+    if (!ctx->opt_image || !g->entries || !g->cells || !g->ref_ids || g->small_cells || g->num_cells <= 0) return HAGRID_OK;
+    if (g->shift < 0 || g->shift > 15) return HAGRID_OK;
+    for (int i = 0; i < 3; i++)
+        if (g->dims[i] <= 0 || (long long)g->dims[i] << g->shift > 65535) return HAGRID_OK;
+    const long long num_top = (long long)g->dims[0] * g->dims[1] * g->dims[2];
+    if (num_top > (1ll << 30)) return HAGRID_OK;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    ImgK k;
+    k.entries = static_cast<const uint32_t*>(g->entries);
+    k.cells = static_cast<const int4*>(g->cells);
+    k.refs = static_cast<const int*>(g->ref_ids);
+    k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
+    TravImageCache img;
+    int rc = HAGRID_OK;
+    switch (g->shift < 3 ? g->shift : 3) {
+        case 0: rc = build_image<0>(ctx, k, img); break;
+        case 1: rc = build_image<1>(ctx, k, img); break;
+        case 2: rc = build_image<2>(ctx, k, img); break;
+        default: rc = build_image<3>(ctx, k, img); break;
+    }
+    if (rc != HAGRID_OK) return rc;
+    img.valid = img.table != nullptr;
+    img.entries = g->entries; img.cells = g->cells; img.refs = g->ref_ids;
+    img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
+    img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
+    ctx->image = img;
+    return HAGRID_OK;
+}

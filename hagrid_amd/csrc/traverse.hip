@@ -38,6 +38,8 @@ struct TraverseArgs {
     int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
     int super_log2;                          // tile packets: tiles per super-tile edge, log2
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
+    const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
+    const unsigned char* __restrict__ img_blocks;
     int num_rays;
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
@@ -381,6 +383,123 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
 }
 
 
+// ---- image kernel: v2 over the traversal image ------------------------------------------------------------------------
+// Same ray arithmetic as v1 / v2 / the oracle; the cell comes from the traversal image (trav_image.hip): the table entry
+// of the top-level cell (kept in registers while the ray stays inside it), one slot byte, one 32-byte record that carries
+// the bounds and -- for lists of up to four -- the reference ids themselves.  The next cell's slot + record are fetched
+// before the current cell's triangles are tested, as in v2.
+__device__ __forceinline__ const uint4* image_record(const TraverseArgs& a, uint2 tab, int vx, int vy, int vz) {
+    const uint32_t meta = tab.y;
+    const int d = int(meta & 3u), w = int((meta >> 2) & 1u);
+    const unsigned char* base = a.img_blocks + size_t(tab.x) * 128u;
+    const int s = a.shift - d, m = (1 << d) - 1;
+    const int idx = ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << d)) << d);   // 0 when d == 0
+    uint32_t slot = base[idx << w];                                                           // d == 0: a byte of the record, ignored
+    if (w) slot |= uint32_t(base[(idx << 1) + 1]) << 8;
+    uint32_t ebytes = (1u << (3 * d)) << w;
+    ebytes = d ? (ebytes < 32u ? 32u : ebytes) : 0u;
+    if (!d) slot = 0;
+    return reinterpret_cast<const uint4*>(base + ebytes + slot * 32u);
+}
+
+// A `deep` record: the block does not resolve this voxel; continue the walk of the construction format at the entry the
+// record names and bring the cell into record form (list by index, never inline).
+__device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb) {
+    uint32_t w = a.entries[cb.x];
+    int depth = int(cb.y);
+    while (w & 3u) {
+        const int k = int(w & 3u);
+        depth += k;
+        const int s = a.shift - depth, m = (1 << k) - 1;
+        w = a.entries[(w >> 2) + ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << k)) << k)];
+    }
+    const int4* p = reinterpret_cast<const int4*>(a.cells) + 2 * size_t(w >> 2);
+    const int4 lo = p[0], hi = p[1];
+    ca.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
+    ca.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
+    ca.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+    ca.w = uint32_t(hi.w - lo.w) | 0x80000000u;
+    cb.x = uint32_t(lo.w);
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
+    const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
+    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
+    const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
+    if (slot >= a.num_rays) return;
+    const int id = a.perm ? a.perm[slot] : slot;
+
+    const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
+    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    const float tmin = r0.w, tmax = r1.w;
+    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+    const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+
+    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+
+    Hit hit(-1, tmax, 0.0f, 0.0f);
+
+    if (!(tstart > tend)) {
+        const vec3 fv = (tstart * dir + org - gmin) * ginv;
+        int vx = min(max(int(fv.x), 0), a.dims_x - 1);
+        int vy = min(max(int(fv.y), 0), a.dims_y - 1);
+        int vz = min(max(int(fv.z), 0), a.dims_z - 1);
+
+        int top_idx = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
+        uint2 tab = a.img_table[top_idx];
+        const uint4* rec = image_record(a, tab, vx, vy, vz);
+        uint4 ca = rec[0], cb = rec[1];
+        if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+
+        for (;;) {
+            const int cx = int(px ? ca.y >> 16 : ca.x & 0xffffu), cy = int(py ? ca.z & 0xffffu : ca.x >> 16), cz = int(pz ? ca.z >> 16 : ca.y & 0xffffu);
+            const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+            const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+            const vec3 ev = (texit * dir + org - gmin) * ginv;
+            const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
+            const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
+            const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+            vx = px ? max(nx, vx) : min(nx, vx);
+            vy = py ? max(ny, vy) : min(ny, vy);
+            vz = pz ? max(nz, vz) : min(nz, vz);
+            const bool outside = (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
+
+            // next cell: table entry (only when the top-level cell changes), slot, record -- in flight during the tests below
+            const int ntop = outside ? top_idx : (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
+            if (ntop != top_idx) { tab = a.img_table[ntop]; top_idx = ntop; }
+            const uint4* nrec = image_record(a, tab, vx, vy, vz);
+            const uint4 na = nrec[0], nb = nrec[1];
+
+            const int n = int(ca.w & 0x7fffffffu);
+            if (!(ca.w >> 31)) {
+                for (int i = 0; i < n; i++) {
+                    const int ref = int(i == 0 ? cb.x : (i == 1 ? cb.y : (i == 2 ? cb.z : cb.w)));
+                    intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                }
+            } else if (n > 0) {
+                const int* list = a.refs + cb.x;
+                int ref = list[0];
+                for (int i = 1; i <= n; i++) {
+                    const int next = list[i < n ? i : 0];
+                    intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    ref = next;
+                }
+            }
+            if (hit.t <= texit || outside) break;
+            ca = na; cb = nb;
+            if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+        }
+    }
+    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
+}
+
+
 // ---- v3: persistent wavefronts, lane refill, vote-scheduled phases -------------------------------------------------
 // Profile of v1/v2 on the 1M-ray batch (profiles/): the SIMDs issue ~80 % of the time while only ~19 % of the lanes
 // of an issued VALU instruction are live -- the kernel is instruction-issue bound and 4 of 5 lanes idle, because (a) a
@@ -622,6 +741,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
+    a.img_table = nullptr; a.img_blocks = nullptr;
     a.num_rays = num_rays; a.shift = g->shift;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
@@ -637,7 +757,8 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
 extern "C" int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid) {
     if (!ctx) return HAGRID_EINVAL;
     TraverseArgs a;
-    return make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a);
+    HG_TRY(make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a));
+    return trav_image_build(ctx, grid);     // "traverse.image" = 0: drops the image, traversal reads the construction format
 }
 
 extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
@@ -667,34 +788,43 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm);
         a.perm = perm;
     }
-    // Kernel choice.  Small batches (a few rays per resident lane) end when their longest rays end: the latency-
-    // oriented v2 wins.  Large batches are throughput-bound: the persistent, vote-scheduled v3 wins (measured
+    // Kernel choice.  With a traversal image (hagrid_setup_traversal built one for this very grid) its kernel is used for
+    // every batch.  Without one: small batches (a few rays per resident lane) end when their longest rays end and the
+    // latency-oriented v2 wins; large batches are throughput-bound and the persistent, vote-scheduled v3 wins (measured
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
-    // hagrid_set_option("traverse.variant", 1|2|3) forces a kernel (tests, experiments).
+    // hagrid_set_option("traverse.variant", 1|2|3|4) forces a kernel (tests, experiments).
+    const bool have_image = ctx->opt_image && trav_image_matches(ctx, grid);
+    if (ctx->opt_variant == 4 && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
     const bool large = num_rays >= 24 * lanes;
-    int variant = ctx->opt_variant ? ctx->opt_variant : (large ? 3 : 2);
-    if (perm) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
-    // Tile packets (v2 only, not for binned batches): "traverse.image_width" > 0 gives the row length, 0 (default) looks
-    // for one on the device, -1 switches the feature off.  A small batch never waits for the answer (the kernel reads it
-    // from device memory); a large one reads it back, because an image-ordered batch is faster with v2 + tiles than with
-    // v3 (4096^2 rays: 2.10 vs 2.61 ms) and the kernel has to be chosen on the host.
-    if (!perm && ctx->opt_image_width >= 0 && (variant == 2 || (!ctx->opt_variant && large))) {
+    int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : (large ? 3 : 2));
+    if (perm && variant != 4) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
+    if (variant == 4) {
+        a.img_table = static_cast<const uint2*>(ctx->image.table);
+        a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
+    }
+    // Tile packets (v2 and the image kernel, not for binned batches): "traverse.image_width" > 0 gives the row length, 0
+    // (default) looks for one on the device, -1 switches the feature off.  The kernel reads the answer from device memory,
+    // nobody waits for it -- except a large batch without a traversal image: image order + tiles + v2 beats v3
+    // (4096^2 rays: 1.96 vs 2.55 ms), so there the kernel is chosen on the host after reading the row length back.
+    if (!perm && ctx->opt_image_width >= 0 && (variant == 2 || variant == 4 || (!ctx->opt_variant && large))) {
         if (ctx->opt_image_width > 0) {
             a.row_len_hint = ctx->opt_image_width;
-            if ((a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
+            if (variant == 3 && (a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
         } else {
             int* row_len = ctx->dscratch + 232;
             detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len);
             a.row_len = row_len;
-            if (variant != 2) {
+            if (variant == 3) {
                 int w = 0;
                 HG_TRY(read_back(ctx, row_len, &w, sizeof(int)));
                 if (w > 0) variant = 2;
             }
         }
     }
-    if (variant == 1) {
+    if (variant == 4) {
+        traverse_kernel_img<64><<<grid_blocks(num_rays, 64), 64, 0, ctx->stream>>>(a);
+    } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
         else                   traverse_kernel<false, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -725,11 +855,11 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
 extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
-        {"traverse.variant", &ctx->opt_variant, 0, 3},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
+        {"traverse.variant", &ctx->opt_variant, 0, 4},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 1},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {
@@ -821,6 +951,18 @@ __global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray a
     out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
 }
 
+__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
+    const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
+    const uint4* rec = image_record(a, tab, vx, vy, vz);
+    uint4 ra = rec[0], rb = rec[1];
+    if (ra.w == 0xffffffffu) { image_resolve_deep(a, vx, vy, vz, ra, rb); ra.w |= 0x40000000u; }     // bit 30: came through a deep link
+    uint32_t* o = out + 8 * size_t(i);
+    o[0] = ra.x; o[1] = ra.y; o[2] = ra.z; o[3] = ra.w; o[4] = rb.x; o[5] = rb.y; o[6] = rb.z; o[7] = rb.w;
+}
+
 struct Staged {   // host array staged on the device through the pool
     hagrid_ctx* ctx; void* d = nullptr; size_t bytes;
     Staged(hagrid_ctx* c, const void* h, size_t b) : ctx(c), bytes(b) {
@@ -900,4 +1042,21 @@ extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len,
     kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(slots);
+}
+
+extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes) {
+    if (!ctx || !grid || n < 0) return HAGRID_EINVAL;
+    if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
+    if (image_bytes) *image_bytes = (int64_t)ctx->image.block_bytes + 8ll * grid->dims[0] * grid->dims[1] * grid->dims[2];
+    if (n == 0) return HAGRID_OK;
+    TraverseArgs a;
+    HG_TRY(make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a));
+    a.img_table = static_cast<const uint2*>(ctx->image.table);
+    a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
+    // staging must not disturb the image: these buffers are not grid arrays
+    Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
+    if (!v.d || !o.d) return HAGRID_ENOMEM;
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d);
+    HG_HIP(ctx, hipGetLastError());
+    return o.fetch(records8);
 }

@@ -118,7 +118,15 @@ int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris, int
 int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
 
 /* ---- traversal (traverse.h:11-14) ------------------------------------------------------------------- */
-/* setup_traversal (traverse.cu:97-109): derives and stores the traversal constants of `grid`. */
+/* setup_traversal (traverse.cu:97-109): prepares the traversal state of `grid`.  The reference uploads constants; here
+ * the constants travel with every launch and this call builds the TRAVERSAL IMAGE of the grid in the context (one per
+ * context: the grid of the last call): per top-level cell one 128-byte aligned block holding a local voxel map and
+ * 32-byte cell records with the reference ids of short lists inline -- a layout chosen for the line-fill economy of the
+ * vector L1.  hagrid_traverse_grid uses the image when it is called with the same grid (same arrays,
+ * same counts); the image is dropped when a construction pass runs in this context or when one of the grid's arrays is
+ * freed or overwritten through this API; without an image traversal reads the construction format.  Hits are identical
+ * either way.  Not built for compressed grids or a virtual resolution above 65535 per axis, or after
+ * hagrid_set_option("traverse.image", 0).  Synchronous (one size read-back). */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
  * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
@@ -138,7 +146,8 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
- * kernel by batch size, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled),
+ * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
+ * kernel, an error without an image), "traverse.image" (1 = hagrid_setup_traversal builds the traversal image, default),
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
@@ -165,6 +174,11 @@ int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_en
  * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */
 int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len);
 int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
+/* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
+ * resolves to -- u16 lo.xyz hi.xyz | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
+ * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
+ * HAGRID_EINVAL when the context holds no image of this grid. */
+int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);
 
 #ifdef __cplusplus
 }

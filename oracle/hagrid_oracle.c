@@ -999,6 +999,10 @@ static inline ovec3 compute_voxel(const TravConsts* k, ovec3 org, ovec3 dir, flo
 
 static inline int clampi(int a, int b, int c) { return imin(c, imax(b, a)); } /* common.h:27 */
 
+/* dev analysis hook (tools/dev_wave_model.py): list length of every visited cell of the ray being traversed */
+static __thread unsigned char* g_trace = NULL;
+static __thread int g_trace_cap = 0, g_trace_len = 0;
+
 static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, const ORay* rp, OHit* out, int* steps_out, OStats* st) {
     ORay ray = *rp;
     ovec3 inv_dir = v3(orc_safe_rcp(ray.dir.x), orc_safe_rcp(ray.dir.y), orc_safe_rcp(ray.dir.z));
@@ -1066,6 +1070,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                 if (st) st->refs += nrefs;
             }
             steps += 1 + nrefs;
+            if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (unsigned char)(nrefs > 255 ? 255 : nrefs); g_trace_len++; }
             if (st) { st->cells++; st->entry_words += words; }
             /* traverse.cu:85-89 */
             if (hit.t <= texit ||
@@ -1082,6 +1087,17 @@ void orc_traverse_grid(const OGrid* grid, const OTri* tris, const ORay* rays, OH
     TravConsts k; setup_consts(grid, &k);
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t i = 0; i < n; i++) traverse_one(&k, grid, tris, &rays[i], &hits[i], steps ? &steps[i] : NULL, stats);
+}
+
+void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t n, int cap, unsigned char* lens, int* num_cells) {
+    TravConsts k; setup_consts(grid, &k);
+    for (int64_t i = 0; i < n; i++) {
+        OHit hit;
+        g_trace = lens + i * cap; g_trace_cap = cap; g_trace_len = 0;
+        traverse_one(&k, grid, tris, &rays[i], &hit, NULL, NULL);
+        num_cells[i] = g_trace_len;
+    }
+    g_trace = NULL;
 }
 
 typedef struct {

@@ -298,3 +298,172 @@ def test_tile_packets_give_identical_hits(mem):
     finally:
         mem.set_option("traverse.image_width", 0); mem.set_option("traverse.super_tile", 5)
     grid.free(); mem.free(d_tris)
+
+
+# ---- traversal image ----------------------------------------------------------------------------------------------------
+
+def _np_lookup(G, vox):
+    """lookup_entry (grid.h:103-116) for many voxels at once: cell index per voxel"""
+    e = G.entries; shift = G.shift; dx, dy, dz = G.dims
+    top = vox >> shift
+    w = e[top[:, 0] + dx * (top[:, 1] + dy * top[:, 2])].astype(np.int64)
+    depth = np.zeros(len(vox), np.int64)
+    while True:
+        k = w & 3
+        live = k != 0
+        if not live.any():
+            break
+        depth = depth + k
+        s = shift - depth
+        m = (1 << k) - 1
+        sub = ((vox[:, 0] >> s) & m) + ((((vox[:, 1] >> s) & m) + (((vox[:, 2] >> s) & m) << k)) << k)
+        nxt = e[np.where(live, (w >> 2) + sub, 0)].astype(np.int64)
+        w = np.where(live, nxt, w)
+        depth = np.where(live, depth, depth - k)
+    return (w >> 2).astype(np.int64)
+
+
+def _expected_records(G, vox):
+    cells = G.cells[_np_lookup(G, vox)]
+    lo, hi = cells["min"].astype(np.uint32), cells["max"].astype(np.uint32)
+    n = (cells["end"] - cells["begin"]).astype(np.int64)
+    rec = np.zeros((len(vox), 8), np.uint32)
+    rec[:, 0] = lo[:, 0] | (lo[:, 1] << 16); rec[:, 1] = lo[:, 2] | (hi[:, 0] << 16); rec[:, 2] = hi[:, 1] | (hi[:, 2] << 16)
+    rec[:, 3] = n.astype(np.uint32)
+    refs = np.concatenate([G.ref_ids, np.zeros(4, np.int32)])
+    for j in range(4):
+        rec[:, 4 + j] = np.where(n > j, refs[cells["begin"] + j], -1).astype(np.int32).view(np.uint32)
+    return rec, cells["begin"].astype(np.uint32)
+
+
+def _check_records(got, want, begin):
+    """got: records as the image resolves them; want: inline form of the construction format"""
+    by_index = (got[:, 3] >> 31) == 1
+    deep = ((got[:, 3] >> 30) & 1) == 1
+    assert (got[:, :3] == want[:, :3]).all() and ((got[:, 3] & 0x3fffffff) == want[:, 3]).all()
+    assert (got[~by_index, 4:] == want[~by_index, 4:]).all() and (want[~by_index, 3] <= 4).all()
+    assert (got[by_index, 4] == begin[by_index]).all()
+    assert ((want[by_index & ~deep, 3] > 4)).all()           # image records list by index only when the list is long
+    return by_index, deep
+
+
+def _image_scenes():
+    sparse = scene.make_soup(3000, seed=5).copy()                      # two clusters far apart: top-level cells without subdivision
+    sparse[:1500, 0:3] *= np.float32(0.2); sparse[1500:, 0:3] = sparse[1500:, 0:3] * np.float32(0.2) + np.float32(3.0)
+    coincident = np.repeat(scene.make_soup(40, seed=6), 30, axis=0)    # lists far longer than four references
+    return {"soup20k": (scene.make_soup(20000), {}), "soup30k_shift3": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),
+            "dense_wide": (scene.make_soup(8000, seed=12), dict(top_density=0.08, snd_density=10.0)),     # a top-level cell with > 255 cells
+            "deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),   # shift 5: blocks stop at depth 3, deep links below
+            "sparse": (sparse, {}), "coincident": (np.concatenate([coincident, scene.make_soup(2000, seed=7)]), {}),
+            "tiny": (scene.make_soup(3, seed=8), {})}
+
+
+@pytest.mark.parametrize("name", list(_image_scenes()))
+def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
+    """Every voxel of the virtual grid resolves, through the image's table / slot / record, to exactly the bounds, list
+    length and reference ids that lookup_entry + cells + ref_ids give in the construction format."""
+    from oracle import oracle as O
+    tris, params = _image_scenes()[name]
+    G = O.Grid.full(tris, **params)
+    grid = upload_oracle_grid(mem, G)
+    from hagrid_amd import api
+    api.setup_traversal(grid)
+    res = np.array(G.dims) << G.shift
+    total = int(res[0]) * int(res[1]) * int(res[2])
+    rng = np.random.default_rng(1)
+    flat = np.arange(total) if total <= 400000 else rng.choice(total, 400000, replace=False)
+    vox = np.stack([flat % res[0], (flat // res[0]) % res[1], flat // (res[0] * res[1])], axis=1).astype(np.int32)
+    got = np.zeros((len(vox), 8), np.uint32); nbytes = C.c_int64(0)
+    rc = mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), vox.ctypes.data_as(C.c_void_p), len(vox), got.ctypes.data_as(C.c_void_p), C.byref(nbytes))
+    assert rc == 0
+    want, begin = _expected_records(G, vox.astype(np.int64))
+    by_index, deep = _check_records(got, want, begin)
+    assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < 64 * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
+    if name == "coincident":
+        assert (by_index & ~deep).any()
+    if name in ("deep", "sparse", "coincident"):
+        assert G.shift > 3 and deep.any() and not deep.all()
+    else:
+        assert not deep.any()
+    if name == "dense_wide":
+        assert G.shift == 3
+        top = vox >> 3
+        per_top = {}
+        key = (top[:, 0] + G.dims[0] * (top[:, 1] + G.dims[1] * top[:, 2])).astype(np.int64) * (G.num_cells + 1) + _np_lookup(G, vox.astype(np.int64))
+        assert np.bincount(np.unique(key) // (G.num_cells + 1)).max() > 255        # the u16 slot form is exercised
+    grid.free()
+    assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
+
+
+@pytest.mark.parametrize("name", list(_image_scenes()))
+def test_image_kernel_gives_the_oracle_hits(mem, name):
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris, params = _image_scenes()[name]
+    G = O.Grid.full(tris, **params)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 256, 128),
+                           scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 60001, 17)]).astype(np.float32)
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    try:
+        for variant in (4, 0, 2):
+            mem.set_option("traverse.variant", variant)
+            for n in (rays.shape[0], 256 * 128, 65, 1):
+                got = gpu_traverse(mem, grid, d_tris, rays[:n])          # calls setup_traversal first
+                assert (got["id"] == want["id"][:n]).all() and (bits(got["t"]) == bits(want["t"][:n])).all(), (variant, n)
+        mem.set_ray_binning(1); mem.set_option("traverse.variant", 4)
+        got = gpu_traverse(mem, grid, d_tris, rays)
+        assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
+    finally:
+        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0)
+    grid.free(); mem.free(d_tris)
+
+
+def test_image_lifetime(mem):
+    """The image belongs to the grid of the last setup_traversal call and never outlives its source arrays."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(5000, seed=21)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    rays = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 20000, 4)
+    want, _ = G.traverse(tris, rays, nthreads=4)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+    has_image = lambda g: mem._L.hagrid_kat_image_records(mem._ctx, C.byref(g.pod), None, 0, None, None) == 0
+    def check():
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+        got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+        assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
+    try:
+        mem.set_option("traverse.variant", 4)
+        with pytest.raises(api.HagridError):            # forced image kernel, no image yet
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+        mem.set_option("traverse.variant", 0)
+        assert not has_image(grid); check()                 # construction format
+        api.setup_traversal(grid); assert has_image(grid); check()
+        # a second grid in the same context takes the image over; the first one still traverses (construction format)
+        grid2 = upload_oracle_grid(mem, G)
+        api.setup_traversal(grid2); assert has_image(grid2) and not has_image(grid); check()
+        grid2.free()
+        api.setup_traversal(grid); assert has_image(grid)
+        # overwriting a source array through the API drops the image
+        cells = mem.download(grid.pod.cells, np.uint8, 32 * G.num_cells)
+        mem.copy_h2d(grid.pod.cells, cells); assert not has_image(grid); check()
+        # a construction pass in the context drops it as well
+        api.setup_traversal(grid); assert has_image(grid)
+        other = api.build_all(mem, d_tris, tris.shape[0]); assert not has_image(grid); check()
+        other.free()
+        # switched off: setup_traversal builds nothing
+        mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid); check()
+        mem.set_option("traverse.image", 1); api.setup_traversal(grid); assert has_image(grid); check()
+        # compressed grids have no image
+        Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
+        api.setup_traversal(gc); assert not has_image(gc); gc.free()
+    finally:
+        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 1)
+    api.setup_traversal(grid); assert has_image(grid)
+    grid.free()                                          # freeing a source array drops the image
+    assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
+    mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)

@@ -87,14 +87,15 @@ void run(const char* name, const uint4* d, uint32_t mask16, uint32_t* out, int w
 }
 
 int main(int argc, char** argv) {
-    const size_t ws_mb = argc > 1 ? atoi(argv[1]) : 16;                 // working set in MiB
+    size_t ws_kb = argc > 1 ? atoi(argv[1]) : 16384;               // working set in KiB (power of two, >= 4)
+    if (ws_kb < 4) ws_kb = 4;
     const int waves = 256 * 32 * 4, iters = 64;
-    const size_t n16 = ws_mb * 1024 * 1024 / 16;
+    const size_t n16 = ws_kb * 1024 / 16;
     uint4* d; uint32_t* out;
     CK(hipMalloc(&d, n16 * 16 + 256)); CK(hipMalloc(&out, 64));
     CK(hipMemset(d, 1, n16 * 16 + 256));
     const uint32_t mask16 = uint32_t(n16 - 1);
-    printf("working set %zu MiB, %d waves x %d iterations x 64 records\n", ws_mb, waves, iters);
+    printf("working set %zu KiB, %d waves x %d iterations x 64 records\n", ws_kb, waves, iters);
     run<5>("4 B per lane, random", d, mask16, out, waves, iters, 4);
     run<0>("16 B per lane, random", d, mask16, out, waves, iters, 16);
     run<2>("32 B record per lane (2 loads)", d, mask16, out, waves, iters, 32);
