@@ -14,6 +14,10 @@ grid = api.build_all(mem, d_tris, N, compress=bool(int(os.environ.get("COMPRESS"
 sets = {"primary1M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
         "incoh1M": scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4),
         "primary16M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096)}
+if os.environ.get("SETS"):
+    sets = {k: v for k, v in sets.items() if k in os.environ["SETS"].split(",")}
+for k, v in (kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv):
+    mem.set_option(k, int(v))
 for name, rays in sets.items():
     n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
