@@ -367,7 +367,9 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
     G = O.Grid.full(tris, **params)
     grid = upload_oracle_grid(mem, G)
     from hagrid_amd import api
+    mem.set_option("traverse.image", 1)
     api.setup_traversal(grid)
+    mem.set_option("traverse.image", 0)
     res = np.array(G.dims) << G.shift
     total = int(res[0]) * int(res[1]) * int(res[2])
     rng = np.random.default_rng(1)
@@ -407,6 +409,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name):
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 60001, 17)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
+        mem.set_option("traverse.image", 1)
         for variant in (4, 0, 2):
             mem.set_option("traverse.variant", variant)
             for n in (rays.shape[0], 256 * 128, 65, 1):
@@ -416,7 +419,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name):
         got = gpu_traverse(mem, grid, d_tris, rays)
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
-        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0)
+        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 0)
     grid.free(); mem.free(d_tris)
 
 
@@ -437,6 +440,8 @@ def test_image_lifetime(mem):
         got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     try:
+        api.setup_traversal(grid); assert not has_image(grid)     # opt-in: nothing is built by default
+        mem.set_option("traverse.image", 1)
         mem.set_option("traverse.variant", 4)
         with pytest.raises(api.HagridError):            # forced image kernel, no image yet
             api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
@@ -461,9 +466,9 @@ def test_image_lifetime(mem):
         # compressed grids have no image
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
         api.setup_traversal(gc); assert not has_image(gc); gc.free()
+        api.setup_traversal(grid); assert has_image(grid)
+        grid.free()                                          # freeing a source array drops the image
+        assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
     finally:
-        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 1)
-    api.setup_traversal(grid); assert has_image(grid)
-    grid.free()                                          # freeing a source array drops the image
-    assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
+        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 0)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
