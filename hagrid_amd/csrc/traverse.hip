@@ -44,6 +44,7 @@ struct TraverseArgs {
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
     int top_x, top_y;             // top-level resolution (x, y)
+    int top_xy;                   // top_x * top_y when it fits 24 bits (NARROW kernels), else 0
     float min_x, min_y, min_z;    // grid box
     float max_x, max_y, max_z;
     float cs_x, cs_y, cs_z;       // cell size
@@ -300,7 +301,16 @@ __global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __
     }
 }
 
-template <bool SMALL, int BLOCK>
+// NARROW: every gather is base (scalar registers) + unsigned 32-bit byte offset (one VALU shift instead of a sign
+// extension and a 64-bit add), index products are 24-bit multiplies (full rate; 32-bit multiplies are quarter rate) and the
+// range test is three unsigned compares.  The host selects it when every array it indexes is smaller than 4 GB and the
+// top-level resolution fits 23 bits per axis.
+template <typename T>
+__device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
+}
+
+template <bool SMALL, int BLOCK, bool NARROW>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
     const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
@@ -335,14 +345,47 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
                 const int k = int(w & 3u);
                 depth += k;
                 const int s = a.shift - depth, m = (1 << k) - 1;
-                w = a.entries[(w >> 2) + ((x >> s) & m) + ((((y >> s) & m) + (((z >> s) & m) << k)) << k)];
+                const uint32_t e = (w >> 2) + ((x >> s) & m) + ((((y >> s) & m) + (((z >> s) & m) << k)) << k);
+                w = NARROW ? gather32<uint32_t>(a.entries, e << 2) : a.entries[e];
             }
             return w;
         };
 
-        int top_idx = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
-        uint32_t topw = a.entries[top_idx];
-        CellBox c = load_cell_box<SMALL>(a.cells, walk(topw, vx, vy, vz) >> 2);
+        auto top_index = [&](int x, int y, int z) -> int {
+            if (NARROW) return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
+            return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
+        };
+        auto entry = [&](int i) -> uint32_t { return NARROW ? gather32<uint32_t>(a.entries, uint32_t(i) << 2) : a.entries[i]; };
+        auto ref_at = [&](int i) -> int { return NARROW ? gather32<int>(a.refs, uint32_t(i) << 2) : a.refs[i]; };
+        auto cell_at = [&](uint32_t i) -> CellBox {
+            if (!NARROW) return load_cell_box<SMALL>(a.cells, i);
+            CellBox c;
+            if (SMALL) {
+                const uint4 w = gather32<uint4>(a.cells, i << 4);
+                c.lx = int(w.x & 0xffffu); c.ly = int(w.x >> 16); c.lz = int(w.y & 0xffffu);
+                c.hx = int(w.y >> 16); c.hy = int(w.z & 0xffffu); c.hz = int(w.z >> 16);
+                c.begin = int(w.w); c.end = 0;
+            } else {
+                const int4 lo = gather32<int4>(a.cells, i << 5), hi = gather32<int4>(a.cells, (i << 5) + 16u);
+                c.lx = lo.x; c.ly = lo.y; c.lz = lo.z; c.begin = lo.w;
+                c.hx = hi.x; c.hy = hi.y; c.hz = hi.z; c.end = hi.w;
+            }
+            return c;
+        };
+        auto tri_at = [&](int ref) -> Tri {
+            if (!NARROW) return load_tri(a.tris, ref);
+            // ref * 48 as two full-rate instructions (the compiler turns the shift-add back into a quarter-rate 32-bit multiply)
+            uint32_t r3, o;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
+            const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+            return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+        };
+
+        int top_idx = top_index(vx, vy, vz);
+        uint32_t topw = entry(top_idx);
+        CellBox c = cell_at(walk(topw, vx, vy, vz) >> 2);
 
         for (;;) {
             const int cx = px ? c.hx : c.lx, cy = py ? c.hy : c.ly, cz = pz ? c.hz : c.lz;
@@ -355,24 +398,25 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
             vx = px ? max(nx, vx) : min(nx, vx);
             vy = py ? max(ny, vy) : min(ny, vy);
             vz = pz ? max(nz, vz) : min(nz, vz);
-            const bool outside = (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
+            const bool outside = NARROW ? (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z))
+                                        : (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
 
             // first reference of this cell and the next cell's top entry: two independent loads in flight
             const int begin = c.begin;
             const bool nonempty = SMALL ? begin >= 0 : begin < c.end;
             int cur = nonempty ? begin : 0;
-            int ref = a.refs[cur];
+            int ref = ref_at(cur);
             cur++;
             if (!nonempty) ref = -1;
-            const int ntop = outside ? top_idx : (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
-            if (ntop != top_idx) { topw = a.entries[ntop]; top_idx = ntop; }
+            const int ntop = outside ? top_idx : top_index(vx, vy, vz);
+            if (ntop != top_idx) { topw = entry(ntop); top_idx = ntop; }
             // next cell: walk + load, overlapping the triangle tests below
-            const CellBox nc = load_cell_box<SMALL>(a.cells, walk(topw, vx, vy, vz) >> 2);
+            const CellBox nc = cell_at(walk(topw, vx, vy, vz) >> 2);
 
             while (ref >= 0) {
-                const int next = SMALL ? a.refs[cur] : (cur < c.end ? a.refs[cur] : -1);
+                const int next = SMALL ? ref_at(cur) : (cur < c.end ? ref_at(cur) : -1);
                 cur++;
-                intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                 ref = next;
             }
             if (hit.t <= texit || outside) break;
@@ -745,6 +789,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.num_rays = num_rays; a.shift = g->shift;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
+    a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
     a.min_x = lo.x; a.min_y = lo.y; a.min_z = lo.z;
     a.max_x = hi.x; a.max_y = hi.y; a.max_z = hi.z;
     a.cs_x = cs.x; a.cs_y = cs.y; a.cs_z = cs.z;
@@ -830,8 +875,22 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         else                   traverse_kernel<false, false><<<blocks, 256, 0, ctx->stream>>>(a);
     } else if (variant == 2) {
         const int blocks = grid_blocks(num_rays, 64);
-        if (grid->small_cells) traverse_kernel_v2<true, 64><<<blocks, 64, 0, ctx->stream>>>(a);
-        else                   traverse_kernel_v2<false, 64><<<blocks, 64, 0, ctx->stream>>>(a);
+        // 32-bit offsets are enough when every gathered array is smaller than 4 GB
+        size_t tri_bytes = ~size_t(0);
+        { hipDeviceptr_t base = nullptr; size_t size = 0;
+          if (hipMemGetAddressRange(&base, &size, const_cast<void*>(tris)) == hipSuccess)
+              tri_bytes = size - size_t(static_cast<const char*>(tris) - static_cast<const char*>(base));
+          else (void)hipGetLastError(); }
+        const bool narrow = ctx->opt_narrow && tri_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
+                            a.top_xy > 0 && grid->dims[2] < (1 << 23) &&
+                            grid->num_entries >= 0 && grid->num_refs >= 0;
+        if (narrow) {
+            if (grid->small_cells) traverse_kernel_v2<true, 64, true><<<blocks, 64, 0, ctx->stream>>>(a);
+            else                   traverse_kernel_v2<false, 64, true><<<blocks, 64, 0, ctx->stream>>>(a);
+        } else {
+            if (grid->small_cells) traverse_kernel_v2<true, 64, false><<<blocks, 64, 0, ctx->stream>>>(a);
+            else                   traverse_kernel_v2<false, 64, false><<<blocks, 64, 0, ctx->stream>>>(a);
+        }
     } else {
         const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
         // rays per cursor atomic: a few chunks per wave for balance, at least one wave-load, at most 1024
@@ -860,6 +919,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
         {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 1},
+        {"traverse.narrow", &ctx->opt_narrow, 0, 1},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {

@@ -149,7 +149,8 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
- * kernel, an error without an image), "traverse.image" (1 = hagrid_setup_traversal builds the traversal image; default 0),
+ * kernel, an error without an image), "traverse.image" (1 = hagrid_setup_traversal builds the traversal image; default 0), "traverse.narrow" (1 = v2 uses 32-bit
+ * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is

@@ -1002,6 +1002,8 @@ static inline int clampi(int a, int b, int c) { return imin(c, imax(b, a)); } /*
 /* dev analysis hook (tools/dev_wave_model.py): list length of every visited cell of the ray being traversed */
 static __thread unsigned char* g_trace = NULL;
 static __thread int g_trace_cap = 0, g_trace_len = 0;
+static __thread int* g_trace_ids = NULL;
+static __thread int g_trace_ids_cap = 0, g_trace_ids_len = 0;
 
 static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, const ORay* rp, OHit* out, int* steps_out, OStats* st) {
     ORay ray = *rp;
@@ -1063,6 +1065,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                 for (int cur = cbegin; cur < cend; cur++) {
                     int ref = g->ref_ids[cur];
                     if (ref < 0) break;
+                    if (g_trace_ids) { if (g_trace_ids_len < g_trace_ids_cap) g_trace_ids[g_trace_ids_len] = ref; g_trace_ids_len++; }
                     ORay r2 = { ray.org, ray.tmin, ray.dir, hit.t };
                     orc_intersect_prim_ray(&tris[ref], &r2, ref, &hit);
                 }
@@ -1089,15 +1092,18 @@ void orc_traverse_grid(const OGrid* grid, const OTri* tris, const ORay* rays, OH
     for (int64_t i = 0; i < n; i++) traverse_one(&k, grid, tris, &rays[i], &hits[i], steps ? &steps[i] : NULL, stats);
 }
 
-void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t n, int cap, unsigned char* lens, int* num_cells) {
+void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t n, int cap, unsigned char* lens, int* num_cells,
+                        int ids_cap, int* ids, int* num_ids) {
     TravConsts k; setup_consts(grid, &k);
     for (int64_t i = 0; i < n; i++) {
         OHit hit;
         g_trace = lens + i * cap; g_trace_cap = cap; g_trace_len = 0;
+        g_trace_ids = ids ? ids + i * ids_cap : NULL; g_trace_ids_cap = ids_cap; g_trace_ids_len = 0;
         traverse_one(&k, grid, tris, &rays[i], &hit, NULL, NULL);
         num_cells[i] = g_trace_len;
+        if (num_ids) num_ids[i] = g_trace_ids_len;
     }
-    g_trace = NULL;
+    g_trace = NULL; g_trace_ids = NULL;
 }
 
 typedef struct {

@@ -200,10 +200,11 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
     rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 640, 480),
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 200003, 31)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
-    settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 3},
+    settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 2, "traverse.narrow": 0}, {"traverse.variant": 3},
                 {"traverse.variant": 3, "traverse.both_phases": 1}, {"traverse.variant": 3, "traverse.refill_at": 1, "traverse.chunk": 64},
                 {"traverse.variant": 3, "traverse.refill_at": 64, "traverse.waves_per_cu": 2, "traverse.chunk": 1024}]
-    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 24, "traverse.chunk": 0, "traverse.waves_per_cu": 32}
+    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 24, "traverse.chunk": 0, "traverse.waves_per_cu": 32,
+                "traverse.narrow": 1}
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():

@@ -18,11 +18,25 @@ idx = (rows[:, None] * W + np.arange(W)[None, :]).reshape(-1)
 r = np.ascontiguousarray(rays[idx]); n = r.shape[0]
 CAP = 320
 lens = np.zeros((n, CAP), np.uint8); nc = np.zeros(n, np.int32)
-L = O.lib(); L.orc_traverse_trace.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]; L.orc_traverse_trace.restype = None
+L = O.lib(); L.orc_traverse_trace.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]; L.orc_traverse_trace.restype = None
+IDCAP = 512
+ids = np.full((n, IDCAP), -1, np.int32); nids = np.zeros(n, np.int32)
 t0 = time.time()
-L.orc_traverse_trace(C.byref(G.g), tris.ctypes.data, r.ctypes.data, n, CAP, lens.ctypes.data, nc.ctypes.data)
+L.orc_traverse_trace(C.byref(G.g), tris.ctypes.data, r.ctypes.data, n, CAP, lens.ctypes.data, nc.ctypes.data, IDCAP, ids.ctypes.data, nids.ctypes.data)
 print("trace", round(time.time() - t0, 1), "s; rays", n, "cells/ray", nc.mean(), "refs/ray", lens.sum() / n, flush=True)
 live = np.arange(CAP)[None, :] < nc[:, None]
+# repeated tests: a reference already tested among the last k tests of the same ray
+valid = np.arange(IDCAP)[None, :] < np.minimum(nids, IDCAP)[:, None]
+rep = {}
+for kwin in (1, 2, 4, 8, 16):
+    seen = np.zeros_like(valid)
+    for d in range(1, kwin + 1):
+        seen[:, d:] |= (ids[:, d:] == ids[:, :-d]) & valid[:, d:]
+    rep[kwin] = float(seen.sum() / valid.sum())
+first = np.zeros_like(valid)
+srt = np.sort(np.where(valid, ids, -1), axis=1)
+distinct = ((srt[:, 1:] != srt[:, :-1]) & (srt[:, 1:] >= 0)).sum() + (srt[:, 0] >= 0).sum()
+print(json.dumps({"tests": int(valid.sum()), "distinct (ray, triangle) pairs": int(distinct), "repeat fraction within last k tests": rep}), flush=True)
 bands = n // (8 * W)
 def waves(order):
     return order.reshape(-1, 64)
