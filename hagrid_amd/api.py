@@ -243,9 +243,14 @@ def setup_traversal(grid: Grid):
     _check(mem, mem._L.hagrid_setup_traversal(mem._ctx, C.byref(grid.pod)), "setup_traversal")
 
 
-def traverse_grid(grid: Grid, tris: int, rays: int, hits: int, num_rays: int):
+ANY_HIT, UVS = 1, 2      # hagrid_traverse_grid_ex flags
+
+
+def traverse_grid(grid: Grid, tris: int, rays: int, hits: int, num_rays: int, flags: int = 0):
+    """traverse_grid (traverse.h:14); flags: ANY_HIT (shadow rays: stop at the first accepted intersection) | UVS
+    (barycentrics stored with the hit, the reference's COMPUTE_UVS build)."""
     mem = grid.mem or _current
-    _check(mem, mem._L.hagrid_traverse_grid(mem._ctx, C.byref(grid.pod), C.c_void_p(tris), C.c_void_p(rays), C.c_void_p(hits), int(num_rays)), "traverse_grid")
+    _check(mem, mem._L.hagrid_traverse_grid_ex(mem._ctx, C.byref(grid.pod), C.c_void_p(tris), C.c_void_p(rays), C.c_void_p(hits), int(num_rays), int(flags)), "traverse_grid")
 
 
 def traverse_grid_stats(grid: Grid, tris: int, rays: int, hits: int, num_rays: int, steps: int = 0) -> dict:

@@ -301,6 +301,33 @@ __global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __
     }
 }
 
+// intersect_prim_ray as the reference compiles it with COMPUTE_UVS (prims.h:266-295, :285-288): same test, the accepted
+// hit also stores its barycentrics.  (include/hagrid/prims.h has the same code behind the same macro; the kernels need both
+// forms in one translation unit.)
+__device__ __forceinline__ bool intersect_prim_ray_uvs(const Tri& tri, const Ray& ray, int id, Hit& hit) {
+    const vec3 n = tri.normal();
+    const vec3 c = tri.v0 - ray.org;
+    const vec3 r = cross(ray.dir, c);
+    const float det = dot(n, ray.dir);
+    const float abs_det = detail::fabs1(det);
+    const float u = prodsign(dot(r, tri.e2), det);
+    const float v = prodsign(dot(r, tri.e1), det);
+    const float w = abs_det - u - v;
+    const float eps = 1e-9f;
+    if (u >= -eps && v >= -eps && w >= -eps) {
+        const float t = prodsign(dot(n, c), det);
+        if (t >= abs_det * ray.tmin && abs_det * ray.tmax > t) {
+            const float inv_det = 1.0f / abs_det;
+            hit.t = t * inv_det;
+            hit.u = u * inv_det;
+            hit.v = v * inv_det;
+            hit.id = id;
+            return true;
+        }
+    }
+    return false;
+}
+
 // NARROW: every gather is base (scalar registers) + unsigned 32-bit byte offset (one VALU shift instead of a sign
 // extension and a 64-bit add), index products are 24-bit multiplies (full rate; 32-bit multiplies are quarter rate) and the
 // range test is three unsigned compares.  The host selects it when every array it indexes is smaller than 4 GB and the
@@ -310,8 +337,11 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
     return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
 }
 
-template <bool SMALL, int BLOCK, bool NARROW>
+// MODE: HAGRID_TRAVERSE_ANY_HIT (the ray is done at its first accepted intersection: shadow rays) and / or
+// HAGRID_TRAVERSE_UVS (barycentrics stored with the hit) -- SURVEY.md 8(f) row 4; 0 is the reference's traversal.
+template <bool SMALL, int BLOCK, bool NARROW, unsigned MODE>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
+    constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
     const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
     const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
@@ -416,14 +446,15 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
             while (ref >= 0) {
                 const int next = SMALL ? ref_at(cur) : (cur < c.end ? ref_at(cur) : -1);
                 cur++;
-                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                ref = next;
+                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                ref = (ANY && got) ? -1 : next;
             }
-            if (hit.t <= texit || outside) break;
+            if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             c = nc;
         }
     }
-    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
+    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
 }
 
 
@@ -767,6 +798,20 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
 struct TableIn { const int* t; __device__ int operator()(int i) const { return t[i]; } };
 struct TableOut { int* t; __device__ void operator()(int i, int s) const { t[i] = s; } };
 
+template <bool SMALL, bool NARROW>
+void launch_v2_mode(hipStream_t st, int blocks, unsigned mode, const TraverseArgs& a) {
+    switch (mode & 3u) {
+        case 0: traverse_kernel_v2<SMALL, 64, NARROW, 0><<<blocks, 64, 0, st>>>(a); break;
+        case 1: traverse_kernel_v2<SMALL, 64, NARROW, 1><<<blocks, 64, 0, st>>>(a); break;
+        case 2: traverse_kernel_v2<SMALL, 64, NARROW, 2><<<blocks, 64, 0, st>>>(a); break;
+        default: traverse_kernel_v2<SMALL, 64, NARROW, 3><<<blocks, 64, 0, st>>>(a); break;
+    }
+}
+void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a) {
+    if (small) { if (narrow) launch_v2_mode<true, true>(st, blocks, mode, a); else launch_v2_mode<true, false>(st, blocks, mode, a); }
+    else       { if (narrow) launch_v2_mode<false, true>(st, blocks, mode, a); else launch_v2_mode<false, false>(st, blocks, mode, a); }
+}
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -808,7 +853,13 @@ extern "C" int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid) 
 
 extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
                                     const void* rays, void* hits, int num_rays) {
+    return hagrid_traverse_grid_ex(ctx, grid, tris, rays, hits, num_rays, 0u);
+}
+
+extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
+                                       const void* rays, void* hits, int num_rays, uint32_t flags) {
     if (!ctx) return HAGRID_EINVAL;
+    if (flags & ~uint32_t(HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid_ex: unknown flag");
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
@@ -844,6 +895,7 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
     const bool large = num_rays >= 24 * lanes;
     int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : (large ? 3 : 2));
     if (perm && variant != 4) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
+    if (flags) variant = 2;                           // any-hit / barycentrics: v2 only
     if (variant == 4) {
         a.img_table = static_cast<const uint2*>(ctx->image.table);
         a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
@@ -884,13 +936,7 @@ extern "C" int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, co
         const bool narrow = ctx->opt_narrow && tri_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             a.top_xy > 0 && grid->dims[2] < (1 << 23) &&
                             grid->num_entries >= 0 && grid->num_refs >= 0;
-        if (narrow) {
-            if (grid->small_cells) traverse_kernel_v2<true, 64, true><<<blocks, 64, 0, ctx->stream>>>(a);
-            else                   traverse_kernel_v2<false, 64, true><<<blocks, 64, 0, ctx->stream>>>(a);
-        } else {
-            if (grid->small_cells) traverse_kernel_v2<true, 64, false><<<blocks, 64, 0, ctx->stream>>>(a);
-            else                   traverse_kernel_v2<false, 64, false><<<blocks, 64, 0, ctx->stream>>>(a);
-        }
+        launch_v2(ctx->stream, blocks, grid->small_cells != nullptr, narrow, flags, a);
     } else {
         const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
         // rays per cursor atomic: a few chunks per wave for balance, at least one wave-load, at most 1024
@@ -981,6 +1027,13 @@ __global__ void kat_prim_ray(const Tri* tris, const Ray* rays, const int* idx, i
     ret[i] = intersect_prim_ray(tris[idx[i]], rays[i], idx[i], h) ? 1 : 0;
     hid[i] = h.id; ht[i] = h.t;
 }
+__global__ void kat_prim_ray_uvs(const Tri* tris, const Ray* rays, const int* idx, int n, int* ret, int* hid, float* ht, float* hu, float* hv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Hit h(-1, rays[i].tmax, 0, 0);
+    ret[i] = intersect_prim_ray_uvs(tris[idx[i]], rays[i], idx[i], h) ? 1 : 0;
+    hid[i] = h.id; ht[i] = h.t; hu[i] = h.u; hv[i] = h.v;
+}
 __global__ void kat_prim_cell(const Tri* tris, const BBox* boxes, const int* idx, int n, int* ret) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1045,6 +1098,19 @@ extern "C" int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, 
     kat_prim_ray<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d);
     HG_HIP(ctx, hipGetLastError());
     HG_TRY(o0.fetch(ret)); HG_TRY(o1.fetch(hit_id)); HG_TRY(o2.fetch(hit_t));
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_kat_intersect_prim_ray_uvs(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
+                                                 int n, int32_t* ret, int32_t* hit_id, float* hit_t, float* hit_u, float* hit_v) {
+    if (!ctx || n <= 0) return HAGRID_EINVAL;
+    int max_idx = 0;
+    for (int i = 0; i < n; i++) max_idx = std::max(max_idx, tri_index[i]);
+    Staged t(ctx, tris, size_t(max_idx + 1) * 48), r(ctx, rays, size_t(n) * 32), ix(ctx, tri_index, size_t(n) * 4);
+    Staged o0(ctx, nullptr, size_t(n) * 4), o1(ctx, nullptr, size_t(n) * 4), o2(ctx, nullptr, size_t(n) * 4), o3(ctx, nullptr, size_t(n) * 4), o4(ctx, nullptr, size_t(n) * 4);
+    kat_prim_ray_uvs<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d, (float*)o3.d, (float*)o4.d);
+    HG_HIP(ctx, hipGetLastError());
+    HG_TRY(o0.fetch(ret)); HG_TRY(o1.fetch(hit_id)); HG_TRY(o2.fetch(hit_t)); HG_TRY(o3.fetch(hit_u)); HG_TRY(o4.fetch(hit_v));
     return HAGRID_OK;
 }
 

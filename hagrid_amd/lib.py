@@ -65,10 +65,12 @@ SIGNATURES = {
     "hagrid_compress_grid": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_setup_traversal": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_traverse_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32]),
+    "hagrid_traverse_grid_ex": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, C.c_uint32]),
     "hagrid_traverse_grid_stats": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, _vp, C.POINTER(TraversalStats)]),
     "hagrid_set_ray_binning": (_i32, [_vp, _i32]),
     "hagrid_set_option": (_i32, [_vp, C.c_char_p, _i32]),
     "hagrid_kat_intersect_prim_ray": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "hagrid_kat_intersect_prim_ray_uvs": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "hagrid_kat_intersect_prim_cell": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "hagrid_kat_compute_range": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "hagrid_kat_compute_grid_dims": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),

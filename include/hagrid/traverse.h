@@ -24,6 +24,17 @@ inline void traverse_grid(const Grid& grid, const Tri* tris, const Ray* rays, Hi
     detail::check(detail::current_ctx(), hagrid_traverse_grid(detail::current_ctx(), &p, tris, rays, hits, num_rays));
 }
 
+/// Extensions over the same walk (no counterpart in src/traverse.h): occlusion rays stop at their first accepted
+/// intersection (hits[i].id >= 0 <=> occluded); `with_uvs` stores the barycentrics like a COMPUTE_UVS build (prims.h:285-288).
+inline void traverse_grid_any_hit(const Grid& grid, const Tri* tris, const Ray* rays, Hit* hits, int num_rays) {
+    hagrid_grid p = detail::to_pod(grid);
+    detail::check(detail::current_ctx(), hagrid_traverse_grid_ex(detail::current_ctx(), &p, tris, rays, hits, num_rays, HAGRID_TRAVERSE_ANY_HIT));
+}
+inline void traverse_grid_with_uvs(const Grid& grid, const Tri* tris, const Ray* rays, Hit* hits, int num_rays) {
+    hagrid_grid p = detail::to_pod(grid);
+    detail::check(detail::current_ctx(), hagrid_traverse_grid_ex(detail::current_ctx(), &p, tris, rays, hits, num_rays, HAGRID_TRAVERSE_UVS));
+}
+
 } // namespace hagrid
 
 #endif // HAGRID_TRAVERSE_H

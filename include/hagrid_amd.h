@@ -134,6 +134,17 @@ int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
  * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
 int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
                          const void* rays, void* hits, int num_rays);
+/* Variants of the same walk (no separate entry point in the reference).  flags:
+ *   HAGRID_TRAVERSE_ANY_HIT  a ray is finished at its FIRST accepted intersection in traversal order (cells along the ray,
+ *                            references in list order): shadow / occlusion rays.  hits[i].id >= 0 exactly when the nearest-hit
+ *                            traversal finds a hit; id and t are those of that first intersection.
+ *   HAGRID_TRAVERSE_UVS      hits[i].u, hits[i].v = barycentrics of the hit, as the reference stores them when it is compiled
+ *                            with COMPUTE_UVS (prims.h:285-288).
+ * flags = 0 is hagrid_traverse_grid. */
+#define HAGRID_TRAVERSE_ANY_HIT 1u
+#define HAGRID_TRAVERSE_UVS 2u
+int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
+                            const void* rays, void* hits, int num_rays, uint32_t flags);
 /* Same traversal, additionally: steps[i] (device int32, may be NULL) = the reference's per-ray step
  * count (traverse.cu:80,93), and *stats (host, may be NULL) = batch totals.  Synchronous. */
 int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,
@@ -166,6 +177,9 @@ int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 /* Each evaluates the named device function for n inputs (host arrays in, host arrays out). */
 int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
                                   int n, int32_t* ret, int32_t* hit_id, float* hit_t);
+/* the same with COMPUTE_UVS: additionally the barycentrics */
+int hagrid_kat_intersect_prim_ray_uvs(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
+                                      int n, int32_t* ret, int32_t* hit_id, float* hit_t, float* hit_u, float* hit_v);
 int hagrid_kat_intersect_prim_cell(hagrid_ctx* ctx, const void* tris, const void* boxes, const int32_t* tri_index,
                                    int n, int32_t* ret);
 int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* grid_bb, const void* obj_bb, int n, int32_t* out6);

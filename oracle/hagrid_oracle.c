@@ -224,6 +224,35 @@ int orc_intersect_prim_ray(const OTri* tri, const ORay* ray, int id, OHit* hit) 
     return 0;
 }
 
+/* prims.h:266-295 with COMPUTE_UVS defined (:285-288): the barycentrics of the accepted hit are stored as well */
+int orc_intersect_prim_ray_uv(const OTri* tri, const ORay* ray, int id, OHit* hit) {
+    ovec3 n = v3(tri->nx, tri->ny, tri->nz);
+    ovec3 c = v3_sub(tri->v0, ray->org);
+    ovec3 r = v3_cross(ray->dir, c);
+    float det = v3_dot(n, ray->dir);
+    float abs_det = fabsf(det);
+    float u = orc_prodsign(v3_dot(r, tri->e2), det);
+    float v = orc_prodsign(v3_dot(r, tri->e1), det);
+    float w = abs_det - u - v;
+    float eps = 1e-9f;
+    if (u >= -eps && v >= -eps && w >= -eps) {
+        float t = orc_prodsign(v3_dot(n, c), det);
+        if (t >= abs_det * ray->tmin && abs_det * ray->tmax > t) {
+            float inv_det = 1.0f / abs_det;
+            hit->t = t * inv_det;
+            hit->u = u * inv_det;
+            hit->v = v * inv_det;
+            hit->id = id;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* traversal mode of the calling thread (orc_traverse_grid_ex): ORC_ANY_HIT stops at the first accepted intersection
+ * (shadow rays), ORC_UVS stores the barycentrics (prims.h:285-288) */
+static __thread unsigned g_mode = 0;
+
 /* ------------------------------------------------------------------------------------------ */
 /* grid lifetime */
 
@@ -1048,7 +1077,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
             voxel.y = ray.dir.y >= 0.0f ? imax(nv.y, voxel.y) : imin(nv.y, voxel.y);
             voxel.z = ray.dir.z >= 0.0f ? imax(nv.z, voxel.z) : imin(nv.z, voxel.z);
             /* foreach_ref grid.h:118-140 */
-            int nrefs = 0;
+            int nrefs = 0, found_any = 0;
             if (g->small_cells) {
                 if (cbegin >= 0) {
                     int cur = cbegin;
@@ -1056,7 +1085,8 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                         int ref = g->ref_ids[cur++];
                         if (ref < 0) break;
                         ORay r2 = { ray.org, ray.tmin, ray.dir, hit.t };
-                        orc_intersect_prim_ray(&tris[ref], &r2, ref, &hit);
+                        int got = (g_mode & ORC_UVS) ? orc_intersect_prim_ray_uv(&tris[ref], &r2, ref, &hit) : orc_intersect_prim_ray(&tris[ref], &r2, ref, &hit);
+                        if (got && (g_mode & ORC_ANY_HIT)) { found_any = 1; break; }
                     }
                     nrefs = cur - cbegin;
                     if (st) { st->refs += nrefs - 1; st->sentinels += 1; }
@@ -1067,7 +1097,8 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                     if (ref < 0) break;
                     if (g_trace_ids) { if (g_trace_ids_len < g_trace_ids_cap) g_trace_ids[g_trace_ids_len] = ref; g_trace_ids_len++; }
                     ORay r2 = { ray.org, ray.tmin, ray.dir, hit.t };
-                    orc_intersect_prim_ray(&tris[ref], &r2, ref, &hit);
+                    int got = (g_mode & ORC_UVS) ? orc_intersect_prim_ray_uv(&tris[ref], &r2, ref, &hit) : orc_intersect_prim_ray(&tris[ref], &r2, ref, &hit);
+                    if (got && (g_mode & ORC_ANY_HIT)) { found_any = 1; break; }
                 }
                 nrefs = cend - cbegin;
                 if (st) st->refs += nrefs;
@@ -1076,7 +1107,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
             if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (unsigned char)(nrefs > 255 ? 255 : nrefs); g_trace_len++; }
             if (st) { st->cells++; st->entry_words += words; }
             /* traverse.cu:85-89 */
-            if (hit.t <= texit ||
+            if (found_any || hit.t <= texit ||
                 ((voxel.x < 0) | (voxel.x >= k->dims.x) | (voxel.y < 0) | (voxel.y >= k->dims.y) | (voxel.z < 0) | (voxel.z >= k->dims.z)))
                 break;
         }
@@ -1107,7 +1138,7 @@ void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, i
 }
 
 typedef struct {
-    const OGrid* grid; const OTri* tris; const ORay* rays; OHit* hits; int64_t begin, end; OStats stats; int num_tris; int brute;
+    const OGrid* grid; const OTri* tris; const ORay* rays; OHit* hits; int64_t begin, end; OStats stats; int num_tris; int brute; unsigned mode;
 } Job;
 
 static void* job_main(void* p) {
@@ -1123,8 +1154,10 @@ static void* job_main(void* p) {
         }
     } else {
         TravConsts k; setup_consts(j->grid, &k);
+        g_mode = j->mode;
         memset(&j->stats, 0, sizeof(j->stats));
         for (int64_t i = j->begin; i < j->end; i++) traverse_one(&k, j->grid, j->tris, &j->rays[i], &j->hits[i], NULL, &j->stats);
+        g_mode = 0;
     }
     return NULL;
 }
@@ -1156,6 +1189,12 @@ void orc_traverse_grid_mt(const OGrid* grid, const OTri* tris, const ORay* rays,
     Job p; memset(&p, 0, sizeof(p));
     p.grid = grid; p.tris = tris; p.rays = rays; p.hits = hits; p.brute = 0;
     run_jobs(&p, n, nthreads, stats);
+}
+
+void orc_traverse_grid_ex(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits, int64_t n, int nthreads, unsigned flags) {
+    Job p; memset(&p, 0, sizeof(p));
+    p.grid = grid; p.tris = tris; p.rays = rays; p.hits = hits; p.brute = 0; p.mode = flags;
+    run_jobs(&p, n, nthreads, NULL);
 }
 
 void orc_brute_force(const OTri* tris, int num_tris, const ORay* rays, OHit* hits, int64_t n, int nthreads) {

@@ -87,6 +87,7 @@ void     orc_compute_grid_dims(const OBBox* bb, int num_prims, float density, oi
 uint32_t orc_lookup_entry(const OEntry* entries, int shift, const oivec3* top_dims, const oivec3* voxel, int* words); /* grid.h:103-116 */
 int      orc_intersect_prim_cell(const OTri* tri, const OBBox* box);            /* prims.h:161-264 */
 int      orc_intersect_prim_ray(const OTri* tri, const ORay* ray, int id, OHit* hit); /* prims.h:266-295 */
+int      orc_intersect_prim_ray_uv(const OTri* tri, const ORay* ray, int id, OHit* hit); /* same with COMPUTE_UVS (prims.h:285-288) */
 
 /* ---- passes (build.h:17-31, traverse.h:11-14) -------------------------------------------- */
 void orc_grid_init(OGrid* g);
@@ -105,6 +106,11 @@ void orc_traverse_grid(const OGrid* grid, const OTri* tris, const ORay* rays, OH
 /* same, contiguous ray ranges over nthreads pthreads (CPU baseline) */
 void orc_traverse_grid_mt(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits,
                           int64_t num_rays, int nthreads, OStats* stats);
+/* traversal variants: ORC_ANY_HIT = the walk stops at the first accepted intersection (shadow rays:
+ * id/t of that intersection), ORC_UVS = hits carry the barycentrics of prims.h:285-288 */
+#define ORC_ANY_HIT 1u
+#define ORC_UVS 2u
+void orc_traverse_grid_ex(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits, int64_t num_rays, int nthreads, unsigned flags);
 /* dev analysis: lens[i*cap + s] = list length of the s-th cell ray i visits (clamped to 255), num_cells[i] = cells visited */
 void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t num_rays, int cap, unsigned char* lens, int* num_cells,
                         int ids_cap, int* ids /* may be NULL: tested reference ids in order */, int* num_ids);

@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         L.orc_lookup_entry.restype = C.c_uint32; L.orc_lookup_entry.argtypes = [vp, i32, vp, vp, vp]
         L.orc_intersect_prim_cell.restype = i32; L.orc_intersect_prim_cell.argtypes = [vp, vp]
         L.orc_intersect_prim_ray.restype = i32; L.orc_intersect_prim_ray.argtypes = [vp, vp, i32, vp]
+        L.orc_intersect_prim_ray_uv.restype = i32; L.orc_intersect_prim_ray_uv.argtypes = [vp, vp, i32, vp]
+        L.orc_traverse_grid_ex.restype = None; L.orc_traverse_grid_ex.argtypes = [vp, vp, vp, vp, i64, i32, C.c_uint]
         L.orc_grid_init.argtypes = [vp]; L.orc_grid_free.argtypes = [vp]
         L.orc_build_grid.restype = i32; L.orc_build_grid.argtypes = [vp, i32, vp, f32, f32]
         L.orc_merge_grid.restype = i32; L.orc_merge_grid.argtypes = [vp, f32]
@@ -109,6 +111,23 @@ def ref_lib():
         R.ref_brute_force.argtypes = [vp, i32, vp, vp, i64, i32]
         _ref = R
     return _ref
+
+
+_ref_uvs = None
+
+
+def ref_lib_uvs():
+    """The reference-header harness compiled with -DCOMPUTE_UVS (prims.h:285-288); only intersect_prim_ray is used."""
+    global _ref_uvs
+    if _ref_uvs is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libhagrid_ref_uvs.so")
+        R = C.CDLL(path)
+        R.ref_intersect_prim_ray.restype = C.c_int; R.ref_intersect_prim_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _ref_uvs = R
+    return _ref_uvs
+
+
+ANY_HIT, UVS = 1, 2
 
 
 def _p(a: np.ndarray):
@@ -235,6 +254,14 @@ class Grid:
         else:
             lib().orc_traverse_grid_mt(C.byref(self.g), _p(tris), _p(rays), _p(hits), n, nthreads, C.byref(st))
         return hits, st.as_dict()
+
+    def traverse_ex(self, tris, rays, flags: int, nthreads: int = 1):
+        """any-hit / barycentric variants of the traversal"""
+        tris = np.ascontiguousarray(tris, dtype=np.float32); rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = rays.shape[0]
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        lib().orc_traverse_grid_ex(C.byref(self.g), _p(tris), _p(rays), _p(hits), n, nthreads, flags)
+        return hits
 
     def check(self, tris, coverage: int = 0):
         tris = np.ascontiguousarray(tris, dtype=np.float32)

@@ -12,6 +12,8 @@ Outputs (data only: inputs + the reference's outputs):
   tests/golden/config1_hits.npz  BASELINE config 1 (soup-10k, 64k incoherent rays): nearest hit
                                  (id, t) per ray by brute force with the reference's
                                  intersect_prim_ray -- grid-independent ground truth
+  tests/golden/l0_kat_uvs.npz    intersect_prim_ray compiled with -DCOMPUTE_UVS (prims.h:285-288) on the inputs of
+                                 l0_kat.npz: (ret, id, t, u, v)      [python tests/golden/make_golden.py uvs]
 """
 import ctypes as C
 import os
@@ -176,5 +178,20 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 
+def uvs():
+    R = O.ref_lib_uvs()
+    kat = np.load(os.path.join(OUT, "l0_kat.npz"))
+    tris = np.ascontiguousarray(kat["tris"]); rays = np.ascontiguousarray(kat["ipr_rays"]); tid = kat["ipr_tid"]
+    n = rays.shape[0]
+    hit = np.zeros(n, dtype=O.HIT_DTYPE); ret = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        h = np.array([(-1, rays[i, 7], 0, 0)], dtype=O.HIT_DTYPE)
+        ret[i] = R.ref_intersect_prim_ray(p(tris[tid[i]:tid[i] + 1]), p(rays[i:i + 1]), int(tid[i]), p(h))
+        hit[i] = h[0]
+    assert (ret == kat["ipr_ret"]).all() and (hit["t"].view(np.uint32) == kat["ipr_hit_t"].view(np.uint32)).all()
+    np.savez_compressed(os.path.join(OUT, "l0_kat_uvs.npz"), ret=ret, id=hit["id"].copy(), t=hit["t"].copy(), u=hit["u"].copy(), v=hit["v"].copy())
+    print("l0_kat_uvs.npz", os.path.getsize(os.path.join(OUT, "l0_kat_uvs.npz")), "bytes;", int(ret.sum()), "hits of", n)
+
+
 if __name__ == "__main__":
-    main()
+    uvs() if sys.argv[1:] == ["uvs"] else main()

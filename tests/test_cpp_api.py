@@ -135,7 +135,7 @@ def test_cli_usage_and_option_errors_need_no_gpu():
     with tempfile.TemporaryDirectory() as d:
         exe = _build_cli(d)
         r = subprocess.run([exe, "--help"], capture_output=True, text=True)
-        assert r.returncode == 0 and "--top-density" in r.stdout and "--ray-file" in r.stdout and "--compress" in r.stdout
+        assert r.returncode == 0 and "--top-density" in r.stdout and "--ray-file" in r.stdout and "--compress" in r.stdout and "--any-hit" in r.stdout
         r = subprocess.run([exe, "--bogus", "x.obj"], capture_output=True, text=True)
         assert r.returncode == 1 and "Unknown argument: --bogus" in r.stderr
         r = subprocess.run([exe, "-td"], capture_output=True, text=True)
@@ -186,6 +186,14 @@ def test_cli_obj_scene_and_ray_file_benchmark():
         r = subprocess.run([exe, "soup:20000", "-z", "-sx", "256", "-sy", "128", "-o", img], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "20000 triangle(s)" in r.stdout and "Tracing one 256x128 frame" in r.stdout
         assert os.path.getsize(img) == len("P5\n256 128\n255\n") + 256 * 128
+        # occlusion rays give the same intersection count (a ray is occluded iff it has a nearest hit),
+        # and the step-count heat map of the viewer (main.cpp:100-107) is written from the statistics entry point
+        heat = os.path.join(d, "steps.pgm")
+        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--any-hit"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and f"{want} intersection(s)." in r.stdout
+        r = subprocess.run([exe, "soup:20000", "-sx", "128", "-sy", "64", "-s", heat], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "Steps per ray: max " in r.stdout, r.stdout + r.stderr
+        assert os.path.getsize(heat) == len("P5\n128 64\n255\n") + 128 * 64
         mem.close()
 
 

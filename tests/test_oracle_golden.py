@@ -221,3 +221,32 @@ def test_precise_expansion_keeps_the_grid_valid(config1):
     D = O.Grid.full(tris)
     _, sd = D.traverse(tris, rays, nthreads=8)
     assert st["cells"] <= sd["cells"]                    # grows cells at least as far as the subset rule
+
+
+def test_intersect_prim_ray_with_uvs(kat, golden_dir):
+    """prims.h:285-288: the oracle's COMPUTE_UVS form against the reference header compiled with -DCOMPUTE_UVS."""
+    uv = np.load(os.path.join(golden_dir, "l0_kat_uvs.npz"))
+    L = O.lib()
+    tris, rays, tid = kat["tris"], kat["ipr_rays"], kat["ipr_tid"]
+    for i in range(rays.shape[0]):
+        h = np.array([(-1, rays[i, 7], 0, 0)], dtype=O.HIT_DTYPE)
+        r = L.orc_intersect_prim_ray_uv(p(np.ascontiguousarray(tris[tid[i]:tid[i] + 1])), p(np.ascontiguousarray(rays[i:i + 1])), int(tid[i]), p(h))
+        assert r == uv["ret"][i] and h["id"][0] == uv["id"][i]
+        assert bits(h["t"])[0] == bits(uv["t"][i:i + 1])[0] and bits(h["u"])[0] == bits(uv["u"][i:i + 1])[0] and bits(h["v"])[0] == bits(uv["v"][i:i + 1])[0]
+
+
+def test_any_hit_and_uvs_walks(config1):
+    """SURVEY 8(f) row 4 in the oracle: barycentrics do not change (id, t); an any-hit walk reports a hit exactly when the
+    nearest-hit walk does, never a nearer one, and agrees with a brute-force existence test."""
+    tris, rays = config1[0], config1[1][:20000].copy()
+    rays[:5000, 7] = 0.25
+    G = O.Grid.full(tris)
+    nearest, _ = G.traverse(tris, rays, nthreads=4)
+    uvs = G.traverse_ex(tris, rays, O.UVS, nthreads=4)
+    assert (uvs["id"] == nearest["id"]).all() and (bits(uvs["t"]) == bits(nearest["t"])).all()
+    hit = nearest["id"] >= 0
+    assert (uvs["u"][hit] + uvs["v"][hit] <= 1 + 1e-5).all() and (uvs["u"][~hit] == 0).all()
+    anyh = G.traverse_ex(tris, rays, O.ANY_HIT, nthreads=4)
+    assert ((anyh["id"] >= 0) == hit).all() and (anyh["t"][hit] >= nearest["t"][hit]).all() and (anyh["id"] != nearest["id"]).any()
+    brute = O.brute_force(tris, rays, nthreads=8)
+    assert ((brute["id"] >= 0) == (anyh["id"] >= 0)).all()

@@ -473,3 +473,67 @@ def test_image_lifetime(mem):
     finally:
         mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 0)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
+
+
+# ---- any-hit and barycentrics ------------------------------------------------------------------------
+
+def test_intersect_prim_ray_with_uvs_matches_reference_header(mem, golden_dir):
+    """The device's COMPUTE_UVS form of intersect_prim_ray against the reference header compiled with -DCOMPUTE_UVS."""
+    kat = np.load(os.path.join(golden_dir, "l0_kat.npz")); uv = np.load(os.path.join(golden_dir, "l0_kat_uvs.npz"))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tris = np.ascontiguousarray(kat["tris"]); rays = np.ascontiguousarray(kat["ipr_rays"]); tid = np.ascontiguousarray(kat["ipr_tid"])
+    n = rays.shape[0]
+    ret = np.zeros(n, np.int32); hid = np.zeros(n, np.int32); ht = np.zeros(n, np.float32); hu = np.zeros(n, np.float32); hv = np.zeros(n, np.float32)
+    assert mem._L.hagrid_kat_intersect_prim_ray_uvs(mem._ctx, p(tris), p(rays), p(tid), n, p(ret), p(hid), p(ht), p(hu), p(hv)) == 0
+    assert (ret == uv["ret"]).all() and (hid == uv["id"]).all() and (bits(ht) == bits(uv["t"])).all()
+    assert (bits(hu) == bits(uv["u"])).all() and (bits(hv) == bits(uv["v"])).all()
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_any_hit_and_uvs_traversal(mem, compressed):
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(50000, seed=77)
+    G = O.Grid.full(tris, compress=compressed)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 320, 200),
+                           scene.make_rays_incoherent(G.bbox_min - 0.1, G.bbox_max + 0.1, 90001, 23)]).astype(np.float32)
+    rays[1000:2000, 7] = 0.3                    # short shadow-ray-like segments
+    n = rays.shape[0]
+    nearest, _ = G.traverse(tris, rays, nthreads=8)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    def run(flags):
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+        return mem.download(d_hits, api.HIT_DTYPE, n)
+    for binning in (0, 1):
+        mem.set_ray_binning(binning)
+        try:
+            got = run(api.UVS)
+            want = G.traverse_ex(tris, rays, O.UVS, nthreads=8)
+            assert (got["id"] == nearest["id"]).all() and (bits(got["t"]) == bits(nearest["t"])).all()
+            assert (bits(got["u"]) == bits(want["u"])).all() and (bits(got["v"]) == bits(want["v"])).all()
+            hit = got["id"] >= 0
+            assert hit.any() and (got["u"][hit] >= -1e-6).all() and (got["v"][hit] >= -1e-6).all() and (got["u"][hit] + got["v"][hit] <= 1 + 1e-5).all()
+            assert (got["u"][~hit] == 0).all() and (got["v"][~hit] == 0).all()
+            # the barycentrics reproduce the hit point: v0 - u*e1 + v*e2 = org + t*dir (Tri stores e1 = v0 - v1, e2 = v2 - v0)
+            t = tris[got["id"][hit]]
+            pt = t[:, 0:3] - got["u"][hit, None] * t[:, 4:7] + got["v"][hit, None] * t[:, 8:11]
+            pr = rays[hit, 0:3] + got["t"][hit, None] * rays[hit, 4:7]
+            assert np.abs(pt - pr).max() < 2e-3
+
+            anyh = run(api.ANY_HIT)
+            want = G.traverse_ex(tris, rays, O.ANY_HIT, nthreads=8)
+            assert (anyh["id"] == want["id"]).all() and (bits(anyh["t"]) == bits(want["t"])).all()
+            assert ((anyh["id"] >= 0) == (nearest["id"] >= 0)).all()             # occluded <=> the nearest-hit walk finds something
+            assert (anyh["t"][hit] >= nearest["t"][hit]).all()
+            assert (anyh["id"] != nearest["id"]).any()                               # and it really stops early somewhere
+            both = run(api.ANY_HIT | api.UVS)
+            want = G.traverse_ex(tris, rays, O.ANY_HIT | O.UVS, nthreads=8)
+            for f in ("id", "t", "u", "v"):
+                assert (bits(both[f]) == bits(want[f])).all() if f != "id" else (both[f] == want[f]).all()
+        finally:
+            mem.set_ray_binning(0)
+    with pytest.raises(api.HagridError):
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n, 8)
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)

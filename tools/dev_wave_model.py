@@ -92,3 +92,30 @@ def periodic(order, Gn, repack_steps, overhead=70):
 for Gn in (4, 8, 16):
     for steps in ((8, 16, 24, 32, 48, 64, 96, 128), (4, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128), (6, 12, 18, 24, 30, 36, 48, 64, 96, 128), tuple(range(2, 200, 2))):
         print(json.dumps({"G": Gn, "repack_at": steps[:6], "VALU/wave": periodic(tile, Gn, steps)}), flush=True)
+
+# k rays per lane, processed one after the other (static assignment: lane l of wave w gets the l-th ray of k consecutive tiles)
+def sequential(order, k):
+    w = order[: (order.shape[0] // (64 * k)) * 64 * k].reshape(-1, k, 64)          # [waves, k, 64]
+    total = np.zeros(w.shape[0]); cells_it = np.zeros(w.shape[0]); tri_it = np.zeros(w.shape[0])
+    for wi in range(0, w.shape[0], 256):
+        ww = w[wi:wi + 256]
+        B = ww.shape[0]
+        seq = np.zeros((B, 64, k * CAP), np.uint8); alive = np.zeros((B, 64, k * CAP), bool)
+        pos = np.zeros((B, 64), np.int64)
+        for j in range(k):
+            r = ww[:, j, :]                                    # [B, 64] ray ids
+            ln = nc[r]                                         # cells of that ray
+            for s in range(CAP):
+                m = s < ln
+                if not m.any(): break
+                bi, li = np.nonzero(m)
+                seq[bi, li, pos[bi, li] + s] = lens[r[bi, li], s]
+                alive[bi, li, pos[bi, li] + s] = True
+            pos += ln
+        ci = alive.any(axis=1).sum(axis=1); ti = seq.max(axis=1).astype(np.int64).sum(axis=1)
+        cells_it[wi:wi + B] = ci; tri_it[wi:wi + B] = ti
+    return float((C_CELL * cells_it + C_TRI * tri_it).mean() / k), float(cells_it.mean() / k), float(tri_it.mean() / k)
+
+for k in (1, 2, 4):
+    v, ci, ti = sequential(tile, k)
+    print(json.dumps({"rays per lane (sequential)": k, "VALU per 64 rays": v, "cell iters per 64 rays": ci, "tri iters per 64 rays": ti}), flush=True)

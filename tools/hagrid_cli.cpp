@@ -30,13 +30,13 @@ using namespace hagrid;
 namespace {
 
 struct Options {
-    std::string scene, ray_file, out_image;
+    std::string scene, ray_file, out_image, steps_image;
     float top_density = 0.12f, snd_density = 2.4f, alpha = 0.995f;
     int exp_iters = 3, width = 1024, height = 1024;
     float clip = 0, fov = 60;
     int build_iter = 1, build_warmup = 0, bench_iter = 1, bench_warmup = 0;
     float tmin = 0, tmax = FLT_MAX;
-    bool keep_alive = false, compress = false, help = false;
+    bool keep_alive = false, compress = false, help = false, any_hit = false;
 };
 
 enum Kind { FLAG, INT, FLOAT, STRING };
@@ -63,6 +63,8 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
         {"-n", "--bench-iter", INT, &o.bench_iter, "Sets the number of benchmarking iterations"},
         {"-w", "--bench-warmup", INT, &o.bench_warmup, "Sets the number of benchmarking warmup iterations"},
         {"-o", "--out", STRING, &o.out_image, "(extension) writes the traced frame as a PGM depth image"},
+        {"-s", "--steps-image", STRING, &o.steps_image, "(extension) writes the per-pixel traversal step count as a PGM heat map"},
+        {"-ah", "--any-hit", FLAG, &o.any_hit, "(extension) occlusion rays: a ray stops at its first intersection"},
     };
     bool have_scene = false;
     for (int i = 1; i < argc; i++) {
@@ -250,10 +252,13 @@ int main(int argc, char** argv) {
     Ray* rays = mem.alloc<Ray>(host_rays.size());
     Hit* hits = mem.alloc<Hit>(host_rays.size());
     mem.copy<Copy::HST_TO_DEV>(rays, host_rays.data(), host_rays.size());
-    for (int i = 0; i < opts.bench_warmup; i++) traverse_grid(grid, tris, rays, hits, int(host_rays.size()));
+    auto trace = [&] {
+        if (opts.any_hit) traverse_grid_any_hit(grid, tris, rays, hits, int(host_rays.size()));
+        else              traverse_grid(grid, tris, rays, hits, int(host_rays.size()));
+    };
+    for (int i = 0; i < opts.bench_warmup; i++) trace();
     std::vector<double> timings;
-    for (int i = 0; i < std::max(opts.bench_iter, 1); i++)
-        timings.push_back(profile([&] { traverse_grid(grid, tris, rays, hits, int(host_rays.size())); }));
+    for (int i = 0; i < std::max(opts.bench_iter, 1); i++) timings.push_back(profile(trace));
     std::vector<Hit> host_hits(host_rays.size());
     mem.copy<Copy::DEV_TO_HST>(host_hits.data(), hits, host_hits.size());
     int intr = 0;
@@ -264,6 +269,21 @@ int main(int argc, char** argv) {
         std::ofstream img(opts.out_image, std::ofstream::binary);
         img << "P5\n" << opts.width << " " << opts.height << "\n255\n";
         for (const auto& h : host_hits) img.put(char(h.id >= 0 ? std::min(255.0f, 255.0f * h.t / opts.clip) : 255));
+    }
+    if (!opts.steps_image.empty() && opts.ray_file.empty()) {
+        // the picture the reference's viewer shows: its kernel returns the step count in Hit::id (traverse.cu:80,93) and
+        // main.cpp:100-107 maps it to a colour; here the count comes from the statistics entry point
+        int* steps = mem.alloc<int>(host_rays.size());
+        hagrid_grid pod = detail::to_pod(grid);
+        detail::check(detail::current_ctx(), hagrid_traverse_grid_stats(detail::current_ctx(), &pod, tris, rays, hits, int(host_rays.size()), steps, nullptr));
+        std::vector<int> host_steps(host_rays.size());
+        mem.copy<Copy::DEV_TO_HST>(host_steps.data(), steps, host_steps.size());
+        const int top = std::max(1, *std::max_element(host_steps.begin(), host_steps.end()));
+        std::ofstream img(opts.steps_image, std::ofstream::binary);
+        img << "P5\n" << opts.width << " " << opts.height << "\n255\n";
+        for (int v : host_steps) img.put(char(255 * v / top));
+        std::cout << "Steps per ray: max " << top << ", mean " << std::accumulate(host_steps.begin(), host_steps.end(), 0.0) / host_steps.size() << std::endl;
+        mem.free(steps);
     }
     mem.free(rays); mem.free(hits); release(); mem.free(tris);
     return 0;
