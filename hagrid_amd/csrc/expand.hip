@@ -18,6 +18,7 @@ using namespace hagrid_impl;
 namespace {
 
 struct ExpandK { ivec3 dims; ivec3 top; int shift; vec3 gmin, cell_size, grid_inv; };   // expand.cu:5-9
+constexpr int kChanged = 1 << 8;     // cell_flags: the cell's box changed in the previous pass (bits 0-2: expand.cu:145-182)
 struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
 
 __device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
@@ -119,6 +120,22 @@ __device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __res
     return d;
 }
 
+template <int axis, bool SUBSET_ONLY>
+__device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
+                                          const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags) {
+    CellRec cell = load_cell(cells, id);
+    bool flag = false;
+    const int ov1 = find_overlap<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    const int ov2 = find_overlap<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
+    if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
+    if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
+    cell_flags[id] = (flag ? 1 << axis : 0) | (flags & ~((1 << axis) | kChanged)) | ((ov1 | ov2) ? kChanged : 0);
+    int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
+    out[0] = make_int4(cell.lo.x, cell.lo.y, cell.lo.z, cell.begin);
+    out[1] = make_int4(cell.hi.x, cell.hi.y, cell.hi.z, cell.end);
+}
+
 // overlap_step (expand.cu:145-182)
 template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
@@ -127,23 +144,84 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_cells) return;
     const int flags = cell_flags[id];
-    int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
     if ((flags & (1 << axis)) == 0) {      // copy through
         const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
+        int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
         const int4 a = p[0], b = p[1];
         out[0] = a; out[1] = b;
+        if (flags & kChanged) cell_flags[id] = flags & ~kChanged;
         return;
     }
-    CellRec cell = load_cell(cells, id);
-    bool flag = false;
-    const int ov1 = find_overlap<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
-    const int ov2 = find_overlap<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
-    if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
-    if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
-    if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
-    cell_flags[id] = (flag ? 1 << axis : 0) | (flags & ~(1 << axis));
-    out[0] = make_int4(cell.lo.x, cell.lo.y, cell.lo.z, cell.begin);
-    out[1] = make_int4(cell.hi.x, cell.hi.y, cell.hi.z, cell.end);
+    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags);
+}
+
+// ---- passes of the later iterations: dense over the cells that are still growing ------------------------------------
+// After the first iteration only a part of the cells is still flagged for an axis (1M-triangle soup: 51 / 39 / 32 % in the
+// second iteration, 12 / 11 / 9 % in the third), scattered so evenly that almost every wavefront of overlap_step holds at
+// least one of them: the all-cells kernel then runs at the latency of the face walk whatever the fraction (137-145 us for
+// the 10 % passes against 164-225 us for the full ones), and the rest is a 270 MB copy-through.  Instead:
+//   expand_select   lists the flagged cells (tile-wise compaction in LDS, one atomic per 8192 cells) and copies through only
+//                   the unflagged cells that CHANGED in the previous pass -- the output buffer is the one of two passes ago,
+//                   so every other unflagged cell already holds its current value there;
+//   expand_listed   one thread per listed cell, same arithmetic as overlap_step.
+// Results are the ones of overlap_step bit for bit (same input snapshot per pass, every cell written by one thread).
+constexpr int kSelectItems = 16;                      // cells per thread
+constexpr int kSelectTile = kBlock * kSelectItems;    // cells per workgroup
+
+template <int axis>
+__global__ void __launch_bounds__(kBlock) expand_select(const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags,
+                                                        int num_cells, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int tile_list[kSelectTile];
+    __shared__ int tile_count, tile_base;
+    if (threadIdx.x == 0) tile_count = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSelectTile;
+    int fl[kSelectItems];
+    #pragma unroll
+    for (int j = 0; j < kSelectItems; j++) {                     // all loads in flight before anything depends on them
+        const int id = base + j * kBlock + threadIdx.x;
+        fl[j] = id < num_cells ? cell_flags[id] : 0;
+    }
+    #pragma unroll
+    for (int j = 0; j < kSelectItems; j++) {
+        const int id = base + j * kBlock + threadIdx.x;
+        const int flags = fl[j];
+        const bool listed = (flags & (1 << axis)) != 0;
+        const unsigned long long m = __ballot(listed);            // one LDS atomic per wavefront
+        int wbase = 0;
+        if (lane_id() == 0 && m) wbase = atomicAdd(&tile_count, __popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (listed) {
+            tile_list[wbase + __popcll(m & ((1ull << lane_id()) - 1ull))] = id;
+        } else if (flags & kChanged) {
+            const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
+            int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
+            const int4 a = p[0], b = p[1];
+            out[0] = a; out[1] = b;
+            cell_flags[id] = flags & ~kChanged;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_base = tile_count ? atomicAdd(count, tile_count) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tile_count; i += kBlock) list[tile_base + i] = tile_list[i];
+}
+
+template <int axis, bool SUBSET_ONLY>
+__global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
+                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
+                                                        int* __restrict__ cell_flags, const int* __restrict__ list, const int* __restrict__ count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *count) return;
+    const int id = list[i];
+    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id]);
+}
+
+template <int axis, bool SUBSET_ONLY>
+void listed_step(hipStream_t st, const ExpandK& k, const Entry* entries, const int* refs, const float4* tris, const Cell* cells, Cell* other,
+                 int* flags, int n, int* list, int* count) {
+    expand_select<axis><<<grid_blocks(n, kSelectTile), kBlock, 0, st>>>(cells, other, flags, n, list, count);
+    expand_listed<axis, SUBSET_ONLY><<<grid_blocks(n, kBlock), kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, list, count);
 }
 
 } // namespace
@@ -175,7 +253,24 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
+    int* list = iters > 1 && ctx->opt_expand_listed ? pool_alloc<int>(ctx, size_t(n)) : nullptr;
+    int* counts = ctx->dscratch + 160;             // one list length per listed pass
+    const int max_listed = 48;
+    if (list) HG_HIP(ctx, hipMemsetAsync(counts, 0, max_listed * sizeof(int), st));
+    int listed = 0;
     for (int it = 0; it < iters; it++) {                                               // expansion_iter, expand.cu:184-197
+        if (it > 0 && list && listed + 3 <= max_listed) {
+            if (subset_only) {
+                listed_step<0, true>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+                listed_step<1, true>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+                listed_step<2, true>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+            } else {
+                listed_step<0, false>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+                listed_step<1, false>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+                listed_step<2, false>(st, k, entries, refs, tris, cells, other, flags, n, list, counts + listed++); std::swap(cells, other);
+            }
+            continue;
+        }
         if (subset_only) {
             overlap_step<0, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
             overlap_step<1, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
@@ -190,6 +285,7 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     HG_HIP(ctx, hipStreamSynchronize(st));
     hagrid_mem_free(ctx, flags);
     hagrid_mem_free(ctx, other);
+    hagrid_mem_free(ctx, list);
     grid->cells = cells;
     if (e != hipSuccess) HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e));
     return HAGRID_OK;
