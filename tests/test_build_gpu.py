@@ -220,3 +220,64 @@ def test_precise_expansion_matches_oracle(mem):
     bf = O.brute_force(tris, rays[:20000], nthreads=8)
     assert (hits["id"][:20000] == bf["id"]).all() and (hits["t"][:20000].view(np.uint32) == bf["t"].view(np.uint32)).all()
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_scenes_and_parameters(mem, seed):
+    """Randomised scenes (sizes 1..4000, clustered / stretched / degenerate variants) with random densities, merge
+    thresholds and expansion counts: every stage bit-identical to the oracle, then hits bit-identical on the finished grid
+    (uncompressed and compressed), with the expansion in both modes."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 40, 333, 1500, 4000]))
+    tris = scene.make_soup(n, seed=500 + seed).copy()
+    kind = seed % 5
+    if kind == 1:                       # anisotropic scene: a thin slab
+        tris[:, [1, 5, 9]] *= np.float32(0.02)
+    elif kind == 2 and n > 10:          # a dense cluster inside the soup
+        m = n // 2
+        tris[:m, 0:3] = tris[:m, 0:3] * np.float32(0.03) + np.float32(0.6); tris[:m, 4:7] *= np.float32(0.03); tris[:m, 8:11] *= np.float32(0.03)
+    elif kind == 3 and n > 3:           # duplicates and zero-area triangles
+        tris[1] = tris[0]; tris[2, 4:7] = 0; tris[2, 8:11] = 0
+    elif kind == 4:                     # large triangles that span the scene
+        tris[: max(1, n // 50), 4:7] *= np.float32(30); tris[: max(1, n // 50), 8:11] *= np.float32(30)
+    e1, e2 = tris[:, 4:7], tris[:, 8:11]                      # normals as the front-end computes them: cross(e1, e2)
+    nrm = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2], e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
+    tris[:, 3] = nrm[:, 0]; tris[:, 7] = nrm[:, 1]; tris[:, 11] = nrm[:, 2]
+    tris = np.ascontiguousarray(tris, np.float32)
+    td = float(rng.choice([0.02, 0.12, 0.5, 1.5])); sd = float(rng.choice([0.5, 2.4, 6.0, 12.0]))
+    alpha = float(rng.choice([0.0, 0.9, 0.995, 0.9999])); exp = int(rng.choice([0, 1, 3, 5]))
+    try:
+        mem.set_option("expand.subset_only", seed % 2)
+        O.lib()                                   # the oracle follows the same option
+        d_tris = mem.upload(tris)
+        grid = api.Grid()
+        api.build_grid(mem, d_tris, n, grid, td, sd); G = O.Grid.build(tris, td, sd)
+        assert_same_grid(grid.download(), G, "build")
+        api.merge_grid(mem, grid, alpha); G.merge(alpha)
+        assert_same_grid(grid.download(), G, "merge")
+        api.flatten_grid(mem, grid); G.flatten()
+        assert_same_grid(grid.download(), G, "flatten")
+        api.expand_grid(mem, grid, d_tris, exp); G.expand(tris, exp, subset_only=bool(seed % 2))
+        assert_same_grid(grid.download(), G, "expand")
+        rays = np.concatenate([scene.make_rays_incoherent(G.bbox_min - 0.3, G.bbox_max + 0.3, 20000, 40 + seed),
+                               scene.make_rays_primary(G.bbox_min, G.bbox_max, 128, 64)]).astype(np.float32)
+        want, _ = G.traverse(tris, rays, nthreads=4)
+        brute = O.brute_force(tris, rays[:4000], nthreads=8)
+        assert (want["id"][:4000] == brute["id"]).all() and (want["t"][:4000].view(np.uint32) == brute["t"].view(np.uint32)).all()
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+        for compressed in (False, True):
+            if compressed:
+                ok = api.compress_grid(mem, grid)
+                assert ok == G.compress()
+                if not ok:
+                    break
+                assert_same_grid(grid.download(), G, "compress")
+            api.setup_traversal(grid)
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+            got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+            assert (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all(), (seed, compressed)
+        mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+    finally:
+        mem.set_option("expand.subset_only", 1)
