@@ -935,7 +935,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
           else (void)hipGetLastError(); }
         const bool narrow = ctx->opt_narrow && tri_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             a.top_xy > 0 && grid->dims[2] < (1 << 23) &&
-                            grid->num_entries >= 0 && grid->num_refs >= 0;
+                            size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
         launch_v2(ctx->stream, blocks, grid->small_cells != nullptr, narrow, flags, a);
     } else {
         const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
