@@ -1028,7 +1028,7 @@ static inline ovec3 compute_voxel(const TravConsts* k, ovec3 org, ovec3 dir, flo
 
 static inline int clampi(int a, int b, int c) { return imin(c, imax(b, a)); } /* common.h:27 */
 
-/* dev analysis hook (tools/dev_wave_model.py): list length of every visited cell of the ray being traversed */
+/* dev analysis hook (tests/analysis/wave_model.py): list length of every visited cell of the ray being traversed */
 static __thread unsigned char* g_trace = NULL;
 static __thread int g_trace_cap = 0, g_trace_len = 0;
 static __thread int* g_trace_ids = NULL;

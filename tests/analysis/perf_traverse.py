@@ -2,7 +2,7 @@
 Used before the GPU construction passes existed and to A/B kernel variants on a fixed grid."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hagrid_amd import api, scene
 from oracle import oracle as O
 

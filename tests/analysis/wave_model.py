@@ -4,7 +4,7 @@ lock-step iterations: cell steps = max cells over the wave, triangle iterations 
 among live lanes; alternatives: pairs packed across lanes, consolidation of thin waves."""
 import os, sys, json, time, ctypes as C
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 from hagrid_amd import scene
 
