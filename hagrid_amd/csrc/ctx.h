@@ -63,7 +63,7 @@ struct hagrid_ctx {
     int opt_expand_listed = 1;   // expand_grid: iterations after the first run dense over the still-growing cells
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
-    int opt_super_log2 = 5;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
+    int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image = 0;          // 1: setup_traversal builds the traversal image (trav_image.hip) and traverse_grid uses it
