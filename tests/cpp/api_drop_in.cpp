@@ -76,6 +76,27 @@ int main(int argc, char** argv) {
         mem.copy<Copy::DEV_TO_HST>(h2.data(), hits, h2.size());
         for (int i = 0; i < nrays; i++) if (h2[i].id != host_hits[i].id || h2[i].t != host_hits[i].t) bad++;
     }
+    // extensions over the same walk: occlusion rays report a hit exactly where the nearest-hit walk does, and the
+    // barycentrics variant leaves (id, t) untouched and puts the hit point at v0 - u e1 + v e2
+    {
+        std::vector<Hit> ha(nrays), hu(nrays);
+        traverse_grid_any_hit(grid, tris, rays, hits, nrays);
+        mem.copy<Copy::DEV_TO_HST>(ha.data(), hits, ha.size());
+        traverse_grid_with_uvs(grid, tris, rays, hits, nrays);
+        mem.copy<Copy::DEV_TO_HST>(hu.data(), hits, hu.size());
+        int bad_ext = 0;
+        for (int i = 0; i < nrays; i++) {
+            if ((ha[i].id >= 0) != (host_hits[i].id >= 0)) bad_ext++;
+            if (hu[i].id != host_hits[i].id || hu[i].t != host_hits[i].t) bad_ext++;
+            if (hu[i].id >= 0) {
+                const Tri& t = host_tris[hu[i].id];
+                const vec3 p = t.v0 - t.e1 * hu[i].u + t.e2 * hu[i].v, q = host_rays[i].org + host_rays[i].dir * hu[i].t;
+                if (length(p - q) > 1e-3f) bad_ext++;
+            }
+        }
+        printf("%d mismatches in the any-hit / barycentric variants\n", bad_ext);
+        bad += bad_ext;
+    }
     mem.free(rays); mem.free(hits);
     mem.free(grid.entries); mem.free(grid.cells); mem.free(grid.ref_ids); mem.free(grid.small_cells); mem.free(tris);
     printf("peak usage %.1f MB, usage after free %zu\n", mem.max_usage() / 1048576.0, mem.usage());

@@ -118,7 +118,7 @@ def test_cpp_program_through_the_headers_on_gpu():
         r = subprocess.run([exe, "20000", "4096"], capture_output=True, text=True, timeout=300)
         sys.stdout.write(r.stdout)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert " 0 mismatches" in r.stdout
+        assert " 0 mismatches vs host" in r.stdout and "\n0 mismatches in the any-hit" in r.stdout, r.stdout
 
 
 def _build_cli(d):
