@@ -74,7 +74,8 @@ class MemManager:
         _check(self, self._L.hagrid_ctx_set_stream(self._ctx, C.c_void_p(stream or 0)), "set_stream")
 
     def set_ray_binning(self, mode: int):
-        """Extension: 1 = bin each ray batch by grid-entry position before traversal (for incoherent batches)."""
+        """Extension: 1 = bin each ray batch by grid-entry position before traversal (for incoherent batches);
+        2 = automatic: the device bins a batch only if it is neither image-ordered nor coherent (no host round trip)."""
         _check(self, self._L.hagrid_set_ray_binning(self._ctx, int(mode)), "set_ray_binning")
 
     def set_option(self, key: str, value: int):

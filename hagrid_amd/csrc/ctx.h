@@ -53,6 +53,7 @@ struct hagrid_ctx {
     int* mailbox = nullptr;
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
+    int* bin_diff = nullptr;             // automatic ray binning: 64 partial counts of neighbouring rays in different bins
 
     // traversal options (hagrid_set_ray_binning, hagrid_set_option)
     int ray_binning = 0;

@@ -45,6 +45,7 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+    if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
     delete ctx;
 }
 

