@@ -492,7 +492,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     if (!counts || !start_emit || !refs_per_cell || !log_dims || !partials) return HAGRID_ENOMEM;
     HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
     count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, refs_per_cell);
-    device_scan<int>(st, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0);
+    if (!ctx_scan<int>(ctx, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0)) return HAGRID_ENOMEM;
     top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1);
     int h2[2];
     HG_TRY(read_back(ctx, dsc, h2, sizeof(h2)));
@@ -529,7 +529,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         if (!part || !masks) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
             mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries);
-        device_scan<int>(st, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0);
+        if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0)) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
             classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
                                                                                masks, L.cell_counts, tot + 1);
@@ -571,8 +571,8 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     if (!part2) return HAGRID_ENOMEM;
     for (int l = 0; l < num_levels; l++) {
         Level& L = levels[l];
-        device_scan<Int2>(st, LeafIn{L.entries, L.cell_counts}, LeafOut{L.start_cell, L.ref_begin}, L.num_cells, part2,
-                          l ? carry + (l - 1) : (const Int2*)nullptr, carry + l);
+        if (!ctx_scan<Int2>(ctx, LeafIn{L.entries, L.cell_counts}, LeafOut{L.start_cell, L.ref_begin}, L.num_cells, part2,
+                            l ? carry + (l - 1) : (const Int2*)nullptr, carry + l)) return HAGRID_ENOMEM;
     }
     int hf[2];
     HG_TRY(read_back(ctx, carry + (num_levels - 1), hf, sizeof(hf)));

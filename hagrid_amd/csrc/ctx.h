@@ -53,6 +53,9 @@ struct hagrid_ctx {
     int* mailbox = nullptr;
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
+    unsigned long long* lb_state = nullptr;   // status words of the look-back scans (wave_prims.h), never cleared: epochs
+    size_t lb_words = 0;
+    unsigned lb_epoch = 0;
     int* bin_diff = nullptr;             // automatic ray binning: 64 partial counts of neighbouring rays in different bins
 
     // traversal options (hagrid_set_ray_binning, hagrid_set_option)
@@ -61,6 +64,7 @@ struct hagrid_ctx {
     int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
     int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
     int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
+    int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_expand_listed = 1;   // expand_grid: iterations after the first run dense over the still-growing cells
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
@@ -108,6 +112,9 @@ inline T* pool_alloc(hagrid_ctx* ctx, size_t n) {
 int read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes);
 
 inline int grid_blocks(long long n, int block) { return (int)((n + block - 1) / block); }
+
+// Status words for one look-back scan of `tiles` tiles with `words_per_tile` words each, and a fresh epoch.
+unsigned long long* lookback_state(hagrid_ctx* ctx, int tiles, int words_per_tile, unsigned* epoch);
 
 // trav_image.hip
 int trav_image_build(hagrid_ctx* ctx, const hagrid_grid* grid);       // leaves the image invalid for grids it does not cover

@@ -46,6 +46,7 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
+    if (ctx->lb_state) (void)hipFree(ctx->lb_state);
     delete ctx;
 }
 
@@ -202,6 +203,25 @@ extern "C" float hagrid_profile_end(hagrid_ctx* ctx) {
     if (hipEventSynchronize(ctx->ev_end) != hipSuccess) return -1.0f;
     if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) return -1.0f;
     return ms;
+}
+
+unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int words_per_tile, unsigned* epoch) {
+    const size_t need = size_t(tiles > 0 ? tiles : 1) * size_t(words_per_tile);
+    if (need > ctx->lb_words || ctx->lb_epoch >= (1u << 30) - 2u) {
+        // grow (or restart the epochs): the words must start out as "never published"
+        (void)hipStreamSynchronize(ctx->stream);
+        if (need > ctx->lb_words) {
+            if (ctx->lb_state) (void)hipFree(ctx->lb_state);
+            ctx->lb_state = nullptr; ctx->lb_words = 0;
+            const size_t words = need + need / 2 + 1024;
+            if (hipMalloc((void**)&ctx->lb_state, words * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            ctx->lb_words = words;
+        }
+        (void)hipMemsetAsync(ctx->lb_state, 0, ctx->lb_words * sizeof(unsigned long long), ctx->stream);
+        ctx->lb_epoch = 0;
+    }
+    *epoch = ++ctx->lb_epoch;
+    return ctx->lb_state;
 }
 
 int hagrid_impl::read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes) {

@@ -119,7 +119,7 @@ extern "C" int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     int groups = 0;
     for (int i = 0; i < shift; i += kFlatLevels, groups++) {
         const int first = first_of(i), num = grid->offsets[i] - first;
-        device_scan<int>(st, BlockSizeIn{depths + first}, StartOut{start + first}, num, partials, carry + groups, carry + groups + 1);
+        if (!ctx_scan<int>(ctx, BlockSizeIn{depths + first}, StartOut{start + first}, num, partials, carry + groups, carry + groups + 1)) { release(); return HAGRID_ENOMEM; }
     }
     int h[HAGRID_MAX_LEVELS + 2];
     int rc = read_back(ctx, carry, h, sizeof(int) * size_t(groups + 1));

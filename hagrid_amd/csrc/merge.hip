@@ -244,7 +244,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             (void)hipMemsetAsync(prevs, 0xFF, size_t(num_cells) * sizeof(int), st);
             merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells);
             cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells);
-            device_scan<Int2>(st, KeepIn{cell_flags, merge_counts}, KeepOut{cell_scan, ref_scan}, num_cells, partials, (const Int2*)nullptr, total);
+            if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts}, KeepOut{cell_scan, ref_scan}, num_cells, partials, (const Int2*)nullptr, total)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
                                                     merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells);
             remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries);

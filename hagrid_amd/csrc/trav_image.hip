@@ -182,7 +182,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     if (!sizes || !metas || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int* total = ctx->dscratch + 224;
     image_top_cell<D, false><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr);
-    device_scan<int>(st, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total);
+    if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int units = 0;
     int rc = read_back(ctx, total, &units, sizeof(int));
     if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }

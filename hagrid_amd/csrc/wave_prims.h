@@ -13,6 +13,7 @@
 //
 // Workgroups are 256 threads = 4 wavefronts of 64 lanes.
 #pragma once
+#include "ctx.h"
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,6 +36,8 @@ __host__ __device__ inline Int2 zero_of(Int2) { return Int2{0, 0}; }
 
 __device__ __forceinline__ int shfl_up_v(int v, int d) { return __shfl_up(v, d, 64); }
 __device__ __forceinline__ Int2 shfl_up_v(Int2 v, int d) { return Int2{__shfl_up(v.a, d, 64), __shfl_up(v.b, d, 64)}; }
+__device__ __forceinline__ int shfl_xor_v(int v, int d) { return __shfl_xor(v, d, 64); }
+__device__ __forceinline__ Int2 shfl_xor_v(Int2 v, int d) { return Int2{__shfl_xor(v.a, d, 64), __shfl_xor(v.b, d, 64)}; }
 __device__ __forceinline__ int shfl_v(int v, int l) { return __shfl(v, l, 64); }
 __device__ __forceinline__ Int2 shfl_v(Int2 v, int l) { return Int2{__shfl(v.a, l, 64), __shfl(v.b, l, 64)}; }
 
@@ -180,7 +183,125 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
     }
 }
 
+// ---- single-pass variant: decoupled look-back ------------------------------------------------------------------------
+// One kernel, every input read once: a tile publishes its aggregate, looks back over its predecessors' published
+// aggregates / inclusive prefixes (64 at a time, one per lane of wavefront 0), publishes its own inclusive prefix and scans
+// its items from registers.  A status word carries (epoch, flag, 32-bit value) and is written / read with one agent-scope
+// 64-bit atomic, so it is valid across the 8 L2s; the epoch makes last call's words invalid without clearing the array.
+// Tiles are taken in blockIdx order: workgroups are dispatched in increasing order on every XCD, so the lowest unfinished
+// tile is always resident and the spin below cannot starve it.
+constexpr unsigned kLbAggregate = 1u, kLbPrefix = 2u;
+
+__device__ __forceinline__ unsigned long long lb_pack(unsigned epoch, unsigned flag, int value) {
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned)value;
+}
+__device__ __forceinline__ void lb_store(unsigned long long* p, unsigned long long w) {
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_publish(unsigned long long* state, int tile, unsigned epoch, unsigned flag, int v) { lb_store(state + tile, lb_pack(epoch, flag, v)); }
+__device__ __forceinline__ void lb_publish(unsigned long long* state, int tile, unsigned epoch, unsigned flag, Int2 v) {
+    lb_store(state + 2 * size_t(tile), lb_pack(epoch, flag, v.a));
+    lb_store(state + 2 * size_t(tile) + 1, lb_pack(epoch, flag, v.b));
+}
+// status of tile `t` once it is valid for this epoch: returns the flag, fills v
+__device__ __forceinline__ unsigned lb_wait(const unsigned long long* state, int t, unsigned epoch, int& v) {
+    unsigned long long w;
+    do { w = lb_load(state + t); } while ((unsigned)(w >> 34) != epoch || ((w >> 32) & 3u) == 0u);
+    v = int(unsigned(w));
+    return unsigned(w >> 32) & 3u;
+}
+__device__ __forceinline__ unsigned lb_wait(const unsigned long long* state, int t, unsigned epoch, Int2& v) {
+    // a tile publishes both words as `aggregate` and later both as `prefix`: read until the two agree
+    int a, b;
+    unsigned fa, fb;
+    do {
+        fa = lb_wait(state, 2 * t, epoch, a);
+        fb = lb_wait(state, 2 * t + 1, epoch, b);
+    } while (fa != fb);
+    v = Int2{a, b};
+    return fa;
+}
+template <typename V> constexpr int lb_words() { return int(sizeof(V) / sizeof(int)); }
+
+template <typename V, typename In, typename Out>
+__global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
+    __shared__ V lds[kWaves];
+    __shared__ V tile_prefix;
+    const int tile = blockIdx.x, base = tile * kScanTile;
+    V v[kScanItems];
+    V sum = zero_of(V());
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        const int i = base + j * kBlock + threadIdx.x;
+        v[j] = i < n ? in(i) : zero_of(V());
+        sum = sum + v[j];
+    }
+    const V wsum = wave_inclusive_scan(sum);
+    if (lane_id() == 63) lds[wave_id()] = wsum;
+    __syncthreads();
+    if (wave_id() == 0) {
+        V agg = lds[0];
+        for (int w = 1; w < kWaves; w++) agg = agg + lds[w];
+        V excl = zero_of(V());
+        if (tile == 0) {
+            if (carry_in) excl = *carry_in;
+        } else {
+            if (lane_id() == 0) lb_publish(state, tile, epoch, kLbAggregate, agg);
+            int p = tile - 1;
+            for (;;) {
+                const int t = p - lane_id();
+                V pv = zero_of(V());
+                unsigned flag = kLbPrefix;                           // lanes before tile 0 end the search with a zero
+                if (t >= 0) flag = lb_wait(state, t, epoch, pv);
+                const unsigned long long is_prefix = __ballot(flag == kLbPrefix);
+                const int first = __ffsll((long long)is_prefix) - 1;                 // nearest predecessor with an inclusive prefix
+                if (first < 0 || lane_id() <= first) excl = excl + pv;
+                if (first >= 0) break;
+                p -= 64;
+            }
+            // sum over the lanes
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) excl = excl + V(shfl_xor_v(excl, d));
+        }
+        if (lane_id() == 0) {
+            lb_publish(state, tile, epoch, kLbPrefix, excl + agg);
+            tile_prefix = excl;
+            if (total_out && tile == int(gridDim.x) - 1) *total_out = excl + agg;
+        }
+    }
+    __syncthreads();
+    V running = tile_prefix;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        const int i = base + j * kBlock + threadIdx.x;
+        if (base + j * kBlock >= n) break;
+        const V incl = wave_inclusive_scan(v[j]);
+        __syncthreads();
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        V excl = running;
+        for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
+        const V prev = shfl_up_v(incl, 1);
+        if (lane_id() > 0) excl = excl + prev;
+        if (i < n) out(i, excl);
+        V t = running;
+        for (int w = 0; w < kWaves; w++) t = t + lds[w];
+        running = t;
+    }
+}
+
 inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
+
+/// Single-pass scan.  `state` holds lb_words<V>() 64-bit words per tile and must never have seen `epoch` before
+/// (hagrid_impl::lookback_state hands out both).
+template <typename V, typename In, typename Out>
+inline void device_scan_lookback(hipStream_t stream, In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
+    const int tiles = scan_num_tiles(n);
+    scan_lookback<V, In, Out><<<tiles > 0 ? tiles : 1, kBlock, 0, stream>>>(in, out, n, state, epoch, carry_in, total_out);
+}
 
 /// Launches the three scan kernels.  `partials` must hold scan_num_tiles(n) values of V.
 /// n == 0 still runs the spine so that total_out = carry.
@@ -190,6 +311,18 @@ inline void device_scan(hipStream_t stream, In in, Out out, int n, V* partials, 
     if (tiles > 0) scan_partials<V, In><<<tiles, kBlock, 0, stream>>>(in, n, partials);
     scan_spine<V><<<1, kBlock, 0, stream>>>(partials, tiles, carry_in, total_out);
     if (tiles > 0) scan_apply<V, In, Out><<<tiles, kBlock, 0, stream>>>(in, out, n, partials);
+}
+
+/// The scan the construction passes call: look-back by default, the three-kernel form with "build.lookback" = 0.
+/// Returns false if the status words could not be allocated.
+template <typename V, typename In, typename Out>
+inline bool ctx_scan(hagrid_ctx* ctx, In in, Out out, int n, V* partials, const V* carry_in, V* total_out) {
+    if (!ctx->opt_lookback) { device_scan<V>(ctx->stream, in, out, n, partials, carry_in, total_out); return true; }
+    unsigned epoch = 0;
+    unsigned long long* state = lookback_state(ctx, scan_num_tiles(n), lb_words<V>(), &epoch);
+    if (!state) return false;
+    device_scan_lookback<V>(ctx->stream, in, out, n, state, epoch, carry_in, total_out);
+    return true;
 }
 
 } // namespace hagrid_impl
