@@ -158,7 +158,7 @@ struct KeepOut {
 __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
                                                        const int* __restrict__ refs, const int* __restrict__ cell_flags,
                                                        const int* __restrict__ cell_scan, const int* __restrict__ ref_scan,
-                                                       const int* __restrict__ merge_counts, int* __restrict__ new_cell_ids,
+                                                       const int* __restrict__ merge_counts, int* new_cell_ids /* holds nexts on entry */,
                                                        Cell* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_cells || !cell_flags[id]) return;
@@ -166,10 +166,12 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     const CellRec cell = load_cell(cells, id);
     const int mc = merge_counts[id];
     const int nb = ref_scan[id];
+    // the array still holds `nexts` (compute_merge_counts' neighbour, = what lookup_entry would find again): only the second
+    // cell of a merging pair is overwritten by another thread, and that cell is residue (flag 0) -- it never gets here
+    const int next_id = new_cell_ids[id];
     new_cell_ids[id] = new_id;
     const int n1 = cell.end - cell.begin;
     if (mc >= 0) {
-        const int next_id = int(lookup_entry(entries, k.shift, k.top, next_cell_pos(axis, cell.lo, cell.hi)));
         const CellRec nc = load_cell(cells, next_id);
         new_cell_ids[next_id] = new_id;
         store_cell(new_cells, new_id, min(nc.lo, cell.lo), nb, max(nc.hi, cell.hi), nb + mc);
