@@ -64,6 +64,7 @@ struct hagrid_ctx {
     int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
     int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
     int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
+    int opt_merge_chain = 1;     // merge_grid: the three axis passes of an iteration without host round trips in between
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_expand_listed = 1;   // expand_grid: iterations after the first run dense over the still-growing cells
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)

@@ -91,9 +91,10 @@ __device__ __forceinline__ void merge_refs(const int* __restrict__ p0, int c0, c
 // compute_merge_counts (merge.cu:91-142)
 __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
                                                               const int* __restrict__ refs, int* __restrict__ merge_counts,
-                                                              int* __restrict__ nexts, int* __restrict__ prevs, int empty_mask, int num_cells) {
+                                                              int* __restrict__ nexts, int* __restrict__ prevs, int empty_mask, int num_cells,
+                                                              const int* __restrict__ n_dev) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= num_cells) return;
+    if (id >= (n_dev ? *n_dev : num_cells)) return;
     const float unit_cost = 1.0f;
     const CellRec c1 = load_cell(cells, id);
     const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
@@ -125,9 +126,9 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
 
 // compute_cell_flags (merge.cu:145-170): chain heads mark every second cell of their chain as residue
 __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ prevs,
-                                                            int* __restrict__ cell_flags, int num_cells) {
+                                                            int* __restrict__ cell_flags, int num_cells, const int* __restrict__ n_dev) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= num_cells) return;
+    if (id >= (n_dev ? *n_dev : num_cells)) return;
     if (prevs[id] < 0) {
         int next_id = nexts[id];
         cell_flags[id] = 1;
@@ -142,16 +143,17 @@ __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restric
 
 // scans of merge.cu:310-311 fused; compute_ref_counts (merge.cu:173-186) folded into the input
 struct KeepIn {
-    const int* cell_flags; const int* merge_counts;
+    const int* cell_flags; const int* merge_counts; const int* n_dev;      // n_dev: the pass's cell count when only the device knows it
     __device__ Int2 operator()(int i) const {
+        if (n_dev && i >= *n_dev) return Int2{0, 0};
         const int f = cell_flags[i];
         const int m = merge_counts[i];
         return Int2{ f ? 1 : 0, f ? (m >= 0 ? m : -(m + 1)) : 0 };
     }
 };
 struct KeepOut {
-    int* cell_scan; int* ref_scan;
-    __device__ void operator()(int i, Int2 v) const { cell_scan[i] = v.a; ref_scan[i] = v.b; }
+    int* cell_scan; int* ref_scan; const int* n_dev;
+    __device__ void operator()(int i, Int2 v) const { if (n_dev && i >= *n_dev) return; cell_scan[i] = v.a; ref_scan[i] = v.b; }
 };
 
 // merge (merge.cu:189-278)
@@ -159,9 +161,9 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
                                                        const int* __restrict__ refs, const int* __restrict__ cell_flags,
                                                        const int* __restrict__ cell_scan, const int* __restrict__ ref_scan,
                                                        const int* __restrict__ merge_counts, int* new_cell_ids /* holds nexts on entry */,
-                                                       Cell* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells) {
+                                                       Cell* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= num_cells || !cell_flags[id]) return;
+    if (id >= (n_dev ? *n_dev : num_cells) || !cell_flags[id]) return;
     const int new_id = cell_scan[id];
     const CellRec cell = load_cell(cells, id);
     const int mc = merge_counts[id];
@@ -241,21 +243,30 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
         const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
+        // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
+        // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
+        // read the real one.  One host round trip per iteration instead of three.
+        Int2* totals[2] = { total, total + 1 };
         for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
             const int blocks = grid_blocks(num_cells, kBlock);
+            Int2* tot = totals[axis & 1];
+            const int* n_dev = axis ? &totals[(axis - 1) & 1]->a : nullptr;
             (void)hipMemsetAsync(prevs, 0xFF, size_t(num_cells) * sizeof(int), st);
-            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells);
-            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells);
-            if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts}, KeepOut{cell_scan, ref_scan}, num_cells, partials, (const Int2*)nullptr, total)) { rc = HAGRID_ENOMEM; break; }
+            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells, n_dev);
+            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells, n_dev);
+            if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
-                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells);
+                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev);
             remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries);
-            int h[2];
-            rc = read_back(ctx, total, h, sizeof(h));
-            if (rc != HAGRID_OK) break;
             std::swap(cells, cells_b);
             std::swap(refs, refs_b);
-            num_cells = h[0]; num_refs = h[1];
+            if (axis == 2 || !ctx->opt_merge_chain) {
+                int h[2];
+                rc = read_back(ctx, tot, h, sizeof(h));
+                if (rc != HAGRID_OK) break;
+                num_cells = h[0]; num_refs = h[1];
+                if (axis < 2) { totals[0] = total; totals[1] = total + 1; }
+            }
         }
         iter++;
     } while (rc == HAGRID_OK && num_cells < alpha * prev_num_cells);
