@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--build-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off, 1 compact, 2 flat (default)")
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 for primary rays")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
@@ -122,7 +123,9 @@ def main():
     d_hits = mem.alloc(16 * n_rays)
     bin_rays = (1 if args.rays == "incoherent" else 0) if args.bin_rays is None else args.bin_rays
     mem.set_ray_binning(bin_rays)
-    api.setup_traversal(grid)
+    mem.set_option("traverse.image", args.image)
+    api.setup_traversal(grid)                        # main.cpp:535; builds the traversal image (outside every timed region)
+    setup_ms = api.profile(lambda: api.setup_traversal(grid), mem)
 
     # exact algorithmic byte counters of this batch (outside the timed region)
     stats = api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n_rays)
@@ -173,14 +176,15 @@ def main():
             "config": {"workload": f"soup-{n_tris} triangles, {args.rays} rays {args.width}x{args.height} per GPU"
                                    f" (BASELINE.json configs[1]), td {args.top_density} sd {args.snd_density} alpha {args.alpha} exp {args.expansion}"
                                    + (" compress" if args.compress else ""),
-                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)", "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
+                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: "flat blocks: one 32-byte record per voxel, built by setup_traversal"}[args.image], "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)", "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),
             "grid_broadcast_ms": round(t_bcast, 3),
+            "setup_traversal_ms": round(setup_ms, 3),
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2",
+                         "kernel": "traverse_kernel_img" if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2"),
                          "kernel_ms": round(kernel_ms, 5),
                          "bytes_per_ray": round(ab["B_ray"] / n_rays, 1),
                          "walk_achieved": round(ab["B_walk"] / (kernel_ms * 1e6), 1),

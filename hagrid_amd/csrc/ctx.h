@@ -28,6 +28,7 @@ struct TravImageCache {
     void* blocks = nullptr;         // 128-byte aligned blocks: local voxel map + 32-byte cell records
     size_t block_bytes = 0;
     bool valid = false;
+    bool flat = false;              // records indexed by the voxel (no slot bytes)
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0};
@@ -72,7 +73,7 @@ struct hagrid_ctx {
     int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
-    int opt_image = 0;          // 1: setup_traversal builds the traversal image (trav_image.hip) and traverse_grid uses it
+    int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
     hagrid_impl::TravImageCache image;

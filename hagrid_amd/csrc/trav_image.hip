@@ -54,7 +54,9 @@ __host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
 
 // One wavefront per top-level cell.  D = min(shift, 3) is the finest resolution a block can have.
 // FILL = false: sizes[T] (128-byte units) and metas[T]; FILL = true: the block.
-template <int D, bool FILL>
+// FLAT: no slot bytes and no de-duplication -- the block is (2^d)^3 records indexed by the voxel, so a cell step is ONE
+// dependent gather (table entry cached per top-level cell -> record) instead of two, at 1.8x the memory.
+template <int D, bool FILL, bool FLAT>
 __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restrict__ sizes, uint32_t* __restrict__ metas,
                                                      const int* __restrict__ offsets, uint2* __restrict__ table, unsigned char* __restrict__ blocks) {
     constexpr int SHIFT = D;                 // index arithmetic inside the block
@@ -120,9 +122,10 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
         if (lane == 0) { rep_mask[p] = mask; rep_prefix[p] = count; }
         count += __popcll(mask);
     }
-    const bool wide = count > 255;
-    const uint32_t meta = uint32_t(d) | (wide ? 4u : 0u) | (uint32_t(count) << 8);
-    const uint32_t ebytes = slot_bytes(d, wide);
+    if (FLAT) count = 1 << (3 * d);
+    const bool wide = !FLAT && count > 255;
+    const uint32_t meta = uint32_t(d) | (wide ? 4u : 0u) | (FLAT ? 8u : 0u) | (uint32_t(count) << 8);
+    const uint32_t ebytes = FLAT ? 0u : slot_bytes(d, wide);
     if (!FILL) {
         if (lane == 0) { sizes[T] = int((ebytes + 32u * uint32_t(count) + 127u) >> 7); metas[T] = meta; }
         return;
@@ -135,13 +138,16 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
     for (int p = 0; p < P; p++) {
         const int f = p * 64 + lane;
         if (f >= V || rep[p] < 0) continue;
-        const int g = rep[p];
-        const int slot = rep_prefix[g >> 6] + __popcll(rep_mask[g >> 6] & ((1ull << (g & 63)) - 1ull));
-        if (d > 0) {
+        int g = rep[p];
+        int slot = rep_prefix[g >> 6] + __popcll(rep_mask[g >> 6] & ((1ull << (g & 63)) - 1ull));
+        {
             const int fx = f & M, fy = (f >> SHIFT) & M, fz = f >> (2 * SHIFT);
             const int idx = (fx >> sd) + (((fy >> sd) + ((fz >> sd) << d)) << d);
-            if (wide) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)slot;
-            else      base[idx] = (unsigned char)slot;
+            if (FLAT) { slot = idx; g = f; }               // every voxel writes its own record
+            else if (d > 0) {
+                if (wide) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)slot;
+                else      base[idx] = (unsigned char)slot;
+            }
         }
         if (g == f && cell[p] < 0) {
             uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
@@ -171,7 +177,7 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
 struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
 struct SizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
 
-template <int D>
+template <int D, bool FLAT>
 int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     hipStream_t st = ctx->stream;
     int* sizes = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
@@ -181,14 +187,14 @@ int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     auto release = [&]() { hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials); };
     if (!sizes || !metas || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int* total = ctx->dscratch + 224;
-    image_top_cell<D, false><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr);
+    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr);
     if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int units = 0;
     int rc = read_back(ctx, total, &units, sizeof(int));
     if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
     unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, size_t(units) * 128u));
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    image_top_cell<D, true><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks);
+    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks);
     hipError_t e = hipGetLastError();
     release();
     if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }
@@ -239,12 +245,14 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
     TravImageCache img;
     int rc = HAGRID_OK;
+    const bool flat = ctx->opt_image == 2;
     switch (g->shift < 3 ? g->shift : 3) {
-        case 0: rc = build_image<0>(ctx, k, img); break;
-        case 1: rc = build_image<1>(ctx, k, img); break;
-        case 2: rc = build_image<2>(ctx, k, img); break;
-        default: rc = build_image<3>(ctx, k, img); break;
+        case 0: rc = flat ? build_image<0, true>(ctx, k, img) : build_image<0, false>(ctx, k, img); break;
+        case 1: rc = flat ? build_image<1, true>(ctx, k, img) : build_image<1, false>(ctx, k, img); break;
+        case 2: rc = flat ? build_image<2, true>(ctx, k, img) : build_image<2, false>(ctx, k, img); break;
+        default: rc = flat ? build_image<3, true>(ctx, k, img) : build_image<3, false>(ctx, k, img); break;
     }
+    img.flat = flat;
     if (rc != HAGRID_OK) return rc;
     img.valid = img.table != nullptr;
     img.entries = g->entries; img.cells = g->cells; img.refs = g->ref_ids;

@@ -465,12 +465,14 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
 // of the top-level cell (kept in registers while the ray stays inside it), one slot byte, one 32-byte record that carries
 // the bounds and -- for lists of up to four -- the reference ids themselves.  The next cell's slot + record are fetched
 // before the current cell's triangles are tested, as in v2.
+template <bool FLAT>
 __device__ __forceinline__ const uint4* image_record(const TraverseArgs& a, uint2 tab, int vx, int vy, int vz) {
     const uint32_t meta = tab.y;
     const int d = int(meta & 3u), w = int((meta >> 2) & 1u);
     const unsigned char* base = a.img_blocks + size_t(tab.x) * 128u;
     const int s = a.shift - d, m = (1 << d) - 1;
     const int idx = ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << d)) << d);   // 0 when d == 0
+    if (FLAT) return reinterpret_cast<const uint4*>(base + uint32_t(idx) * 32u);             // the record itself: one gather per step
     uint32_t slot = base[idx << w];                                                           // d == 0: a byte of the record, ignored
     if (w) slot |= uint32_t(base[(idx << 1) + 1]) << 8;
     uint32_t ebytes = (1u << (3 * d)) << w;
@@ -499,7 +501,8 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
     cb.x = uint32_t(lo.w);
 }
 
-template <int BLOCK>
+// NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
+template <int BLOCK, bool FLAT, bool NARROW>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
@@ -529,13 +532,41 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         int vy = min(max(int(fv.y), 0), a.dims_y - 1);
         int vz = min(max(int(fv.z), 0), a.dims_z - 1);
 
-        int top_idx = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
-        uint2 tab = a.img_table[top_idx];
-        const uint4* rec = image_record(a, tab, vx, vy, vz);
-        uint4 ca = rec[0], cb = rec[1];
-        if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+        auto top_index = [&](int x, int y, int z) -> int {
+            if (NARROW) return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
+            return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
+        };
+        auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
+        // record of a voxel: FLAT + NARROW is one address computation off the scalar base
+        auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
+            if (FLAT && NARROW) {
+                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+                const uint32_t o = (tab.x << 7) + (idx << 5);
+                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
+                ra = p[0]; rb = p[1];
+            } else {
+                const uint4* p = image_record<FLAT>(a, tab, x, y, z);
+                ra = p[0]; rb = p[1];
+            }
+        };
+        auto tri_at = [&](int ref) -> Tri {
+            if (!NARROW) return load_tri(a.tris, ref);
+            uint32_t r3, o;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
+            const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+            return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+        };
+
+        int top_idx = top_index(vx, vy, vz);
+        uint2 tab = table_at(top_idx);
+        uint4 ca, cb;
+        record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
+            if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
             const int cx = int(px ? ca.y >> 16 : ca.x & 0xffffu), cy = int(py ? ca.z & 0xffffu : ca.x >> 16), cz = int(pz ? ca.z >> 16 : ca.y & 0xffffu);
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
             const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
@@ -546,32 +577,25 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             vx = px ? max(nx, vx) : min(nx, vx);
             vy = py ? max(ny, vy) : min(ny, vy);
             vz = pz ? max(nz, vz) : min(nz, vz);
-            const bool outside = (vx < 0) | (vx >= a.dims_x) | (vy < 0) | (vy >= a.dims_y) | (vz < 0) | (vz >= a.dims_z);
+            const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
 
-            // next cell: table entry (only when the top-level cell changes), slot, record -- in flight during the tests below
-            const int ntop = outside ? top_idx : (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
-            if (ntop != top_idx) { tab = a.img_table[ntop]; top_idx = ntop; }
-            const uint4* nrec = image_record(a, tab, vx, vy, vz);
-            const uint4 na = nrec[0], nb = nrec[1];
+            // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
+            const int ntop = outside ? top_idx : top_index(vx, vy, vz);
+            if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
+            uint4 na, nb;
+            record(tab, vx, vy, vz, na, nb);
 
             const int n = int(ca.w & 0x7fffffffu);
-            if (!(ca.w >> 31)) {
-                for (int i = 0; i < n; i++) {
-                    const int ref = int(i == 0 ? cb.x : (i == 1 ? cb.y : (i == 2 ? cb.z : cb.w)));
-                    intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                }
-            } else if (n > 0) {
-                const int* list = a.refs + cb.x;
-                int ref = list[0];
-                for (int i = 1; i <= n; i++) {
-                    const int next = list[i < n ? i : 0];
-                    intersect_prim_ray(load_tri(a.tris, ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    ref = next;
-                }
+            const bool by_index = (ca.w >> 31) != 0;
+            uint32_t q0 = cb.x, q1 = cb.y, q2 = cb.z, q3 = cb.w;           // the inline ids, consumed front to back
+#pragma unroll 1
+            for (int i = 0; i < n; i++) {
+                const int ref = by_index ? a.refs[cb.x + uint32_t(i)] : int(q0);
+                q0 = q1; q1 = q2; q2 = q3;
+                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
             }
             if (hit.t <= texit || outside) break;
             ca = na; cb = nb;
-            if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
         }
     }
     nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
@@ -840,6 +864,14 @@ void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mod
     else       { if (narrow) launch_v2_mode<false, true>(st, blocks, mode, a); else launch_v2_mode<false, false>(st, blocks, mode, a); }
 }
 
+// bytes from p to the end of the device allocation that holds it (all bits set if the runtime does not know the pointer)
+size_t buffer_bytes_from(const void* p) {
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) == hipSuccess) return size - size_t(static_cast<const char*>(p) - static_cast<const char*>(base));
+    (void)hipGetLastError();
+    return ~size_t(0);
+}
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -967,7 +999,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
     }
     if (variant == 4) {
-        traverse_kernel_img<64><<<grid_blocks(num_rays, 64), 64, 0, ctx->stream>>>(a);
+        const int blocks = grid_blocks(num_rays, 64);
+        const bool narrow = ctx->opt_narrow && a.top_xy > 0 && grid->dims[2] < (1 << 23) && buffer_bytes_from(tris) < (size_t(1) << 32) &&
+                            ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
+                            size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
+        if (ctx->image.flat) { if (narrow) traverse_kernel_img<64, true, true><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, true, false><<<blocks, 64, 0, ctx->stream>>>(a); }
+        else                 { if (narrow) traverse_kernel_img<64, false, true><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -975,11 +1012,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     } else if (variant == 2) {
         const int blocks = grid_blocks(num_rays, 64);
         // 32-bit offsets are enough when every gathered array is smaller than 4 GB
-        size_t tri_bytes = ~size_t(0);
-        { hipDeviceptr_t base = nullptr; size_t size = 0;
-          if (hipMemGetAddressRange(&base, &size, const_cast<void*>(tris)) == hipSuccess)
-              tri_bytes = size - size_t(static_cast<const char*>(tris) - static_cast<const char*>(base));
-          else (void)hipGetLastError(); }
+        const size_t tri_bytes = buffer_bytes_from(tris);
         const bool narrow = ctx->opt_narrow && tri_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             a.top_xy > 0 && grid->dims[2] < (1 << 23) &&
                             size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
@@ -1011,7 +1044,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 1},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
     };
@@ -1112,12 +1145,12 @@ __global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray a
     out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
 }
 
-__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out) {
+__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
     const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
-    const uint4* rec = image_record(a, tab, vx, vy, vz);
+    const uint4* rec = flat ? image_record<true>(a, tab, vx, vy, vz) : image_record<false>(a, tab, vx, vy, vz);
     uint4 ra = rec[0], rb = rec[1];
     if (ra.w == 0xffffffffu) { image_resolve_deep(a, vx, vy, vz, ra, rb); ra.w |= 0x40000000u; }     // bit 30: came through a deep link
     uint32_t* o = out + 8 * size_t(i);
@@ -1230,7 +1263,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }

@@ -119,16 +119,18 @@ int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
 
 /* ---- traversal (traverse.h:11-14) ------------------------------------------------------------------- */
 /* setup_traversal (traverse.cu:97-109): prepares the traversal state of `grid`.  The reference uploads constants; here
- * the constants travel with every launch, so by default this call only validates the grid.
- * After hagrid_set_option("traverse.image", 1) it also builds the TRAVERSAL IMAGE of the grid in the context (one per
- * context: the grid of the last call): per top-level cell one 128-byte aligned block holding a local voxel map and
- * 32-byte cell records with the reference ids of short lists inline -- fewer distinct cache lines per cell step.  It
- * pays for batches without spatial order that are not binned (16M uniform-random rays: 16.0 -> 14.4 ms) and costs ~12 %
- * on image-ordered batches, hence opt-in.  hagrid_traverse_grid uses the image when it is called with
- * the same grid (same arrays, same counts); the image is dropped when a construction pass runs in this context or when
- * one of the grid's arrays is freed or overwritten through this API; without an image traversal reads the construction
- * format.  Hits are identical either way.  Not built for compressed grids or a virtual resolution above 65535 per
- * axis.  Synchronous when it builds (one size read-back). */
+ * the constants travel with every launch and this call builds the TRAVERSAL IMAGE of the grid in the context (one per
+ * context: the grid of the last call).  Default form ("traverse.image" = 2, flat): per top-level cell one 128-byte aligned
+ * block of (2^d)^3 records of 32 bytes, indexed by the voxel -- u16 cell bounds, list length and the reference ids of lists
+ * of up to four inline -- so that a cell step is ONE dependent gather (the block's table entry is kept while the ray stays in
+ * the top-level cell) instead of entry -> entry -> cell, and the reference-id gather disappears for short lists; blocks
+ * resolve three levels, deeper subdivisions link back into the construction format.  "traverse.image" = 1 is the compact
+ * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.
+ * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
+ * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
+ * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for
+ * compressed grids or a virtual resolution above 65535 per axis.  Synchronous (one size read-back); 0.17 ms and 256 MB for
+ * the 1M-triangle scene of BASELINE.md. */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
  * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
@@ -163,7 +165,7 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
- * kernel, an error without an image), "traverse.image" (1 = hagrid_setup_traversal builds the traversal image; default 0), "traverse.narrow" (1 = v2 uses 32-bit
+ * kernel, an error without an image), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing), "traverse.narrow" (1 = v2 uses 32-bit
  * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)

@@ -359,8 +359,9 @@ def _image_scenes():
             "tiny": (scene.make_soup(3, seed=8), {})}
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("name", list(_image_scenes()))
-def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
+def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt):
     """Every voxel of the virtual grid resolves, through the image's table / slot / record, to exactly the bounds, list
     length and reference ids that lookup_entry + cells + ref_ids give in the construction format."""
     from oracle import oracle as O
@@ -368,9 +369,9 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
     G = O.Grid.full(tris, **params)
     grid = upload_oracle_grid(mem, G)
     from hagrid_amd import api
-    mem.set_option("traverse.image", 1)
+    mem.set_option("traverse.image", fmt)          # 1: compact blocks (slot bytes + de-duplicated records), 2: flat (a record per voxel)
     api.setup_traversal(grid)
-    mem.set_option("traverse.image", 0)
+    mem.set_option("traverse.image", 2)
     res = np.array(G.dims) << G.shift
     total = int(res[0]) * int(res[1]) * int(res[2])
     rng = np.random.default_rng(1)
@@ -381,7 +382,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
     assert rc == 0
     want, begin = _expected_records(G, vox.astype(np.int64))
     by_index, deep = _check_records(got, want, begin)
-    assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < 64 * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
+    assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
         assert (by_index & ~deep).any()
     if name in ("deep", "sparse", "coincident"):
@@ -398,8 +399,9 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name):
     assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("name", list(_image_scenes()))
-def test_image_kernel_gives_the_oracle_hits(mem, name):
+def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
     from oracle import oracle as O
     from hagrid_amd import api
     tris, params = _image_scenes()[name]
@@ -410,7 +412,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name):
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 60001, 17)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
-        mem.set_option("traverse.image", 1)
+        mem.set_option("traverse.image", fmt)
         for variant in (4, 0, 2):
             mem.set_option("traverse.variant", variant)
             for n in (rays.shape[0], 256 * 128, 65, 1):
@@ -420,7 +422,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name):
         got = gpu_traverse(mem, grid, d_tris, rays)
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
-        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 0)
+        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2)
     grid.free(); mem.free(d_tris)
 
 
@@ -441,7 +443,8 @@ def test_image_lifetime(mem):
         got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     try:
-        api.setup_traversal(grid); assert not has_image(grid)     # opt-in: nothing is built by default
+        api.setup_traversal(grid); assert has_image(grid)          # built by default (flat blocks)
+        mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid)
         mem.set_option("traverse.image", 1)
         mem.set_option("traverse.variant", 4)
         with pytest.raises(api.HagridError):            # forced image kernel, no image yet
@@ -471,7 +474,7 @@ def test_image_lifetime(mem):
         grid.free()                                          # freeing a source array drops the image
         assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
     finally:
-        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 0)
+        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
 
 

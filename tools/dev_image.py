@@ -6,7 +6,7 @@ from hagrid_amd import api, scene
 
 N = int(os.environ.get("N", 1000000))
 mem = api.MemManager(keep=True)
-mem.set_option("traverse.image", 1)
+mem.set_option("traverse.image", int(os.environ.get("FMT", 1)))
 tris = scene.make_soup(N); d_tris = mem.upload(tris)
 params = dict(top_density=float(os.environ.get("TD", 0.12)), snd_density=float(os.environ.get("SD", 2.4)))
 grid = api.build_all(mem, d_tris, N, **params)

@@ -16,7 +16,8 @@ CONFIGS = [
     dict(name="5: soup-8M --compress, 8M bounce, not binned", tris=8_000_000, rays=("bounce", 2896), params=dict(compress=True)),
     dict(name="5: soup-8M --compress, 8M bounce, image width given (tile packets)", tris=8_000_000, rays=("bounce", 2896), params=dict(compress=True), width=2896),
     dict(name="2: soup-1M, 1M primary, occlusion rays (any-hit)", tris=1_000_000, rays=("primary", 1024), params={}, flags=1),
-    dict(name="4: soup-1M, 16M incoherent, traversal image", tris=1_000_000, rays=("incoherent", 1 << 24), params={}, image=1),
+    dict(name="4: soup-1M, 16M incoherent, binned, construction format (no image)", tris=1_000_000, rays=("incoherent", 1 << 24), params={}, bin=1, image=0),
+    dict(name="2: soup-1M, 1M primary, construction format (no image)", tris=1_000_000, rays=("primary", 1024), params={}, image=0),
 ]
 cache = {}
 for c in CONFIGS:
@@ -44,14 +45,14 @@ for c in CONFIGS:
         mem.copy_h2d(d_rays, rays)
     mem.set_ray_binning(c.get("bin", 0))
     mem.set_option("traverse.image_width", c.get("width", 0))
-    mem.set_option("traverse.image", c.get("image", 0))
+    mem.set_option("traverse.image", c.get("image", 2))
     api.setup_traversal(grid)
     flags = c.get("flags", 0)
     st = api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, nr)
     ab = api.algorithmic_bytes(st, bool(grid.small_cells))
     for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, nr, flags)
     t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, nr, flags)) for _ in range(7))
-    mem.set_ray_binning(0); mem.set_option("traverse.image_width", 0); mem.set_option("traverse.image", 0)
+    mem.set_ray_binning(0); mem.set_option("traverse.image_width", 0); mem.set_option("traverse.image", 2)
     print(json.dumps({"config": c["name"], "grid": grid.summary(), "build_ms": round(float(np.mean(bt)), 2), "rays": nr,
                       "traverse_ms_median": round(t[3], 3), "mrays": round(nr / t[3] / 1e3, 1), "hit_fraction": round(st["hits"] / nr, 3),
                       "bytes_per_ray": round(ab["B_ray"] / nr, 1), "alg_GBps": round(ab["B_ray"] / t[3] / 1e6, 1)}), flush=True)

@@ -22,7 +22,8 @@ def pmc(dirname, counter):
         return None
     tot = 0.0; n = 0
     for r in csv.DictReader(open(f)):
-        if "traverse_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+        # the timed kernels only (v2 / v3 / image), not the one-off statistics launch `traverse_kernel<...>`
+        if "traverse_kernel_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
             tot += float(r["Counter_Value"]); n += 1
     return (tot / n, n) if n else None
 
