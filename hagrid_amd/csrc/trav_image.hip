@@ -58,7 +58,8 @@ __host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
 // dependent gather (table entry cached per top-level cell -> record) instead of two, at 1.8x the memory.
 template <int D, bool FILL, bool FLAT>
 __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restrict__ sizes, uint32_t* __restrict__ metas,
-                                                     const int* __restrict__ offsets, uint2* __restrict__ table, unsigned char* __restrict__ blocks) {
+                                                     const int* __restrict__ offsets, uint2* __restrict__ table, unsigned char* __restrict__ blocks,
+                                                     int uniform) {
     constexpr int SHIFT = D;                 // index arithmetic inside the block
     constexpr int V = 1 << (3 * D), P = (V + 63) / 64, M = (1 << D) - 1;
     __shared__ unsigned long long rep_mask[P];
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
             depth_max = max(depth_max, depth);
         }
     }
-    const int d = wave_max(depth_max);
+    // uniform: every block has the full resolution D and block T starts at T * (2^D)^3 records -- no table needed to find it
+    const int d = uniform ? D : wave_max(depth_max);
     const int sd = D - d;
     __syncthreads();
 
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
         return;
     }
     __syncthreads();
-    const uint32_t off = uint32_t(offsets[T]);
+    const uint32_t off = uniform ? uint32_t(T) * uint32_t((32u << (3 * D)) >> 7) : uint32_t(offsets[T]);
     if (lane == 0) table[T] = make_uint2(off, meta);
     unsigned char* base = blocks + size_t(off) * 128u;
     #pragma unroll
@@ -187,14 +189,20 @@ int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     auto release = [&]() { hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials); };
     if (!sizes || !metas || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int* total = ctx->dscratch + 224;
-    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr);
+    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr, 0);
     if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int units = 0;
     int rc = read_back(ctx, total, &units, sizeof(int));
     if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
+    // Uniform layout when it costs at most a quarter more memory than the adaptive one (every top-level cell subdivided to the
+    // full depth, as in evenly filled scenes): the record of a voxel is then found by arithmetic alone.
+    const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
+    const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && uniform_units * 4 <= (long long)units * 5 && uniform_units < (1ll << 31);
+    if (uniform) units = int(uniform_units);
     unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, size_t(units) * 128u));
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks);
+    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks, uniform ? 1 : 0);
+    img.uniform = uniform;
     hipError_t e = hipGetLastError();
     release();
     if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }

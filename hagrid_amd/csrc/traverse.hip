@@ -502,7 +502,8 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
 }
 
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
-template <int BLOCK, bool FLAT, bool NARROW>
+// UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
@@ -539,7 +540,13 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
         // record of a voxel: FLAT + NARROW is one address computation off the scalar base
         auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
-            if (FLAT && NARROW) {
+            if (UNIFORM) {
+                const int d = a.shift, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+                const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 5;
+                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
+                ra = p[0]; rb = p[1];
+            } else if (FLAT && NARROW) {
                 const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
                 const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
                 const uint32_t o = (tab.x << 7) + (idx << 5);
@@ -560,8 +567,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
 
-        int top_idx = top_index(vx, vy, vz);
-        uint2 tab = table_at(top_idx);
+        int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
+        uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
         uint4 ca, cb;
         record(tab, vx, vy, vz, ca, cb);
 
@@ -580,10 +587,13 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
 
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
-            const int ntop = outside ? top_idx : top_index(vx, vy, vz);
-            if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
+            if (!UNIFORM) {
+                const int ntop = outside ? top_idx : top_index(vx, vy, vz);
+                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
+            }
             uint4 na, nb;
-            record(tab, vx, vy, vz, na, nb);
+            if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
+            else record(tab, vx, vy, vz, na, nb);
 
             const int n = int(ca.w & 0x7fffffffu);
             const bool by_index = (ca.w >> 31) != 0;
@@ -1003,8 +1013,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const bool narrow = ctx->opt_narrow && a.top_xy > 0 && grid->dims[2] < (1 << 23) && buffer_bytes_from(tris) < (size_t(1) << 32) &&
                             ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
-        if (ctx->image.flat) { if (narrow) traverse_kernel_img<64, true, true><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, true, false><<<blocks, 64, 0, ctx->stream>>>(a); }
-        else                 { if (narrow) traverse_kernel_img<64, false, true><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
+        if (ctx->image.flat && ctx->image.uniform && narrow) traverse_kernel_img<64, true, true, true><<<blocks, 64, 0, ctx->stream>>>(a);
+        else if (ctx->image.flat) { if (narrow) traverse_kernel_img<64, true, true, false><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, true, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
+        else                      { if (narrow) traverse_kernel_img<64, false, true, false><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, false, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1044,7 +1055,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 1},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
     };

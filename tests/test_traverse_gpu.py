@@ -413,16 +413,19 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
         mem.set_option("traverse.image", fmt)
-        for variant in (4, 0, 2):
-            mem.set_option("traverse.variant", variant)
-            for n in (rays.shape[0], 256 * 128, 65, 1):
-                got = gpu_traverse(mem, grid, d_tris, rays[:n])          # calls setup_traversal first
-                assert (got["id"] == want["id"][:n]).all() and (bits(got["t"]) == bits(want["t"][:n])).all(), (variant, n)
+        for uniform in ((1, 0) if fmt == 2 else (1,)):          # flat blocks: table-free layout allowed / not allowed
+            mem.set_option("traverse.image_uniform", uniform)
+            for variant in (4, 0, 2):
+                mem.set_option("traverse.variant", variant)
+                for n in (rays.shape[0], 256 * 128, 65, 1):
+                    got = gpu_traverse(mem, grid, d_tris, rays[:n])          # calls setup_traversal first
+                    assert (got["id"] == want["id"][:n]).all() and (bits(got["t"]) == bits(want["t"][:n])).all(), (uniform, variant, n)
+        mem.set_option("traverse.image_uniform", 1)
         mem.set_ray_binning(1); mem.set_option("traverse.variant", 4)
         got = gpu_traverse(mem, grid, d_tris, rays)
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
-        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2)
+        mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_uniform", 1)
     grid.free(); mem.free(d_tris)
 
 
