@@ -8,6 +8,7 @@ N = int(os.environ.get("N", 1000000))
 mem = api.MemManager(keep=True)
 tris = scene.make_soup(N); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, N, compress=bool(int(os.environ.get("COMPRESS", "0"))))
+api.setup_traversal(grid)
 sets = {"primary1M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
         "incoh1M": scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4),
         "primary16M": scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096)}

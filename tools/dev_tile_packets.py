@@ -8,6 +8,7 @@ N = int(os.environ.get("N", 1000000))
 mem = api.MemManager(keep=True)
 tris = scene.make_soup(N); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, N, compress=bool(int(os.environ.get("COMPRESS", "0"))))
+api.setup_traversal(grid)
 
 def bench(d_rays, d_hits, n, rounds=11):
     for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
@@ -19,7 +20,7 @@ for W, H in ((1024, 1024), (1920, 1080), (1280, 720), (4096, 4096)):
     n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     res = {"W": W, "H": H}
-    for variant in (2,):
+    for variant in (0,):
         mem.set_option("traverse.variant", variant)
         for width in (-1, 0):
             mem.set_option("traverse.image_width", width)
