@@ -503,8 +503,9 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
 
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
-template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM>
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
+    constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
@@ -602,13 +603,15 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             for (int i = 0; i < n; i++) {
                 const int ref = by_index ? a.refs[cb.x + uint32_t(i)] : int(q0);
                 q0 = q1; q1 = q2; q2 = q3;
-                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                if (ANY && got) break;
             }
-            if (hit.t <= texit || outside) break;
+            if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;
         }
     }
-    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
+    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
 }
 
 
@@ -882,6 +885,26 @@ size_t buffer_bytes_from(const void* p) {
     return ~size_t(0);
 }
 
+// the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
+template <unsigned MODE>
+bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, const TraverseArgs& a) {
+    if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
+    else if (flat && narrow)       traverse_kernel_img<64, true, true, false, MODE><<<blocks, 64, 0, st>>>(a);
+    else if (MODE != 0)            return false;
+    else if (flat)                 traverse_kernel_img<64, true, false, false, 0><<<blocks, 64, 0, st>>>(a);
+    else if (narrow)               traverse_kernel_img<64, false, true, false, 0><<<blocks, 64, 0, st>>>(a);
+    else                           traverse_kernel_img<64, false, false, false, 0><<<blocks, 64, 0, st>>>(a);
+    return true;
+}
+bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, unsigned mode, const TraverseArgs& a) {
+    switch (mode & 3u) {
+        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, a);
+        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, a);
+        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, a);
+        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, a);
+    }
+}
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -984,7 +1007,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     const bool large = num_rays >= 24 * lanes;
     int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : (large ? 3 : 2));
     if (perm && variant != 4) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
-    if (flags) variant = 2;                           // any-hit / barycentrics: v2 only
+    const bool img_narrow = have_image && ctx->opt_narrow && a.top_xy > 0 && grid->dims[2] < (1 << 23) && buffer_bytes_from(tris) < (size_t(1) << 32) &&
+                            ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
+                            size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
+    // any-hit / barycentrics: the flat narrow image kernels and v2 have these variants
+    if (flags && !(variant == 4 && ctx->image.flat && img_narrow)) variant = 2;
     if (variant == 4) {
         a.img_table = static_cast<const uint2*>(ctx->image.table);
         a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
@@ -1010,12 +1037,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     }
     if (variant == 4) {
         const int blocks = grid_blocks(num_rays, 64);
-        const bool narrow = ctx->opt_narrow && a.top_xy > 0 && grid->dims[2] < (1 << 23) && buffer_bytes_from(tris) < (size_t(1) << 32) &&
-                            ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
-                            size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
-        if (ctx->image.flat && ctx->image.uniform && narrow) traverse_kernel_img<64, true, true, true><<<blocks, 64, 0, ctx->stream>>>(a);
-        else if (ctx->image.flat) { if (narrow) traverse_kernel_img<64, true, true, false><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, true, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
-        else                      { if (narrow) traverse_kernel_img<64, false, true, false><<<blocks, 64, 0, ctx->stream>>>(a); else traverse_kernel_img<64, false, false, false><<<blocks, 64, 0, ctx->stream>>>(a); }
+        const bool narrow = img_narrow;
+        launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);

@@ -512,8 +512,9 @@ def test_any_hit_and_uvs_traversal(mem, compressed):
     def run(flags):
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
         return mem.download(d_hits, api.HIT_DTYPE, n)
-    for binning in (0, 1):
-        mem.set_ray_binning(binning)
+    api.setup_traversal(grid)                   # uncompressed: the image kernel has these variants too; compressed: v2
+    for binning, variant in ((0, 0), (1, 0), (0, 2)):
+        mem.set_ray_binning(binning); mem.set_option("traverse.variant", variant)
         try:
             got = run(api.UVS)
             want = G.traverse_ex(tris, rays, O.UVS, nthreads=8)
@@ -539,7 +540,7 @@ def test_any_hit_and_uvs_traversal(mem, compressed):
             for f in ("id", "t", "u", "v"):
                 assert (bits(both[f]) == bits(want[f])).all() if f != "id" else (both[f] == want[f]).all()
         finally:
-            mem.set_ray_binning(0)
+            mem.set_ray_binning(0); mem.set_option("traverse.variant", 0)
     with pytest.raises(api.HagridError):
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n, 8)
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
