@@ -596,16 +596,26 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
             else record(tab, vx, vy, vz, na, nb);
 
-            const int n = int(ca.w & 0x7fffffffu);
-            const bool by_index = (ca.w >> 31) != 0;
-            uint32_t q0 = cb.x, q1 = cb.y, q2 = cb.z, q3 = cb.w;           // the inline ids, consumed front to back
+            int n = int(ca.w);                                             // bit 31: the list is given by index (rare: > 4 ids, deep cells)
+            if (n < 0) {
+                n &= 0x7fffffff;
 #pragma unroll 1
-            for (int i = 0; i < n; i++) {
-                const int ref = by_index ? a.refs[cb.x + uint32_t(i)] : int(q0);
-                q0 = q1; q1 = q2; q2 = q3;
-                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                if (ANY && got) break;
+                for (int i = 0; i < n; i++) {
+                    const int ref = a.refs[cb.x + uint32_t(i)];
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    if (ANY && got) break;
+                }
+            } else {
+                uint32_t q0 = cb.x, q1 = cb.y, q2 = cb.z, q3 = cb.w;       // the inline ids, consumed front to back
+#pragma unroll 1
+                for (; n > 0; n--) {
+                    const int ref = int(q0);
+                    q0 = q1; q1 = q2; q2 = q3;
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    if (ANY && got) break;
+                }
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;
