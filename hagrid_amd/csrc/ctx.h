@@ -32,7 +32,7 @@ struct TravImageCache {
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
-    int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0};
+    int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;
 };
 
 } // namespace hagrid_impl

@@ -26,7 +26,7 @@
 // construction format (tests/test_traverse_gpu.py).
 //
 // Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal state), owned by
-// the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids with a
+// the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids and compressed grids of up to three levels, with a
 // virtual resolution below 65536 per axis; otherwise traversal reads the construction format.
 #include "ctx.h"
 #include "wave_prims.h"
@@ -40,7 +40,8 @@ namespace {
 
 struct ImgK {
     const uint32_t* __restrict__ entries;
-    const int4* __restrict__ cells;        // two int4 per cell
+    const int4* __restrict__ cells;        // two int4 per cell; null for a compressed grid
+    const uint4* __restrict__ small_cells; // compressed grid: one uint4 per cell (grid.h:36-45), lists end with a negative id
     const int* __restrict__ refs;
     int top_x, top_y, num_top;
     int shift;
@@ -156,12 +157,21 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
             rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu);
             rec[1] = make_uint4(uint32_t(-1 - cell[p]), uint32_t(dep[p]), 0u, 0u);
         } else if (g == f) {
-            const int4 lo = k.cells[2 * size_t(cell[p])], hi = k.cells[2 * size_t(cell[p]) + 1];
-            const int begin = lo.w, n = hi.w - lo.w;
+            int begin, n;
             uint4 a, b;
-            a.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
-            a.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
-            a.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+            if (k.small_cells) {
+                const uint4 sc = k.small_cells[cell[p]];        // the u16 bounds are packed exactly as the record packs them
+                a.x = sc.x; a.y = sc.y; a.z = sc.z;
+                begin = int(sc.w); n = 0;
+                if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
+                else begin = 0;
+            } else {
+                const int4 lo = k.cells[2 * size_t(cell[p])], hi = k.cells[2 * size_t(cell[p]) + 1];
+                begin = lo.w; n = hi.w - lo.w;
+                a.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
+                a.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
+                a.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+            }
             a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
             if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }
             else {
@@ -222,7 +232,7 @@ void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
 
 bool hagrid_impl::trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* g) {
     const TravImageCache& img = ctx->image;
-    return img.valid && g->entries == img.entries && g->cells == img.cells && g->ref_ids == img.refs && !g->small_cells &&
+    return img.valid && g->entries == img.entries && (g->small_cells ? g->small_cells : g->cells) == img.cells && g->ref_ids == img.refs &&
            g->num_cells == img.num_cells && g->num_entries == img.num_entries && g->num_refs == img.num_refs && g->shift == img.shift &&
            g->dims[0] == img.dims[0] && g->dims[1] == img.dims[1] && g->dims[2] == img.dims[2];
 }
@@ -233,13 +243,14 @@ void hagrid_impl::trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, si
     const char* lo = static_cast<const char*>(ptr);
     const char* hi = lo + (bytes ? bytes : 1);
     auto overlaps = [&](const void* p, size_t n) { const char* q = static_cast<const char*>(p); return q < hi && lo < q + n; };
-    if (overlaps(img.entries, size_t(img.num_entries) * 4) || overlaps(img.cells, size_t(img.num_cells) * 32) || overlaps(img.refs, size_t(img.num_refs) * 4))
+    if (overlaps(img.entries, size_t(img.num_entries) * 4) || overlaps(img.cells, size_t(img.num_cells) * size_t(img.cell_bytes)) || overlaps(img.refs, size_t(img.num_refs) * 4))
         trav_image_drop(ctx);
 }
 
 int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     trav_image_drop(ctx);
-    if (!ctx->opt_image || !g->entries || !g->cells || !g->ref_ids || g->small_cells || g->num_cells <= 0) return HAGRID_OK;
+    if (!ctx->opt_image || !g->entries || (!g->cells && !g->small_cells) || !g->ref_ids || g->num_cells <= 0) return HAGRID_OK;
+    if (g->small_cells && g->shift > 3) return HAGRID_OK;      // deep links resolve through 32-byte cells only
     if (g->shift < 0 || g->shift > 15) return HAGRID_OK;
     for (int i = 0; i < 3; i++)
         if (g->dims[i] <= 0 || (long long)g->dims[i] << g->shift > 65535) return HAGRID_OK;
@@ -248,7 +259,8 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     HG_HIP(ctx, hipSetDevice(ctx->device));
     ImgK k;
     k.entries = static_cast<const uint32_t*>(g->entries);
-    k.cells = static_cast<const int4*>(g->cells);
+    k.cells = g->small_cells ? nullptr : static_cast<const int4*>(g->cells);
+    k.small_cells = static_cast<const uint4*>(g->small_cells);
     k.refs = static_cast<const int*>(g->ref_ids);
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
     TravImageCache img;
@@ -263,7 +275,8 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.flat = flat;
     if (rc != HAGRID_OK) return rc;
     img.valid = img.table != nullptr;
-    img.entries = g->entries; img.cells = g->cells; img.refs = g->ref_ids;
+    img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
+    img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
     img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
     ctx->image = img;

@@ -303,6 +303,9 @@ def test_tile_packets_give_identical_hits(mem):
 
 # ---- traversal image ----------------------------------------------------------------------------------------------------
 
+O_CELL_DTYPE = np.dtype([("min", "<i4", 3), ("begin", "<i4"), ("max", "<i4", 3), ("end", "<i4")])
+
+
 def _np_lookup(G, vox):
     """lookup_entry (grid.h:103-116) for many voxels at once: cell index per voxel"""
     e = G.entries; shift = G.shift; dx, dy, dz = G.dims
@@ -325,7 +328,16 @@ def _np_lookup(G, vox):
 
 
 def _expected_records(G, vox):
-    cells = G.cells[_np_lookup(G, vox)]
+    if G.cells is None:                     # compressed grid: SmallCell + lists that end with a negative id
+        sc = G.small_cells; refs_all = G.ref_ids
+        ends = np.flatnonzero(refs_all < 0)
+        begin_all = sc["begin"].astype(np.int64)
+        n_all = np.where(begin_all >= 0, ends[np.searchsorted(ends, np.maximum(begin_all, 0))] - begin_all, 0)
+        cells = np.zeros(len(sc), dtype=O_CELL_DTYPE)
+        cells["min"] = sc["min"]; cells["max"] = sc["max"]; cells["begin"] = np.maximum(begin_all, 0); cells["end"] = np.maximum(begin_all, 0) + n_all
+        cells = cells[_np_lookup(G, vox)]
+    else:
+        cells = G.cells[_np_lookup(G, vox)]
     lo, hi = cells["min"].astype(np.uint32), cells["max"].astype(np.uint32)
     n = (cells["end"] - cells["begin"]).astype(np.int64)
     rec = np.zeros((len(vox), 8), np.uint32)
@@ -356,7 +368,9 @@ def _image_scenes():
             "dense_wide": (scene.make_soup(8000, seed=12), dict(top_density=0.08, snd_density=10.0)),     # a top-level cell with > 255 cells
             "deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),   # shift 5: blocks stop at depth 3, deep links below
             "sparse": (sparse, {}), "coincident": (np.concatenate([coincident, scene.make_soup(2000, seed=7)]), {}),
-            "tiny": (scene.make_soup(3, seed=8), {})}
+            "tiny": (scene.make_soup(3, seed=8), {}),
+            "compressed": (scene.make_soup(20000, seed=14), dict(compress=True)),
+            "compressed_long_lists": (np.concatenate([np.repeat(scene.make_soup(30, seed=15), 12, axis=0), scene.make_soup(6000, seed=16)]), dict(compress=True, top_density=0.3, snd_density=1.0))}
 
 
 @pytest.mark.parametrize("fmt", [1, 2])
@@ -470,9 +484,9 @@ def test_image_lifetime(mem):
         # switched off: setup_traversal builds nothing
         mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid); check()
         mem.set_option("traverse.image", 1); api.setup_traversal(grid); assert has_image(grid); check()
-        # compressed grids have no image
+        # compressed grids get one as well (shift <= 3)
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
-        api.setup_traversal(gc); assert not has_image(gc); gc.free()
+        api.setup_traversal(gc); assert has_image(gc) == (Gc.shift <= 3); gc.free()
         api.setup_traversal(grid); assert has_image(grid)
         grid.free()                                          # freeing a source array drops the image
         assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
