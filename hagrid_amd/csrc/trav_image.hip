@@ -11,8 +11,9 @@
 //                                          y = depth d | wide << 2 | count << 8
 //   block     [ (2^d)^3 local slots, u8 (u16 if wide), padded to >= 32 B ]   only if d > 0
 //             [ count records of 32 bytes ]
-//   record    u16 lo.x lo.y lo.z hi.x hi.y hi.z | u32 n | the reference ids inline (unused = -1)          n <= 4
-//             u16 lo.x lo.y lo.z hi.x hi.y hi.z | u32 n | 1 << 31 | first reference index into ref_ids    n  > 4
+//   record    u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | u32 n | the reference ids inline (unused = -1)          n <= 4
+//             u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | u32 n | 1 << 31 | first reference index into ref_ids    n  > 4
+//             (one word per axis: the traversal takes lo or hi with a single bit-field extract)
 //             0 0 0 | 0xffffffff | entry index, depth of that entry                                        deep
 //
 // d is the deepest subdivision inside the top-level cell, capped at 3 (512 slots); a slot names one of the cells that
@@ -161,16 +162,19 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
             uint4 a, b;
             if (k.small_cells) {
                 const uint4 sc = k.small_cells[cell[p]];        // the u16 bounds are packed exactly as the record packs them
-                a.x = sc.x; a.y = sc.y; a.z = sc.z;
+                // SmallCell: min.x min.y | min.z max.x | max.y max.z  ->  record: one word per axis, lo | hi << 16
+                a.x = (sc.x & 0xffffu) | (sc.y & 0xffff0000u);
+                a.y = (sc.x >> 16) | (sc.z << 16);
+                a.z = (sc.y & 0xffffu) | (sc.z & 0xffff0000u);
                 begin = int(sc.w); n = 0;
                 if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
                 else begin = 0;
             } else {
                 const int4 lo = k.cells[2 * size_t(cell[p])], hi = k.cells[2 * size_t(cell[p]) + 1];
                 begin = lo.w; n = hi.w - lo.w;
-                a.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
-                a.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
-                a.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+                a.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
+                a.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
+                a.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
             }
             a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
             if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }

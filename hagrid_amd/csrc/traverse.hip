@@ -494,9 +494,9 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
     }
     const int4* p = reinterpret_cast<const int4*>(a.cells) + 2 * size_t(w >> 2);
     const int4 lo = p[0], hi = p[1];
-    ca.x = uint32_t(lo.x) | (uint32_t(lo.y) << 16);
-    ca.y = uint32_t(lo.z) | (uint32_t(hi.x) << 16);
-    ca.z = uint32_t(hi.y) | (uint32_t(hi.z) << 16);
+    ca.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
+    ca.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
+    ca.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
     ca.w = uint32_t(hi.w - lo.w) | 0x80000000u;
     cb.x = uint32_t(lo.w);
 }
@@ -568,6 +568,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
 
+        const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
+        const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
         int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
         uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
         uint4 ca, cb;
@@ -575,13 +577,14 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 
         for (;;) {
             if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
-            const int cx = int(px ? ca.y >> 16 : ca.x & 0xffffu), cy = int(py ? ca.z & 0xffffu : ca.x >> 16), cz = int(pz ? ca.z >> 16 : ca.y & 0xffffu);
+            // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
+            const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
             const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
             const vec3 ev = (texit * dir + org - gmin) * ginv;
-            const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
-            const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
-            const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+            const int nx = texit == tcell.x ? cx + bx : int(ev.x);
+            const int ny = texit == tcell.y ? cy + by : int(ev.y);
+            const int nz = texit == tcell.z ? cz + bz : int(ev.z);
             vx = px ? max(nx, vx) : min(nx, vx);
             vy = py ? max(ny, vy) : min(ny, vy);
             vz = pz ? max(nz, vz) : min(nz, vz);

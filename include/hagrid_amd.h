@@ -197,7 +197,7 @@ int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_en
 int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len);
 int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
 /* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
- * resolves to -- u16 lo.xyz hi.xyz | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
+ * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
  * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
  * HAGRID_EINVAL when the context holds no image of this grid. */
 int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);

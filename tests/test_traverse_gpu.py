@@ -341,7 +341,7 @@ def _expected_records(G, vox):
     lo, hi = cells["min"].astype(np.uint32), cells["max"].astype(np.uint32)
     n = (cells["end"] - cells["begin"]).astype(np.int64)
     rec = np.zeros((len(vox), 8), np.uint32)
-    rec[:, 0] = lo[:, 0] | (lo[:, 1] << 16); rec[:, 1] = lo[:, 2] | (hi[:, 0] << 16); rec[:, 2] = hi[:, 1] | (hi[:, 2] << 16)
+    rec[:, 0] = lo[:, 0] | (hi[:, 0] << 16); rec[:, 1] = lo[:, 1] | (hi[:, 1] << 16); rec[:, 2] = lo[:, 2] | (hi[:, 2] << 16)
     rec[:, 3] = n.astype(np.uint32)
     refs = np.concatenate([G.ref_ids, np.zeros(4, np.int32)])
     for j in range(4):
