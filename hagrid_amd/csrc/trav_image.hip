@@ -30,6 +30,8 @@
 // the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids and compressed grids of up to three levels, with a
 // virtual resolution below 65536 per axis; otherwise traversal reads the construction format.
 #include "ctx.h"
+
+#include <algorithm>
 #include "wave_prims.h"
 
 #include "hagrid/grid.h"
@@ -46,6 +48,7 @@ struct ImgK {
     const int* __restrict__ refs;
     int top_x, top_y, num_top;
     int shift;
+    long long source_bytes;                // entries + cells of the construction format
 };
 
 __host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
@@ -210,6 +213,9 @@ int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
     // Uniform layout when it costs at most a quarter more memory than the adaptive one (every top-level cell subdivided to the
     // full depth, as in evenly filled scenes): the record of a voxel is then found by arithmetic alone.
+    // a flat image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed): a very deep grid
+    // falls back to the compact form
+    if (FLAT && (long long)units * 128 > (ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes))) { release(); hagrid_mem_free(ctx, table); return 1; }
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && uniform_units * 4 <= (long long)units * 5 && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
@@ -267,14 +273,19 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     k.small_cells = static_cast<const uint4*>(g->small_cells);
     k.refs = static_cast<const int*>(g->ref_ids);
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
+    k.source_bytes = 4ll * g->num_entries + (g->small_cells ? 16ll : 32ll) * g->num_cells;
     TravImageCache img;
     int rc = HAGRID_OK;
-    const bool flat = ctx->opt_image == 2;
-    switch (g->shift < 3 ? g->shift : 3) {
-        case 0: rc = flat ? build_image<0, true>(ctx, k, img) : build_image<0, false>(ctx, k, img); break;
-        case 1: rc = flat ? build_image<1, true>(ctx, k, img) : build_image<1, false>(ctx, k, img); break;
-        case 2: rc = flat ? build_image<2, true>(ctx, k, img) : build_image<2, false>(ctx, k, img); break;
-        default: rc = flat ? build_image<3, true>(ctx, k, img) : build_image<3, false>(ctx, k, img); break;
+    bool flat = ctx->opt_image == 2;
+    for (;;) {
+        switch (g->shift < 3 ? g->shift : 3) {
+            case 0: rc = flat ? build_image<0, true>(ctx, k, img) : build_image<0, false>(ctx, k, img); break;
+            case 1: rc = flat ? build_image<1, true>(ctx, k, img) : build_image<1, false>(ctx, k, img); break;
+            case 2: rc = flat ? build_image<2, true>(ctx, k, img) : build_image<2, false>(ctx, k, img); break;
+            default: rc = flat ? build_image<3, true>(ctx, k, img) : build_image<3, false>(ctx, k, img); break;
+        }
+        if (rc == 1 && flat) { flat = false; continue; }     // too big as a flat image: compact form
+        break;
     }
     img.flat = flat;
     if (rc != HAGRID_OK) return rc;

@@ -125,7 +125,8 @@ int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
  * of up to four inline -- so that a cell step is ONE dependent gather (the block's table entry is kept while the ray stays in
  * the top-level cell) instead of entry -> entry -> cell, and the reference-id gather disappears for short lists; blocks
  * resolve three levels, deeper subdivisions link back into the construction format.  "traverse.image" = 1 is the compact
- * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.
+ * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.  A flat
+ * image that would exceed max(1 GB, 8x the entries + cells it replaces) ("traverse.image_max_mb") is built in the compact form.
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
  * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
  * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for

@@ -484,6 +484,15 @@ def test_image_lifetime(mem):
         # switched off: setup_traversal builds nothing
         mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid); check()
         mem.set_option("traverse.image", 1); api.setup_traversal(grid); assert has_image(grid); check()
+        # a flat image above the size limit is replaced by the compact form
+        mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 1)
+        big = O.Grid.full(scene.make_soup(40000, seed=22)); gb = upload_oracle_grid(mem, big)
+        nb = C.c_int64(0)
+        api.setup_traversal(gb)
+        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value < (7 << 20)
+        mem.set_option("traverse.image_max_mb", 0); api.setup_traversal(gb)
+        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value > (8 << 20)
+        gb.free(); mem.set_option("traverse.image", 1)
         # compressed grids get one as well (shift <= 3)
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
         api.setup_traversal(gc); assert has_image(gc) == (Gc.shift <= 3); gc.free()
@@ -491,7 +500,7 @@ def test_image_lifetime(mem):
         grid.free()                                          # freeing a source array drops the image
         assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
     finally:
-        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2)
+        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 0)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
 
 
