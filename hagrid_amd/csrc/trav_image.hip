@@ -217,7 +217,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     // falls back to the compact form
     if (FLAT && (long long)units * 128 > (ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes))) { release(); hagrid_mem_free(ctx, table); return 1; }
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
-    const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && uniform_units * 4 <= (long long)units * 5 && uniform_units < (1ll << 31);
+    const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
     unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, size_t(units) * 128u));
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }

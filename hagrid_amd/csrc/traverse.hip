@@ -1091,7 +1091,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 1},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
