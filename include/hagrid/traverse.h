@@ -11,7 +11,8 @@
 
 namespace hagrid {
 
-/// Validates the grid and derives its traversal constants.
+/// Prepares the traversal of `grid` (traverse.cu:97-109): validates it and builds the context's traversal image
+/// (hagrid_amd.h: hagrid_setup_traversal).  Call it again whenever the grid was rebuilt, as the reference's front-end does.
 inline void setup_traversal(const Grid& grid) {
     hagrid_grid p = detail::to_pod(grid);
     detail::check(detail::current_ctx(), hagrid_setup_traversal(detail::current_ctx(), &p));
