@@ -58,6 +58,7 @@ struct hagrid_ctx {
     unsigned long long* lb_state = nullptr;   // status words of the look-back scans (wave_prims.h), never cleared: epochs
     size_t lb_words = 0;
     unsigned lb_epoch = 0;
+    int* row_scores = nullptr;           // row-length detection from origins: one score per candidate + a ticket counter
     int* bin_diff = nullptr;             // automatic ray binning: 64 partial counts of neighbouring rays in different bins
 
     // traversal options (hagrid_set_ray_binning, hagrid_set_option)
@@ -74,6 +75,7 @@ struct hagrid_ctx {
     int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
+    int opt_detect_origins = 1; // row length of image-ordered batches also from the origins (bounce rays)
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it

@@ -274,31 +274,114 @@ __device__ __forceinline__ float ray_step_dev2(const float4* __restrict__ rays, 
     return d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
 }
 
-__global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __restrict__ rays, int n, int* __restrict__ out) {
+// Second criterion, for image-ordered batches whose directions are not a function of the pixel (bounce rays leaving the
+// primary hit points): the ORIGINS of vertically neighbouring pixels are close.  Every candidate row length w = 64, 72, ...
+// gets the clamped mean squared distance |org[i + w] - org[i]|^2 / tau^2 over 256 sampled i (tau = 1/64 of the grid
+// diagonal); the true row length is the minimum (one pixel apart; w +- 8 is eight pixels apart, 2w two rows).  Accepted if
+// it stands out from the mean over all candidates and horizontally neighbouring origins are as close (but not all identical).  Blocks 1.. of the same
+// launch do the scoring, the block that finishes last picks -- no extra launch, nothing waits; used only when the first
+// criterion found nothing.  Like the first one it can only cost speed if it is wrong.
+constexpr int kRowCandidates = 2048;                 // w = 8 * (c + 8): 64 .. 16440
+constexpr int kRowSamples = 256;
+
+__global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __restrict__ rays, int n, int* __restrict__ out,
+                                                                int* __restrict__ scores, float inv_tau2, int origins_only) {
     __shared__ int first_break;
-    if (threadIdx.x == 0) { first_break = 0x7fffffff; out[0] = 0; }
-    if (n < 128) return;
-    const float4 a0 = rays[0], a1 = rays[1], b0 = rays[2], b1 = rays[3];
-    const float s[6] = {b0.x - a0.x, b0.y - a0.y, b0.z - a0.z, b1.x - a1.x, b1.y - a1.y, b1.z - a1.z};
-    const float s2 = s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
-    if (!(s2 > 0.0f) || !(s2 < 3.0e38f)) return;
-    const float tol = 0.25f * s2;
-    const int limit = min(n - 1, kDetectLimit);              // pairs (i, i + 1) with i < limit
-    __syncthreads();
-    for (int base = 1; base < limit; base += kDetectBlock) {
-        const int i = base + int(threadIdx.x);
-        if (i < limit && !(ray_step_dev2(rays, i, s) <= tol)) atomicMin(&first_break, i + 1);
+    __shared__ int lds_score[kDetectBlock / 64];
+    __shared__ int ticket;
+    __shared__ unsigned long long best[kDetectBlock / 64];
+    __shared__ long long sums[kDetectBlock / 64];
+    __shared__ int counts[kDetectBlock / 64];
+    // origins_only: a second launch after the first criterion; nothing to do if that one found the row length
+    if (origins_only && __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) return;
+    if (blockIdx.x == 0 && !origins_only) {
+        if (threadIdx.x == 0) { first_break = 0x7fffffff; out[0] = 0; }
+        int w1 = 0;
+        if (n >= 128) {
+            const float4 a0 = rays[0], a1 = rays[1], b0 = rays[2], b1 = rays[3];
+            const float s[6] = {b0.x - a0.x, b0.y - a0.y, b0.z - a0.z, b1.x - a1.x, b1.y - a1.y, b1.z - a1.z};
+            const float s2 = s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+            if ((s2 > 0.0f) && (s2 < 3.0e38f)) {
+                const float tol = 0.25f * s2;
+                const int limit = min(n - 1, kDetectLimit);              // pairs (i, i + 1) with i < limit
+                __syncthreads();
+                for (int base = 1; base < limit; base += kDetectBlock) {
+                    const int i = base + int(threadIdx.x);
+                    if (i < limit && !(ray_step_dev2(rays, i, s) <= tol)) atomicMin(&first_break, i + 1);
+                    __syncthreads();
+                    const int found = first_break;
+                    __syncthreads();
+                    if (found != 0x7fffffff) break;
+                }
+                if (threadIdx.x == 0) {
+                    const int w = first_break;
+                    bool ok = w != 0x7fffffff && w >= 8 && (w & 7) == 0 && n / w >= 8;
+                    if (ok) ok = ray_step_dev2(rays, w, s) <= tol;                                   // second row advances like the first
+                    if (ok && n > 2 * w) ok = !(ray_step_dev2(rays, 2 * w - 1, s) <= tol);            // and ends where the first did
+                    w1 = ok ? w : 0;
+                }
+            }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(out, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.x == 1) return;
+    } else if (blockIdx.x != 0) {
+        // four candidates per block, one per group of 256 threads; candidate kRowCandidates is the horizontal neighbour (w = 1)
+        const int c = (int(blockIdx.x) - 1) * 4 + int(threadIdx.x >> 8);
+        const int w = c < kRowCandidates ? 8 * (c + 8) : 1;
+        int v = 1024;
+        if (c <= kRowCandidates && n - w > 0) {
+            uint32_t h = uint32_t(c) * 2654435761u + (threadIdx.x & 255u) * 40503u + 12345u;
+            h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+            const int i = int(h % uint32_t(n - w));
+            const float4 p = rays[2 * size_t(i)], q = rays[2 * size_t(i + w)];
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            const float d2 = (dx * dx + dy * dy + dz * dz) * inv_tau2;
+            v = d2 < 1.0f ? int(d2 * 1024.0f) : 1024;            // NaN -> 1024
+        }
+        v = wave_sum(v);
+        if (lane_id() == 0) lds_score[wave_id()] = v;
         __syncthreads();
-        const int found = first_break;
-        __syncthreads();
-        if (found != 0x7fffffff) break;
+        if ((threadIdx.x & 255) == 0 && c <= kRowCandidates) {
+            const int g = int(threadIdx.x >> 8) * 4;
+            __hip_atomic_store(scores + c, lds_score[g] + lds_score[g + 1] + lds_score[g + 2] + lds_score[g + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    // the block that finishes last picks.  Scores and out[0] travel as agent-scope atomics (a __threadfence per thread costs an
+    // L2 write-back each on this part: 150 us for the launch); the ticket is the release / acquire point.
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(scores + kRowCandidates + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != int(gridDim.x) - 1) return;
+    unsigned long long m = ~0ull;                                    // (score << 32 | w), minimum
+    long long total = 0; int counted = 0;                            // mean score of the candidates
+    for (int c = int(threadIdx.x); c < kRowCandidates; c += kDetectBlock) {
+        const int w = 8 * (c + 8);
+        if (n / w >= 8) {
+            const unsigned sc = (unsigned)__hip_atomic_load(scores + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long key = ((unsigned long long)sc << 32) | unsigned(w);
+            m = key < m ? key : m;
+            total += sc; counted++;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(m, d, 64); m = o < m ? o : m;
+        total += __shfl_xor(total, d, 64); counted += __shfl_xor(counted, d, 64);
+    }
+    if (lane_id() == 0) { best[wave_id()] = m; sums[wave_id()] = total; counts[wave_id()] = counted; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const int w = first_break;
-        bool ok = w != 0x7fffffff && w >= 8 && (w & 7) == 0 && n / w >= 8;
-        if (ok) ok = ray_step_dev2(rays, w, s) <= tol;                                   // second row advances like the first
-        if (ok && n > 2 * w) ok = !(ray_step_dev2(rays, 2 * w - 1, s) <= tol);            // and ends where the first did
-        out[0] = ok ? w : 0;
+        for (int i = 1; i < kDetectBlock / 64; i++) { m = best[i] < m ? best[i] : m; total += sums[i]; counted += counts[i]; }
+        // The row length stands out: its score lies clearly (8 % of the clamp) below the mean of all candidates, and so does the
+        // score of horizontally neighbouring origins.  Unrelated origins score ~1.0 everywhere; rows of hit points with
+        // silhouettes and rays that left the scene 0.2-0.9.  horizontal == 0: all origins coincide (a pinhole camera) -- no information.
+        const int full = kRowSamples * 1024;
+        const long long mean = counted ? total / counted : 0;
+        const int horizontal = __hip_atomic_load(scores + kRowCandidates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int w1 = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long bar = mean - full * 8 / 100;
+        if (w1 == 0 && m != ~0ull && (long long)(m >> 32) < bar && horizontal < bar && horizontal > 0) out[0] = int(unsigned(m));
+        scores[kRowCandidates + 1] = 0;                              // ready for the next batch
     }
 }
 
@@ -918,6 +1001,22 @@ bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform
     }
 }
 
+// row length of an image-ordered batch -> row_len[0] on the device.  The origin criterion costs ~17 us (2049 candidates x 256
+// sampled pairs) and only pays where tile packets pay for bounce rays: it runs as a second launch for batches of at least
+// kOriginMinRays rays and returns at once when the first criterion has already answered.
+constexpr int kOriginMinRays = 1 << 22;
+void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays) {
+    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0);
+    const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
+    const float tau = length(ext) / 64.0f;
+    if (!ctx->opt_detect_origins || num_rays < origin_min_rays || !(tau > 0.0f) || !(tau < 3.0e18f)) return;
+    if (!ctx->row_scores) {
+        if (hipMalloc((void**)&ctx->row_scores, (kRowCandidates + 8) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->row_scores = nullptr; return; }
+        (void)hipMemsetAsync(ctx->row_scores, 0, (kRowCandidates + 8) * sizeof(int), ctx->stream);
+    }
+    detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1);
+}
+
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -994,7 +1093,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 HG_HIP(ctx, hipMalloc((void**)&ctx->bin_diff, 64 * sizeof(int)));
                 HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));
             }
-            detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
+            launch_detect(ctx, a, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
             ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff);
             (void)ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
             ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag);
@@ -1039,7 +1138,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             if (variant == 3 && (a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
         } else {
             int* row_len = ctx->dscratch + 232;
-            detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len);
+            launch_detect(ctx, a, num_rays, row_len);
             a.row_len = row_len;
             if (variant == 3) {
                 int w = 0;
@@ -1092,7 +1191,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
         {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},
-        {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
+        {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20}, {"traverse.detect_origins", &ctx->opt_detect_origins, 0, 1},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
     };
@@ -1278,10 +1377,14 @@ extern "C" int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries,
     return o.fetch(out);
 }
 
-extern "C" int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len) {
+extern "C" int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, float bbox_diag, int32_t* row_len) {
     if (!ctx || !rays_dev || num_rays < 0 || !row_len) return HAGRID_EINVAL;
     int* d = ctx->dscratch + 232;
-    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(static_cast<const float4*>(rays_dev), num_rays, d);
+    TraverseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rays = static_cast<const float4*>(rays_dev);
+    a.max_x = bbox_diag; a.min_x = 0.0f;                 // only the diagonal matters
+    launch_detect(ctx, a, num_rays, d, 65536);            // the test hook runs the origin criterion from 64k rays on
     HG_HIP(ctx, hipGetLastError());
     return read_back(ctx, d, row_len, sizeof(int));
 }

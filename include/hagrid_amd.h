@@ -171,8 +171,9 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
- * looked for on the device at every call (constant (origin, direction) step along a row), > 0 = w given by the
- * caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
+ * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
+ * also from the origins alone -- bounce rays in the image order of their primary hits -- unless
+ * "traverse.detect_origins" = 0), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
  * "expand.subset_only" (1 = the reference's compiled setting, default; 0 = the precise expansion of
  * expand.cu:39-57,96-127 -- this one changes the grid, not the hits).  Returns HAGRID_EINVAL for an
@@ -195,7 +196,7 @@ int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_en
 /* Tile packets (see "traverse.image_width"): the row length the device finds for a ray buffer in device memory (0 = not
  * image-ordered), and the ray slot every lane of every 64-lane block gets for a batch of num_rays rays with rows of
  * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */
-int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, int32_t* row_len);
+int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, float bbox_diag, int32_t* row_len);
 int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
 /* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
  * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the

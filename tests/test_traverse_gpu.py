@@ -250,9 +250,9 @@ def test_tile_packets_assign_every_ray_to_exactly_one_lane(mem, n, w):
 
 def test_row_length_detection(mem):
     lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
-    def detect(rays):
+    def detect(rays, diag=1.7320508):
         d = mem.upload(np.ascontiguousarray(rays, np.float32)); w = C.c_int32(-1)
-        assert mem._L.hagrid_kat_detect_ray_rows(mem._ctx, C.c_void_p(d), rays.shape[0], C.byref(w)) == 0
+        assert mem._L.hagrid_kat_detect_ray_rows(mem._ctx, C.c_void_p(d), rays.shape[0], C.c_float(diag), C.byref(w)) == 0
         mem.free(d)
         return w.value
     assert detect(scene.make_rays_primary(lo, hi, 1024, 512)) == 1024
@@ -274,6 +274,19 @@ def test_row_length_detection(mem):
     assert detect(ortho) == 320
     nan = prim.copy(); nan[1, 4] = np.nan
     assert detect(nan) == 0
+    # second criterion: image-ordered ORIGINS with unrelated directions (bounce rays leaving the primary hit points)
+    from oracle import oracle as O
+    tris = scene.make_soup(20000, seed=41)
+    G = O.Grid.full(tris)
+    diag = float(np.linalg.norm(G.bbox_max - G.bbox_min))
+    for w, h in ((512, 256), (640, 480), (800, 400)):
+        p = scene.make_rays_primary(G.bbox_min, G.bbox_max, w, h)
+        hp, _ = G.traverse(tris, p, nthreads=8)
+        b = scene.make_rays_bounce(tris, p, hp, G.bbox_min, G.bbox_max, 99)
+        assert detect(b, diag) == w, (w, h)
+        assert detect(b[: 40000], diag) == 0                                   # below 64k rays the origin criterion is not run
+    assert detect(scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 200000, 8), diag) == 0
+    assert detect(scene.make_rays_primary(G.bbox_min, G.bbox_max, 1024, 256), diag) == 1024     # the first criterion still decides
 
 
 def test_tile_packets_give_identical_hits(mem):
