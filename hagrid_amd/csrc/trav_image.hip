@@ -47,8 +47,15 @@ struct ImgK {
     const uint4* __restrict__ small_cells; // compressed grid: one uint4 per cell (grid.h:36-45), lists end with a negative id
     const int* __restrict__ refs;
     int top_x, top_y, num_top;
-    int shift;
+    int shift, num_entries;
     long long source_bytes;                // entries + cells of the construction format
+    // nested blocks (flat form, grids deeper than three levels): the entries at which a block stops resolving become roots
+    int* claim;                            // per entry: -1, or the index of its root
+    int2* roots;                           // (entry index, depth of that entry)
+    int* num_roots;
+    const int* nested_off;                 // fill pass: block offset of every root, in 128-byte units, relative to nested_base
+    const int* nested_d;                   // fill pass: depth of every root's block
+    int nested_base;
 };
 
 __host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
@@ -129,6 +136,22 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
         if (lane == 0) { rep_mask[p] = mask; rep_prefix[p] = count; }
         count += __popcll(mask);
     }
+    if (FLAT && !FILL && k.claim) {
+        // every entry a voxel of this block stops at becomes the root of a nested block; the first voxel to claim it registers it
+        #pragma unroll
+        for (int p = 0; p < P; p++) {
+            const bool want = (p * 64 + lane) < V && cell[p] < 0 && atomicCAS(k.claim + (-1 - cell[p]), -1, -2) == -1;
+            const unsigned long long m = __ballot(want);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(k.num_roots, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (want) {
+                const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+                k.roots[r] = make_int2(-1 - cell[p], dep[p]);
+                k.claim[-1 - cell[p]] = r;
+            }
+        }
+    }
     if (FLAT) count = 1 << (3 * d);
     const bool wide = !FLAT && count > 255;
     const uint32_t meta = uint32_t(d) | (wide ? 4u : 0u) | (FLAT ? 8u : 0u) | (uint32_t(count) << 8);
@@ -158,8 +181,14 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
         }
         if (g == f && cell[p] < 0) {
             uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
-            rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu);
-            rec[1] = make_uint4(uint32_t(-1 - cell[p]), uint32_t(dep[p]), 0u, 0u);
+            const int root = (FLAT && k.claim) ? k.claim[-1 - cell[p]] : -1;
+            if (root >= 0) {     // nested block: offset | its depth, depth of the entry it resolves
+                rec[0] = make_uint4(0u, 0u, 0u, 0xfffffffeu);
+                rec[1] = make_uint4(uint32_t(k.nested_base + k.nested_off[root]), uint32_t(k.nested_d[root]) | (uint32_t(dep[p]) << 8), 0u, 0u);
+            } else {
+                rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu);
+                rec[1] = make_uint4(uint32_t(-1 - cell[p]), uint32_t(dep[p]), 0u, 0u);
+            }
         } else if (g == f) {
             int begin, n;
             uint4 a, b;
@@ -193,40 +222,145 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
     }
 }
 
+// the 32-byte record of a leaf cell
+__device__ __forceinline__ void write_cell_record(const ImgK& k, int c, uint4* rec) {
+    int begin, n;
+    uint4 a, b;
+    if (k.small_cells) {
+        const uint4 sc = k.small_cells[c];
+        a.x = (sc.x & 0xffffu) | (sc.y & 0xffff0000u);
+        a.y = (sc.x >> 16) | (sc.z << 16);
+        a.z = (sc.y & 0xffffu) | (sc.z & 0xffff0000u);
+        begin = int(sc.w); n = 0;
+        if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
+        else begin = 0;
+    } else {
+        const int4 lo = k.cells[2 * size_t(c)], hi = k.cells[2 * size_t(c) + 1];
+        begin = lo.w; n = hi.w - lo.w;
+        a.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
+        a.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
+        a.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
+    }
+    a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
+    if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }
+    else {
+        b.x = n > 0 ? uint32_t(k.refs[begin]) : ~0u;
+        b.y = n > 1 ? uint32_t(k.refs[begin + 1]) : ~0u;
+        b.z = n > 2 ? uint32_t(k.refs[begin + 2]) : ~0u;
+        b.w = n > 3 ? uint32_t(k.refs[begin + 3]) : ~0u;
+    }
+    rec[0] = a; rec[1] = b;
+}
+
+// Nested blocks: one wavefront per root (an entry at depth `dep` whose subtree the block above does not resolve).  The block
+// resolves up to three more levels below the root; what lies deeper still is a `deep` link into the construction format.
+template <bool FILL>
+__global__ void __launch_bounds__(64) image_nested(const ImgK k, int num_roots, int* __restrict__ sizes, int* __restrict__ depths,
+                                                   const int* __restrict__ offsets, unsigned char* __restrict__ blocks) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= num_roots) return;
+    const int2 root = k.roots[r];
+    const int dep0 = root.y, Dr = min(3, k.shift - dep0), V = 1 << (3 * Dr), up = k.shift - dep0 - Dr, M = (1 << Dr) - 1;
+    const uint32_t w0 = k.entries[root.x];
+    auto resolve = [&](int f, int& depth, int& eidx) -> uint32_t {
+        const int rx = (f & M) << up, ry = ((f >> Dr) & M) << up, rz = (f >> (2 * Dr)) << up;
+        uint32_t w = w0;
+        depth = dep0; eidx = root.x;
+        while ((w & 3u) && (depth - dep0) + int(w & 3u) <= Dr) {
+            const int kk = int(w & 3u);
+            depth += kk;
+            const int s = k.shift - depth, m = (1 << kk) - 1;
+            eidx = int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk);
+            w = k.entries[eidx];
+        }
+        return w;
+    };
+    int d;
+    if (!FILL) {
+        int dmax = 0;
+        for (int f = lane; f < V; f += 64) { int depth, eidx; (void)resolve(f, depth, eidx); dmax = max(dmax, depth - dep0); }
+        d = wave_max(dmax);
+        if (lane == 0) { sizes[r] = ((32 << (3 * d)) + 127) >> 7; depths[r] = d; }
+        return;
+    }
+    d = depths[r];
+    const int sd = Dr - d;
+    unsigned char* base = blocks + size_t(offsets[r]) * 128u;
+    for (int f = lane; f < V; f += 64) {
+        const int fx = f & M, fy = (f >> Dr) & M, fz = f >> (2 * Dr);
+        if ((fx | fy | fz) & ((1 << sd) - 1)) continue;                       // not a voxel of depth d
+        int depth, eidx;
+        const uint32_t w = resolve(f, depth, eidx);
+        const int idx = (fx >> sd) + (((fy >> sd) + ((fz >> sd) << d)) << d);
+        uint4* rec = reinterpret_cast<uint4*>(base + size_t(idx) * 32u);
+        if (w & 3u) { rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu); rec[1] = make_uint4(uint32_t(eidx), uint32_t(depth), 0u, 0u); }
+        else write_cell_record(k, int(w >> 2), rec);
+    }
+}
+
 struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
 struct SizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
 
 template <int D, bool FLAT>
-int build_image(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
+int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     hipStream_t st = ctx->stream;
+    ImgK k = k0;
+    const bool nest = FLAT && k.shift > 3;                     // blocks resolve three levels; deeper grids get nested blocks
     int* sizes = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
     uint32_t* metas = pool_alloc<uint32_t>(ctx, size_t(k.num_top) + 1);   // lives until the fill pass re-derives it
-    int* partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(k.num_top)) + 1);
+    int* partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(std::max(k.num_top, k.num_entries))) + 1);
     uint2* table = pool_alloc<uint2>(ctx, size_t(k.num_top));
-    auto release = [&]() { hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials); };
-    if (!sizes || !metas || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    int* total = ctx->dscratch + 224;
+    int* claim = nest ? pool_alloc<int>(ctx, size_t(k.num_entries)) : nullptr;
+    int2* roots = nest ? pool_alloc<int2>(ctx, size_t(k.num_entries)) : nullptr;
+    int* sizes1 = nullptr; int* depths1 = nullptr;
+    auto release = [&]() {
+        hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials);
+        hagrid_mem_free(ctx, claim); hagrid_mem_free(ctx, roots); hagrid_mem_free(ctx, sizes1); hagrid_mem_free(ctx, depths1);
+    };
+    if (!sizes || !metas || !partials || !table || (nest && (!claim || !roots))) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    int* total = ctx->dscratch + 224;          // [0] level-0 units, [1] roots, [2] nested units
+    if (nest) {
+        (void)hipMemsetAsync(claim, 0xFF, size_t(k.num_entries) * sizeof(int), st);
+        (void)hipMemsetAsync(total + 1, 0, sizeof(int), st);
+        k.claim = claim; k.roots = roots; k.num_roots = total + 1;
+    }
     image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr, 0);
     if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    int units = 0;
-    int rc = read_back(ctx, total, &units, sizeof(int));
+    int h[2] = {0, 0};
+    int rc = read_back(ctx, total, h, sizeof(h));
+    int units = h[0];
+    const int num_roots = nest ? h[1] : 0;
     if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
+    int units1 = 0;
+    if (num_roots > 0) {
+        sizes1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
+        depths1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
+        if (!sizes1 || !depths1) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+        image_nested<false><<<num_roots, 64, 0, st>>>(k, num_roots, sizes1, depths1, nullptr, nullptr);
+        if (!ctx_scan<int>(ctx, SizeIn{sizes1}, SizeOut{sizes1}, num_roots, partials, (const int*)nullptr, total + 2)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+        rc = read_back(ctx, total + 2, &units1, sizeof(int));
+        if (rc != HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return rc; }
+    }
+    // a flat image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed): beyond that the
+    // compact form is built
+    if (FLAT && ((long long)units + units1) * 128 > (ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes))) { release(); hagrid_mem_free(ctx, table); return 1; }
     // Uniform layout when it costs at most a quarter more memory than the adaptive one (every top-level cell subdivided to the
     // full depth, as in evenly filled scenes): the record of a voxel is then found by arithmetic alone.
-    // a flat image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed): a very deep grid
-    // falls back to the compact form
-    if (FLAT && (long long)units * 128 > (ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes))) { release(); hagrid_mem_free(ctx, table); return 1; }
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
-    unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, size_t(units) * 128u));
+    if ((long long)units + units1 >= (1ll << 31)) { release(); hagrid_mem_free(ctx, table); return 1; }
+    unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, (size_t(units) + size_t(units1)) * 128u));
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    k.nested_off = sizes1; k.nested_d = depths1; k.nested_base = units;
+    if (num_roots == 0) k.claim = nullptr;
     image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks, uniform ? 1 : 0);
+    if (num_roots > 0) image_nested<true><<<num_roots, 64, 0, st>>>(k, num_roots, nullptr, depths1, sizes1, blocks + size_t(units) * 128u);
     img.uniform = uniform;
     hipError_t e = hipGetLastError();
     release();
     if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }
-    img.table = table; img.blocks = blocks; img.block_bytes = size_t(units) * 128u;
+    img.table = table; img.blocks = blocks; img.block_bytes = (size_t(units) + size_t(units1)) * 128u;
     return HAGRID_OK;
 }
 
@@ -274,6 +408,8 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     k.refs = static_cast<const int*>(g->ref_ids);
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
     k.source_bytes = 4ll * g->num_entries + (g->small_cells ? 16ll : 32ll) * g->num_cells;
+    k.num_entries = g->num_entries;
+    k.claim = nullptr; k.roots = nullptr; k.num_roots = nullptr; k.nested_off = nullptr; k.nested_d = nullptr; k.nested_base = 0;
     TravImageCache img;
     int rc = HAGRID_OK;
     bool flat = ctx->opt_image == 2;

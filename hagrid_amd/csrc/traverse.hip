@@ -584,6 +584,18 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
     cb.x = uint32_t(lo.w);
 }
 
+// Records that are links: 0xfffffffe = nested block (three more levels of the same flat form), 0xffffffff = deep (construction
+// format).  Dense spots of very non-uniform scenes only; the common record never gets here.
+__device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb) {
+    while (ca.w == 0xfffffffeu) {
+        const int d = int(cb.y & 3u), s = a.shift - int(cb.y >> 8) - d, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t((vx >> s) & m) + (uint32_t(((vy >> s) & m) + (((vz >> s) & m) << d)) << d);
+        const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + size_t(cb.x) * 128u + size_t(idx) * 32u);
+        ca = p[0]; cb = p[1];
+    }
+    if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+}
+
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
 template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE>
@@ -659,7 +671,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
-            if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+            if (ca.w >= 0xfffffffeu) image_resolve_links(a, vx, vy, vz, ca, cb);
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
             const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
@@ -1299,7 +1311,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
     const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
     const uint4* rec = flat ? image_record<true>(a, tab, vx, vy, vz) : image_record<false>(a, tab, vx, vy, vz);
     uint4 ra = rec[0], rb = rec[1];
-    if (ra.w == 0xffffffffu) { image_resolve_deep(a, vx, vy, vz, ra, rb); ra.w |= 0x40000000u; }     // bit 30: came through a deep link
+    if (ra.w >= 0xfffffffeu) { image_resolve_links(a, vx, vy, vz, ra, rb); ra.w |= 0x40000000u; }     // bit 30: came through a nested block or a deep link
     uint32_t* o = out + 8 * size_t(i);
     o[0] = ra.x; o[1] = ra.y; o[2] = ra.z; o[3] = ra.w; o[4] = rb.x; o[5] = rb.y; o[6] = rb.z; o[7] = rb.w;
 }

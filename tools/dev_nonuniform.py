@@ -1,0 +1,38 @@
+"""DEV TOOL: traversal image vs construction format on a very non-uniform scene (dense clusters inside a sparse soup, walls)."""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hagrid_amd import api, scene
+mem = api.MemManager(keep=True)
+big = scene.make_soup(100000, seed=7)
+parts = [big]
+for k in range(6):
+    c = scene.make_soup(150000, seed=20 + k).copy()
+    ctr = np.float32([0.15 + 0.14 * k, 0.3 + 0.08 * k, 0.2 + 0.1 * k])
+    c[:, 0:3] = c[:, 0:3] * np.float32(0.04) + ctr; c[:, 4:7] *= np.float32(0.03); c[:, 8:11] *= np.float32(0.03)
+    e1, e2 = c[:, 4:7], c[:, 8:11]
+    nrm = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2], e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
+    c[:, 3] = nrm[:, 0]; c[:, 7] = nrm[:, 1]; c[:, 11] = nrm[:, 2]
+    parts.append(c)
+tris = np.ascontiguousarray(np.concatenate(parts), np.float32); N = tris.shape[0]
+d_tris = mem.upload(tris)
+grid = api.build_all(mem, d_tris, N)
+print(json.dumps({"triangles": N, "grid": grid.summary()}), flush=True)
+for label, rays in (("primary1M", scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024)),
+                    ("incoh1M", scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, 9))):
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    res = {"rays": label}; ref = None
+    for img in (0, 1, 2):
+        mem.set_option("traverse.image", img); api.setup_traversal(grid)
+        import ctypes as C
+        nb = C.c_int64(0)
+        if img and mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0: res[f"image{img}_MB"] = round(nb.value / 1e6, 1)
+        for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(9))
+        res[f"image{img}"] = round(t[4], 4)
+        h = mem.download(d_hits, api.HIT_DTYPE, n)
+        if ref is None: ref = h
+        else: assert (h["id"] == ref["id"]).all() and (h["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+    print(json.dumps(res), flush=True)
+    mem.free(d_rays); mem.free(d_hits)
