@@ -694,26 +694,26 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
             else record(tab, vx, vy, vz, na, nb);
 
-            int n = int(ca.w);                                             // bit 31: the list is given by index (rare: > 4 ids, deep cells)
-            if (n < 0) {
-                n &= 0x7fffffff;
+            // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two
+            // longest.  Inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
+            // than four ids, deep cells) fetches the id of the next test one test ahead, as v2 does.
+            const bool by_index = int(ca.w) < 0;
+            auto ref_at = [&](uint32_t i) -> int { return NARROW ? gather32<int>(a.refs, i << 2) : a.refs[i]; };
+            uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;                       // inline: the ids still to test
+            int ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
+            if (by_index) {                                                 // by index: q1 = index of the next id, q2 = end of the list
+                q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
+                ref = q1 < q2 ? ref_at(q1) : -1;
+                q1++;
+            }
 #pragma unroll 1
-                for (int i = 0; i < n; i++) {
-                    const int ref = a.refs[cb.x + uint32_t(i)];
-                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    if (ANY && got) break;
-                }
-            } else {
-                uint32_t q0 = cb.x, q1 = cb.y, q2 = cb.z, q3 = cb.w;       // the inline ids, consumed front to back
-#pragma unroll 1
-                for (; n > 0; n--) {
-                    const int ref = int(q0);
-                    q0 = q1; q1 = q2; q2 = q3;
-                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    if (ANY && got) break;
-                }
+            while (ref >= 0) {
+                int next;
+                if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
+                else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                ref = (ANY && got) ? -1 : next;
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;
