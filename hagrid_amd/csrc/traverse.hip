@@ -586,8 +586,9 @@ __device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx
 
 // Records that are links: 0xfffffffe = nested block (three more levels of the same flat form), 0xffffffff = deep (construction
 // format).  Dense spots of very non-uniform scenes only; the common record never gets here.
-__device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb) {
+__device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb, uint32_t& nest_off, uint32_t& nest_meta) {
     while (ca.w == 0xfffffffeu) {
+        nest_off = cb.x; nest_meta = cb.y;
         const int d = int(cb.y & 3u), s = a.shift - int(cb.y >> 8) - d, m = (1 << d) - 1;
         const uint32_t idx = uint32_t((vx >> s) & m) + (uint32_t(((vy >> s) & m) + (((vz >> s) & m) << d)) << d);
         const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + size_t(cb.x) * 128u + size_t(idx) * 32u);
@@ -634,6 +635,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
         };
         auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
+        uint32_t nest = ~0u, nest_key = 0u;                                     // innermost nested block the ray is inside (FLAT + NARROW, table layout)
         // record of a voxel: FLAT + NARROW is one address computation off the scalar base
         auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
             if (UNIFORM) {
@@ -643,9 +645,17 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
                 ra = p[0]; rb = p[1];
             } else if (FLAT && NARROW) {
-                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
+                int d = int(tab.y & 3u), s = a.shift - d;
+                uint32_t base = tab.x;
+                if (nest != ~0u) {                                          // same top-level cell (reset below when it changes)
+                    const int sr = a.shift - int(nest >> 27), m = (1 << a.shift) - 1; // finest-level voxels per root cell of the nested block, log2
+                    const uint32_t hi = uint32_t((m >> sr) << sr);
+                    const uint32_t pv = uint32_t(x & m) | uint32_t(y & m) << a.shift | uint32_t(z & m) << (2 * a.shift);
+                    if (((pv ^ nest_key) & (hi | hi << a.shift | hi << (2 * a.shift))) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
+                }
+                const int m = (1 << d) - 1;
                 const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                const uint32_t o = (tab.x << 7) + (idx << 5);
+                const uint32_t o = (base << 7) + (idx << 5);
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
                 ra = p[0]; rb = p[1];
             } else {
@@ -671,7 +681,17 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
-            if (ca.w >= 0xfffffffeu) image_resolve_links(a, vx, vy, vz, ca, cb);
+            if (ca.w >= 0xfffffffeu) {
+                // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
+                // cell the next records are fetched from it directly (one gather per step again)
+                uint32_t off = ~0u, meta = 0u;
+                image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
+                if (!UNIFORM && FLAT && NARROW && a.shift <= 10 && off != ~0u) {
+                    const int m = (1 << a.shift) - 1;
+                    nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;        // offset < 2^25 units (NARROW), depth of the block, depth of its root
+                    nest_key = uint32_t(vx & m) | uint32_t(vy & m) << a.shift | uint32_t(vz & m) << (2 * a.shift);
+                }
+            }
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
             const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
@@ -688,7 +708,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
             if (!UNIFORM) {
                 const int ntop = outside ? top_idx : top_index(vx, vy, vz);
-                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
+                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; nest = ~0u; }
             }
             uint4 na, nb;
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
@@ -703,16 +723,26 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             int ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
             if (by_index) {                                                 // by index: q1 = index of the next id, q2 = end of the list
                 q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                ref = q1 < q2 ? ref_at(q1) : -1;
+                ref = -1;
+                if (q1 < q2) ref = ref_at(q1);
                 q1++;
             }
 #pragma unroll 1
             while (ref >= 0) {
                 int next;
-                if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                if (UNIFORM) {
+                    // shallow grids, long lists are rare: the fewest instructions for the inline form
+                    if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
+                    else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                }
+                int pre = -1;
+                if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
                 const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
                                      : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                if (!UNIFORM) {
+                    if (by_index) { next = pre; q1++; }
+                    else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                }
                 ref = (ANY && got) ? -1 : next;
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
@@ -1311,7 +1341,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
     const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
     const uint4* rec = flat ? image_record<true>(a, tab, vx, vy, vz) : image_record<false>(a, tab, vx, vy, vz);
     uint4 ra = rec[0], rb = rec[1];
-    if (ra.w >= 0xfffffffeu) { image_resolve_links(a, vx, vy, vz, ra, rb); ra.w |= 0x40000000u; }     // bit 30: came through a nested block or a deep link
+    if (ra.w >= 0xfffffffeu) { uint32_t off, meta; image_resolve_links(a, vx, vy, vz, ra, rb, off, meta); ra.w |= 0x40000000u; }     // bit 30: came through a nested block or a deep link
     uint32_t* o = out + 8 * size_t(i);
     o[0] = ra.x; o[1] = ra.y; o[2] = ra.z; o[3] = ra.w; o[4] = rb.x; o[5] = rb.y; o[6] = rb.z; o[7] = rb.w;
 }
