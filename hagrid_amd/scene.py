@@ -78,6 +78,22 @@ def make_soup(num_tris: int, seed: int | None = None, first: int = 0, count: int
     return tris_from_vertices(c, c + a, c + b)
 
 
+def make_clustered(num_sparse: int = 100000, clusters: int = 6, per_cluster: int = 150000) -> np.ndarray:
+    """A very non-uniform scene (teapot in a stadium, the case irregular grids exist for): a sparse soup over the unit cube
+    and `clusters` dense blobs, each a soup shrunk to 4 % of the cube.  With the defaults: 1M triangles, grid shift 6, cell
+    lists of up to ~20 references inside the blobs.  Normals are recomputed from the scaled edges as make_soup does."""
+    parts = [make_soup(num_sparse, seed=7)]
+    for k in range(clusters):
+        c = make_soup(per_cluster, seed=20 + k).copy()
+        centre = np.float32([0.15 + 0.14 * k, 0.3 + 0.08 * k, 0.2 + 0.1 * k])
+        c[:, 0:3] = c[:, 0:3] * np.float32(0.04) + centre
+        c[:, 4:7] *= np.float32(0.03); c[:, 8:11] *= np.float32(0.03)
+        n = _cross(c[:, 4:7], c[:, 8:11]).astype(np.float32)
+        c[:, 3] = n[:, 0]; c[:, 7] = n[:, 1]; c[:, 11] = n[:, 2]
+        parts.append(c)
+    return np.ascontiguousarray(np.concatenate(parts), np.float32)
+
+
 def tris_bbox(tris: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     """Scene bounding box over the three vertices (prims.h:27-31)."""
     v0 = tris[:, 0:3]; v1 = v0 - tris[:, 4:7]; v2 = v0 + tris[:, 8:11]

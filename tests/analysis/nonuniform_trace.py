@@ -5,10 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 from hagrid_amd import scene
-src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tools", "dev_nonuniform.py")).read()
-ns = {"np": np, "scene": scene}
-exec(src.split("mem = api.MemManager(keep=True)")[1].split("d_tris = mem.upload(tris)")[0], ns)
-tris = ns["tris"]
+tris = scene.make_clustered()
 t0 = time.time(); G = O.Grid.full(tris); print("oracle build", round(time.time() - t0, 1), "s", G.summary(), flush=True)
 rays = scene.make_rays_primary(G.bbox_min, G.bbox_max, 1024, 1024).reshape(128, 8, 128, 8, 8)
 L = O.lib(); L.orc_traverse_trace.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]; L.orc_traverse_trace.restype = None

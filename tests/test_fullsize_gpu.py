@@ -137,3 +137,36 @@ def test_config5_8M_triangles_compressed_bounce_rays():
     bf = O.brute_force(tris, np.ascontiguousarray(bounce[sel]), nthreads=cores)
     assert same_hits(hb[sel], bf)
     plain.free(); comp.free(); mem.close()
+
+
+def test_clustered_scene_structure_and_hits_match_oracle():
+    """A very non-uniform 1M-triangle scene (scene.make_clustered: six dense blobs in a sparse soup; grid shift 6, lists of
+    up to ~20 references): grid arrays identical to the oracle's; primary and incoherent hits identical to the oracle's with
+    the construction-format kernel and with both image formats (nested blocks, by-index lists)."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_clustered()
+    mem = api.MemManager(keep=True)
+    try:
+        d_tris = mem.upload(tris)
+        grid = api.build_all(mem, d_tris, tris.shape[0])
+        G = O.Grid.full(tris)
+        d = grid.download()
+        assert grid.summary() == G.summary() and grid.summary()["shift"] > 3
+        assert (d["entries"] == G.entries).all() and (d["ref_ids"] == G.ref_ids).all()
+        assert d["cells"].tobytes() == G.cells.tobytes()
+        aimed = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 17, 12).copy()   # towards the blobs, with some spread
+        k = np.arange(aimed.shape[0]) % 6
+        centre = np.stack([0.17 + 0.14 * k, 0.32 + 0.08 * k, 0.22 + 0.1 * k], axis=1).astype(np.float32)
+        aimed[:, 4:7] = centre - aimed[:, 0:3] + np.float32(0.02) * aimed[:, 4:7]
+        rays = np.concatenate([scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 512),
+                               scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 18, 11), aimed]).astype(np.float32)
+        oh, _ = G.traverse(tris, rays, nthreads=8)
+        assert (oh["id"] >= 1_00_000).sum() > 1000            # rays that end inside a blob
+        for image in (2, 1, 0):
+            mem.set_option("traverse.image", image)
+            assert same_hits(traverse(mem, grid, d_tris, rays), oh), f"traverse.image={image}"
+        mem.set_option("traverse.image", 2)
+        grid.free()
+    finally:
+        mem.close()

@@ -4,17 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hagrid_amd import api, scene
 mem = api.MemManager(keep=True)
-big = scene.make_soup(100000, seed=7)
-parts = [big]
-for k in range(6):
-    c = scene.make_soup(150000, seed=20 + k).copy()
-    ctr = np.float32([0.15 + 0.14 * k, 0.3 + 0.08 * k, 0.2 + 0.1 * k])
-    c[:, 0:3] = c[:, 0:3] * np.float32(0.04) + ctr; c[:, 4:7] *= np.float32(0.03); c[:, 8:11] *= np.float32(0.03)
-    e1, e2 = c[:, 4:7], c[:, 8:11]
-    nrm = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2], e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
-    c[:, 3] = nrm[:, 0]; c[:, 7] = nrm[:, 1]; c[:, 11] = nrm[:, 2]
-    parts.append(c)
-tris = np.ascontiguousarray(np.concatenate(parts), np.float32); N = tris.shape[0]
+tris = scene.make_clustered(); N = tris.shape[0]
 d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, N)
 print(json.dumps({"triangles": N, "grid": grid.summary()}), flush=True)
