@@ -124,7 +124,8 @@ int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
  * block of (2^d)^3 records of 32 bytes, indexed by the voxel -- u16 cell bounds, list length and the reference ids of lists
  * of up to four inline -- so that a cell step is ONE dependent gather (the block's table entry is kept while the ray stays in
  * the top-level cell) instead of entry -> entry -> cell, and the reference-id gather disappears for short lists; blocks
- * resolve three levels, deeper subdivisions link back into the construction format.  "traverse.image" = 1 is the compact
+ * resolve three levels, deeper subdivisions are links to nested blocks of the same form (three more levels each; below
+ * six levels a link back into the construction format).  "traverse.image" = 1 is the compact
  * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.  A flat
  * image that would exceed max(1 GB, 8x the entries + cells it replaces) ("traverse.image_max_mb") is built in the compact form.
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
