@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
-            if (ca.w >= 0xfffffffeu) {
+            if (!UNIFORM && ca.w >= 0xfffffffeu) {                          // (the table-free layout needs shift <= 3: every block resolves its cell fully)
                 // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
                 // cell the next records are fetched from it directly (one gather per step again)
                 uint32_t off = ~0u, meta = 0u;
