@@ -18,13 +18,17 @@ CONFIGS = [
     dict(name="2: soup-1M, 1M primary, occlusion rays (any-hit)", tris=1_000_000, rays=("primary", 1024), params={}, flags=1),
     dict(name="4: soup-1M, 16M incoherent, binned, construction format (no image)", tris=1_000_000, rays=("incoherent", 1 << 24), params={}, bin=1, image=0),
     dict(name="2: soup-1M, 1M primary, construction format (no image)", tris=1_000_000, rays=("primary", 1024), params={}, image=0),
+    dict(name="6 (extra): clustered-1M (six dense blobs in a sparse soup, shift 6), 1M primary", tris=1_000_000, scene="clustered", rays=("primary", 1024), params={}),
+    dict(name="6 (extra): clustered-1M, 1M primary, construction format (no image)", tris=1_000_000, scene="clustered", rays=("primary", 1024), params={}, image=0),
+    dict(name="6 (extra): clustered-1M, 1M incoherent", tris=1_000_000, scene="clustered", rays=("incoherent", 1 << 20), params={}),
+    dict(name="6 (extra): clustered-1M, 1M incoherent, construction format (no image)", tris=1_000_000, scene="clustered", rays=("incoherent", 1 << 20), params={}, image=0),
 ]
 cache = {}
 for c in CONFIGS:
     n = c["tris"]
-    if cache.get("n") != n:
+    if cache.get("n") != (n, c.get("scene")):
         if cache.get("d_tris"): mem.free(cache["d_tris"])
-        cache = {"n": n, "tris": scene.make_soup(n)}
+        cache = {"n": (n, c.get("scene")), "tris": scene.make_clustered() if c.get("scene") == "clustered" else scene.make_soup(n)}
         cache["d_tris"] = mem.upload(cache["tris"])
     tris, d_tris = cache["tris"], cache["d_tris"]
     grid = api.build_all(mem, d_tris, n, **c["params"])
