@@ -51,3 +51,18 @@ def test_ray_conventions():
     assert np.isclose(p[0, 7], np.sqrt(3), rtol=1e-6)              # tmax = clip = |extents|
     # the centre column / row have an exactly zero direction component (kx = 0, ky = 0)
     assert (p[np.arange(64) * 64 + 32, 4] == 0).all() and (p[32 * 64:33 * 64, 5] == 0).all()
+
+
+def test_clustered_scene_is_pinned_and_well_formed():
+    """scene.make_clustered: same bits everywhere (the GPU box regenerates it), normals = cross(e1, e2) of the scaled edges,
+    blobs where the docstring says."""
+    import hashlib
+    t = scene.make_clustered(2000, 3, 1000)
+    assert t.shape == (5000, 12) and t.dtype == np.float32
+    assert hashlib.sha256(t.tobytes()).hexdigest()[:16] == "9700c36972a7f1aa"
+    e1, e2 = t[:, 4:7], t[:, 8:11]
+    n = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2],
+                  e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1).astype(np.float32)
+    assert (n[:, 0] == t[:, 3]).all() and (n[:, 1] == t[:, 7]).all() and (n[:, 2] == t[:, 11]).all()
+    blob = t[2000:3000, 0:3]
+    assert (blob >= np.float32([0.15, 0.30, 0.20])).all() and (blob <= np.float32([0.19, 0.34, 0.24]) + 1e-6).all()
