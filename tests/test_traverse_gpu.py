@@ -582,6 +582,41 @@ def test_any_hit_and_uvs_traversal(mem, compressed):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
+def test_any_hit_and_uvs_on_a_deep_clustered_grid(mem):
+    """The table-layout image kernels (nested blocks, lists by index, the per-ray nested-block state) in their any-hit and
+    barycentric variants, with and without the binning permutation: a small clustered scene with a grid deeper than three levels."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_clustered(3000, 3, 4000)
+    G = O.Grid.full(tris)
+    assert G.shift > 3
+    d_tris = mem.upload(tris)
+    grid = upload_oracle_grid(mem, G)
+    aimed = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 60000, 5).copy()
+    k = np.arange(aimed.shape[0]) % 3
+    centre = np.stack([0.17 + 0.14 * k, 0.32 + 0.08 * k, 0.22 + 0.1 * k], axis=1).astype(np.float32)
+    aimed[:, 4:7] = centre - aimed[:, 0:3] + np.float32(0.03) * aimed[:, 4:7]
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 256, 128), aimed,
+                           scene.make_rays_incoherent(G.bbox_min - 0.1, G.bbox_max + 0.1, 30001, 6)]).astype(np.float32)
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    try:
+        for binning in (0, 1):
+            mem.set_ray_binning(binning)
+            for flags, oflags in ((0, 0), (api.ANY_HIT, O.ANY_HIT), (api.UVS, O.UVS), (api.ANY_HIT | api.UVS, O.ANY_HIT | O.UVS)):
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                want = G.traverse_ex(tris, rays, oflags, nthreads=8)
+                assert (got["id"] == want["id"]).all(), (binning, flags)
+                for f in ("t", "u", "v"):
+                    assert (bits(got[f]) == bits(want[f])).all(), (binning, flags, f)
+                if flags == 0: assert (got["id"] >= 3000).sum() > 500          # rays that end inside a blob
+    finally:
+        mem.set_ray_binning(0)
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
 def test_automatic_ray_binning(mem):
     """mode 2: identical hits whatever the device decides, and the decision is the expected one (observed through timing-free
     means: the permutation is only used for the unordered batch -- checked with the hits of a deliberately ordered copy)."""
