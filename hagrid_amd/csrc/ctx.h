@@ -74,6 +74,8 @@ struct hagrid_ctx {
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
+    unsigned long long* kat_wave_times = nullptr;   // diagnostic: see hagrid_kat_wave_times
+    const int* kat_tile_order = nullptr;
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_detect_origins = 1; // row length of image-ordered batches also from the origins (bounce rays)
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built

@@ -39,6 +39,8 @@ struct TraverseArgs {
     int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
     int super_log2;                          // tile packets: tiles per super-tile edge, log2
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
+    const int* __restrict__ tile_order;      // diagnostic (hagrid_kat_tile_order): packet b processes tile tile_order[b]
+    unsigned long long* __restrict__ wave_times; // diagnostic (hagrid_kat_wave_times): start / end of every wavefront, 100 MHz wall clock
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
     int num_rays;
@@ -599,13 +601,19 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
 
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
-template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE>
+// TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
+    struct Stamp {
+        unsigned long long* p;
+        __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
+        __device__ ~Stamp() { if (TIMES) { const unsigned long long t = wall_clock64(); atomicMax(p + 1, t); } }   // the last lane to leave
+    } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-    const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * BLOCK + threadIdx.x;
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, threadIdx.x) : b * BLOCK + threadIdx.x;
     if (slot >= a.num_rays) return;
     const int id = perm ? perm[slot] : slot;
 
@@ -1026,7 +1034,8 @@ size_t buffer_bytes_from(const void* p) {
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, const TraverseArgs& a) {
-    if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
+    if (flat && narrow && uniform && MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true><<<blocks, 64, 0, st>>>(a);
+    else if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow)       traverse_kernel_img<64, true, true, false, MODE><<<blocks, 64, 0, st>>>(a);
     else if (MODE != 0)            return false;
     else if (flat)                 traverse_kernel_img<64, true, false, false, 0><<<blocks, 64, 0, st>>>(a);
@@ -1075,7 +1084,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.tris = static_cast<const float4*>(tris);
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
-    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr;
+    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.img_table = nullptr; a.img_blocks = nullptr;
     a.num_rays = num_rays; a.shift = g->shift;
@@ -1192,6 +1201,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     if (variant == 4) {
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
+        a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
         launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
@@ -1442,6 +1452,13 @@ extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len,
     kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(slots);
+}
+
+extern "C" int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_dev, const int* tile_order_dev) {
+    if (!ctx) return HAGRID_EINVAL;
+    ctx->kat_wave_times = times_dev;
+    ctx->kat_tile_order = tile_order_dev;
+    return HAGRID_OK;
 }
 
 extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes) {

@@ -199,6 +199,12 @@ int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_en
  * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */
 int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, float bbox_diag, int32_t* row_len);
 int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
+/* Diagnostic: when `times_dev` is not null the next hagrid_traverse_grid calls that take the table-free image kernel (nearest
+ * hit, no flags) record, per wavefront b (64 rays), the 100 MHz wall clock at its start in times_dev[2b] and at its end in
+ * times_dev[2b + 1] (the caller zeroes the buffer).  Null switches it off.  `tile_order_dev` (or null): packet b of an
+ * image-ordered batch then processes the 8x8 tile tile_order_dev[b] of the default order -- an experiment on dispatch order.
+ * tools/dev_wave_timeline.py. */
+int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_dev, const int* tile_order_dev);
 /* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
  * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
  * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
