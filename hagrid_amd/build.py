@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "libhagrid_amd.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-DHOST=__host__", "-DDEVICE=__device__",
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
