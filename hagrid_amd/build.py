@@ -26,7 +26,7 @@ FLAGS = [
     "-DHOST=__host__", "-DDEVICE=__device__",
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
     "-Wall", "-Wno-unused-function",
-]
+] + os.environ.get("HAGRID_HIPCC_EXTRA", "").split()     # experiments only (tools/dev_flags.sh)
 
 
 def _newer(target: str, deps: list[str]) -> bool:
