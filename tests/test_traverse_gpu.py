@@ -646,3 +646,31 @@ def test_automatic_ray_binning(mem):
     finally:
         mem.set_ray_binning(0); mem.set_option("traverse.image_width", 0)
     grid.free(); mem.free(d_tris)
+
+
+def test_wave_time_diagnostic_does_not_change_hits(mem):
+    """hagrid_kat_wave_times: the stamped instantiation gives the same hits, every wavefront has start <= end, and a tile order
+    (here: reversed) only changes which wavefront takes which tile."""
+    from hagrid_amd import api
+    tris = scene.make_soup(30000, seed=3)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 256, 128)
+    n = rays.shape[0]; nw = n // 64
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n); d_times = mem.alloc(16 * nw)
+    api.setup_traversal(grid)
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+    ref = mem.download(d_hits, api.HIT_DTYPE, n)
+    d_order = mem.upload(np.arange(nw, dtype=np.int32)[::-1].copy())
+    try:
+        for order in (None, d_order):
+            mem.zero(d_times, 16 * nw); mem.zero(d_hits, 16 * n)
+            assert mem._L.hagrid_kat_wave_times(mem._ctx, d_times, order) == 0
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            got = mem.download(d_hits, api.HIT_DTYPE, n)
+            t = mem.download(d_times, np.uint64, 2 * nw).reshape(nw, 2)
+            assert (got["id"] == ref["id"]).all() and (bits(got["t"]) == bits(ref["t"])).all()
+            assert (t[:, 0] > 0).all() and (t[:, 1] >= t[:, 0]).all()
+    finally:
+        mem._L.hagrid_kat_wave_times(mem._ctx, None, None)
+    mem.free(d_order); mem.free(d_times); mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
