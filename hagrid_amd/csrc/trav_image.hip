@@ -394,7 +394,10 @@ void hagrid_impl::trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, si
 int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     trav_image_drop(ctx);
     if (!ctx->opt_image || !g->entries || (!g->cells && !g->small_cells) || !g->ref_ids || g->num_cells <= 0) return HAGRID_OK;
-    if (g->small_cells && g->shift > 3) return HAGRID_OK;      // deep links resolve through 32-byte cells only
+    // deep links (below six levels, or below three in the compact form) resolve through 32-byte cells only: a compressed grid
+    // gets an image when blocks + nested blocks cover it
+    const bool compressed_deep = g->small_cells && g->shift > 3;
+    if (compressed_deep && (g->shift > 6 || ctx->opt_image != 2)) return HAGRID_OK;
     if (g->shift < 0 || g->shift > 15) return HAGRID_OK;
     for (int i = 0; i < 3; i++)
         if (g->dims[i] <= 0 || (long long)g->dims[i] << g->shift > 65535) return HAGRID_OK;
@@ -420,6 +423,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
             case 2: rc = flat ? build_image<2, true>(ctx, k, img) : build_image<2, false>(ctx, k, img); break;
             default: rc = flat ? build_image<3, true>(ctx, k, img) : build_image<3, false>(ctx, k, img); break;
         }
+        if (rc == 1 && flat && compressed_deep) return HAGRID_OK;   // too big, and the compact form cannot describe it: no image
         if (rc == 1 && flat) { flat = false; continue; }     // too big as a flat image: compact form
         break;
     }

@@ -131,7 +131,7 @@ int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
  * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
  * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for
- * a virtual resolution above 65535 per axis or for compressed grids deeper than three levels.  Synchronous (one size read-back); 0.17 ms and 256 MB for
+ * a virtual resolution above 65535 per axis or for compressed grids deeper than six levels (three in the compact form).  Synchronous (one size read-back); 0.17 ms and 256 MB for
  * the 1M-triangle scene of BASELINE.md. */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
