@@ -643,7 +643,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
         };
         auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
-        uint32_t nest = ~0u, nest_key = 0u;                                     // innermost nested block the ray is inside (FLAT + NARROW, table layout)
+        uint32_t nest = ~0u;                                                    // innermost nested block the ray is inside (FLAT + NARROW, table layout)
+        int nest_x = 0, nest_y = 0, nest_z = 0;                                 // ... and the voxel that led there
         // record of a voxel: FLAT + NARROW is one address computation off the scalar base
         auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
             if (UNIFORM) {
@@ -655,11 +656,9 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
-                if (nest != ~0u) {                                          // same top-level cell (reset below when it changes)
-                    const int sr = a.shift - int(nest >> 27), m = (1 << a.shift) - 1; // finest-level voxels per root cell of the nested block, log2
-                    const uint32_t hi = uint32_t((m >> sr) << sr);
-                    const uint32_t pv = uint32_t(x & m) | uint32_t(y & m) << a.shift | uint32_t(z & m) << (2 * a.shift);
-                    if (((pv ^ nest_key) & (hi | hi << a.shift | hi << (2 * a.shift))) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
+                if (nest != ~0u) {
+                    const int sr = a.shift - int(nest >> 27);               // finest-level voxels per root cell of the nested block, log2
+                    if ((((x ^ nest_x) | (y ^ nest_y) | (z ^ nest_z)) >> sr) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
                 }
                 const int m = (1 << d) - 1;
                 const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
@@ -694,10 +693,9 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 // cell the next records are fetched from it directly (one gather per step again)
                 uint32_t off = ~0u, meta = 0u;
                 image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
-                if (!UNIFORM && FLAT && NARROW && a.shift <= 10 && off != ~0u) {
-                    const int m = (1 << a.shift) - 1;
+                if (!UNIFORM && FLAT && NARROW && off != ~0u) {
                     nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;        // offset < 2^25 units (NARROW), depth of the block, depth of its root
-                    nest_key = uint32_t(vx & m) | uint32_t(vy & m) << a.shift | uint32_t(vz & m) << (2 * a.shift);
+                    nest_x = vx; nest_y = vy; nest_z = vz;
                 }
             }
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
@@ -716,7 +714,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
             if (!UNIFORM) {
                 const int ntop = outside ? top_idx : top_index(vx, vy, vz);
-                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; nest = ~0u; }
+                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
             }
             uint4 na, nb;
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
