@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline benchmark: Mrays/s of primary-ray traversal (+ grid build ms) on the 1M-triangle
-synthetic scene, BASELINE.json configs[1], on N MI355X of one node.
+"""bench.py -- Mrays/s of ray traversal (+ grid build ms) on the BASELINE scenes, on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                       # the headline: BASELINE.json configs[1]
+    python bench.py --config 3|4|5 [--scaling weak|strong]               # the other GPU configurations of BASELINE.md section 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config C]
 
-One "step" = one traverse_grid call over this rank's batch of rays (1024 x 1024 primary rays per GPU: weak
-scaling -- rank r traverses sub-pixel sample r of N of the same camera, so every rank's batch is statistically
-identical).  The grid is built on rank 0 with the gfx950 construction passes and broadcast once (RCCL); no
-collective sits on the timed path.  Rank 0 prints ONE JSON line.
+--config uses BASELINE.md's numbering (config C = BASELINE.json configs[C - 1]):
+  2  soup-1M, defaults, 1024 x 1024 primary rays PER GPU (weak scaling: rank r traces sub-pixel sample r of N)
+  3  soup-1M, --top-density 0.15 --snd-density 3.0 --expansion 3, 4096 x 4096 primary rays
+  4  soup-1M, defaults, 128M incoherent rays (random origin + direction), ray binning on
+  5  soup-8M, defaults + --compress, 64M diffuse-bounce rays leaving the hit points of an 8192 x 8192 primary image
+Configs 3-5 shard ONE batch over the ranks (strong scaling, contiguous ranges: hagrid_amd.scene.shard_range) unless
+--scaling weak is given; config 2 is weak unless --scaling strong is given.
 
-Everything measured runs through the C ABI (hagrid_amd/libhagrid_amd.so).  The CPU oracle is used only (a) as
-the checker of the GPU hits and (b) as the timed `cpu_baseline` (rank 0, N = 1), never as the thing measured.
+One "step" = one traverse_grid call over this rank's rays, resident in HBM.  The grid is built on rank 0 with the gfx950
+construction passes and broadcast once (RCCL); no collective sits on the timed path.  Rank 0 prints ONE JSON line.
+
+Everything measured runs through the C ABI (hagrid_amd/libhagrid_amd.so).  The CPU oracle is used only (a) as the checker
+of the GPU hits and (b) as the timed `cpu_baseline` (rank 0, N = 1), never as the thing measured.
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -29,9 +36,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    2: dict(baseline="1M-triangle synthetic scene, default densities, 1M primary rays on 1xMI355X", tris=1_000_000, rays="primary",
+            width=1024, height=1024, scaling="weak", params={}),
+    3: dict(baseline="1M-triangle scene, --top-density 0.15 --snd-density 3.0 --expansion 3, 16M rays, 1xMI355X (build-time + traversal bench)",
+            tris=1_000_000, rays="primary", width=4096, height=4096, scaling="strong", params=dict(top_density=0.15, snd_density=3.0, expansion=3)),
+    4: dict(baseline="1M-triangle scene, 128M incoherent (random origin+dir) rays sharded across 8xMI355X via RCCL grid broadcast",
+            tris=1_000_000, rays="incoherent", total=1 << 27, scaling="strong", params={}, bin_rays=1),
+    5: dict(baseline="8M-triangle scene with --compress voxel map, 64M diffuse-bounce rays, 8xMI355X",
+            tris=8_000_000, rays="bounce", width=8192, height=8192, scaling="strong", params=dict(compress=True)),
+}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def upload_generated(mem, d_rays, gen, first, count, chunk=1 << 20, threads=None, keep_host=0):
+    """Generates rays [first, first + count) in chunks on a thread pool (the generators are counter-based: any slice is
+    reproducible) and copies each chunk to its place in the device buffer.  Returns the first `keep_host` rays."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    starts = list(range(0, count, chunk))
+    kept = []
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        for off, arr in zip(starts, ex.map(lambda o: gen(first + o, min(chunk, count - o)), starts)):
+            mem.copy_h2d(d_rays + 32 * off, arr)
+            if off < keep_host:
+                kept.append(arr[:keep_host - off])
+    return np.concatenate(kept) if kept else np.zeros((0, 8), np.float32)
 
 
 def main():
@@ -39,25 +71,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tris", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--rays", choices=["primary", "incoherent"], default="primary")
-    ap.add_argument("--eye-dist", type=float, default=0.8, help="camera distance in scene diagonals (SURVEY proposed 1.5, where only ~17 %% of the pixels see the scene; DESIGN.md section 5)")
-    ap.add_argument("--top-density", type=float, default=0.12)
-    ap.add_argument("--snd-density", type=float, default=2.4)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.md configuration (config C = BASELINE.json configs[C - 1])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak for config 2, strong (one batch sharded over the ranks) for 3-5")
+    ap.add_argument("--tris", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--rays", choices=["primary", "incoherent", "bounce"], default=None)
+    ap.add_argument("--total-rays", type=int, default=None, help="size of the incoherent batch (config 4: 2^27)")
+    ap.add_argument("--eye-dist", type=float, default=0.8, help="camera distance in scene diagonals (SURVEY proposed 1.5, where no ray reaches the grid within tmax = clip; DESIGN.md section 5)")
+    ap.add_argument("--top-density", type=float, default=None)
+    ap.add_argument("--snd-density", type=float, default=None)
     ap.add_argument("--alpha", type=float, default=0.995)
-    ap.add_argument("--expansion", type=int, default=3)
+    ap.add_argument("--expansion", type=int, default=None)
     ap.add_argument("--compress", action="store_true")
     ap.add_argument("--build-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-cores baseline sample")
     ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off, 1 compact, 2 flat (default)")
-    ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 for primary rays")
+    ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 otherwise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, broadcast, all-reduce) even with one rank")
     args = ap.parse_args()
+
+    cfg = CONFIGS[args.config]
+    n_tris = args.tris or cfg["tris"]
+    ray_kind = args.rays or cfg["rays"]
+    width = args.width or cfg.get("width", 1024)
+    height = args.height or cfg.get("height", 1024)
+    scaling = args.scaling or cfg["scaling"]
+    top_density = args.top_density if args.top_density is not None else cfg["params"].get("top_density", 0.12)
+    snd_density = args.snd_density if args.snd_density is not None else cfg["params"].get("snd_density", 2.4)
+    expansion = args.expansion if args.expansion is not None else cfg["params"].get("expansion", 3)
+    compress = args.compress or cfg["params"].get("compress", False)
 
     import torch
     import torch.distributed as dist
@@ -91,21 +137,29 @@ def main():
     info = mem.device_info()
 
     # ---- scene + grid: built on rank 0, broadcast once -------------------------------------------------------------
-    n_tris = args.tris
     build_ms = None
+    build_block = None
     grid = None
     d_tris = 0
     t_bcast = 0.0
+    tris_host = None
+    if rank == 0 or ray_kind == "bounce":
+        tris_host = scene.make_soup(n_tris)             # bounce rays need the hit triangles' normals on every rank
     if rank == 0:
-        tris = scene.make_soup(n_tris)
-        d_tris = mem.upload(tris)
-        build = lambda g=None: api.build_all(mem, d_tris, n_tris, args.top_density, args.snd_density, args.alpha, args.expansion, args.compress, g)
+        d_tris = mem.upload(tris_host)
+        build = lambda g=None: api.build_all(mem, d_tris, n_tris, top_density, snd_density, args.alpha, expansion, compress, g)
         grid = build()                                  # warm-up build (also fills the buffer pool)
         times = []
         for _ in range(max(args.build_iter, 1)):        # main.cpp:494-508: free the grid, then time one full construction
             grid.free()
             times.append(api.profile(lambda: build(grid), mem))
         build_ms = float(np.mean(times))
+        bc = mem.build_counts()
+        bb = api.build_algorithmic_bytes(bc)
+        build_block = {"bytes": bb, "ms": round(build_ms, 3), "achieved": round(bb["total"] / (build_ms * 1e6), 1), "unit": "GB/s",
+                       "frac": round(bb["total"] / (build_ms * 1e6) / HBM_PEAK_GBPS, 4),
+                       "formula": "SURVEY.md 8(d) 'algorithmic bytes -- build' on the sizes the passes recorded (hagrid_get_build_counts)",
+                       "counts": {k: bc[k] for k in ("top_refs", "level_refs", "level_cells", "build_cells", "build_refs", "build_entries", "merge_passes", "merged_cells", "merged_refs", "flatten_entries_out")}}
         log(f"[bench] grid {grid.summary()} build_ms {build_ms:.2f} (min {min(times):.2f})")
     if multi:
         barrier(); t0 = time.perf_counter()
@@ -113,19 +167,50 @@ def main():
         barrier(); t_bcast = (time.perf_counter() - t0) * 1e3
     compressed = bool(grid.small_cells)
 
-    # ---- this rank's ray batch ---------------------------------------------------------------------------------------
-    n_rays = args.width * args.height
-    if args.rays == "primary":
-        rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, args.width, args.height, eye_dist=args.eye_dist, sample=rank, num_samples=world)
+    # ---- this rank's rays ------------------------------------------------------------------------------------------------
+    # weak: every rank traces a batch of the configuration's full size (primary: sub-pixel sample `rank` of `world` of the same
+    # camera; incoherent / bounce: its own stretch of the sequence).  strong: the ONE batch is cut into contiguous ranges.
+    if ray_kind == "incoherent":
+        total = args.total_rays or cfg.get("total", width * height)
     else:
-        rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, n_rays, scene.RAY_SEED_BASE + 4, first=rank * n_rays)
-    d_rays = mem.upload(rays)
+        total = width * height
+    if scaling == "strong":
+        first, end = scene.shard_range(total, rank, world)
+        n_rays = end - first
+        sample, nsamples = 0, 1
+    else:
+        first, n_rays = (0, total) if ray_kind != "incoherent" else (rank * total, total)
+        sample, nsamples = rank, world
+    d_rays = mem.alloc(32 * n_rays)
     d_hits = mem.alloc(16 * n_rays)
-    bin_rays = (1 if args.rays == "incoherent" else 0) if args.bin_rays is None else args.bin_rays
-    mem.set_ray_binning(bin_rays)
+    keep = min(n_rays, 1 << 20)                         # host copy of the first rays: CPU baseline + parity sample
+    t_gen = time.perf_counter()
+    if ray_kind == "incoherent":
+        gen = lambda f, c: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, c, scene.RAY_SEED_BASE + 4, first=f)
+        rays_head = upload_generated(mem, d_rays, gen, first, n_rays, keep_host=keep)
+    else:
+        gen = lambda f, c: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, first=f, count=c, eye_dist=args.eye_dist, sample=sample, num_samples=nsamples)
+        rays_head = upload_generated(mem, d_rays, gen, first, n_rays, chunk=1 << 22, keep_host=keep)
+    bin_rays = (cfg.get("bin_rays", 1 if ray_kind == "incoherent" else 0)) if args.bin_rays is None else args.bin_rays
     mem.set_option("traverse.image", args.image)
     api.setup_traversal(grid)                        # main.cpp:535; builds the traversal image (outside every timed region)
     setup_ms = api.profile(lambda: api.setup_traversal(grid), mem)
+    if ray_kind == "bounce":
+        # BASELINE config 5: diffuse-bounce rays leaving the primary hit points, in the image order of the primary rays
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
+        chunk = 1 << 22
+        kept = []
+        for off in range(0, n_rays, chunk):
+            c = min(chunk, n_rays - off)
+            prim = mem.download(d_rays + 32 * off, np.float32, 8 * c).reshape(c, 8)
+            ph = mem.download(d_hits + 16 * off, api.HIT_DTYPE, c)
+            b = scene.make_rays_bounce(tris_host, prim, ph, grid.bbox_min, grid.bbox_max, scene.RAY_SEED_BASE + 5, first=first + off)
+            mem.copy_h2d(d_rays + 32 * off, b)
+            if off < keep:
+                kept.append(b[:keep - off])
+        rays_head = np.concatenate(kept)
+    log(f"[bench] rank {rank}: {n_rays} {ray_kind} rays [{first}, {first + n_rays}) generated in {time.perf_counter() - t_gen:.1f} s")
+    mem.set_ray_binning(bin_rays)
 
     # exact algorithmic byte counters of this batch (outside the timed region)
     stats = api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n_rays)
@@ -143,52 +228,80 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0                                       # this rank's K steps; MAX over ranks below
     barrier()
+    sums = [ab["B_ray"], ab["B_walk"], stats["hits"], stats["rays_hit_grid"], n_rays, ab["B_image"]]
     if multi:
         t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_total = float(t[0]), float(t[1])
-        s = torch.tensor([ab["B_ray"], ab["B_walk"], stats["hits"], stats["rays_hit_grid"]], dtype=torch.float64, device="cuda")
+        s = torch.tensor(sums, dtype=torch.float64, device="cuda")
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        tot_bytes, tot_walk, tot_hits, tot_in = (float(v) for v in s)
-    else:
-        tot_bytes, tot_walk, tot_hits, tot_in = float(ab["B_ray"]), float(ab["B_walk"]), float(stats["hits"]), float(stats["rays_hit_grid"])
+        sums = [float(v) for v in s]
+    tot_bytes, tot_walk, tot_hits, tot_in, total_rays, tot_image = sums
 
-    hits = mem.download(d_hits, api.HIT_DTYPE, n_rays)
+    n_head = rays_head.shape[0]
+    hits = mem.download(d_hits, api.HIT_DTYPE, n_head)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        total_rays = n_rays * world
         value = total_rays / (ms_per_step * 1e3)                   # Mrays/s, whole job
-        kernel_ms = kernel_ms_total / args.steps                   # average launch duration (HIP events)
-        achieved = ab["B_ray"] / (kernel_ms * 1e6)                 # GB/s of algorithmic bytes, rank-0 kernel
-        traffic = None
+        kernel_ms = kernel_ms_total / args.steps                   # average duration of a step on the launch stream (HIP events)
+        achieved = ab["B_ray"] / (kernel_ms * 1e6)                 # GB/s of algorithmic bytes (SURVEY formula), rank-0 kernel
+        achieved_img = ab["B_image"] / (kernel_ms * 1e6)           # GB/s of the bytes the image kernel gathers for the same walk
+        peak = mem.bandwidth_probe(1 << 30, 5)                     # measured in this process: float4 copy / triad over 1 GiB arrays
+        traffic = None; traffic_source = None; l2_hit = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and world == 1 and args.rays == "primary" and not args.compress and n_tris == 1_000_000:
+        if os.path.exists(tpath) and world == 1 and args.config == 2 and args.image == 2 and n_tris == 1_000_000 and (width, height) == (1024, 1024):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate")
+                traffic_source = "profiles/traffic_latest.json: " + tj.get("source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/gpu_round.sh), FETCH x2 per the gfx950 note; NOT measured in this run")
             except Exception:
                 traffic = None
+        kernel_name = "traverse_kernel_img" if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2")
+        cells_b = grid.num_cells * (16 if compressed else 32)
+        image_b = mem.image_bytes(grid)
         out = {
             "metric": "Mrays/s (primary traversal) + grid build ms, 1M-tri scene @1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"soup-{n_tris} triangles, {args.rays} rays {args.width}x{args.height} per GPU"
-                                   f" (BASELINE.json configs[1]), td {args.top_density} sd {args.snd_density} alpha {args.alpha} exp {args.expansion}"
-                                   + (" compress" if args.compress else ""),
-                       "rays_per_gpu": n_rays, "triangles": n_tris, "ray_binning": bin_rays, "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: "flat blocks: one 32-byte record per voxel, built by setup_traversal"}[args.image], "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)", "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world}, grid broadcast once",
+            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['baseline']} -- soup-{n_tris} triangles, "
+                                   + (f"{ray_kind} rays, {total} in the batch" + (f" ({width}x{height})" if ray_kind != "incoherent" else ""))
+                                   + (f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
+                                   + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
+                       "baseline_config": args.config, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
+                       "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: "flat blocks: one 32-byte record per voxel, built by setup_traversal"}[args.image],
+                       "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)",
+                       "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),
             "grid_broadcast_ms": round(t_bcast, 3),
             "setup_traversal_ms": round(setup_ms, 3),
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "traverse_kernel_img" if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2"),
-                         "kernel_ms": round(kernel_ms, 5),
-                         "bytes_per_ray": round(ab["B_ray"] / n_rays, 1),
-                         "walk_achieved": round(ab["B_walk"] / (kernel_ms * 1e6), 1),
-                         "walk_frac": round(ab["B_walk"] / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4)},
+            "roofline": {
+                # the contract's figure: ALGORITHMIC bytes (SURVEY.md 8(d) formula on the construction format) / launch duration / HBM peak
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                # what binds according to the counters (profiles/): the working set is L2 / Infinity-Cache resident, the kernel is
+                # limited by instruction issue with partly idle wavefronts and by the line rate of the vector L1, NOT by HBM bandwidth
+                "binding_resource": "instruction issue + vector-L1 line rate (cache-resident working set); HBM itself runs at `hbm_measured`",
+                "hbm_measured": None if traffic is None else round(traffic / (kernel_ms * 1e6), 1),
+                "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
+                "l2_hit_rate": l2_hit,
+                "peak_measured": {"copy": round(peak["copy_GBps"], 1), "triad": round(peak["triad_GBps"], 1), "unit": "GB/s",
+                                  "frac_of_copy": round(achieved / max(peak["copy_GBps"], 1e-9), 4)},
+                "kernel": kernel_name, "kernel_ms": round(kernel_ms, 5),
+                "bytes_per_ray": round(ab["B_ray"] / n_rays, 1),
+                "bytes_per_ray_image": round(ab["B_image"] / n_rays, 1),
+                "achieved_image": round(achieved_img, 1), "frac_image": round(achieved_img / HBM_PEAK_GBPS, 4),
+                "walk_achieved": round(ab["B_walk"] / (kernel_ms * 1e6), 1),
+                "walk_frac": round(ab["B_walk"] / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
+                "walk_target": 0.40,
+                "walk_achieved_image": round(ab["B_image_walk"] / (kernel_ms * 1e6), 1)},
+            "roofline_build": build_block,
+            "memory": {"cells": cells_b, "entries": 4 * grid.num_entries, "refs": 4 * grid.num_refs, "tris": 48 * n_tris,
+                       "traversal_image": image_b, "rays": 32 * n_rays, "hits": 16 * n_rays, "pool_now": mem.usage(), "pool_peak": mem.max_usage(),
+                       "unit": "bytes", "reference": "main.cpp:523-533"},
         }
         # ---- CPU baseline + parity check: the oracle on the SAME grid, rank 0, N = 1 only ---------------------------------
         if world == 1 and not args.no_cpu_baseline:
@@ -196,19 +309,29 @@ def main():
             d = grid.download()
             G = O.Grid.from_arrays(d["entries"], d["ref_ids"], d["cells"], d["small_cells"], d["bbox_min"], d["bbox_max"], d["dims"], d["shift"], d["offsets"])
             cores = os.cpu_count() or 1
-            tris_h = scene.make_soup(n_tris)
-            probe = min(65536, n_rays)
-            t0 = time.perf_counter(); oh, _ = G.traverse(tris_h, rays[:probe], nthreads=cores); t_probe = time.perf_counter() - t0
-            sample = int(min(n_rays, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
-            t0 = time.perf_counter(); oh, _ = G.traverse(tris_h, rays[:sample], nthreads=cores); t_cpu = time.perf_counter() - t0
+            probe = min(65536, n_head)
+            t0 = time.perf_counter(); oh, _ = G.traverse(tris_host, rays_head[:probe], nthreads=cores); t_probe = time.perf_counter() - t0
+            sample_n = int(min(n_head, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
+            t0 = time.perf_counter(); oh, _ = G.traverse(tris_host, rays_head[:sample_n], nthreads=cores); t_cpu = time.perf_counter() - t0
             reps = 1
-            while t_cpu < 0.5 * args.cpu_seconds and reps < 512:        # the whole batch is too small: repeat it
-                t0 = time.perf_counter(); G.traverse(tris_h, rays[:sample], nthreads=cores); t_cpu += time.perf_counter() - t0; reps += 1
-            same_id = bool((hits["id"][:sample] == oh["id"]).all())
-            same_t = bool((hits["t"][:sample].view(np.uint32) == oh["t"].view(np.uint32)).all())
-            out["cpu_baseline"] = {"value": round(sample * reps / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "sample": f"first {sample} rays of the batch x{reps}, oracle traversal of the GPU-built grid, {cores} threads"}
-            out["parity"] = {"rays_checked": sample, "ids_identical": same_id, "t_bit_identical": same_t}
+            while t_cpu < 0.5 * args.cpu_seconds and reps < 512:        # the whole sample is too small: repeat it
+                t0 = time.perf_counter(); G.traverse(tris_host, rays_head[:sample_n], nthreads=cores); t_cpu += time.perf_counter() - t0; reps += 1
+            same_id = bool((hits["id"][:sample_n] == oh["id"]).all())
+            same_t = bool((hits["t"][:sample_n].view(np.uint32) == oh["t"].view(np.uint32)).all())
+            # one thread: a bounded slice of the same rays (about a third of the all-cores budget)
+            one_n = int(min(sample_n, 16384))
+            t0 = time.perf_counter(); G.traverse(tris_host, rays_head[:one_n], nthreads=1); t1 = time.perf_counter() - t0
+            one_n = int(min(sample_n, max(one_n, one_n * 0.3 * args.cpu_seconds / max(t1, 1e-6))))
+            t0 = time.perf_counter(); G.traverse(tris_host, rays_head[:one_n], nthreads=1); t1 = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(sample_n * reps / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {sample_n} rays of the batch x{reps}, oracle traversal of the GPU-built grid, {cores} threads",
+                                   "single_thread": {"value": round(one_n / t1 / 1e6, 4), "unit": "Mrays/s", "cores": 1, "sample": f"first {one_n} rays of the batch"}}
+            if n_tris <= 1_000_000:      # CPU construction of the same grid, one core (the oracle's passes are scalar)
+                t0 = time.perf_counter()
+                Gc = O.Grid.full(tris_host, top_density, snd_density, args.alpha, expansion, compress)
+                out["cpu_baseline"]["cpu_build_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                out["cpu_baseline"]["cpu_build_matches_gpu"] = bool(Gc.summary() == grid.summary())
+            out["parity"] = {"rays_checked": sample_n, "ids_identical": same_id, "t_bit_identical": same_t}
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

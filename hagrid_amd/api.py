@@ -124,6 +124,24 @@ class MemManager:
     def debug_slots(self):
         self._L.hagrid_mem_debug_slots(self._ctx)
 
+    def bandwidth_probe(self, nbytes: int = 1 << 30, iters: int = 5) -> dict:
+        """Measured device copy / triad bandwidth in GB/s (SURVEY.md 8(d) BW_peak, 'measured in the same run')."""
+        c = C.c_float(); t = C.c_float()
+        _check(self, self._L.hagrid_bandwidth_probe(self._ctx, int(nbytes), int(iters), C.byref(c), C.byref(t)), "bandwidth_probe")
+        return {"copy_GBps": float(c.value), "triad_GBps": float(t.value)}
+
+    def image_bytes(self, grid: "Grid") -> int:
+        """Size of the traversal image this manager holds for `grid` (0 when it holds none)."""
+        b = C.c_int64(0)
+        rc = self._L.hagrid_kat_image_records(self._ctx, C.byref(grid.pod), None, 0, None, C.byref(b))
+        return int(b.value) if rc == 0 else 0
+
+    def build_counts(self) -> dict:
+        """Sizes the construction passes of this manager went through since its last build_grid."""
+        bc = _lib.BuildCounts()
+        _check(self, self._L.hagrid_get_build_counts(self._ctx, C.byref(bc)), "get_build_counts")
+        return bc.as_dict()
+
     # -- conveniences ----------------------------------------------------------------------------------
     def upload(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr)
@@ -273,14 +291,40 @@ def profile(fn, mem: MemManager | None = None) -> float:
     return float(ms)
 
 
+def build_algorithmic_bytes(bc: dict) -> dict:
+    """Compulsory HBM traffic of the construction per stage, SURVEY.md 8(d) "algorithmic bytes -- build", from the sizes the
+    passes recorded (MemManager.build_counts): N triangles, R0 top-level references, R_l / C_l / split_l per level, C / R / E."""
+    N, R0 = bc["num_tris"], bc["top_refs"]
+    build = (48 * N + 32 * N + 32 * N) + (32 * N + 8 * R0) + (R0 * (8 + 48 + 32) + 8 * R0)          # bboxes, emit, filter
+    L = bc["num_levels"]
+    for l in range(L):
+        R_l, C_l = bc["level_refs"][l], bc["level_cells"][l]
+        split_l = R_l - bc["level_kept"][l] if l + 1 < L else 0
+        R_next = bc["level_refs"][l + 1] if l + 1 < L else 0
+        C_next = bc["level_cells"][l + 1] if l + 1 < L else 0
+        build += R_l * (12 + 8) + split_l * (8 + 48 + 32) + 8 * R_next + 32 * C_next + 2 * 4 * C_l
+    R, Cc, E = bc["build_refs"], bc["build_cells"], bc["build_entries"]
+    build += (8 * R + 8 * R + 32 * Cc + 4 * E) + 2 * 16 * R                                        # concat, sort
+    merge = sum(c * (32 + 32) + r * (4 + 4) + 2 * 4 * E + 5 * 4 * c for c, r in zip(bc["merge_cells"], bc["merge_refs"]))
+    flatten = 4 * bc["flatten_entries_in"] + 4 * bc["flatten_entries_out"]
+    expand = bc["expand_passes"] * bc["expand_cells"] * (32 + 32)
+    compress = (32 * bc["compress_cells"] + 16 * bc["compress_cells"] + 8 * bc["compress_refs_out"]) if bc["compressed"] else 0
+    out = {"build": int(build), "merge": int(merge), "flatten": int(flatten), "expand": int(expand), "compress": int(compress)}
+    out["total"] = sum(out.values())
+    return out
+
+
 def algorithmic_bytes(stats: dict, compressed: bool) -> dict:
     """DESIGN.md / BASELINE.md section 4: bytes the algorithm must touch for a batch, from exact counters."""
     s_cell = 16 if compressed else 32
     walk = 4 * stats["entry_words"] + s_cell * stats["cells"]
     total = 48 * stats["rays"] + walk + 52 * stats["refs"] + 4 * stats["sentinels"]
-    return {"B_ray": int(total), "B_walk": int(walk)}
+    # what the traversal-image kernel gathers for the same walk: one 32-byte record per visited cell (bounds + list length +
+    # up to four ids inline), a 48-byte triangle per test, and a 4-byte id only for lists of more than four
+    image = 48 * stats["rays"] + 32 * stats["cells"] + 48 * stats["refs"] + 4 * stats.get("long_list_refs", 0)
+    return {"B_ray": int(total), "B_walk": int(walk), "B_image": int(image), "B_image_walk": int(32 * stats["cells"])}
 
 
 __all__ = ["MemManager", "Grid", "build_grid", "merge_grid", "flatten_grid", "expand_grid", "compress_grid", "build_all",
-           "setup_traversal", "traverse_grid", "traverse_grid_stats", "profile", "algorithmic_bytes", "HagridError",
+           "setup_traversal", "traverse_grid", "traverse_grid_stats", "profile", "algorithmic_bytes", "build_algorithmic_bytes", "HagridError",
            "HIT_DTYPE", "CELL_DTYPE", "SMALL_CELL_DTYPE"]

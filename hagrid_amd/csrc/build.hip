@@ -21,6 +21,7 @@
 #include "hagrid/grid.h"
 #include "hagrid/prims.h"
 
+#include <cstring>
 #include <vector>
 
 using namespace hagrid;
@@ -438,14 +439,7 @@ struct Level {
     int* start_cell = nullptr; int* ref_begin = nullptr;
 };
 
-struct Temps {           // pool buffers released on every exit path
-    hagrid_ctx* ctx;
-    std::vector<void*> ptrs;
-    explicit Temps(hagrid_ctx* c) : ctx(c) {}
-    template <typename T> T* get(size_t n) { T* p = pool_alloc<T>(ctx, n); if (p) ptrs.push_back(p); return p; }
-    void drop(void* p) { for (auto& q : ptrs) if (q == p) { hagrid_mem_free(ctx, p); q = nullptr; } }
-    ~Temps() { for (void* p : ptrs) if (p) hagrid_mem_free(ctx, p); }
-};
+using Temps = PoolTemps;
 
 } // namespace
 
@@ -502,6 +496,9 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     k.shift = shift;
     k.cell_size = gb.extents() / vec3(dims << shift);
     tmp.drop(counts); tmp.drop(refs_per_cell);
+    hagrid_build_counts& bc = ctx->counts;
+    memset(&bc, 0, sizeof(bc));
+    bc.num_tris = num_tris; bc.top_cells = num_top; bc.top_refs = R0;
 
     std::vector<Level> levels;
     {
@@ -536,6 +533,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         int h3[3];
         HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
         const int num_new_cells = h3[0], num_children = h3[1];
+        if (level < HAGRID_MAX_LEVELS) { bc.level_refs[level] = L.num_refs; bc.level_cells[level] = L.num_cells; bc.level_kept[level] = h3[2]; bc.num_levels = level + 1; }
         tmp.drop(part);
         if (num_new_cells == 0) { tmp.drop(masks); break; }              // build.cu:583-587
         if (num_new_cells < 0 || num_children < 0 || num_children > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: level too large");
@@ -595,8 +593,12 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
                                                                                   L.ref_begin, out_refs);
     }
     sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs);
-    HG_HIP(ctx, hipGetLastError());
-    HG_HIP(ctx, hipStreamSynchronize(st));      // temporaries are released below
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // temporaries are released below
+    if (e != hipSuccess) {
+        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
+        HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e));
+    }
 
     memset(grid, 0, sizeof(*grid));
     grid->entries = out_entries; grid->ref_ids = out_refs; grid->cells = out_cells; grid->small_cells = nullptr;
@@ -604,6 +606,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     grid->bbox_max[0] = gb.max.x; grid->bbox_max[1] = gb.max.y; grid->bbox_max[2] = gb.max.z;
     grid->dims[0] = dims.x; grid->dims[1] = dims.y; grid->dims[2] = dims.z;
     grid->num_cells = new_total_cells; grid->num_entries = total_cells; grid->num_refs = total_refs;
+    bc.build_cells = new_total_cells; bc.build_entries = total_cells; bc.build_refs = total_refs;
     grid->shift = shift;                         // the cell-coordinate shift
     grid->num_offsets = shift + 1;
     for (int i = 0, off = 0; i <= shift; i++) {  // build.cu:711-715, padded when the deepest level is empty

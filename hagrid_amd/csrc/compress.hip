@@ -68,8 +68,9 @@ extern "C" int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     scan_apply<int, SentinelIn, SmallCellOut><<<std::max(scan_num_tiles(n), 1), kBlock, 0, st>>>(
         SentinelIn{cells}, SmallCellOut{cells, static_cast<const int*>(grid->ref_ids), small, srefs}, n, partials);
     hipError_t e = hipGetLastError();
-    HG_HIP(ctx, hipStreamSynchronize(st));
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     hagrid_mem_free(ctx, partials);
+    ctx->counts.compressed = 1; ctx->counts.compress_cells = n; ctx->counts.compress_refs_out = h;
     if (e != hipSuccess) { hagrid_mem_free(ctx, small); hagrid_mem_free(ctx, srefs); HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e)); }
     hagrid_mem_free(ctx, grid->cells);          // compress.cu:55-60
     hagrid_mem_free(ctx, grid->ref_ids);

@@ -84,6 +84,7 @@ struct hagrid_ctx {
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
     hagrid_impl::TravImageCache image;
+    hagrid_build_counts counts = {};      // sizes of the last construction (hagrid_get_build_counts)
 
     std::string err;
 };
@@ -116,6 +117,19 @@ template <typename T>
 inline T* pool_alloc(hagrid_ctx* ctx, size_t n) {
     return static_cast<T*>(hagrid_mem_alloc(ctx, (n ? n : 1) * sizeof(T)));
 }
+
+// Pool buffers that are released on every exit path of a pass.
+struct PoolTemps {
+    hagrid_ctx* ctx;
+    std::vector<void*> ptrs;
+    explicit PoolTemps(hagrid_ctx* c) : ctx(c) {}
+    PoolTemps(const PoolTemps&) = delete;
+    PoolTemps& operator=(const PoolTemps&) = delete;
+    template <typename T> T* get(size_t n) { T* p = pool_alloc<T>(ctx, n); if (p) ptrs.push_back(p); return p; }
+    void drop(void* p) { for (auto& q : ptrs) if (q == p && p) { hagrid_mem_free(ctx, p); q = nullptr; } }
+    void* keep(void* p) { for (auto& q : ptrs) if (q == p) q = nullptr; return p; }       // ownership passes to the caller
+    ~PoolTemps() { for (void* p : ptrs) if (p) hagrid_mem_free(ctx, p); }
+};
 
 // Reads `count` ints from device memory into host memory after draining the stream.
 int read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes);

@@ -53,7 +53,19 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
 
 extern "C" int hagrid_ctx_set_stream(hagrid_ctx* ctx, void* stream) {
     if (!ctx) return HAGRID_EINVAL;
-    ctx->stream = static_cast<hipStream_t>(stream);
+    hipStream_t next = static_cast<hipStream_t>(stream);
+    if (next == ctx->stream) return HAGRID_OK;
+    // Pool slots freed in keep mode, the device scratch words and the look-back status words are re-used under the
+    // assumption that all work of a context is ordered by ONE stream: drain the old stream before switching.
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = next;
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_get_build_counts(const hagrid_ctx* ctx, hagrid_build_counts* out) {
+    if (!ctx || !out) return HAGRID_EINVAL;
+    *out = ctx->counts;
     return HAGRID_OK;
 }
 
@@ -158,6 +170,7 @@ extern "C" int hagrid_mem_copy_d2d(hagrid_ctx* ctx, void* dst, const void* src, 
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
     trav_image_source_touched(ctx, dst, bytes);
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return HAGRID_OK;
 }
@@ -165,6 +178,7 @@ extern "C" int hagrid_mem_zero(hagrid_ctx* ctx, void* ptr, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
     trav_image_source_touched(ctx, ptr, bytes);
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
     return HAGRID_OK;
 }
@@ -172,6 +186,7 @@ extern "C" int hagrid_mem_one(hagrid_ctx* ctx, void* ptr, size_t bytes) {
     if (!ctx) return HAGRID_EINVAL;
     if (!bytes) return HAGRID_OK;
     trav_image_source_touched(ctx, ptr, bytes);
+    HG_HIP(ctx, hipSetDevice(ctx->device));
     HG_HIP(ctx, hipMemsetAsync(ptr, 0xFF, bytes, ctx->stream));
     return HAGRID_OK;
 }
@@ -204,6 +219,49 @@ extern "C" float hagrid_profile_end(hagrid_ctx* ctx) {
     if (hipEventSynchronize(ctx->ev_end) != hipSuccess) return -1.0f;
     if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) return -1.0f;
     return ms;
+}
+
+// ---- measured bandwidth peak (SURVEY.md 8(d) "BW_peak": a device copy / triad figure from the same run) ---------------------
+namespace {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) bw_copy_kernel(const f32x4_t* __restrict__ a, f32x4_t* __restrict__ c, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) c[i] = a[i];
+}
+__global__ void __launch_bounds__(256) bw_triad_kernel(const f32x4_t* __restrict__ a, const f32x4_t* __restrict__ b, f32x4_t* __restrict__ c, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) c[i] = a[i] + 3.0f * b[i];
+}
+} // namespace
+
+extern "C" int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, float* copy_gbps, float* triad_gbps) {
+    if (!ctx || iters <= 0 || bytes < (size_t(1) << 20)) return HAGRID_EINVAL;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = bytes / 16;
+    f32x4_t* a = pool_alloc<f32x4_t>(ctx, n);
+    f32x4_t* b = pool_alloc<f32x4_t>(ctx, n);
+    f32x4_t* c = pool_alloc<f32x4_t>(ctx, n);
+    int rc = HAGRID_OK;
+    if (!a || !b || !c) rc = HAGRID_ENOMEM;
+    if (rc == HAGRID_OK) {
+        (void)hipMemsetAsync(a, 0, n * 16, ctx->stream); (void)hipMemsetAsync(b, 0, n * 16, ctx->stream);
+        const int blocks = ctx->num_cus * 16;
+        float best_copy = 0.0f, best_triad = 0.0f;
+        for (int it = 0; it < iters + 1 && rc == HAGRID_OK; it++) {           // the first round is a warm-up
+            float ms = -1.0f;
+            if (hagrid_profile_begin(ctx) != HAGRID_OK) { rc = HAGRID_EHIP; break; }
+            bw_copy_kernel<<<blocks, 256, 0, ctx->stream>>>(a, c, n);
+            ms = hagrid_profile_end(ctx);
+            if (ms > 0.0f && it) best_copy = std::max(best_copy, float(2.0 * double(n) * 16.0 / (double(ms) * 1e6)));
+            if (hagrid_profile_begin(ctx) != HAGRID_OK) { rc = HAGRID_EHIP; break; }
+            bw_triad_kernel<<<blocks, 256, 0, ctx->stream>>>(a, b, c, n);
+            ms = hagrid_profile_end(ctx);
+            if (ms > 0.0f && it) best_triad = std::max(best_triad, float(3.0 * double(n) * 16.0 / (double(ms) * 1e6)));
+        }
+        if (copy_gbps) *copy_gbps = best_copy;
+        if (triad_gbps) *triad_gbps = best_triad;
+        if (hipGetLastError() != hipSuccess) rc = HAGRID_EHIP;
+    }
+    hagrid_mem_free(ctx, a); hagrid_mem_free(ctx, b); hagrid_mem_free(ctx, c);
+    return rc;
 }
 
 unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int words_per_tile, unsigned* epoch) {

@@ -249,14 +249,14 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     Cell* other = pool_alloc<Cell>(ctx, size_t(n));
     int* flags = pool_alloc<int>(ctx, size_t(n));
     if (!other || !flags) { hagrid_mem_free(ctx, other); hagrid_mem_free(ctx, flags); return HAGRID_ENOMEM; }
-    HG_HIP(ctx, hipMemsetAsync(flags, 0xFF, size_t(n) * sizeof(int), st));              // expand.cu:206
+    (void)hipMemsetAsync(flags, 0xFF, size_t(n) * sizeof(int), st);                     // expand.cu:206 (errors surface at the final check)
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
     int* list = iters > 1 && ctx->opt_expand_listed ? pool_alloc<int>(ctx, size_t(n)) : nullptr;
     int* counts = ctx->dscratch + 160;             // one list length per listed pass
     const int max_listed = 48;
-    if (list) HG_HIP(ctx, hipMemsetAsync(counts, 0, max_listed * sizeof(int), st));
+    if (list) (void)hipMemsetAsync(counts, 0, max_listed * sizeof(int), st);
     int listed = 0;
     for (int it = 0; it < iters; it++) {                                               // expansion_iter, expand.cu:184-197
         if (it > 0 && list && listed + 3 <= max_listed) {
@@ -282,7 +282,8 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
         }
     }
     hipError_t e = hipGetLastError();
-    HG_HIP(ctx, hipStreamSynchronize(st));
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    ctx->counts.expand_passes = 3 * iters; ctx->counts.expand_cells = n;
     hagrid_mem_free(ctx, flags);
     hagrid_mem_free(ctx, other);
     hagrid_mem_free(ctx, list);

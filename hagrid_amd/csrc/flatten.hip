@@ -138,10 +138,11 @@ extern "C" int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     }
     new_offsets[num_new++] = total_entries;
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { release(); hagrid_mem_free(ctx, out); HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e)); }
-    HG_HIP(ctx, hipStreamSynchronize(st));
     release();
     hagrid_mem_free(ctx, entries);               // flatten.cu:168-170
+    ctx->counts.flatten_entries_in = num_entries; ctx->counts.flatten_entries_out = total_entries;
     grid->entries = out;
     grid->num_entries = total_entries;
     grid->num_offsets = num_new;

@@ -201,6 +201,8 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     if (!ctx || !grid) return HAGRID_EINVAL;
     trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     if (!grid->cells || !grid->entries || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "merge_grid: incomplete (or compressed) grid");
+    ctx->counts.merge_passes = 0;
+    ctx->counts.merged_cells = grid->num_cells; ctx->counts.merged_refs = grid->num_refs;
     if (!(alpha > 0)) return HAGRID_OK;
     HG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -246,11 +248,11 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
         // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
         // read the real one.  One host round trip per iteration instead of three.
-        Int2* totals[2] = { total, total + 1 };
+        const bool chain = ctx->opt_merge_chain != 0;
         for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
             const int blocks = grid_blocks(num_cells, kBlock);
-            Int2* tot = totals[axis & 1];
-            const int* n_dev = axis ? &totals[(axis - 1) & 1]->a : nullptr;
+            Int2* tot = total + axis;
+            const int* n_dev = (chain && axis) ? &total[axis - 1].a : nullptr;
             (void)hipMemsetAsync(prevs, 0xFF, size_t(num_cells) * sizeof(int), st);
             merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells, n_dev);
             cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells, n_dev);
@@ -260,12 +262,17 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries);
             std::swap(cells, cells_b);
             std::swap(refs, refs_b);
-            if (axis == 2 || !ctx->opt_merge_chain) {
-                int h[2];
-                rc = read_back(ctx, tot, h, sizeof(h));
+            if (axis == 2 || !chain) {
+                int h[6];
+                rc = read_back(ctx, total, h, sizeof(int) * 2 * size_t(axis + 1));
                 if (rc != HAGRID_OK) break;
-                num_cells = h[0]; num_refs = h[1];
-                if (axis < 2) { totals[0] = total; totals[1] = total + 1; }
+                hagrid_build_counts& bc = ctx->counts;                     // sizes that entered the passes (diagnostics)
+                auto record = [&](int c, int r) {
+                    if (bc.merge_passes < HAGRID_MAX_MERGE_PASSES) { bc.merge_cells[bc.merge_passes] = c; bc.merge_refs[bc.merge_passes] = r; bc.merge_passes++; }
+                };
+                record(num_cells, num_refs);
+                if (chain) { record(h[0], h[1]); record(h[2], h[3]); }
+                num_cells = h[2 * axis]; num_refs = h[2 * axis + 1];
             }
         }
         iter++;
@@ -280,5 +287,6 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     hagrid_mem_free(ctx, refs_b);
     grid->cells = cells; grid->ref_ids = refs;
     grid->num_cells = num_cells; grid->num_refs = num_refs;
+    ctx->counts.merged_cells = num_cells; ctx->counts.merged_refs = num_refs;
     return rc;
 }

@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
 
     // The voxels that name one cell form a box (the cell before expand_grid stretched its bounds; the voxel map is not
     // touched by the expansion).  Its representative is the lowest corner of that box inside this block, found by walking
-    // the runs of equal ids down x, then y, then z.  Whatever the shape, the representative names the same cell as the
-    // voxel, so a region that is not a box only costs duplicate records.
+    // the runs of equal ids down x, then y, then z until nothing moves: the walk ends on a voxel that is its own representative
+    // and names the same cell as the voxel it started from, so a region that is not a box (hand-made voxel maps) only costs
+    // duplicate records.
     int count = 0;
     #pragma unroll
     for (int p = 0; p < P; p++) {
@@ -125,9 +126,13 @@ __global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restri
             if (((fx | fy | fz) & ((1 << sd) - 1)) == 0) {                           // a voxel of depth d
                 const int step = 1 << sd, c = cell[p];
                 int x = fx, y = fy, z = fz;
-                while (x > 0 && ids[(x - step) + (y << SHIFT) + (z << (2 * SHIFT))] == c) x -= step;
-                while (y > 0 && ids[x + ((y - step) << SHIFT) + (z << (2 * SHIFT))] == c) y -= step;
-                while (z > 0 && ids[x + (y << SHIFT) + ((z - step) << (2 * SHIFT))] == c) z -= step;
+                for (;;) {                                        // to a fixed point: a voxel with no equal neighbour below it on any axis
+                    const int x0 = x, y0 = y, z0 = z;
+                    while (x > 0 && ids[(x - step) + (y << SHIFT) + (z << (2 * SHIFT))] == c) x -= step;
+                    while (y > 0 && ids[x + ((y - step) << SHIFT) + (z << (2 * SHIFT))] == c) y -= step;
+                    while (z > 0 && ids[x + (y << SHIFT) + ((z - step) << (2 * SHIFT))] == c) z -= step;
+                    if (x == x0 && y == y0 && z == z0) break;
+                }
                 rep[p] = x + (y << SHIFT) + (z << (2 * SHIFT));
                 is_rep = rep[p] == f;
             }

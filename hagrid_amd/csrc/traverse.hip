@@ -32,7 +32,7 @@ struct TraverseArgs {
     const float4* __restrict__ rays;
     float4* __restrict__ hits;
     int* __restrict__ steps;                 // optional per-ray step counter
-    unsigned long long* __restrict__ stats;  // optional 7 batch counters
+    unsigned long long* __restrict__ stats;  // optional 8 batch counters
     const int* __restrict__ perm;            // optional traversal order (ray binning): slot i processes ray perm[i]
     const int* __restrict__ perm_flag;       // optional, device: 0 = ignore perm (automatic binning decided against it)
     const int* __restrict__ row_len;         // optional, device: row length found by detect_ray_rows (0 = none)
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
 
     Hit hit(-1, tmax, 0.0f, 0.0f);
     int steps = 0;
-    unsigned n_cells = 0, n_words = 0, n_refs = 0, n_sent = 0;
+    unsigned n_cells = 0, n_words = 0, n_refs = 0, n_sent = 0, n_long = 0;
 
     if (!(tstart > tend)) {
         const vec3 fv = (tstart * dir + org - gmin) * ginv;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
                         ref = next;
                     }
                     consumed = cur - c.begin;
-                    if (STATS) { n_refs += unsigned(consumed - 1); n_sent++; }
+                    if (STATS) { n_refs += unsigned(consumed - 1); n_sent++; if (consumed - 1 > 4) n_long += unsigned(consumed - 1); }
                 }
             } else {
                 int cur = c.begin;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
                     ref = next;
                 }
                 consumed = c.end - c.begin;
-                if (STATS) n_refs += unsigned(consumed);
+                if (STATS) { n_refs += unsigned(consumed); if (consumed > 4) n_long += unsigned(consumed); }
             }
             steps += 1 + consumed;
             if (STATS) n_cells++;
@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
             atomicAdd(a.stats + 4, (unsigned long long)n_refs);
             atomicAdd(a.stats + 5, (unsigned long long)n_sent);
             atomicAdd(a.stats + 6, (unsigned long long)(hit.id >= 0));
+            atomicAdd(a.stats + 7, (unsigned long long)n_long);
         }
     }
 }
@@ -1118,21 +1119,18 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
     HG_HIP(ctx, hipSetDevice(ctx->device));
+    // binning buffers: released on every exit path.  The pool hands them to nobody else before the kernels below are done: in
+    // keep mode free() only marks the slot (work of one context is stream-ordered), otherwise free() synchronises the stream first
+    PoolTemps tmp(ctx);
     int* perm = nullptr;
-    unsigned short* bin_keys = nullptr;
-    int* bin_table = nullptr;
-    int* bin_partials = nullptr;
     if (ctx->ray_binning && num_rays > kBinTile) {
         const int tiles = grid_blocks(num_rays, kBinTile);
         const int table_n = kBins * tiles;
-        perm = pool_alloc<int>(ctx, size_t(num_rays));
-        bin_keys = pool_alloc<unsigned short>(ctx, size_t(num_rays));
-        bin_table = pool_alloc<int>(ctx, size_t(table_n));
-        bin_partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(table_n)) + 1);
-        if (!perm || !bin_keys || !bin_table || !bin_partials) {
-            hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
-            return HAGRID_ENOMEM;
-        }
+        perm = tmp.get<int>(size_t(num_rays));
+        unsigned short* bin_keys = tmp.get<unsigned short>(size_t(num_rays));
+        int* bin_table = tmp.get<int>(size_t(table_n));
+        int* bin_partials = tmp.get<int>(size_t(scan_num_tiles(table_n)) + 1);
+        if (!perm || !bin_keys || !bin_table || !bin_partials) return HAGRID_ENOMEM;
         if (ctx->ray_binning == 2) {
             // automatic: everything is decided on the device, nobody waits.  row length (image-ordered batches are left to the
             // tile packets) -> keys + coherence estimate -> scan -> decision -> scatter; the traversal kernel reads the decision.
@@ -1225,11 +1223,6 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
     }
     HG_HIP(ctx, hipGetLastError());
-    if (perm) {
-        // the pool hands these buffers to nobody else before the kernels above are done: in keep mode free() only marks
-        // the slot (work of one context is stream-ordered), without keep mode free() synchronises the stream first
-        hagrid_mem_free(ctx, perm); hagrid_mem_free(ctx, bin_keys); hagrid_mem_free(ctx, bin_table); hagrid_mem_free(ctx, bin_partials);
-    }
     return HAGRID_OK;
 }
 
@@ -1286,7 +1279,7 @@ extern "C" int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* gr
         HG_TRY(read_back(ctx, dstats, h, sizeof(h)));
         stats->rays = (int64_t)h[0]; stats->rays_hit_grid = (int64_t)h[1]; stats->cells = (int64_t)h[2];
         stats->entry_words = (int64_t)h[3]; stats->refs = (int64_t)h[4]; stats->sentinels = (int64_t)h[5];
-        stats->hits = (int64_t)h[6];
+        stats->hits = (int64_t)h[6]; stats->long_list_refs = (int64_t)h[7];
         hagrid_mem_free(ctx, dstats);
     } else {
         HG_HIP(ctx, hipStreamSynchronize(ctx->stream));

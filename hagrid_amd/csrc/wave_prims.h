@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 namespace hagrid_impl {
 
 constexpr int kBlock = 256;
@@ -188,8 +190,11 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
 // aggregates / inclusive prefixes (64 at a time, one per lane of wavefront 0), publishes its own inclusive prefix and scans
 // its items from registers.  A status word carries (epoch, flag, 32-bit value) and is written / read with one agent-scope
 // 64-bit atomic, so it is valid across the 8 L2s; the epoch makes last call's words invalid without clearing the array.
-// Tiles are taken in blockIdx order: workgroups are dispatched in increasing order on every XCD, so the lowest unfinished
-// tile is always resident and the spin below cannot starve it.
+// Forward progress does not depend on the dispatch order of workgroups: the launch has at most kLbBlocksPerCu workgroups per
+// CU -- fewer than the part keeps resident of this kernel, so all of them run concurrently -- and workgroup b owns the tiles
+// b, b + G, b + 2G, ... in increasing order.  The lowest unfinished tile therefore always belongs to a running workgroup that
+// has nothing left to wait for.
+constexpr int kLbBlocksPerCu = 4;
 constexpr unsigned kLbAggregate = 1u, kLbPrefix = 2u;
 
 __device__ __forceinline__ unsigned long long lb_pack(unsigned epoch, unsigned flag, int value) {
@@ -227,70 +232,74 @@ __device__ __forceinline__ unsigned lb_wait(const unsigned long long* state, int
 template <typename V> constexpr int lb_words() { return int(sizeof(V) / sizeof(int)); }
 
 template <typename V, typename In, typename Out>
-__global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
+__global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
     __shared__ V lds[kWaves];
     __shared__ V tile_prefix;
-    const int tile = blockIdx.x, base = tile * kScanTile;
-    V v[kScanItems];
-    V sum = zero_of(V());
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int base = tile * kScanTile;
+        V v[kScanItems];
+        V sum = zero_of(V());
 #pragma unroll
-    for (int j = 0; j < kScanItems; j++) {
-        const int i = base + j * kBlock + threadIdx.x;
-        v[j] = i < n ? in(i) : zero_of(V());
-        sum = sum + v[j];
-    }
-    const V wsum = wave_inclusive_scan(sum);
-    if (lane_id() == 63) lds[wave_id()] = wsum;
-    __syncthreads();
-    if (wave_id() == 0) {
-        V agg = lds[0];
-        for (int w = 1; w < kWaves; w++) agg = agg + lds[w];
-        V excl = zero_of(V());
-        if (tile == 0) {
-            if (carry_in) excl = *carry_in;
-        } else {
-            if (lane_id() == 0) lb_publish(state, tile, epoch, kLbAggregate, agg);
-            int p = tile - 1;
-            for (;;) {
-                const int t = p - lane_id();
-                V pv = zero_of(V());
-                unsigned flag = kLbPrefix;                           // lanes before tile 0 end the search with a zero
-                if (t >= 0) flag = lb_wait(state, t, epoch, pv);
-                const unsigned long long is_prefix = __ballot(flag == kLbPrefix);
-                const int first = __ffsll((long long)is_prefix) - 1;                 // nearest predecessor with an inclusive prefix
-                if (first < 0 || lane_id() <= first) excl = excl + pv;
-                if (first >= 0) break;
-                p -= 64;
+        for (int j = 0; j < kScanItems; j++) {
+            const int i = base + j * kBlock + threadIdx.x;
+            v[j] = i < n ? in(i) : zero_of(V());
+            sum = sum + v[j];
+        }
+        const V wsum = wave_inclusive_scan(sum);
+        __syncthreads();                                                 // the previous tile's readers of lds / tile_prefix are done
+        if (lane_id() == 63) lds[wave_id()] = wsum;
+        __syncthreads();
+        if (wave_id() == 0) {
+            V agg = lds[0];
+            for (int w = 1; w < kWaves; w++) agg = agg + lds[w];
+            V excl = zero_of(V());
+            if (tile == 0) {
+                if (carry_in) excl = *carry_in;
+            } else {
+                if (lane_id() == 0) lb_publish(state, tile, epoch, kLbAggregate, agg);
+                int p = tile - 1;
+                for (;;) {
+                    const int t = p - lane_id();
+                    V pv = zero_of(V());
+                    unsigned flag = kLbPrefix;                           // lanes before tile 0 end the search with a zero
+                    if (t >= 0) flag = lb_wait(state, t, epoch, pv);
+                    const unsigned long long is_prefix = __ballot(flag == kLbPrefix);
+                    const int first = __ffsll((long long)is_prefix) - 1;                 // nearest predecessor with an inclusive prefix
+                    if (first < 0 || lane_id() <= first) excl = excl + pv;
+                    if (first >= 0) break;
+                    p -= 64;
+                }
+                // sum over the lanes
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) excl = excl + V(shfl_xor_v(excl, d));
             }
-            // sum over the lanes
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) excl = excl + V(shfl_xor_v(excl, d));
+            if (lane_id() == 0) {
+                lb_publish(state, tile, epoch, kLbPrefix, excl + agg);
+                tile_prefix = excl;
+                if (total_out && tile == tiles - 1) *total_out = excl + agg;
+            }
         }
-        if (lane_id() == 0) {
-            lb_publish(state, tile, epoch, kLbPrefix, excl + agg);
-            tile_prefix = excl;
-            if (total_out && tile == int(gridDim.x) - 1) *total_out = excl + agg;
+        __syncthreads();
+        V running = tile_prefix;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            const int i = base + j * kBlock + threadIdx.x;
+            if (base + j * kBlock >= n) break;
+            const V incl = wave_inclusive_scan(v[j]);
+            __syncthreads();
+            if (lane_id() == 63) lds[wave_id()] = incl;
+            __syncthreads();
+            V excl = running;
+            for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
+            const V prev = shfl_up_v(incl, 1);
+            if (lane_id() > 0) excl = excl + prev;
+            if (i < n) out(i, excl);
+            V t = running;
+            for (int w = 0; w < kWaves; w++) t = t + lds[w];
+            running = t;
         }
     }
-    __syncthreads();
-    V running = tile_prefix;
-#pragma unroll
-    for (int j = 0; j < kScanItems; j++) {
-        const int i = base + j * kBlock + threadIdx.x;
-        if (base + j * kBlock >= n) break;
-        const V incl = wave_inclusive_scan(v[j]);
-        __syncthreads();
-        if (lane_id() == 63) lds[wave_id()] = incl;
-        __syncthreads();
-        V excl = running;
-        for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
-        const V prev = shfl_up_v(incl, 1);
-        if (lane_id() > 0) excl = excl + prev;
-        if (i < n) out(i, excl);
-        V t = running;
-        for (int w = 0; w < kWaves; w++) t = t + lds[w];
-        running = t;
-    }
+    if (tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = carry_in ? *carry_in : zero_of(V());
 }
 
 inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
@@ -298,9 +307,10 @@ inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
 /// Single-pass scan.  `state` holds lb_words<V>() 64-bit words per tile and must never have seen `epoch` before
 /// (hagrid_impl::lookback_state hands out both).
 template <typename V, typename In, typename Out>
-inline void device_scan_lookback(hipStream_t stream, In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
+inline void device_scan_lookback(hipStream_t stream, int num_cus, In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
     const int tiles = scan_num_tiles(n);
-    scan_lookback<V, In, Out><<<tiles > 0 ? tiles : 1, kBlock, 0, stream>>>(in, out, n, state, epoch, carry_in, total_out);
+    const int blocks = std::max(1, std::min(tiles, std::max(num_cus, 1) * kLbBlocksPerCu));
+    scan_lookback<V, In, Out><<<blocks, kBlock, 0, stream>>>(in, out, n, tiles, state, epoch, carry_in, total_out);
 }
 
 /// Launches the three scan kernels.  `partials` must hold scan_num_tiles(n) values of V.
@@ -321,7 +331,7 @@ inline bool ctx_scan(hagrid_ctx* ctx, In in, Out out, int n, V* partials, const 
     unsigned epoch = 0;
     unsigned long long* state = lookback_state(ctx, scan_num_tiles(n), lb_words<V>(), &epoch);
     if (!state) return false;
-    device_scan_lookback<V>(ctx->stream, in, out, n, state, epoch, carry_in, total_out);
+    device_scan_lookback<V>(ctx->stream, ctx->num_cus, in, out, n, state, epoch, carry_in, total_out);
     return true;
 }
 

@@ -31,10 +31,35 @@ class GridPOD(C.Structure):
 
 
 class TraversalStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("rays", "rays_hit_grid", "cells", "entry_words", "refs", "sentinels", "hits")]
+    _fields_ = [(n, C.c_int64) for n in ("rays", "rays_hit_grid", "cells", "entry_words", "refs", "sentinels", "hits", "long_list_refs")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+MAX_MERGE_PASSES = 96
+
+
+class BuildCounts(C.Structure):
+    """struct hagrid_build_counts (include/hagrid_amd.h): sizes the construction passes went through."""
+    _fields_ = [("num_tris", C.c_int64), ("top_cells", C.c_int64), ("top_refs", C.c_int64),
+                ("num_levels", C.c_int32), ("merge_passes", C.c_int32), ("expand_passes", C.c_int32), ("compressed", C.c_int32),
+                ("level_refs", C.c_int64 * MAX_LEVELS), ("level_cells", C.c_int64 * MAX_LEVELS), ("level_kept", C.c_int64 * MAX_LEVELS),
+                ("build_cells", C.c_int64), ("build_refs", C.c_int64), ("build_entries", C.c_int64),
+                ("merge_cells", C.c_int64 * MAX_MERGE_PASSES), ("merge_refs", C.c_int64 * MAX_MERGE_PASSES),
+                ("merged_cells", C.c_int64), ("merged_refs", C.c_int64),
+                ("flatten_entries_in", C.c_int64), ("flatten_entries_out", C.c_int64),
+                ("expand_cells", C.c_int64), ("compress_cells", C.c_int64), ("compress_refs_out", C.c_int64)]
+
+    def as_dict(self) -> dict:
+        d = {}
+        for n, t in self._fields_:
+            v = getattr(self, n)
+            d[n] = int(v) if not hasattr(v, "__len__") else [int(x) for x in v]
+        d["level_refs"] = d["level_refs"][:d["num_levels"]]; d["level_cells"] = d["level_cells"][:d["num_levels"]]
+        d["level_kept"] = d["level_kept"][:d["num_levels"]]
+        d["merge_cells"] = d["merge_cells"][:d["merge_passes"]]; d["merge_refs"] = d["merge_refs"][:d["merge_passes"]]
+        return d
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -56,6 +81,8 @@ SIGNATURES = {
     "hagrid_mem_usage": (_sz, [_vp]),
     "hagrid_mem_max_usage": (_sz, [_vp]),
     "hagrid_mem_debug_slots": (None, [_vp]),
+    "hagrid_bandwidth_probe": (_i32, [_vp, _sz, _i32, C.POINTER(_f32), C.POINTER(_f32)]),
+    "hagrid_get_build_counts": (_i32, [_vp, C.POINTER(BuildCounts)]),
     "hagrid_profile_begin": (_i32, [_vp]),
     "hagrid_profile_end": (_f32, [_vp]),
     "hagrid_build_grid": (_i32, [_vp, _vp, _i32, C.POINTER(GridPOD), _f32, _f32]),
@@ -75,6 +102,7 @@ SIGNATURES = {
     "hagrid_kat_compute_range": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "hagrid_kat_compute_grid_dims": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "hagrid_kat_lookup_entry": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "hagrid_kat_wave_times": (_i32, [_vp, _vp, _vp]),

@@ -219,6 +219,23 @@ def make_rays_bounce(tris: np.ndarray, rays: np.ndarray, hits: np.ndarray, bbox_
     return out.astype(np.float32)
 
 
+def generate_parallel(gen, first: int, count: int, chunk: int = 1 << 20, threads: int | None = None) -> np.ndarray:
+    """gen(first, count) -> (count, 8) float32 for any slice (the generators above are counter-based): builds
+    [first, first + count) from chunks made on a thread pool (numpy releases the GIL inside its loops)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty((count, 8), dtype=np.float32)
+    starts = list(range(0, count, chunk))
+
+    def work(o):
+        c = min(chunk, count - o)
+        out[o:o + c] = gen(first + o, c)
+
+    with ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 1)) as ex:
+        list(ex.map(work, starts))
+    return out
+
+
 def shard_range(num_items: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous ray range of rank ``rank``: [g*n/G, (g+1)*n/G)."""
     return (num_items * rank) // world, (num_items * (rank + 1)) // world

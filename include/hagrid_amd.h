@@ -65,7 +65,26 @@ typedef struct hagrid_grid {
 /* Per-batch traversal counters (exact integers; the algorithmic-bytes formula of DESIGN.md). */
 typedef struct hagrid_traversal_stats {
     int64_t rays, rays_hit_grid, cells, entry_words, refs, sentinels, hits;
+    int64_t long_list_refs;   /* of `refs`: tested in lists of more than four ids (shorter lists are inline in the traversal image) */
 } hagrid_traversal_stats;
+
+/* Sizes the construction passes of a context went through since its last hagrid_build_grid (diagnostics: the inputs of the
+ * compulsory-traffic formula of SURVEY.md 8(d) "algorithmic bytes -- build"; bench.py: roofline_build). */
+#define HAGRID_MAX_MERGE_PASSES 96
+typedef struct hagrid_build_counts {
+    int64_t num_tris, top_cells, top_refs;                 /* N, T, R0 (references emitted at the top level, before the SAT filter) */
+    int32_t num_levels, merge_passes, expand_passes, compressed;
+    int64_t level_refs[HAGRID_MAX_LEVELS];                 /* R_l: references entering level l */
+    int64_t level_cells[HAGRID_MAX_LEVELS];                /* C_l: cells of level l */
+    int64_t level_kept[HAGRID_MAX_LEVELS];                 /* references of level l that stay in a leaf (R_l - kept = split_l) */
+    int64_t build_cells, build_refs, build_entries;        /* C, R, E after build_grid */
+    int64_t merge_cells[HAGRID_MAX_MERGE_PASSES];          /* cells / references entering each merge axis pass */
+    int64_t merge_refs[HAGRID_MAX_MERGE_PASSES];
+    int64_t merged_cells, merged_refs;                     /* after merge_grid */
+    int64_t flatten_entries_in, flatten_entries_out;       /* E, E' */
+    int64_t expand_cells;                                  /* C of every expand axis pass */
+    int64_t compress_cells, compress_refs_out;             /* compress_grid: C and R + sentinels */
+} hagrid_build_counts;
 
 /* ---- context ----------------------------------------------------------------------------------- */
 
@@ -97,6 +116,13 @@ size_t hagrid_mem_usage(const hagrid_ctx* ctx);
 size_t hagrid_mem_max_usage(const hagrid_ctx* ctx);
 /* debug_slots(): prints the slot table to stdout. */
 void hagrid_mem_debug_slots(const hagrid_ctx* ctx);
+
+/* Diagnostics for the bench record (SURVEY.md 8(d) "BW_peak": a measured device copy / triad figure from the same run):
+ * streams `bytes` per array through a float4 copy (c = a) and a triad (c = a + 3 b) kernel `iters` times and returns the best
+ * rate of each in GB/s (copy: 2 * bytes, triad: 3 * bytes per pass). */
+int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, float* copy_gbps, float* triad_gbps);
+/* The sizes recorded by the construction passes of this context (see hagrid_build_counts). */
+int hagrid_get_build_counts(const hagrid_ctx* ctx, hagrid_build_counts* out);
 
 /* ---- profile (common.h:15, profile.cu:5-18) ------------------------------------------------------- */
 /* Event pair on the context's stream around arbitrary host code; end returns the elapsed ms. */
@@ -194,6 +220,11 @@ int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* 
 int hagrid_kat_compute_grid_dims(hagrid_ctx* ctx, const void* bb, const int32_t* num_prims, const float* density, int n, int32_t* out3);
 int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_entries, int shift, const int32_t* top_dims3,
                             const int32_t* voxels3, int n, uint32_t* out);
+/* The device-wide ordered exclusive scan the construction passes use in place of cub::DeviceScan::ExclusiveSum (parallel.cuh:31-42):
+ * out[i] = carry + sum of values[0..i), total = carry + sum of all; words = 1 (int) or 2 (pairs of ints, interleaved); carry_in =
+ * `words` ints or NULL; lookback != 0 runs the single-pass decoupled look-back form, 0 the three-kernel reduce-then-scan form. */
+int hagrid_kat_scan(hagrid_ctx* ctx, const int32_t* values, int n, int words, const int32_t* carry_in, int lookback,
+                    int32_t* out, int32_t* total);
 /* Tile packets (see "traverse.image_width"): the row length the device finds for a ray buffer in device memory (0 = not
  * image-ordered), and the ray slot every lane of every 64-lane block gets for a batch of num_rays rays with rows of
  * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */

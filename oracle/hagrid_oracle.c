@@ -1089,7 +1089,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                         if (got && (g_mode & ORC_ANY_HIT)) { found_any = 1; break; }
                     }
                     nrefs = cur - cbegin;
-                    if (st) { st->refs += nrefs - 1; st->sentinels += 1; }
+                    if (st) { st->refs += nrefs - 1; st->sentinels += 1; if (nrefs - 1 > 4) st->long_list_refs += nrefs - 1; }
                 }
             } else {
                 for (int cur = cbegin; cur < cend; cur++) {
@@ -1101,7 +1101,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                     if (got && (g_mode & ORC_ANY_HIT)) { found_any = 1; break; }
                 }
                 nrefs = cend - cbegin;
-                if (st) st->refs += nrefs;
+                if (st) { st->refs += nrefs; if (nrefs > 4) st->long_list_refs += nrefs; }
             }
             steps += 1 + nrefs;
             if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (unsigned char)(nrefs > 255 ? 255 : nrefs); g_trace_len++; }
@@ -1180,6 +1180,7 @@ static void run_jobs(Job* proto, int64_t n, int nthreads, OStats* stats) {
             stats->rays += jobs[t].stats.rays; stats->rays_hit_grid += jobs[t].stats.rays_hit_grid;
             stats->cells += jobs[t].stats.cells; stats->entry_words += jobs[t].stats.entry_words;
             stats->refs += jobs[t].stats.refs; stats->sentinels += jobs[t].stats.sentinels; stats->hits += jobs[t].stats.hits;
+            stats->long_list_refs += jobs[t].stats.long_list_refs;
         }
     }
     free(jobs); free(th);

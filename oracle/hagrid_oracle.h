@@ -73,6 +73,7 @@ typedef struct {
     int64_t refs;            /* tested references (one ref id + one Tri each) */
     int64_t sentinels;       /* sentinel words read (compressed grids only) */
     int64_t hits;            /* rays with id >= 0 */
+    int64_t long_list_refs;  /* of `refs`: those tested in lists of more than four ids (the traversal image keeps shorter lists inline) */
 } OStats;
 
 /* ---- L0 -------------------------------------------------------------------------------- */

@@ -31,7 +31,7 @@ class OGrid(C.Structure):
 
 
 class OStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("rays", "rays_hit_grid", "cells", "entry_words", "refs", "sentinels", "hits")]
+    _fields_ = [(n, C.c_int64) for n in ("rays", "rays_hit_grid", "cells", "entry_words", "refs", "sentinels", "hits", "long_list_refs")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -32,9 +32,28 @@ def test_header_symbols_exported(built):
 
 
 def test_struct_layout_matches_header(built):
+    """ctypes mirrors == what a C compiler makes of include/hagrid_amd.h (sizes and the offsets of a few members)."""
     import ctypes as C
+    import subprocess, tempfile
     assert C.sizeof(built.GridPOD) == 4 * 8 + 6 * 4 + 3 * 4 + 5 * 4 + 32 * 4
-    assert C.sizeof(built.TraversalStats) == 56
+    prog = r'''#include <stdio.h>
+#include <stddef.h>
+#include "hagrid_amd.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(hagrid_grid), sizeof(hagrid_traversal_stats), sizeof(hagrid_build_counts),
+           offsetof(hagrid_grid, offsets), offsetof(hagrid_build_counts, level_refs), offsetof(hagrid_build_counts, merge_cells),
+           offsetof(hagrid_build_counts, compress_refs_out));
+    return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c"); exe = os.path.join(d, "s")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    B = built.BuildCounts
+    want = [C.sizeof(built.GridPOD), C.sizeof(built.TraversalStats), C.sizeof(B), built.GridPOD.offsets.offset,
+            B.level_refs.offset, B.merge_cells.offset, B.compress_refs_out.offset]
+    assert got == want
 
 
 def test_no_gpu_means_loud_failure(built):

@@ -1,0 +1,99 @@
+"""Two contexts, two HIP streams, two host threads at once: include/hagrid_amd.h promises that contexts are independent
+(the reference keeps per-TU __constant__ state and allows one grid per process, traverse.cu:7-12).  Each thread builds its
+own scene and traverses its own rays repeatedly; results must equal the ones of a quiet, single-context run."""
+import threading
+
+import numpy as np
+import pytest
+
+from hagrid_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def run_once(mem, tris, rays, rounds, out, key, barrier=None):
+    from hagrid_amd import api
+    try:
+        d_tris = mem.upload(tris)
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+        res = []
+        for r in range(rounds):
+            if barrier is not None:
+                barrier.wait()
+            grid = api.build_all(mem, d_tris, tris.shape[0], compress=bool(r & 1))
+            api.setup_traversal(grid)
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
+            hits = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+            d = grid.download()
+            res.append((grid.summary(), int(d["entries"].astype(np.int64).sum()), int(d["ref_ids"].astype(np.int64).sum()), hits.copy()))
+            grid.free()
+        out[key] = res
+    except Exception as e:          # surfaces in the main thread
+        out[key] = e
+
+
+def test_two_contexts_two_streams_concurrently():
+    import torch
+    from hagrid_amd import api
+    scenes = [scene.make_soup(200_000), scene.make_soup(150_000, seed=99)]
+    lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
+    rays = [scene.make_rays_primary(lo, hi, 512, 512), scene.make_rays_incoherent(lo, hi, 300_000, 5)]
+    rounds = 4
+    # quiet reference runs, one context at a time on the null stream
+    quiet = {}
+    for i in range(2):
+        m = api.MemManager(keep=True)
+        run_once(m, scenes[i], rays[i], rounds, quiet, i)
+        m.close()
+        assert not isinstance(quiet[i], Exception), quiet[i]
+    # concurrent: each context on its own stream, driven by its own host thread
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    mems = [api.MemManager(keep=True), api.MemManager(keep=False)]
+    for m, s in zip(mems, streams):
+        m.use_stream(s.cuda_stream)
+    busy = {}
+    bar = threading.Barrier(2)
+    threads = [threading.Thread(target=run_once, args=(mems[i], scenes[i], rays[i], rounds, busy, i, bar)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive()
+    for i in range(2):
+        assert not isinstance(busy[i], Exception), busy[i]
+        for r in range(rounds):
+            qs, qe, qr, qh = quiet[i][r]
+            bs, be, br, bh = busy[i][r]
+            assert qs == bs and qe == be and qr == br, (i, r)
+            assert (qh["id"] == bh["id"]).all() and (qh["t"].view(np.uint32) == bh["t"].view(np.uint32)).all(), (i, r)
+    for m in mems:
+        m.close()
+
+
+def test_set_stream_drains_the_old_stream():
+    """Switching streams must not let work queued on the old stream race with re-used pool slots: traverse on
+    stream A, switch to stream B, free + re-use buffers, then read the hits back -- identical to a synchronous run."""
+    import torch
+    from hagrid_amd import api
+    tris = scene.make_soup(100_000)
+    mem = api.MemManager(keep=True)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024)
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+    want = mem.download(d_hits, api.HIT_DTYPE, n)
+    mem.zero(d_hits, 16 * n)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    mem.use_stream(a.cuda_stream)
+    mem.set_ray_binning(1)                       # allocates and frees pool buffers around the launch
+    for _ in range(5):
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+    mem.use_stream(b.cuda_stream)                # drains stream a
+    scratch = mem.alloc(64 << 20); mem.one(scratch, 64 << 20); mem.free(scratch)
+    got = mem.download(d_hits, api.HIT_DTYPE, n)
+    assert (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    mem.use_stream(None)
+    mem.close()

@@ -31,8 +31,25 @@ def test_bench_two_ranks_share_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["config"]["rays_per_gpu"] == 512 * 512
+    assert out["config"]["rays_rank0"] == 512 * 512 and out["config"]["rays_total"] == 2 * 512 * 512
     assert 0.3 < out["hit_fraction"] <= 1.0
+
+
+@pytest.mark.parametrize("config,extra", [(4, ["--total-rays", "300001"]), (3, ["--width", "512", "--height", "256"]),
+                                          (5, ["--width", "256", "--height", "256"])])
+def test_bench_strong_scaling_two_ranks(config, extra):
+    """bench.py --config 3/4/5 shards ONE batch over the ranks (strong scaling): the job total is the batch, not N batches."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(config),
+           "--tris", "100000", "--backend", "gloo", "--device", "0", "--build-iter", "1"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    total = 300001 if config == 4 else int(extra[1]) * int(extra[3])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["rays_total"] == total
+    assert out["config"]["rays_rank0"] == total // 2 and out["config"]["baseline_config"] == config
+    assert out["config"]["grid"]["compressed"] == (config == 5)
+    assert 0.2 < out["hit_fraction"] <= 1.0
 
 
 def _worker(rank, port, q):

@@ -1,5 +1,7 @@
-"""Full BASELINE sizes on the GPU: the 1M-triangle scene (configs[1], [2]).  Structure parity against the
-oracle (about 12 s of CPU), hit parity on the whole primary batch, and size-independent properties."""
+"""Full BASELINE sizes on the GPU, every configuration of BASELINE.json at its stated size (multi-GPU configurations with
+the per-GPU share of an 8-GPU run): structure parity against the oracle (about 12 s of CPU per 1M-triangle grid), hit
+parity against the oracle / a brute force on samples the CPU can afford, identical hits across every traversal path,
+and size-independent properties."""
 import numpy as np
 import pytest
 
@@ -55,6 +57,83 @@ def test_config2_structure_and_hits_match_oracle(world):
         h = O.brute_force(tris[hits["id"][i]:hits["id"][i] + 1], rays[i:i + 1])
         assert h["id"][0] == 0 and h["t"].view(np.uint32)[0] == hits["t"].view(np.uint32)[i]
     grid.free()
+
+
+def test_config3_dense_grid_16M_primary_rays(world):
+    """configs[2]: soup-1M, --top-density 0.15 --snd-density 3.0 --expansion 3, 4096 x 4096 primary rays.  Grid arrays identical
+    to the oracle's; identical hits from the flat image, the compact image and the construction format; the oracle on a strided
+    1M-ray sample; a brute force over all triangles on 1024 rays."""
+    import os
+    from hagrid_amd import api
+    from oracle import oracle as O
+    mem, tris, d_tris = world
+    cores = os.cpu_count() or 8
+    grid = api.build_all(mem, d_tris, tris.shape[0], top_density=0.15, snd_density=3.0, exp_iters=3)
+    G = O.Grid.full(tris, 0.15, 3.0, 0.995, 3)
+    d = grid.download()
+    assert grid.summary() == G.summary()
+    assert (d["entries"] == G.entries).all() and (d["ref_ids"] == G.ref_ids).all() and d["cells"].tobytes() == G.cells.tobytes()
+    w = h = 4096
+    rays = scene.generate_parallel(lambda f, c: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, w, h, first=f, count=c), 0, w * h, chunk=1 << 21)
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    got = {}
+    for image in (2, 1, 0):
+        mem.set_option("traverse.image", image)
+        api.setup_traversal(grid)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        got[image] = mem.download(d_hits, api.HIT_DTYPE, n)
+    mem.set_option("traverse.image", 2)
+    assert same_hits(got[2], got[1]) and same_hits(got[2], got[0])
+    hits = got[2]
+    assert (hits["id"] >= 0).mean() > 0.7
+    sel = np.arange(7, n, 16)                                   # 1M rays spread over the whole image
+    oh, _ = G.traverse(tris, np.ascontiguousarray(rays[sel]), nthreads=cores)
+    assert same_hits(hits[sel], oh)
+    sel = np.arange(3, n, n // 1024)[:1024]
+    assert same_hits(hits[sel], O.brute_force(tris, np.ascontiguousarray(rays[sel]), nthreads=cores))
+    mem.free(d_rays); mem.free(d_hits); grid.free()
+
+
+def test_config4_share_16M_incoherent_rays_binned_and_unbinned(world):
+    """configs[3], the per-GPU share of the 8-GPU run: rays [3 * 2^24, 4 * 2^24) of the 128M incoherent batch on the default
+    grid.  Ray binning off / on / automatic give identical hits (large-batch kernel choice, binning above 300k rays); the oracle
+    on a strided 1M-ray sample."""
+    import os
+    from hagrid_amd import api
+    from oracle import oracle as O
+    mem, tris, d_tris = world
+    cores = os.cpu_count() or 8
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    n = 1 << 24
+    first, end = scene.shard_range(1 << 27, 3, 8)
+    assert end - first == n
+    rays = scene.generate_parallel(lambda f, c: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, c, scene.RAY_SEED_BASE + 4, first=f), first, n)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    got = {}
+    for mode in (0, 1, 2):
+        mem.set_ray_binning(mode)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        got[mode] = mem.download(d_hits, api.HIT_DTYPE, n)
+    mem.set_ray_binning(0)
+    assert same_hits(got[0], got[1]) and same_hits(got[0], got[2])
+    # without the traversal image the batch takes the persistent large-batch kernel (unbinned) and v2 (binned)
+    mem.set_option("traverse.image", 0)
+    api.setup_traversal(grid)
+    for mode in (0, 1):
+        mem.set_ray_binning(mode)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        assert same_hits(got[0], mem.download(d_hits, api.HIT_DTYPE, n)), f"construction format, binning {mode}"
+    mem.set_ray_binning(0); mem.set_option("traverse.image", 2)
+    hits = got[0]
+    assert 0.5 < (hits["id"] >= 0).mean() <= 1.0
+    d = grid.download()
+    G = O.Grid.from_arrays(d["entries"], d["ref_ids"], d["cells"], None, d["bbox_min"], d["bbox_max"], d["dims"], d["shift"], d["offsets"])
+    sel = np.arange(5, n, 16)
+    oh, _ = G.traverse(tris, np.ascontiguousarray(rays[sel]), nthreads=cores)
+    assert same_hits(hits[sel], oh)
+    mem.free(d_rays); mem.free(d_hits); grid.free()
 
 
 def test_hits_do_not_depend_on_grid_parameters(world):
@@ -136,7 +215,42 @@ def test_config5_8M_triangles_compressed_bounce_rays():
     sel = np.arange(0, bounce.shape[0], 1021)[:1024]
     bf = O.brute_force(tris, np.ascontiguousarray(bounce[sel]), nthreads=cores)
     assert same_hits(hb[sel], bf)
-    plain.free(); comp.free(); mem.close()
+    plain.free()
+
+    # the configuration at its size: the per-GPU share of the 64M-ray batch = rows 3072..4095 of the 8192 x 8192 primary image
+    # (8 388 608 rays), bounce rays in the image order of their primary rays.  The >= 4M-ray origin criterion of the row
+    # detection and the compressed image kernel run at size; tile packets on (detected), off, and with the width given, ray
+    # binning, and the construction format must all give the same hits; the oracle checks a strided 200k-ray sample.
+    W = 8192
+    first, end = scene.shard_range(W * W, 3, 8)
+    n8 = end - first
+    assert n8 == 8_388_608 and first % W == 0
+    prim = scene.generate_parallel(lambda f, c: scene.make_rays_primary(comp.bbox_min, comp.bbox_max, W, W, first=f, count=c), first, n8, chunk=1 << 21)
+    h0 = traverse(mem, comp, d_tris, prim)
+    bounce = np.empty_like(prim)
+    for off in range(0, n8, 1 << 21):
+        sl = slice(off, min(off + (1 << 21), n8))
+        bounce[sl] = scene.make_rays_bounce(tris, prim[sl], h0[sl], comp.bbox_min, comp.bbox_max, scene.RAY_SEED_BASE + 5, first=first + off)
+    del prim
+    d_rays = mem.upload(bounce); d_hits = mem.alloc(16 * n8)
+    api.setup_traversal(comp)
+    variants = {}
+    for name, opts in (("detect", dict(width=0)), ("off", dict(width=-1)), ("given", dict(width=W)), ("binned", dict(width=0, bin=1)),
+                       ("construction format", dict(width=0, image=0))):
+        mem.set_option("traverse.image_width", opts["width"]); mem.set_ray_binning(opts.get("bin", 0))
+        if "image" in opts:
+            mem.set_option("traverse.image", opts["image"]); api.setup_traversal(comp)
+        api.traverse_grid(comp, d_tris, d_rays, d_hits, n8)
+        variants[name] = mem.download(d_hits, api.HIT_DTYPE, n8)
+    mem.set_option("traverse.image_width", 0); mem.set_ray_binning(0); mem.set_option("traverse.image", 2)
+    for name, v in variants.items():
+        assert same_hits(variants["detect"], v), name
+    hb8 = variants["detect"]
+    assert 0.5 < (hb8["id"] >= 0).mean() <= 1.0
+    sel = np.arange(11, n8, 41)[:200_000]
+    oh, _ = G.traverse(tris, np.ascontiguousarray(bounce[sel]), nthreads=cores)
+    assert same_hits(hb8[sel], oh)
+    comp.free(); mem.close()
 
 
 def test_clustered_scene_structure_and_hits_match_oracle():
