@@ -83,15 +83,6 @@ struct hagrid_ctx {
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
-    int opt_prio_step = 0;      // image kernel: cell steps after which a wavefront raises its issue priority (0 = never)
-    int opt_generations = 0;    // image kernel in bounded passes with compaction in between (traverse.hip: generational traversal)
-    int opt_gen_schedule = 8 | (8 << 6) | (16 << 12) | (32 << 18);   // cell steps per generation, 6 bits each, 0 ends the list; the last generation runs to the end
-    int opt_gen_min_rays = 1 << 16;
-    // queues of the generational traversal: two (uint4, uint32) array pairs, grown on demand, and 8 counters per generation
-    void* gen_queue[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t gen_queue_entries = 0;
-    int* gen_counts = nullptr;
-
     hagrid_impl::TravImageCache image;
     hagrid_build_counts counts = {};      // sizes of the last construction (hagrid_get_build_counts)
 

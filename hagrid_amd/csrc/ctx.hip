@@ -48,8 +48,6 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
     if (ctx->row_scores) (void)hipFree(ctx->row_scores);
     if (ctx->lb_state) (void)hipFree(ctx->lb_state);
-    for (void* q : ctx->gen_queue) if (q) (void)hipFree(q);
-    if (ctx->gen_counts) (void)hipFree(ctx->gen_counts);
     delete ctx;
 }
 

@@ -44,7 +44,6 @@ struct TraverseArgs {
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
     int num_rays;
-    int prio_step;                // > 0: a wavefront raises its issue priority after this many cell steps, again after 2x and 4x
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
     int top_x, top_y;             // top-level resolution (x, y)
@@ -689,17 +688,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         uint4 ca, cb;
         record(tab, vx, vy, vz, ca, cb);
 
-        // A launch ends when its longest rays end, and those wavefronts spend most of their life competing for issue slots with
-        // wavefronts that are about to finish anyway: a wavefront that is still walking after prio_step cell steps raises its
-        // priority (again after 2x and 4x as many), so the critical path of the launch runs at the pace of an unloaded SIMD.
-        int wave_steps = 0;
         for (;;) {
-            if (a.prio_step > 0) {
-                wave_steps++;                                               // wave-uniform: one count per lock-step iteration
-                if (wave_steps == a.prio_step) __builtin_amdgcn_s_setprio(1);
-                else if (wave_steps == 2 * a.prio_step) __builtin_amdgcn_s_setprio(2);
-                else if (wave_steps == 4 * a.prio_step) __builtin_amdgcn_s_setprio(3);
-            }
             if (!UNIFORM && ca.w >= 0xfffffffeu) {                          // (the table-free layout needs shift <= 3: every block resolves its cell fully)
                 // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
                 // cell the next records are fetched from it directly (one gather per step again)
@@ -768,209 +757,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         }
     }
     nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
-}
-
-
-// ---- generational traversal: the image kernel in bounded passes with compaction in between ---------------------------
-// What the counters say about the one-pass kernel above (profiles/pmc_r1k_traverse_img.txt): it is bound by instruction
-// issue, and only 22 % of the lanes of an issued VALU instruction carry a live ray -- a wavefront lives as long as its
-// longest ray (34 cell steps against 10.6 on average for the 1024^2 primary batch) and the launch ends with a long drain of
-// thin wavefronts.  Here the walk is cut into GENERATIONS: generation g advances every ray it holds by at most limit[g] cell
-// steps; rays that are not finished by then are appended -- compacted, 20 bytes of state each -- to a queue, and the next
-// launch packs 64 of them per wavefront again.  With limits 8, 8, 16, 32, rest the model on the oracle's per-ray traces
-// (tests/analysis/wave_model.py) gives 48 % fewer issued instructions, and every wavefront of a generation runs about the
-// same number of steps, so a launch no longer drains.  The arithmetic per ray is that of the one-pass kernel (and the
-// oracle) step for step -- a ray's state at a generation boundary is exactly (next voxel, hit) -- so hits are identical.
-// Queues: kGenRegions regions (region = blockIdx & 63 in every generation, so a ray stays on one XCD and its L2); a
-// wavefront appends its survivors with one atomic on its region's counter -- the counters sit 128 bytes apart: device-scope
-// atomics are served memory-side at ~88 per microsecond and LINE, and the wavefronts of a bounded generation all finish
-// at about the same time; the next generation's workgroups (persistent: region blockIdx & 63, chunks of 64 entries taken in
-// turn) read the counters from device memory -- the host never waits.
-constexpr int kGenRegions = 64;
-constexpr int kGenCountStride = 32;          // ints between two region counters (one 128-byte line each)
-struct GenArgs {
-    const uint4* __restrict__ in_a;          // (ray id, hit id, hit t, vz)
-    const uint32_t* __restrict__ in_b;       // vx | vy << 16
-    const int* __restrict__ in_count;        // 8 region counters of the input queue
-    uint4* __restrict__ out_a;
-    uint32_t* __restrict__ out_b;
-    int* __restrict__ out_count;
-    int region_cap;                          // entries per region
-    int limit;                               // cell steps of this generation (<= 0: until the ray is finished)
-};
-
-// GEN 0: first generation (rays from the ray buffer, tile packets / binning order as in the one-pass kernel); GEN 1: later
-template <bool UNIFORM, int GEN>
-__global__ void __launch_bounds__(64, 8) traverse_kernel_gen(const TraverseArgs a, const GenArgs q) {
-    const int region = blockIdx.x & (kGenRegions - 1);
-    const int* perm = (GEN == 0 && a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
-    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
-    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
-    const int in_n = GEN ? __builtin_amdgcn_readfirstlane(q.in_count[region * kGenCountStride]) : 0;
-#pragma unroll 1
-    for (int chunk = int(blockIdx.x / kGenRegions);; chunk += int(gridDim.x / kGenRegions)) {
-        int id = -1, vx = 0, vy = 0, vz = 0;
-        Hit hit(-1, 0.0f, 0.0f, 0.0f);
-        bool alive = false;
-        if (GEN == 0) {
-            const int w = !perm ? tile_packet_row_len(a) : 0;
-            const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-            const int slot = w ? tile_packet_slot(a, w, b, threadIdx.x) : b * 64 + threadIdx.x;
-            if (slot < a.num_rays) { id = perm ? perm[slot] : slot; alive = true; }
-        } else {
-            if (chunk * 64 >= in_n) return;
-            const int e = chunk * 64 + int(threadIdx.x);
-            if (e < in_n) {
-                const size_t at = size_t(region) * size_t(q.region_cap) + size_t(e);
-                const uint4 sa = q.in_a[at];
-                const uint32_t sb = q.in_b[at];
-                id = int(sa.x); hit.id = int(sa.y); hit.t = __uint_as_float(sa.z); vz = int(sa.w);
-                vx = int(sb & 0xffffu); vy = int(sb >> 16);
-                alive = true;
-            }
-        }
-        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        if (alive) { r0 = nt_load4(a.rays + 2 * size_t(id)); r1 = nt_load4(a.rays + 2 * size_t(id) + 1); }
-        const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
-        const float tmin = r0.w, tmax = r1.w;
-        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-        const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
-        if (GEN == 0 && alive) {
-            const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
-            const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
-            const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
-            const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
-            hit = Hit(-1, tmax, 0.0f, 0.0f);
-            if (tstart > tend) {
-                nt_store4(a.hits + id, __int_as_float(-1), tmax, 0.0f, 0.0f);          // misses the grid
-                alive = false;
-            } else {
-                const vec3 fv = (tstart * dir + org - gmin) * ginv;
-                vx = min(max(int(fv.x), 0), a.dims_x - 1);
-                vy = min(max(int(fv.y), 0), a.dims_y - 1);
-                vz = min(max(int(fv.z), 0), a.dims_z - 1);
-            }
-        }
-
-        if (alive) {
-            auto top_index = [&](int x, int y, int z) -> int {
-                return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
-            };
-            auto table_at = [&](int t) -> uint2 { return gather32<uint2>(a.img_table, uint32_t(t) << 3); };
-            uint32_t nest = ~0u;
-            int nest_x = 0, nest_y = 0, nest_z = 0;
-            auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
-                if (UNIFORM) {
-                    const int d = a.shift, m = (1 << d) - 1;
-                    const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-                    const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 5;
-                    const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                    ra = p[0]; rb = p[1];
-                } else {
-                    int d = int(tab.y & 3u), s = a.shift - d;
-                    uint32_t base = tab.x;
-                    if (nest != ~0u) {
-                        const int sr = a.shift - int(nest >> 27);
-                        if ((((x ^ nest_x) | (y ^ nest_y) | (z ^ nest_z)) >> sr) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
-                    }
-                    const int m = (1 << d) - 1;
-                    const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                    const uint32_t o = (base << 7) + (idx << 5);
-                    const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                    ra = p[0]; rb = p[1];
-                }
-            };
-            auto tri_at = [&](int ref) -> Tri {
-                uint32_t r3, o;
-                asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-                asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-                const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
-                const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-                return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-            };
-            auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
-
-            const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;
-            const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;
-            int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
-            uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
-            uint4 ca, cb;
-            record(tab, vx, vy, vz, ca, cb);
-            int steps_left = q.limit > 0 ? q.limit : 0x7fffffff;
-            for (;;) {
-                if (!UNIFORM && ca.w >= 0xfffffffeu) {
-                    uint32_t off = ~0u, meta = 0u;
-                    image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
-                    if (off != ~0u) {
-                        nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;
-                        nest_x = vx; nest_y = vy; nest_z = vz;
-                    }
-                }
-                const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
-                const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
-                const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
-                const vec3 ev = (texit * dir + org - gmin) * ginv;
-                const int nx = texit == tcell.x ? cx + bx : int(ev.x);
-                const int ny = texit == tcell.y ? cy + by : int(ev.y);
-                const int nz = texit == tcell.z ? cz + bz : int(ev.z);
-                vx = px ? max(nx, vx) : min(nx, vx);
-                vy = py ? max(ny, vy) : min(ny, vy);
-                vz = pz ? max(nz, vz) : min(nz, vz);
-                const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
-                if (!UNIFORM) {
-                    const int ntop = outside ? top_idx : top_index(vx, vy, vz);
-                    if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
-                }
-                uint4 na, nb;
-                if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
-                else record(tab, vx, vy, vz, na, nb);
-
-                const bool by_index = int(ca.w) < 0;
-                uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;
-                int ref = int(cb.x);
-                if (by_index) {
-                    q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                    ref = -1;
-                    if (q1 < q2) ref = ref_at(q1);
-                    q1++;
-                }
-#pragma unroll 1
-                while (ref >= 0) {
-                    int next;
-                    if (UNIFORM) {
-                        if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
-                    }
-                    int pre = -1;
-                    if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);
-                    intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    if (!UNIFORM) {
-                        if (by_index) { next = pre; q1++; }
-                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
-                    }
-                    ref = next;
-                }
-                if (hit.t <= texit || outside) { alive = false; break; }
-                if (--steps_left == 0) break;
-                ca = na; cb = nb;
-            }
-            if (!alive) nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
-        }
-        // survivors of this wavefront -> the next generation's queue (one atomic per wavefront)
-        const unsigned long long m = __ballot(alive);
-        if (m) {
-            int base = 0;
-            if (threadIdx.x == 0) base = atomicAdd(q.out_count + region * kGenCountStride, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (alive) {
-                const int rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0));
-                const size_t at = size_t(region) * size_t(q.region_cap) + size_t(base + rank);
-                q.out_a[at] = make_uint4(uint32_t(id), uint32_t(hit.id), __float_as_uint(hit.t), uint32_t(vz));
-                q.out_b[at] = uint32_t(vx) | (uint32_t(vy) << 16);
-            }
-        }
-        if (GEN == 0) return;
-    }
 }
 
 
@@ -1281,52 +1067,6 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
     detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1);
 }
 
-// The generational traversal: generation 0 over the ray buffer, then one launch per further generation over the queue the
-// previous one filled.  Everything is enqueued at once; counts stay on the device.
-constexpr int kMaxGenerations = 6;
-int launch_generations(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, bool uniform) {
-    const int blocks0 = grid_blocks(num_rays, 64);
-    const int per_region = (blocks0 + kGenRegions - 1) / kGenRegions;
-    const size_t region_cap = size_t(per_region) * 64;
-    const size_t entries = region_cap * kGenRegions;
-    if (entries > ctx->gen_queue_entries) {
-        HG_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // earlier launches may still read the old queues
-        for (void*& q : ctx->gen_queue) { if (q) (void)hipFree(q); q = nullptr; }
-        ctx->gen_queue_entries = 0;
-        const size_t grown = entries + entries / 8;
-        for (int i = 0; i < 4; i++) HG_HIP(ctx, hipMalloc(&ctx->gen_queue[i], grown * (i & 1 ? sizeof(uint32_t) : sizeof(uint4))));
-        ctx->gen_queue_entries = grown;
-    }
-    constexpr size_t kCountInts = size_t(kGenRegions) * kGenCountStride;               // per generation
-    if (!ctx->gen_counts) HG_HIP(ctx, hipMalloc((void**)&ctx->gen_counts, (kMaxGenerations + 1) * kCountInts * sizeof(int)));
-    HG_HIP(ctx, hipMemsetAsync(ctx->gen_counts, 0, (kMaxGenerations + 1) * kCountInts * sizeof(int), ctx->stream));
-    int limits[kMaxGenerations], gens = 0;
-    for (; gens < kMaxGenerations - 1; gens++) {
-        const int l = (ctx->opt_gen_schedule >> (6 * gens)) & 63;
-        if (!l) break;
-        limits[gens] = l;
-    }
-    limits[gens++] = 0;                                                // the last generation runs every ray to its end
-    for (int g = 0; g < gens; g++) {
-        GenArgs q;
-        q.in_a = static_cast<const uint4*>(ctx->gen_queue[2 * ((g + 1) & 1)]); q.in_b = static_cast<const uint32_t*>(ctx->gen_queue[2 * ((g + 1) & 1) + 1]);
-        q.out_a = static_cast<uint4*>(ctx->gen_queue[2 * (g & 1)]);           q.out_b = static_cast<uint32_t*>(ctx->gen_queue[2 * (g & 1) + 1]);
-        q.in_count = ctx->gen_counts + kCountInts * g; q.out_count = ctx->gen_counts + kCountInts * (g + 1);
-        q.region_cap = int(region_cap); q.limit = limits[g];
-        if (g == 0) {
-            if (uniform) traverse_kernel_gen<true, 0><<<blocks0, 64, 0, ctx->stream>>>(a, q);
-            else         traverse_kernel_gen<false, 0><<<blocks0, 64, 0, ctx->stream>>>(a, q);
-        } else {
-            // persistent workgroups: a region's chunks are taken in turn, so any count is covered; sized for the expected survivors
-            const int per = std::max(std::min(per_region >> (g - 1), 128), std::min(per_region, 4));
-            if (uniform) traverse_kernel_gen<true, 1><<<per * kGenRegions, 64, 0, ctx->stream>>>(a, q);
-            else         traverse_kernel_gen<false, 1><<<per * kGenRegions, 64, 0, ctx->stream>>>(a, q);
-        }
-    }
-    HG_HIP(ctx, hipGetLastError());
-    return HAGRID_OK;
-}
-
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
@@ -1346,7 +1086,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.num_rays = num_rays; a.shift = g->shift; a.prio_step = ctx->opt_prio_step;
+    a.num_rays = num_rays; a.shift = g->shift;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -1454,9 +1194,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             }
         }
     }
-    if (variant == 4 && ctx->opt_generations && flags == 0 && ctx->image.flat && img_narrow && num_rays >= ctx->opt_gen_min_rays && !ctx->kat_wave_times) {
-        HG_TRY(launch_generations(ctx, a, num_rays, ctx->image.uniform));
-    } else if (variant == 4) {
+    if (variant == 4) {
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
@@ -1499,9 +1237,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20}, {"traverse.detect_origins", &ctx->opt_detect_origins, 0, 1},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
-        {"traverse.prio_step", &ctx->opt_prio_step, 0, 1 << 20},
-        {"traverse.generations", &ctx->opt_generations, 0, 1}, {"traverse.gen_schedule", &ctx->opt_gen_schedule, 0, (1 << 30) - 1},
-        {"traverse.gen_min_rays", &ctx->opt_gen_min_rays, 0, 1 << 30},
+
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {
