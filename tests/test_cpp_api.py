@@ -80,7 +80,8 @@ unsigned p_entry(unsigned a, unsigned b) { return as<unsigned>(make_entry(a, b))
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
 def test_reference_main_cpp_parses_against_our_headers():
-    """API-compat: the reference's own front-end, syntax-checked against include/hagrid/*.h.  Its SDL2 include is
+    """API-compat: the reference's own front-end, syntax-checked against include/hagrid/*.h (load_obj.h included: main.cpp
+    defines its own static load_model, which must not collide with ours).  Its SDL2 include is
     satisfied by a declarations-only stand-in created in a temp dir (this checks OUR headers, it builds nothing)."""
     ref = "/root/reference/src"
     with tempfile.TemporaryDirectory() as d:
@@ -97,7 +98,6 @@ int SDL_UpdateWindowSurface(SDL_Window*); void SDL_DestroyWindow(SDL_Window*); v
 ''')
         # main.cpp uses quote-includes ("build.h"): put OUR headers next to a symlink of main.cpp so they win
         os.symlink(os.path.join(ref, "main.cpp"), os.path.join(d, "src", "main.cpp"))
-        os.symlink(os.path.join(ref, "load_obj.h"), os.path.join(d, "src", "load_obj.h"))
         for h in os.listdir(os.path.join(INC, "hagrid")):
             os.symlink(os.path.join(INC, "hagrid", h), os.path.join(d, "src", h))
         os.symlink(os.path.join(INC, "hagrid_amd.h"), os.path.join(d, "hagrid_amd.h"))

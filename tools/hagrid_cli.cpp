@@ -3,8 +3,9 @@
 // report), minus the SDL viewer: without a ray file it traces ONE frame of primary rays -- the viewer's initial view, gen_camera / gen_rays formulas
 // (main.cpp:42-66, :572-598) -- and can write it as a PGM depth image instead of opening a window.
 //
-// SURVEY.md 8(f) rows 1 and 2 ("next" rows): CLI parity and a Wavefront OBJ reader (vertices + faces, fan triangulation,
-// negative indices, v/vt/vn index forms), so that logs of the two binaries can be compared line by line.
+// SURVEY.md 8(f) rows 1 and 2 ("next" rows): CLI parity and the Wavefront OBJ reader of include/hagrid/load_obj.h (the
+// reference's ObjLoader interface and behaviour, pinned to its load_obj.cpp by tests/test_obj_loader.py), so that logs of
+// the two binaries can be compared line by line.
 // Extension: a model name of the form soup:N generates the synthetic triangle soup of BASELINE.md instead of reading a file.
 //
 //   g++ -std=c++11 -O2 -DHOST= -DDEVICE= -Iinclude tools/hagrid_cli.cpp -o hagrid_cli -Lhagrid_amd -lhagrid_amd -lamdhip64
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "hagrid/build.h"
+#include "hagrid/load_obj.h"
 #include "hagrid/mem_manager.h"
 #include "hagrid/traverse.h"
 
@@ -99,38 +101,6 @@ Tri make_tri(const vec3& v0, const vec3& v1, const vec3& v2) {     // packing of
     return Tri(v0, n.x, e1, n.y, e2, n.z);
 }
 
-// Wavefront OBJ: "v x y z" and "f i[/t[/n]] ..." lines; polygons are triangulated as a fan around their first vertex
-// (what main.cpp:253-270 does with the loader's faces); negative indices count from the end.
-bool load_obj(const std::string& name, std::vector<Tri>& tris) {
-    std::ifstream in(name);
-    if (!in) return false;
-    std::vector<vec3> verts;
-    std::string line;
-    while (std::getline(in, line)) {
-        size_t p = line.find_first_not_of(" \t\r");
-        if (p == std::string::npos || line[p] == '#') continue;
-        if (line.compare(p, 2, "v ") == 0 || line.compare(p, 2, "v\t") == 0) {
-            std::istringstream ss(line.substr(p + 2));
-            vec3 v(0.0f);
-            ss >> v.x >> v.y >> v.z;
-            verts.push_back(v);
-        } else if (line.compare(p, 2, "f ") == 0 || line.compare(p, 2, "f\t") == 0) {
-            std::istringstream ss(line.substr(p + 2));
-            std::string tok;
-            std::vector<int> idx;
-            while (ss >> tok) {
-                long i = strtol(tok.c_str(), nullptr, 10);          // stops at '/'
-                if (i == 0) return false;
-                i = i < 0 ? long(verts.size()) + i : i - 1;
-                if (i < 0 || i >= long(verts.size())) return false;
-                idx.push_back(int(i));
-            }
-            for (size_t k = 1; k + 1 < idx.size(); k++) tris.push_back(make_tri(verts[idx[0]], verts[idx[k]], verts[idx[k + 1]]));
-        }
-    }
-    return !tris.empty();
-}
-
 uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
 }
@@ -185,7 +155,7 @@ int main(int argc, char** argv) {
 
     std::vector<Tri> host_tris;
     if (opts.scene.compare(0, 5, "soup:") == 0) make_soup(atoi(opts.scene.c_str() + 5), host_tris);
-    else if (!load_obj(opts.scene, host_tris)) {
+    else if (!load_obj_triangles(opts.scene, host_tris)) {
         std::cerr << "Scene cannot be loaded (file not present or contains errors)" << std::endl;
         return 1;
     }
