@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not _newer(LIB, objs):
-        run(["g++", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"])
+        run(["g++", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread", "-ldl"])
     return LIB
 
 

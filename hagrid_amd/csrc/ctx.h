@@ -16,6 +16,7 @@ struct Slot {
     void* ptr = nullptr;
     size_t size = 0;
     bool in_use = false;
+    int refs = 0;          // tracked pointers into this slot: 1 after alloc; an unpacked grid blob is one slot with four
 };
 
 } // namespace hagrid_impl
@@ -130,6 +131,10 @@ struct PoolTemps {
     void* keep(void* p) { for (auto& q : ptrs) if (q == p) q = nullptr; return p; }       // ownership passes to the caller
     ~PoolTemps() { for (void* p : ptrs) if (p) hagrid_mem_free(ctx, p); }
 };
+
+// Turns the pool buffer `base` into `n` separately freeable buffers parts[0..n) that lie inside it (a grid blob unpacked in
+// place): `base` stops being a pool pointer, every part becomes one, the memory is released with the last of them.
+int pool_split(hagrid_ctx* ctx, void* base, void* const* parts, int n);
 
 // Reads `count` ints from device memory into host memory after draining the stream.
 int read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes);

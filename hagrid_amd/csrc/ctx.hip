@@ -127,8 +127,26 @@ extern "C" void* hagrid_mem_alloc(hagrid_ctx* ctx, size_t bytes) {
     }
     Slot& s = ctx->slots[idx];
     s.in_use = true;
+    s.refs = 1;
     ctx->tracker[s.ptr] = idx;
     return s.ptr;
+}
+
+int hagrid_impl::pool_split(hagrid_ctx* ctx, void* base, void* const* parts, int n) {
+    auto it = ctx->tracker.find(base);
+    if (it == ctx->tracker.end() || n <= 0) HG_FAIL(ctx, HAGRID_EINVAL, "pool_split: not a pool buffer");
+    const int idx = it->second;
+    Slot& s = ctx->slots[idx];
+    if (s.refs != 1 || s.ptr != base) HG_FAIL(ctx, HAGRID_EINVAL, "pool_split: buffer is already split");
+    for (int i = 0; i < n; i++) {
+        const char* p = static_cast<const char*>(parts[i]);
+        if (p < static_cast<const char*>(base) || p >= static_cast<const char*>(base) + s.size) HG_FAIL(ctx, HAGRID_EINVAL, "pool_split: part outside the buffer");
+        for (int j = 0; j < i; j++) if (parts[j] == parts[i]) HG_FAIL(ctx, HAGRID_EINVAL, "pool_split: parts coincide");
+    }
+    ctx->tracker.erase(it);
+    for (int i = 0; i < n; i++) ctx->tracker[parts[i]] = idx;
+    s.refs = n;
+    return HAGRID_OK;
 }
 
 extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
@@ -140,6 +158,7 @@ extern "C" int hagrid_mem_free(hagrid_ctx* ctx, void* ptr) {
     it = ctx->tracker.find(ptr);
     Slot& s = ctx->slots[it->second];
     ctx->tracker.erase(it);
+    if (--s.refs > 0) return HAGRID_OK;          // other parts of a split buffer are still alive
     s.in_use = false;
     if (!ctx->keep) {
         // buffers may still be read by work queued on the stream

@@ -40,6 +40,16 @@ class TraversalStats(C.Structure):
 MAX_MERGE_PASSES = 96
 
 
+class BlobHeader(C.Structure):
+    """struct hagrid_blob_header (include/hagrid_amd.h): the first 256 bytes of a grid blob / grid file."""
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("dims", C.c_int32 * 3), ("shift", C.c_int32),
+                ("num_cells", C.c_int32), ("num_entries", C.c_int32), ("num_refs", C.c_int32), ("num_tris", C.c_int32),
+                ("compressed", C.c_int32), ("num_offsets", C.c_int32), ("offsets", C.c_int32 * MAX_LEVELS),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("off_entries", C.c_uint64), ("off_cells", C.c_uint64), ("off_refs", C.c_uint64), ("off_tris", C.c_uint64), ("total_bytes", C.c_uint64),
+                ("reserved", C.c_uint8 * 16)]
+
+
 class BuildCounts(C.Structure):
     """struct hagrid_build_counts (include/hagrid_amd.h): sizes the construction passes went through."""
     _fields_ = [("num_tris", C.c_int64), ("top_cells", C.c_int64), ("top_refs", C.c_int64),
@@ -90,6 +100,12 @@ SIGNATURES = {
     "hagrid_flatten_grid": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_expand_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _i32]),
     "hagrid_compress_grid": (_i32, [_vp, C.POINTER(GridPOD)]),
+    "hagrid_grid_blob_bytes": (_sz, [C.POINTER(GridPOD), _i32]),
+    "hagrid_grid_pack": (_i32, [_vp, C.POINTER(GridPOD), _vp, _i32, C.POINTER(_vp), C.POINTER(_sz)]),
+    "hagrid_grid_unpack": (_i32, [_vp, _vp, _sz, C.POINTER(GridPOD), C.POINTER(_vp), C.POINTER(_i32)]),
+    "hagrid_grid_save": (_i32, [_vp, C.POINTER(GridPOD), _vp, _i32, C.c_char_p]),
+    "hagrid_grid_load": (_i32, [_vp, C.c_char_p, C.POINTER(GridPOD), C.POINTER(_vp), C.POINTER(_i32)]),
+    "hagrid_grid_broadcast": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(GridPOD), C.POINTER(_vp), C.POINTER(_i32)]),
     "hagrid_setup_traversal": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_traverse_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32]),
     "hagrid_traverse_grid_ex": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, C.c_uint32]),

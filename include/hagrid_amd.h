@@ -143,6 +143,36 @@ int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris, int
  * fit 16 bits (grid untouched), negative on error. */
 int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid);
 
+/* ---- the grid as one buffer: multi-GPU broadcast and save / load (no reference counterpart) -------------- */
+/* Blob = header (256 bytes) + entries + cells | small_cells + ref_ids + triangles, every section 128-byte aligned.  The same bytes
+ * are the file form.  Little-endian, offsets in bytes from the start of the blob. */
+typedef struct hagrid_blob_header {
+    uint32_t magic, version;                       /* "HGRB", 1 */
+    int32_t dims[3], shift;
+    int32_t num_cells, num_entries, num_refs, num_tris;
+    int32_t compressed, num_offsets;
+    int32_t offsets[HAGRID_MAX_LEVELS];
+    float bbox_min[3], bbox_max[3];
+    uint64_t off_entries, off_cells, off_refs, off_tris, total_bytes;
+    uint8_t reserved[16];
+} hagrid_blob_header;
+/* Size of the blob of `grid` with `num_tris` triangles (0 for an incomplete grid). */
+size_t hagrid_grid_blob_bytes(const hagrid_grid* grid, int num_tris);
+/* Copies grid + triangles into one new pool buffer (device-to-device); release it with hagrid_mem_free. */
+int hagrid_grid_pack(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris, int num_tris, void** blob, size_t* bytes);
+/* Turns a blob held in a pool buffer of this context into a grid IN PLACE: the buffer is split into the four arrays, which from then
+ * on are ordinary pool buffers (grid->entries, grid->cells | small_cells, grid->ref_ids, *tris: each released with hagrid_mem_free, in
+ * any order, like the arrays of a built grid); `blob` itself must not be freed afterwards.  Nothing is copied. */
+int hagrid_grid_unpack(hagrid_ctx* ctx, void* blob, size_t bytes, hagrid_grid* grid, void** tris, int* num_tris);
+/* The blob as a file. */
+int hagrid_grid_save(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris, int num_tris, const char* path);
+int hagrid_grid_load(hagrid_ctx* ctx, const char* path, hagrid_grid* grid, void** tris, int* num_tris);
+/* One process per GPU: rank `root` passes its grid and triangles (they stay untouched), every other rank receives them (grid, *tris,
+ * *num_tris are outputs there, arrays owned as after hagrid_grid_unpack).  `comm` is an ncclComm_t of RCCL spanning the ranks; two
+ * ncclBroadcast calls on the context's stream: the 256-byte header, then the blob, straight from / into pool memory.  RCCL is
+ * looked up in the running process (the copy PyTorch or the host program loaded, else /opt/rocm/lib/librccl.so).  Blocking. */
+int hagrid_grid_broadcast(hagrid_ctx* ctx, void* comm, int rank, int root, hagrid_grid* grid, void** tris, int* num_tris);
+
 /* ---- traversal (traverse.h:11-14) ------------------------------------------------------------------- */
 /* setup_traversal (traverse.cu:97-109): prepares the traversal state of `grid`.  The reference uploads constants; here
  * the constants travel with every launch and this call builds the TRAVERSAL IMAGE of the grid in the context (one per

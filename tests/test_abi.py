@@ -40,9 +40,10 @@ def test_struct_layout_matches_header(built):
 #include <stddef.h>
 #include "hagrid_amd.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(hagrid_grid), sizeof(hagrid_traversal_stats), sizeof(hagrid_build_counts),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hagrid_grid), sizeof(hagrid_traversal_stats), sizeof(hagrid_build_counts),
            offsetof(hagrid_grid, offsets), offsetof(hagrid_build_counts, level_refs), offsetof(hagrid_build_counts, merge_cells),
-           offsetof(hagrid_build_counts, compress_refs_out));
+           offsetof(hagrid_build_counts, compress_refs_out), sizeof(hagrid_blob_header), offsetof(hagrid_blob_header, bbox_min),
+           offsetof(hagrid_blob_header, off_entries));
     return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -52,7 +53,8 @@ int main(void) {
         got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     B = built.BuildCounts
     want = [C.sizeof(built.GridPOD), C.sizeof(built.TraversalStats), C.sizeof(B), built.GridPOD.offsets.offset,
-            B.level_refs.offset, B.merge_cells.offset, B.compress_refs_out.offset]
+            B.level_refs.offset, B.merge_cells.offset, B.compress_refs_out.offset, C.sizeof(built.BlobHeader),
+            built.BlobHeader.bbox_min.offset, built.BlobHeader.off_entries.offset]
     assert got == want
 
 

@@ -126,7 +126,7 @@ def _build_cli(d):
     hip_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
     exe = os.path.join(d, "hagrid_cli")
     subprocess.run(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DHOST=", "-DDEVICE=", "-I", INC, os.path.join(ROOT, "tools", "hagrid_cli.cpp"),
-                    "-o", exe, "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-L", hip_lib, "-lamdhip64",
+                    "-o", exe, "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-L", hip_lib, "-lamdhip64", "-ldl",
                     "-Wl,-rpath," + os.path.join(ROOT, "hagrid_amd"), "-Wl,-rpath," + hip_lib, "-Wl,--allow-shlib-undefined"], check=True)
     return exe
 
@@ -194,6 +194,19 @@ def test_cli_obj_scene_and_ray_file_benchmark():
         r = subprocess.run([exe, "soup:20000", "-sx", "128", "-sy", "64", "-s", heat], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "Steps per ray: max " in r.stdout, r.stdout + r.stderr
         assert os.path.getsize(heat) == len("P5\n128 64\n255\n") + 128 * 64
+        # the grid as a file: --save-grid, then --load-grid instead of a scene gives the same grid and the same intersections
+        gfile = os.path.join(d, "soup.grid")
+        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--save-grid", gfile], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and f"{want} intersection(s)." in r.stdout and os.path.getsize(gfile) % 128 == 0
+        r = subprocess.run([exe, "--load-grid", gfile, "-r", rfile], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "5000 triangle(s)" in r.stdout and "Grid loaded (" in r.stdout and f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
+        assert f"{want} intersection(s)." in r.stdout
+        # one process per GPU, the grid broadcast from C++ with RCCL (here: one rank, all this box has)
+        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--gpus", "1", "-n", "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "1 rank(s), grid broadcast in " in r.stdout and f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
+        assert f"{want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout
         mem.close()
 
 

@@ -11,14 +11,36 @@ from hagrid_amd import dist as hdist
 from hagrid_amd import scene
 
 
-def test_header_roundtrip():
-    h = hdist.pack_header((50, 52, 54), 2, [10, 20, 30], np.float32([-0.5, 0.25, 1e-3]), np.float32([1.5, 2.0, 3.0]), 30, 17, 99, 12, True)
-    d = hdist.unpack_header(h)
-    assert d["dims"] == (50, 52, 54) and d["shift"] == 2 and d["offsets"] == [10, 20, 30] and d["compressed"]
-    assert (d["bbox_min"] == np.float32([-0.5, 0.25, 1e-3])).all() and (d["bbox_max"] == np.float32([1.5, 2.0, 3.0])).all()
-    assert hdist.array_nbytes(d) == {"entries": 120, "cells": 16 * 17, "ref_ids": 396, "tris": 48 * 12}
+def test_blob_header_and_host_roundtrip():
+    """The numpy packer writes the layout of struct hagrid_blob_header (include/hagrid_amd.h) and reads it back."""
+    import ctypes as C
+    from hagrid_amd import lib
+    assert C.sizeof(lib.BlobHeader) == hdist.BLOB_HEADER.itemsize == 256
+    for name, _ in lib.BlobHeader._fields_:
+        assert getattr(lib.BlobHeader, name).offset == hdist.BLOB_HEADER.fields[name][1], name
+    rng = np.random.default_rng(3)
+    for compressed in (False, True):
+        entries = rng.integers(0, 1 << 30, 30, dtype=np.uint32); refs = rng.integers(0, 12, 99).astype(np.int32)
+        cells = np.zeros(17, dtype=hdist.SMALL_CELL_DTYPE if compressed else hdist.CELL_DTYPE)
+        cells["begin"] = np.arange(17)
+        tris = rng.normal(size=(12, 12)).astype(np.float32)
+        blob = hdist.pack_blob_host(entries, refs, None if compressed else cells, cells if compressed else None,
+                                    np.float32([-0.5, 0.25, 1e-3]), np.float32([1.5, 2.0, 3.0]), (50, 52, 54), 2, [10, 20, 30], tris)
+        assert blob.size % 128 == 0
+        d = hdist.unpack_blob_host(blob)
+        assert d["dims"] == (50, 52, 54) and d["shift"] == 2 and d["offsets"] == [10, 20, 30] and d["compressed"] == compressed
+        assert (d["bbox_min"] == np.float32([-0.5, 0.25, 1e-3])).all() and (d["bbox_max"] == np.float32([1.5, 2.0, 3.0])).all()
+        assert (d["entries"] == entries).all() and (d["ref_ids"] == refs).all() and (d["tris"] == tris).all()
+        got = d["small_cells"] if compressed else d["cells"]
+        assert got.tobytes() == cells.tobytes() and (d["cells"] is None) == compressed
+        assert all(d[k] % 128 == 0 for k in ("off_entries", "off_cells", "off_refs", "off_tris"))
     with pytest.raises(ValueError):
-        hdist.unpack_header(np.zeros(64, dtype=np.int64))
+        hdist.parse_header(np.zeros(256, dtype=np.uint8))
+    bad = blob.copy(); bad[200:208] = 255                      # off_entries
+    with pytest.raises(ValueError):
+        hdist.parse_header(bad[:256])
+    with pytest.raises(ValueError):
+        hdist.unpack_blob_host(blob[:-128])
 
 
 def test_shard_ranges_partition_the_batch():
@@ -37,19 +59,14 @@ def _worker(rank, world, port, compress, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tris_full = scene.make_soup(4000)
-        header = arrays = None
+        blob = None
         if rank == 0:       # only the building rank has the scene and the grid
             G = O.Grid.full(tris_full, compress=compress)
-            cells = G.small_cells if compress else G.cells
-            header = hdist.pack_header(G.dims, G.shift, G.offsets, G.bbox_min, G.bbox_max, G.num_entries, G.num_cells, G.num_refs, tris_full.shape[0], compress)
-            as_u8 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy())
-            arrays = {"entries": as_u8(G.entries), "cells": as_u8(cells), "ref_ids": as_u8(G.ref_ids), "tris": as_u8(tris_full)}
-        hd, out = hdist.broadcast_payload(header, arrays, lambda n: torch.empty(int(n), dtype=torch.uint8), src=0)
-        ent = out["entries"].numpy().view(np.uint32); refs = out["ref_ids"].numpy().view(np.int32)
-        tris = out["tris"].numpy().view(np.float32).reshape(-1, 12)
-        cells = out["cells"].numpy().view(O.SMALL_CELL_DTYPE if hd["compressed"] else O.CELL_DTYPE)
-        G2 = O.Grid.from_arrays(ent, refs, None if hd["compressed"] else cells, cells if hd["compressed"] else None,
-                                hd["bbox_min"], hd["bbox_max"], hd["dims"], hd["shift"], hd["offsets"])
+            blob = torch.from_numpy(hdist.pack_blob_host(G.entries, G.ref_ids, G.cells, G.small_cells, G.bbox_min, G.bbox_max, G.dims, G.shift, G.offsets, tris_full))
+        blob = hdist.broadcast_blob(blob, lambda n: torch.empty(int(n), dtype=torch.uint8), src=0)
+        hd = hdist.unpack_blob_host(blob.numpy())
+        tris = hd["tris"]
+        G2 = O.Grid.from_arrays(hd["entries"], hd["ref_ids"], hd["cells"], hd["small_cells"], hd["bbox_min"], hd["bbox_max"], hd["dims"], hd["shift"], hd["offsets"])
         n_rays = 20001
         rays = scene.make_rays_incoherent(hd["bbox_min"], hd["bbox_max"], n_rays, 77)
         b, e = scene.shard_range(n_rays, rank, world)

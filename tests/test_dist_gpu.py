@@ -107,6 +107,70 @@ def test_broadcast_grid_and_sharded_traversal():
     mem.close()
 
 
+@pytest.mark.parametrize("compress", [False, True])
+def test_grid_blob_pack_unpack_save_load(compress, tmp_path):
+    """The C packer writes the bytes of the numpy packer; a blob unpacks IN PLACE into a grid whose arrays are ordinary pool
+    buffers (freed one by one, the memory goes with the last); the file form loads into another context; hits never change."""
+    import ctypes as C
+    from hagrid_amd import api, dist as hdist
+    n_tris = 50_000
+    tris = scene.make_soup(n_tris)
+    mem = api.MemManager(keep=False)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, n_tris, compress=compress)
+    rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 100_000, 3)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
+
+    def hits_of(m, g, t, dr, dh):
+        api.setup_traversal(g)
+        api.traverse_grid(g, t, dr, dh, rays.shape[0])
+        return m.download(dh, api.HIT_DTYPE, rays.shape[0])
+
+    want = hits_of(mem, grid, d_tris, d_rays, d_hits)
+    # pack == the host packer on the downloaded arrays
+    p = C.c_void_p(); nb = C.c_size_t()
+    api._check(mem, mem._L.hagrid_grid_pack(mem._ctx, C.byref(grid.pod), C.c_void_p(d_tris), n_tris, C.byref(p), C.byref(nb)), "pack")
+    assert nb.value == mem._L.hagrid_grid_blob_bytes(C.byref(grid.pod), n_tris) and nb.value % 128 == 0
+    blob = mem.download(p.value, np.uint8, nb.value)
+    d = grid.download()
+    host = hdist.pack_blob_host(d["entries"], d["ref_ids"], d["cells"], d["small_cells"], d["bbox_min"], d["bbox_max"], d["dims"], d["shift"], d["offsets"], tris)
+    assert blob.tobytes() == host.tobytes()
+    # unpack in place: no new memory, four separately freeable arrays
+    usage = mem.usage()
+    g2 = api.Grid(); g2.mem = mem
+    t2 = C.c_void_p(); nt = C.c_int()
+    api._check(mem, mem._L.hagrid_grid_unpack(mem._ctx, p, nb.value, C.byref(g2.pod), C.byref(t2), C.byref(nt)), "unpack")
+    assert mem.usage() == usage and nt.value == n_tris and g2.summary() == grid.summary()
+    with pytest.raises(api.HagridError):
+        mem.free(p.value)                                   # the blob pointer is no pool pointer any more
+    got = hits_of(mem, g2, t2.value, d_rays, d_hits)
+    assert (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    g2.free()
+    assert mem.usage() == usage                             # the triangles of the blob are still alive
+    mem.free(t2.value)
+    assert mem.usage() == usage - nb.value                  # keep = False: the slot is released with its last part
+    # a damaged header is refused and leaves the buffer alone
+    api._check(mem, mem._L.hagrid_grid_pack(mem._ctx, C.byref(grid.pod), C.c_void_p(d_tris), n_tris, C.byref(p), C.byref(nb)), "pack")
+    mem.zero(p.value + 200, 8)
+    rc = mem._L.hagrid_grid_unpack(mem._ctx, p, nb.value, C.byref(g2.pod), C.byref(t2), C.byref(nt))
+    assert rc < 0
+    mem.free(p.value)
+    # the file form, into another context
+    path = str(tmp_path / "grid.blob")
+    hdist.save_grid(mem, grid, d_tris, n_tris, path)
+    assert open(path, "rb").read() == host.tobytes()
+    mem2 = api.MemManager(keep=True)
+    g3, t3, n3 = hdist.load_grid(mem2, path)
+    assert n3 == n_tris and g3.summary() == grid.summary()
+    dr = mem2.upload(rays); dh = mem2.alloc(16 * rays.shape[0])
+    got = hits_of(mem2, g3, t3, dr, dh)
+    assert (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    open(path, "wb").write(host.tobytes()[:-4096])
+    with pytest.raises(api.HagridError):
+        hdist.load_grid(mem2, path)
+    mem2.close(); mem.close()
+
+
 def test_bench_rccl_path_with_one_rank():
     """The RCCL code path (process group on backend nccl, barrier, grid broadcast, all-reduce) with world size 1."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")

@@ -7,6 +7,9 @@
 // reference's ObjLoader interface and behaviour, pinned to its load_obj.cpp by tests/test_obj_loader.py), so that logs of
 // the two binaries can be compared line by line.
 // Extension: a model name of the form soup:N generates the synthetic triangle soup of BASELINE.md instead of reading a file.
+// Extension: --gpus N runs one process per GPU (this program re-executes itself N times): rank 0 builds, the grid is broadcast
+// once with RCCL (ncclBroadcast from C++, include/hagrid/multi_gpu.h), every rank traces its contiguous share of the rays, the
+// report is the reference's with whole-job figures.  --save-grid / --load-grid write / read the grid blob.
 //
 //   g++ -std=c++11 -O2 -DHOST= -DDEVICE= -Iinclude tools/hagrid_cli.cpp -o hagrid_cli -Lhagrid_amd -lhagrid_amd -lamdhip64
 #include <algorithm>
@@ -22,9 +25,14 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "hagrid/build.h"
 #include "hagrid/load_obj.h"
 #include "hagrid/mem_manager.h"
+#include "hagrid/multi_gpu.h"
 #include "hagrid/traverse.h"
 
 using namespace hagrid;
@@ -32,7 +40,8 @@ using namespace hagrid;
 namespace {
 
 struct Options {
-    std::string scene, ray_file, out_image, steps_image;
+    std::string scene, ray_file, out_image, steps_image, save_grid, load_grid;
+    int gpus = 0;
     float top_density = 0.12f, snd_density = 2.4f, alpha = 0.995f;
     int exp_iters = 3, width = 1024, height = 1024;
     float clip = 0, fov = 60;
@@ -67,6 +76,9 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
         {"-o", "--out", STRING, &o.out_image, "(extension) writes the traced frame as a PGM depth image"},
         {"-s", "--steps-image", STRING, &o.steps_image, "(extension) writes the per-pixel traversal step count as a PGM heat map"},
         {"-ah", "--any-hit", FLAG, &o.any_hit, "(extension) occlusion rays: a ray stops at its first intersection"},
+        {"-g", "--gpus", INT, &o.gpus, "(extension) one process per GPU: the grid is built once and broadcast (RCCL), the rays are sharded"},
+        {"-sg", "--save-grid", STRING, &o.save_grid, "(extension) writes the finished grid (and the triangles) to a file"},
+        {"-lg", "--load-grid", STRING, &o.load_grid, "(extension) reads grid and triangles from a file instead of building"},
     };
     bool have_scene = false;
     for (int i = 1; i < argc; i++) {
@@ -86,7 +98,7 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
         else if (d->kind == FLOAT) *static_cast<float*>(d->dst) = strtof(v, nullptr);
         else *static_cast<std::string*>(d->dst) = v;
     }
-    if (!have_scene && !o.help) { std::cerr << "No model specified" << std::endl; return false; }
+    if (!have_scene && !o.help && o.load_grid.empty()) { std::cerr << "No model specified" << std::endl; return false; }
     return true;
 }
 
@@ -144,6 +156,61 @@ void report_timings(std::vector<double> t, size_t rays_per_iter, int intr) {    
     std::cout << "# Min: " << t.front() << " ms" << std::endl;
 }
 
+extern "C" int hipSetDevice(int);      // the one HIP runtime call of this front-end (the process links libamdhip64 for the library's sake)
+int hipSetDeviceShim(int device) { return hipSetDevice(device); }
+
+// ---- multi-GPU: RCCL bound at run time, one process per GPU ---------------------------------------------------------------
+struct NcclId { char internal[128]; };                       // ncclUniqueId (rccl.h:43)
+struct Rccl {
+    int (*get_unique_id)(NcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, NcclId, int) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    bool load() {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return false;
+        get_unique_id = reinterpret_cast<int (*)(NcclId*)>(dlsym(h, "ncclGetUniqueId"));
+        comm_init_rank = reinterpret_cast<int (*)(void**, int, NcclId, int)>(dlsym(h, "ncclCommInitRank"));
+        all_reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, void*)>(dlsym(h, "ncclAllReduce"));
+        comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+        return get_unique_id && comm_init_rank && all_reduce && comm_destroy;
+    }
+};
+constexpr int kNcclSum = 0, kNcclMax = 2, kNcclInt32 = 2, kNcclFloat32 = 7;       // rccl.h:448-466
+
+// The launcher: creates the RCCL id, starts one copy of this program per GPU (rank and id travel in the environment) and waits.
+int launch_ranks(char** argv, int world) {
+    Rccl r;
+    if (!r.load()) { std::cerr << "--gpus needs RCCL (librccl.so)" << std::endl; return 1; }
+    NcclId id;
+    if (r.get_unique_id(&id) != 0) { std::cerr << "ncclGetUniqueId failed" << std::endl; return 1; }
+    std::string hex;
+    for (unsigned char ch : id.internal) { char b[3]; snprintf(b, sizeof(b), "%02x", ch); hex += b; }
+    std::vector<pid_t> kids;
+    for (int rank = 0; rank < world; rank++) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::cerr << "fork failed" << std::endl; return 1; }
+        if (pid == 0) {
+            setenv("HAGRID_CLI_RANK", std::to_string(rank).c_str(), 1);
+            setenv("HAGRID_CLI_NCCL_ID", hex.c_str(), 1);
+            setenv("HAGRID_DEVICE", std::to_string(rank).c_str(), 1);
+            execv("/proc/self/exe", argv);
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : kids) {
+        int status = 0;
+        waitpid(pid, &status, 0);
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128;
+        worst = std::max(worst, code);
+    }
+    return worst;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
@@ -153,22 +220,45 @@ int main(int argc, char** argv) {
     if (!parse(argc, argv, opts, table)) return 1;
     if (opts.help) { usage(table); return 0; }
 
-    std::vector<Tri> host_tris;
-    if (opts.scene.compare(0, 5, "soup:") == 0) make_soup(atoi(opts.scene.c_str() + 5), host_tris);
-    else if (!load_obj_triangles(opts.scene, host_tris)) {
-        std::cerr << "Scene cannot be loaded (file not present or contains errors)" << std::endl;
-        return 1;
+    // --gpus N: the first invocation only starts the ranks
+    const char* env_rank = getenv("HAGRID_CLI_RANK");
+    if (opts.gpus > 0 && !env_rank) return launch_ranks(argv, opts.gpus);
+    const int world = opts.gpus > 0 ? opts.gpus : 1, rank = env_rank ? atoi(env_rank) : 0;
+    const bool root = rank == 0;
+    Rccl rccl;
+    void* comm = nullptr;
+    if (opts.gpus > 0) {
+        const char* hex = getenv("HAGRID_CLI_NCCL_ID");
+        NcclId id;
+        if (!rccl.load() || !hex || strlen(hex) != 256) { std::cerr << "rank " << rank << ": no RCCL / no id" << std::endl; return 1; }
+        for (int i = 0; i < 128; i++) { unsigned v = 0; sscanf(hex + 2 * i, "%2x", &v); id.internal[i] = char(v); }
+        if (hipSetDeviceShim(rank) != 0 || rccl.comm_init_rank(&comm, world, id, rank) != 0) { std::cerr << "rank " << rank << ": ncclCommInitRank failed" << std::endl; return 1; }
     }
-    std::cout << host_tris.size() << " triangle(s)" << std::endl;
 
+    std::vector<Tri> host_tris;
     MemManager mem(opts.keep_alive);
-    Tri* tris = mem.alloc<Tri>(host_tris.size());
-    mem.copy<Copy::HST_TO_DEV>(tris, host_tris.data(), host_tris.size());
-
+    Tri* tris = nullptr;
+    int num_tris = 0;
     Grid grid;
     grid.entries = nullptr; grid.cells = nullptr; grid.ref_ids = nullptr; grid.small_cells = nullptr;
+    const bool build_here = root && opts.load_grid.empty();
+    if (build_here) {
+        if (opts.scene.compare(0, 5, "soup:") == 0) make_soup(atoi(opts.scene.c_str() + 5), host_tris);
+        else if (!load_obj_triangles(opts.scene, host_tris)) {
+            std::cerr << "Scene cannot be loaded (file not present or contains errors)" << std::endl;
+            return 1;
+        }
+        std::cout << host_tris.size() << " triangle(s)" << std::endl;
+        num_tris = int(host_tris.size());
+        tris = mem.alloc<Tri>(host_tris.size());
+        mem.copy<Copy::HST_TO_DEV>(tris, host_tris.data(), host_tris.size());
+    } else if (root) {
+        if (!load_grid(mem, opts.load_grid, grid, tris, num_tris)) { std::cerr << "Grid file cannot be loaded" << std::endl; return 1; }
+        std::cout << num_tris << " triangle(s)" << std::endl;
+    }
+
     auto construct = [&] {
-        build_grid(mem, tris, int(host_tris.size()), grid, opts.top_density, opts.snd_density);
+        build_grid(mem, tris, num_tris, grid, opts.top_density, opts.snd_density);
         merge_grid(mem, grid, opts.alpha);
         flatten_grid(mem, grid);
         expand_grid(mem, grid, tris, opts.exp_iters);
@@ -178,24 +268,34 @@ int main(int argc, char** argv) {
         mem.free(grid.entries); mem.free(grid.cells); mem.free(grid.ref_ids); mem.free(grid.small_cells);
         grid.entries = nullptr; grid.cells = nullptr; grid.ref_ids = nullptr; grid.small_cells = nullptr;
     };
-    for (int i = 0; i < opts.build_warmup; i++) { release(); construct(); }
     double total_time = 0;
-    for (int i = 0; i < opts.build_iter; i++) { release(); total_time += profile(construct); }
-    if (opts.compress && !grid.small_cells) std::cerr << "Could not compress grid. Continuing with uncompressed structure." << std::endl;
+    if (build_here) {
+        for (int i = 0; i < opts.build_warmup; i++) { release(); construct(); }
+        for (int i = 0; i < opts.build_iter; i++) { release(); total_time += profile(construct); }
+        if (opts.compress && !grid.small_cells) std::cerr << "Could not compress grid. Continuing with uncompressed structure." << std::endl;
+        if (!opts.save_grid.empty()) save_grid(mem, grid, tris, num_tris, opts.save_grid);
+    }
+    if (comm) {                                      // the ONE exchange step: the finished grid from rank 0 to everybody
+        const double ms = profile([&] { broadcast_grid(mem, grid, tris, num_tris, comm, rank, 0); });
+        if (root) std::cout << world << " rank(s), grid broadcast in " << ms << " ms" << std::endl;
+    }
 
-    const ivec3 dims = grid.dims << grid.shift;
-    std::cout << "Grid built in " << total_time / opts.build_iter << " ms (" << dims.x << "x" << dims.y << "x" << dims.z << ", "
-              << grid.num_cells << " cells, " << grid.num_refs << " references)" << std::endl;
-    const size_t cells_mem = size_t(grid.num_cells) * (grid.small_cells ? sizeof(SmallCell) : sizeof(Cell));
-    const size_t entries_mem = size_t(grid.num_entries) * sizeof(int), refs_mem = size_t(grid.num_refs) * sizeof(int);
-    const size_t tris_mem = host_tris.size() * sizeof(Tri);
-    const double mb = 1024.0 * 1024.0;
-    std::cout << "Total memory: " << (cells_mem + entries_mem + refs_mem + tris_mem) / mb << " MB" << std::endl;
-    std::cout << "Cells: " << cells_mem / mb << " MB" << std::endl;
-    std::cout << "Entries: " << entries_mem / mb << " MB" << std::endl;
-    std::cout << "References: " << refs_mem / mb << " MB" << std::endl;
-    std::cout << "Triangles: " << tris_mem / mb << " MB" << std::endl;
-    std::cout << "Peak usage: " << mem.max_usage() / mb << " MB" << std::endl;
+    if (root) {
+        const ivec3 dims = grid.dims << grid.shift;
+        if (build_here) std::cout << "Grid built in " << total_time / opts.build_iter << " ms (";
+        else std::cout << "Grid loaded (";
+        std::cout << dims.x << "x" << dims.y << "x" << dims.z << ", " << grid.num_cells << " cells, " << grid.num_refs << " references)" << std::endl;
+        const size_t cells_mem = size_t(grid.num_cells) * (grid.small_cells ? sizeof(SmallCell) : sizeof(Cell));
+        const size_t entries_mem = size_t(grid.num_entries) * sizeof(int), refs_mem = size_t(grid.num_refs) * sizeof(int);
+        const size_t tris_mem = size_t(num_tris) * sizeof(Tri);
+        const double mb = 1024.0 * 1024.0;
+        std::cout << "Total memory: " << (cells_mem + entries_mem + refs_mem + tris_mem) / mb << " MB" << std::endl;
+        std::cout << "Cells: " << cells_mem / mb << " MB" << std::endl;
+        std::cout << "Entries: " << entries_mem / mb << " MB" << std::endl;
+        std::cout << "References: " << refs_mem / mb << " MB" << std::endl;
+        std::cout << "Triangles: " << tris_mem / mb << " MB" << std::endl;
+        std::cout << "Peak usage: " << mem.max_usage() / mb << " MB" << std::endl;
+    }
 
     setup_traversal(grid);
     const float scene_size = length(grid.bbox.extents());
@@ -204,11 +304,11 @@ int main(int argc, char** argv) {
 
     std::vector<Ray> host_rays;
     if (!opts.ray_file.empty()) {
-        std::cout << "Entering benchmark mode" << std::endl;
+        if (root) std::cout << "Entering benchmark mode" << std::endl;
         if (!load_rays(opts.ray_file, host_rays, opts.tmin, opts.tmax)) { std::cerr << "Cannot load ray file" << std::endl; return 1; }
     } else {
         // one frame of the viewer's initial view (main.cpp:572-579, :592-598): eye at the scene centre, looking down +z
-        std::cout << "Tracing one " << opts.width << "x" << opts.height << " frame (no interactive viewer in this front-end)" << std::endl;
+        if (root) std::cout << "Tracing one " << opts.width << "x" << opts.height << " frame (no interactive viewer in this front-end)" << std::endl;
         const vec3 eye = center, forward(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
         const float f = tanf(float(M_PI) * opts.fov / 360.0f), ratio = float(opts.width) / float(opts.height);
         const vec3 dir = normalize((eye + forward * 100.0f) - eye), right = normalize(cross(dir, up)) * (f * ratio), cup = normalize(cross(right, dir)) * f;
@@ -219,6 +319,11 @@ int main(int argc, char** argv) {
                 host_rays[size_t(y) * opts.width + x] = Ray(eye, 0.0f, dir + right * kx + cup * ky, opts.clip);
             }
     }
+    // this rank's contiguous share of the batch (the whole batch without --gpus)
+    const size_t all_rays = host_rays.size();
+    size_t first = 0, last = all_rays;
+    shard_range(all_rays, rank, world, first, last);
+    if (world > 1) host_rays = std::vector<Ray>(host_rays.begin() + first, host_rays.begin() + last);
     Ray* rays = mem.alloc<Ray>(host_rays.size());
     Hit* hits = mem.alloc<Hit>(host_rays.size());
     mem.copy<Copy::HST_TO_DEV>(rays, host_rays.data(), host_rays.size());
@@ -227,20 +332,32 @@ int main(int argc, char** argv) {
         else              traverse_grid(grid, tris, rays, hits, int(host_rays.size()));
     };
     for (int i = 0; i < opts.bench_warmup; i++) trace();
-    std::vector<double> timings;
+    std::vector<float> timings;
     for (int i = 0; i < std::max(opts.bench_iter, 1); i++) timings.push_back(profile(trace));
     std::vector<Hit> host_hits(host_rays.size());
     mem.copy<Copy::DEV_TO_HST>(host_hits.data(), hits, host_hits.size());
     int intr = 0;
     for (const auto& h : host_hits) intr += h.id >= 0;
-    report_timings(timings, host_rays.size(), intr);
+    if (comm) {
+        // whole-job figures: an iteration takes as long as its slowest rank, intersections add up
+        float* d_t = mem.alloc<float>(timings.size());
+        int* d_n = mem.alloc<int>(1);
+        mem.copy<Copy::HST_TO_DEV>(d_t, timings.data(), timings.size());
+        mem.copy<Copy::HST_TO_DEV>(d_n, &intr, 1);
+        if (rccl.all_reduce(d_t, d_t, timings.size(), kNcclFloat32, kNcclMax, comm, nullptr) != 0 ||
+            rccl.all_reduce(d_n, d_n, 1, kNcclInt32, kNcclSum, comm, nullptr) != 0) { std::cerr << "ncclAllReduce failed" << std::endl; return 1; }
+        mem.copy<Copy::DEV_TO_HST>(timings.data(), d_t, timings.size());
+        mem.copy<Copy::DEV_TO_HST>(&intr, d_n, 1);
+        mem.free(d_t); mem.free(d_n);
+    }
+    if (root) report_timings(std::vector<double>(timings.begin(), timings.end()), all_rays, intr);
 
-    if (!opts.out_image.empty() && opts.ray_file.empty()) {
+    if (!opts.out_image.empty() && opts.ray_file.empty() && world == 1) {
         std::ofstream img(opts.out_image, std::ofstream::binary);
         img << "P5\n" << opts.width << " " << opts.height << "\n255\n";
         for (const auto& h : host_hits) img.put(char(h.id >= 0 ? std::min(255.0f, 255.0f * h.t / opts.clip) : 255));
     }
-    if (!opts.steps_image.empty() && opts.ray_file.empty()) {
+    if (!opts.steps_image.empty() && opts.ray_file.empty() && world == 1) {
         // the picture the reference's viewer shows: its kernel returns the step count in Hit::id (traverse.cu:80,93) and
         // main.cpp:100-107 maps it to a colour; here the count comes from the statistics entry point
         int* steps = mem.alloc<int>(host_rays.size());
@@ -256,5 +373,6 @@ int main(int argc, char** argv) {
         mem.free(steps);
     }
     mem.free(rays); mem.free(hits); release(); mem.free(tris);
+    if (comm) rccl.comm_destroy(comm);
     return 0;
 }
