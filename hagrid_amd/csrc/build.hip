@@ -260,7 +260,8 @@ __device__ __forceinline__ int split_mask(const BuildK& k, ivec3 lo, ivec3 hi, c
 __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
                                                         const float4* __restrict__ tris, const Cell* __restrict__ cells,
                                                         const uint32_t* __restrict__ entries, BuildK k,
-                                                        unsigned char* __restrict__ masks, int* __restrict__ cell_counts, int* __restrict__ totals) {
+                                                        unsigned char* __restrict__ masks, int* __restrict__ cell_counts, int* __restrict__ ranks,
+                                                        int* __restrict__ totals) {
     __shared__ int lds[kWaves];
     int children = 0, kept = 0;
     // grid-stride: the two totals cost one atomic pair per workgroup (a same-word atomic per 256 references
@@ -271,7 +272,10 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
         if (c >= 0) {
             if ((entries[c] & 3u) == 0) {
                 kept++;
-                atomicAdd(cell_counts + c, 1);
+                // the count and the reference's slot inside its cell's list in ONE atomic: random atomics run at ~26 per ns on this
+                // part whatever their scope or whether they return a value (tools/micro/atomic_scope.hip), so the scatter pass must
+                // not pay for a second one per reference
+                ranks[i] = atomicAdd(cell_counts + c, 1);
             } else {
                 const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
                 const int4 a = p[0], b = p[1];
@@ -383,16 +387,16 @@ __global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restric
     }
 }
 
-// copy_refs + remap_refs + the scatter half of the sort (build.cu:634-647, :681, :691): slot from a per-cell cursor
+// copy_refs + remap_refs + the scatter half of the sort (build.cu:634-647, :681, :691): the slot inside the cell's list is
+// the rank classify_refs drew for the reference
 __global__ void __launch_bounds__(kBlock) scatter_kept_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                            const uint32_t* __restrict__ entries, int* __restrict__ cell_counts,
+                                                            const uint32_t* __restrict__ entries, const int* __restrict__ ranks,
                                                             const int* __restrict__ ref_begin, int* __restrict__ out_refs) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_refs) return;
     const int c = cell_ids[i];
     if (c < 0 || (entries[c] & 3u) != 0) return;
-    const int slot = atomicSub(cell_counts + c, 1) - 1;
-    out_refs[ref_begin[c] + slot] = ref_ids[i];
+    out_refs[ref_begin[c] + ranks[i]] = ref_ids[i];
 }
 
 } // namespace
@@ -436,6 +440,7 @@ struct Level {
     int* ref_ids = nullptr; int* cell_ids = nullptr; int num_refs = 0;
     Cell* cells = nullptr; uint32_t* entries = nullptr; int num_cells = 0;
     int* cell_counts = nullptr;                 // kept references per cell
+    int* ranks = nullptr;                       // per kept reference: its slot inside its cell's list
     int* start_cell = nullptr; int* ref_begin = nullptr;
 };
 
@@ -506,9 +511,9 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         L.num_refs = R0; L.num_cells = num_top;
         L.ref_ids = tmp.get<int>(size_t(R0)); L.cell_ids = tmp.get<int>(size_t(R0));
         L.cells = tmp.get<Cell>(size_t(num_top)); L.entries = tmp.get<uint32_t>(size_t(num_top) + 1);
-        L.cell_counts = tmp.get<int>(size_t(num_top));
+        L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
         L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
-        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
+        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
         emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids);
         emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k);
         HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
@@ -529,7 +534,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0)) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
             classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
-                                                                               masks, L.cell_counts, tot + 1);
+                                                                               masks, L.cell_counts, L.ranks, tot + 1);
         int h3[3];
         HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
         const int num_new_cells = h3[0], num_children = h3[1];
@@ -543,9 +548,9 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         N.num_refs = num_children; N.num_cells = num_new_cells;
         N.ref_ids = tmp.get<int>(size_t(num_children)); N.cell_ids = tmp.get<int>(size_t(num_children));
         N.cells = tmp.get<Cell>(size_t(num_new_cells)); N.entries = tmp.get<uint32_t>(size_t(num_new_cells) + 1);
-        N.cell_counts = tmp.get<int>(size_t(num_new_cells));
+        N.cell_counts = tmp.get<int>(size_t(num_new_cells)); N.ranks = tmp.get<int>(size_t(num_children));
         N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
-        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
+        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
         HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
@@ -589,7 +594,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         concat_level<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.cell_counts, L.start_cell, L.ref_begin,
                                                                           L.num_cells, off, out_cells, out_entries);
         if (L.num_refs > 0)
-            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.entries, L.cell_counts,
+            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.entries, L.ranks,
                                                                                   L.ref_begin, out_refs);
     }
     sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs);

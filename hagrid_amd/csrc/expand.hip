@@ -2,7 +2,7 @@
 // is a subset of its own, on gfx950.
 //
 // Replaces the reference's expand.cu: expand (:199-223), expansion_iter (:184-197), overlap_step<axis> (:145-182),
-// find_overlap (:60-143), is_subset (:21-36), compute_overlap (:39-57).  subset_only = true is the reference's compiled setting
+// find_overlap (:60-143 -> face_growth), is_subset (:21-36 -> contains_all), compute_overlap (:39-57 -> room_before_prim).  subset_only = true is the reference's compiled setting
 // (:159) and the default; the precise mode (subset_only = false) is selected with hagrid_set_option("expand.subset_only", 0).
 // Bit-identical to the CPU oracle.  Cells that are not processed in a step are copied through to the new
 // buffer (the reference leaves them stale, expand.cu:154-155,181 -- DESIGN.md D2).
@@ -29,32 +29,38 @@ __device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
 }
 __device__ __forceinline__ int comp(const ivec3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
-// expand.cu:21-36
-__device__ __forceinline__ bool is_subset(const int* __restrict__ p0, int c0, const int* __restrict__ p1, int c1) {
-    if (c1 > c0) return false;
-    if (c1 == 0) return true;
-    int i = 0, j = 0;
-    do {
-        const int a = p0[i], b = p1[j];
-        if (b < a) return false;
-        j += (a == b);
-        i++;
-    } while ((i < c0) & (j < c1));
-    return j == c1;
+// ---- sorted id lists -------------------------------------------------------------------------------------------------------
+// Reference lists are ascending and free of duplicates (the construction sorts them; expand.cu:20 relies on it).  They hold one
+// to two ids on average and rarely more than a handful, so the common case (both lists of at most four ids) is decided in
+// registers, every id against every id, without a loop or a data-dependent branch; longer lists: a binary search per id.
+
+// position of the first element of a[0..n) that is >= x
+__device__ __forceinline__ int lower_bound_in(const int* __restrict__ a, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
-// compute_overlap (expand.cu:39-57): how far the cell may grow along `axis` before it would have to reference `prim`
-template <int axis, bool dir>
-__device__ __forceinline__ int compute_overlap(const ExpandK& k, const Tri& prim, const CellRec& cell, const BBox& cb, int d) {
-    constexpr int axis1 = (axis + 1) % 3, axis2 = (axis + 2) % 3;
-    const BBox pb = prim.bbox();
-    if (get<axis1>(pb.min) <= get<axis1>(cb.max) && get<axis1>(pb.max) >= get<axis1>(cb.min) &&
-        get<axis2>(pb.min) <= get<axis2>(cb.max) && get<axis2>(pb.max) >= get<axis2>(cb.min)) {
-        const int prim_d = int(((dir ? get<axis>(pb.min) : get<axis>(pb.max)) - get<axis>(k.gmin)) * get<axis>(k.grid_inv));
-        d = dir ? min(d, prim_d - comp(cell.hi, axis)) : max(d, prim_d - comp(cell.lo, axis) + 1);
-        d = dir ? max(d, 0) : min(d, 0);
+// does list `big` contain every id of list `small`?  (the question is_subset of expand.cu:21-36 answers)
+__device__ __forceinline__ bool contains_all(const int* __restrict__ big, int nbig, const int* __restrict__ small, int nsmall) {
+    if (nsmall > nbig) return false;
+    if (nsmall == 0) return true;
+    if (nbig <= 4) {
+        // both lists in registers (eight independent loads), sixteen compares, no loop: unused slots of the big list hold -1
+        // (ids are >= 0: never equal), unused slots of the small list repeat its first id
+        const int b0 = big[0], b1 = nbig > 1 ? big[1] : -1, b2 = nbig > 2 ? big[2] : -1, b3 = nbig > 3 ? big[3] : -1;
+        const int s0 = small[0], s1 = nsmall > 1 ? small[1] : s0, s2 = nsmall > 2 ? small[2] : s0, s3 = nsmall > 3 ? small[3] : s0;
+        auto in_big = [&](int x) { return (x == b0) | (x == b1) | (x == b2) | (x == b3); };
+        return in_big(s0) & in_big(s1) & in_big(s2) & in_big(s3);
     }
-    return d;
+    for (int j = 0; j < nsmall; j++) {
+        const int x = small[j], at = lower_bound_in(big, nbig, x);
+        if (at == nbig || big[at] != x) return false;
+    }
+    return true;
 }
 
 __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) {
@@ -63,61 +69,69 @@ __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) 
     return Tri(vec3(a.x, a.y, a.z), a.w, vec3(b.x, b.y, b.z), b.w, vec3(c.x, c.y, c.z), c.w);
 }
 
-// find_overlap (expand.cu:60-143)
-template <int axis, bool dir, bool SUBSET_ONLY>
-__device__ __forceinline__ int find_overlap(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
-                                            const Cell* __restrict__ cells, const CellRec& cell, bool& continue_overlap) {
-    constexpr int axis1 = (axis + 1) % 3, axis2 = (axis + 2) % 3;
-    if (dir) { if (!(comp(cell.hi, axis) < comp(k.dims, axis))) return 0; }     // overlap_possible, expand.cu:12-18
-    else     { if (!(comp(cell.lo, axis) > 0)) return 0; }
-    int d = dir ? comp(k.dims, axis) : -comp(k.dims, axis);
-    int k2 = comp(k.dims, axis2);
-    int i = comp(cell.lo, axis1), j = comp(cell.lo, axis2);
-    int max_d = d;
-    const int a = dir ? comp(cell.hi, axis) : comp(cell.lo, axis) - 1;
+// Precise mode (expand.cu:39-57): a triangle the neighbour references and the cell does not limits the growth to the voxel layer
+// where its bounding box begins -- if the box overlaps the cell's cross-section at all.  `room` is the number of layers the face
+// may still move (a magnitude, whatever the direction).
+template <int AXIS, bool UP>
+__device__ __forceinline__ int room_before_prim(const ExpandK& k, const Tri& prim, const CellRec& cell, const BBox& cross, int room) {
+    constexpr int A1 = (AXIS + 1) % 3, A2 = (AXIS + 2) % 3;
+    const BBox pb = prim.bbox();
+    const bool overlaps = get<A1>(pb.min) <= get<A1>(cross.max) && get<A1>(pb.max) >= get<A1>(cross.min) &&
+                          get<A2>(pb.min) <= get<A2>(cross.max) && get<A2>(pb.max) >= get<A2>(cross.min);
+    if (!overlaps) return room;
+    const int layer = int(((UP ? get<AXIS>(pb.min) : get<AXIS>(pb.max)) - get<AXIS>(k.gmin)) * get<AXIS>(k.grid_inv));
+    const int free_layers = UP ? layer - comp(cell.hi, AXIS) : comp(cell.lo, AXIS) - layer - 1;
+    return max(min(room, free_layers), 0);
+}
+
+// One growth direction of one cell (find_overlap, expand.cu:60-143).  Returns the signed number of voxel layers the face moves;
+// sets `again` when the move used all the room the neighbours leave, i.e. the cell may grow further in the next iteration.
+// The face is swept row by row in the order the reference sweeps it -- a neighbour's (possibly already expanded) box decides how
+// far the sweep jumps, so the set of neighbours looked at is part of the result.  Quantities are kept as magnitudes:
+//   reach = the least extent of a neighbour seen so far beyond the face, room = min(reach, limits from references).
+template <int AXIS, bool UP, bool SUBSET_ONLY>
+__device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
+                                           const Cell* __restrict__ cells, const CellRec& cell, bool& again) {
+    constexpr int A1 = (AXIS + 1) % 3, A2 = (AXIS + 2) % 3;
+    const int face = UP ? comp(cell.hi, AXIS) : comp(cell.lo, AXIS);
+    const int extent = comp(k.dims, AXIS);
+    if (UP ? face >= extent : face <= 0) return 0;                       // the face lies on the grid boundary (expand.cu:12-18)
+    const int layer = UP ? face : face - 1;                               // the voxel layer just beyond the face
+    const int lo1 = comp(cell.lo, A1), hi1 = comp(cell.hi, A1), lo2 = comp(cell.lo, A2), hi2 = comp(cell.hi, A2);
+    const int own = cell.end - cell.begin;
+    int reach = extent, room = extent;
+    int u = lo1, v = lo2, row_step = comp(k.dims, A2);
     for (;;) {
-        const ivec3 np = axis == 0 ? ivec3(a, i, j) : (axis == 1 ? ivec3(j, a, i) : ivec3(i, j, a));
-        const CellRec next = load_cell(cells, int(lookup_entry(entries, k.shift, k.top, np)));
-        max_d = dir ? min(max_d, comp(next.hi, axis) - comp(cell.hi, axis)) : max(max_d, comp(next.lo, axis) - comp(cell.lo, axis));
-        d = dir ? min(d, max_d) : max(d, max_d);
+        const ivec3 at = AXIS == 0 ? ivec3(layer, u, v) : (AXIS == 1 ? ivec3(v, layer, u) : ivec3(u, v, layer));
+        const CellRec nb = load_cell(cells, int(lookup_entry(entries, k.shift, k.top, at)));
+        reach = min(reach, UP ? comp(nb.hi, AXIS) - face : face - comp(nb.lo, AXIS));
+        room = min(room, reach);
+        const int theirs = nb.end - nb.begin;
         if (SUBSET_ONLY) {
-            if (!is_subset(refs + cell.begin, cell.end - cell.begin, refs + next.begin, next.end - next.begin)) { d = 0; break; }
-        } else {
-            // expand.cu:96-127: references of the neighbour that the cell does not hold limit the growth
-            if (next.begin < next.end) {
-                const BBox cb(k.gmin + k.cell_size * vec3(cell.lo), k.gmin + k.cell_size * vec3(cell.hi));
-                int p1 = cell.begin, p2 = next.begin;
-                int ref2 = refs[p2];
-                for (;;) {
-                    while (p1 < cell.end) {
-                        const int ref1 = refs[p1];
-                        if (ref1 > ref2) break;
-                        if (ref1 == ref2) {
-                            if (++p2 >= next.end) break;
-                            ref2 = refs[p2];
-                        }
-                        p1++;
-                    }
-                    if (p2 >= next.end) break;
-                    d = compute_overlap<axis, dir>(k, load_tri(tris, ref2), cell, cb, d);
-                    if (d == 0 || ++p2 >= next.end) break;
-                    ref2 = refs[p2];
-                }
+            if (!contains_all(refs + cell.begin, own, refs + nb.begin, theirs)) { room = 0; break; }
+        } else if (theirs > 0) {
+            // every id of the neighbour that the cell does not hold limits the growth (expand.cu:96-127); both lists ascend,
+            // so one cursor into the cell's list is enough
+            const BBox cross(k.gmin + k.cell_size * vec3(cell.lo), k.gmin + k.cell_size * vec3(cell.hi));
+            int mine = 0;
+            for (int j = 0; j < theirs && room > 0; j++) {
+                const int id = refs[nb.begin + j];
+                while (mine < own && refs[cell.begin + mine] < id) mine++;
+                if (mine < own && refs[cell.begin + mine] == id) continue;
+                room = room_before_prim<AXIS, UP>(k, load_tri(tris, id), cell, cross, room);
             }
-            if (d == 0) break;
+            if (room == 0) break;
         }
-        const int k1 = comp(next.hi, axis1) - i;
-        k2 = min(k2, comp(next.hi, axis2) - j);
-        i += k1;
-        if (i >= comp(cell.hi, axis1)) {
-            i = comp(cell.lo, axis1);
-            j += k2;
-            k2 = comp(k.dims, axis2);
-            if (j >= comp(cell.hi, axis2)) break;
+        // next neighbour of the row, or the next row (a row advances by the smallest extent of the neighbours it crossed)
+        row_step = min(row_step, comp(nb.hi, A2) - v);
+        u = comp(nb.hi, A1);
+        if (u >= hi1) {
+            u = lo1; v += row_step; row_step = comp(k.dims, A2);
+            if (v >= hi2) break;
         }
     }
-    continue_overlap |= d == max_d;
-    return d;
+    again |= room == reach;
+    return UP ? room : -room;
 }
 
 template <int axis, bool SUBSET_ONLY>
@@ -125,8 +139,8 @@ __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restr
                                           const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags) {
     CellRec cell = load_cell(cells, id);
     bool flag = false;
-    const int ov1 = find_overlap<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
-    const int ov2 = find_overlap<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    const int ov1 = face_growth<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    const int ov2 = face_growth<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
     if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
     if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
     if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }

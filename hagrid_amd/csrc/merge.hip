@@ -65,33 +65,55 @@ __device__ __forceinline__ bool merge_allowed(const MergeK& k, int empty_mask, i
 __device__ __forceinline__ ivec3 next_cell_pos(int axis, const ivec3& lo, const ivec3& hi) {
     return ivec3(axis == 0 ? hi.x : lo.x, axis == 1 ? hi.y : lo.y, axis == 2 ? hi.z : lo.z);
 }
-// merge.cu:58-69
-__device__ __forceinline__ int count_union(const int* __restrict__ p0, int c0, const int* __restrict__ p1, int c1) {
-    int i = 0, j = 0, c = 0;
-    while ((i < c0) & (j < c1)) {
-        const int a = p0[i], b = p1[j];
-        i += (a <= b); j += (a >= b); c++;
+// ---- sorted id lists ---------------------------------------------------------------------------------------------------
+// Reference lists are ascending and free of duplicates (merge.cu:57 relies on it), one to two ids on average.
+// |A u B| = |A| + |B| - |A n B| (what count_union of merge.cu:58-69 returns): lists of at most four ids each sit in registers and
+// every id is compared against every id -- no loop, no data-dependent branch; otherwise the ids of the shorter list are looked
+// up in the longer one by binary search.
+__device__ __forceinline__ int lower_bound_in(const int* __restrict__ a, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
     }
-    return c + (c1 - j) + (c0 - i);
+    return lo;
 }
-// merge.cu:72-88
-__device__ __forceinline__ void merge_refs(const int* __restrict__ p0, int c0, const int* __restrict__ p1, int c1, int* __restrict__ q) {
-    int i = 0, j = 0;
-    while (i < c0 && j < c1) {
-        const int a = p0[i], b = p1[j];
-        *(q++) = (a < b) ? a : b;
-        i += (a <= b); j += (a >= b);
+__device__ __forceinline__ int union_size(const int* __restrict__ a, int na, const int* __restrict__ b, int nb) {
+    if (na == 0 || nb == 0) return na + nb;
+    int common = 0;
+    if (na <= 4 && nb <= 4) {
+        // both lists in registers (eight independent loads), sixteen compares: unused slots hold -1 / -2 (ids are >= 0)
+        const int a0 = a[0], a1 = na > 1 ? a[1] : -1, a2 = na > 2 ? a[2] : -1, a3 = na > 3 ? a[3] : -1;
+        const int b0 = b[0], b1 = nb > 1 ? b[1] : -2, b2 = nb > 2 ? b[2] : -2, b3 = nb > 3 ? b[3] : -2;
+        auto hits = [&](int x) { return int(x == b0) + int(x == b1) + int(x == b2) + int(x == b3); };
+        common = hits(a0) + hits(a1) + hits(a2) + hits(a3);
+    } else {
+        if (nb > na) { const int* t = a; a = b; b = t; const int n = na; na = nb; nb = n; }      // b is the shorter list
+        for (int j = 0; j < nb; j++) {
+            const int x = b[j], at = lower_bound_in(a, na, x);
+            common += at < na && a[at] == x;
+        }
     }
-    int kk = i < c0 ? i : j;
-    const int c = i < c0 ? c0 : c1;
-    const int* p = i < c0 ? p0 : p1;
-    while (kk < c) *(q++) = p[kk++];
+    return na + nb - common;
+}
+// The union itself, ascending, n_out = union_size ids (merge_refs of merge.cu:72-88): an exhausted list reads as +infinity, the
+// loop runs over the OUTPUT, so there is no tail to copy.
+__device__ __forceinline__ void write_union(const int* __restrict__ a, int na, const int* __restrict__ b, int nb, int* __restrict__ out, int n_out) {
+    const int inf = 0x7fffffff;
+    int i = 0, j = 0;
+    int x = na > 0 ? a[0] : inf, y = nb > 0 ? b[0] : inf;
+    for (int o = 0; o < n_out; o++) {
+        const int m = min(x, y);
+        out[o] = m;
+        if (x == m) { i++; x = i < na ? a[i] : inf; }
+        if (y == m) { j++; y = j < nb ? b[j] : inf; }
+    }
 }
 
 // compute_merge_counts (merge.cu:91-142)
 __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
                                                               const int* __restrict__ refs, int* __restrict__ merge_counts,
-                                                              int* __restrict__ nexts, int* __restrict__ prevs, int empty_mask, int num_cells,
+                                                              int* __restrict__ nexts, int* __restrict__ has_prev, int pass_tag, int empty_mask, int num_cells,
                                                               const int* __restrict__ n_dev) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= (n_dev ? *n_dev : num_cells)) return;
@@ -112,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
             const int n1 = c1.end - c1.begin, n2 = c2.end - c2.begin;
             const float cc1 = a1 * (n1 + unit_cost), cc2 = a2 * (n2 + unit_cost);
             if (a * (max(n1, n2) + unit_cost) <= cc1 + cc2) {
-                const int n = count_union(refs + c1.begin, n1, refs + c2.begin, n2);
+                const int n = union_size(refs + c1.begin, n1, refs + c2.begin, n2);
                 const float c = a * (n + unit_cost);
                 if (c <= cc1 + cc2) count = n;
             }
@@ -121,15 +143,17 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
     merge_counts[id] = count;
     next_id = count >= 0 ? next_id : -1;
     nexts[id] = next_id;
-    if (next_id >= 0) prevs[next_id] = id;      // at most one predecessor can be aligned with a cell
+    // merge.cu:141 stores the predecessor's id; only "has a predecessor" is ever read (compute_cell_flags, merge.cu:152), so the
+    // array holds the tag of the pass that last gave the cell one: no clearing between the passes
+    if (next_id >= 0) has_prev[next_id] = pass_tag;
 }
 
 // compute_cell_flags (merge.cu:145-170): chain heads mark every second cell of their chain as residue
-__global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ prevs,
+__global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ has_prev, int pass_tag,
                                                             int* __restrict__ cell_flags, int num_cells, const int* __restrict__ n_dev) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= (n_dev ? *n_dev : num_cells)) return;
-    if (prevs[id] < 0) {
+    if (has_prev[id] != pass_tag) {
         int next_id = nexts[id];
         cell_flags[id] = 1;
         int count = 1;
@@ -178,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
         new_cell_ids[next_id] = new_id;
         store_cell(new_cells, new_id, min(nc.lo, cell.lo), nb, max(nc.hi, cell.hi), nb + mc);
         if (nc.begin < nc.end) {
-            merge_refs(refs + cell.begin, n1, refs + nc.begin, nc.end - nc.begin, new_refs + nb);
+            write_union(refs + cell.begin, n1, refs + nc.begin, nc.end - nc.begin, new_refs + nb, mc);
             return;
         }
     } else {
@@ -241,7 +265,8 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     const int num_entries = grid->num_entries;
 
     int rc = HAGRID_OK;
-    int prev_num_cells = 0, iter = 0;
+    int prev_num_cells = 0, iter = 0, pass_tag = 0;
+    (void)hipMemsetAsync(prevs, 0, nc0 * sizeof(int), st);                 // tag 0 = never had a predecessor
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
         const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
@@ -253,9 +278,9 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             const int blocks = grid_blocks(num_cells, kBlock);
             Int2* tot = total + axis;
             const int* n_dev = (chain && axis) ? &total[axis - 1].a : nullptr;
-            (void)hipMemsetAsync(prevs, 0xFF, size_t(num_cells) * sizeof(int), st);
-            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, mask, num_cells, n_dev);
-            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, cell_flags, num_cells, n_dev);
+            pass_tag++;
+            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
+            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev);
             if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
                                                     merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev);

@@ -190,11 +190,13 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
 // aggregates / inclusive prefixes (64 at a time, one per lane of wavefront 0), publishes its own inclusive prefix and scans
 // its items from registers.  A status word carries (epoch, flag, 32-bit value) and is written / read with one agent-scope
 // 64-bit atomic, so it is valid across the 8 L2s; the epoch makes last call's words invalid without clearing the array.
-// Forward progress does not depend on the dispatch order of workgroups: the launch has at most kLbBlocksPerCu workgroups per
-// CU -- fewer than the part keeps resident of this kernel, so all of them run concurrently -- and workgroup b owns the tiles
-// b, b + G, b + 2G, ... in increasing order.  The lowest unfinished tile therefore always belongs to a running workgroup that
-// has nothing left to wait for.
-constexpr int kLbBlocksPerCu = 4;
+// Forward progress does not depend on the dispatch order of workgroups: the launch has no more workgroups than the part keeps
+// resident of this kernel (occupancy query minus one per CU, lb_resident_blocks), so all of them run concurrently, and
+// workgroup b owns the tiles b, b + G, b + 2G, ... in increasing order.  The lowest unfinished tile therefore always belongs to
+// a running workgroup that has nothing left to wait for.
+constexpr int kLbItems = 8;                          // items per thread of the look-back scan
+constexpr int kLbWindows = 4;                        // predecessors examined per look-back round: 64 lanes x kLbWindows
+constexpr int kLbTile = kBlock * kLbItems;
 constexpr unsigned kLbAggregate = 1u, kLbPrefix = 2u;
 
 __device__ __forceinline__ unsigned long long lb_pack(unsigned epoch, unsigned flag, int value) {
@@ -229,6 +231,17 @@ __device__ __forceinline__ unsigned lb_wait(const unsigned long long* state, int
     v = Int2{a, b};
     return fa;
 }
+// one look at tile `t`: false while its status is not valid for this epoch (Int2: while its two words disagree)
+__device__ __forceinline__ bool lb_try(const unsigned long long* state, int t, unsigned epoch, int& v, unsigned& flag) {
+    const unsigned long long w = lb_load(state + t);
+    v = int(unsigned(w)); flag = unsigned(w >> 32) & 3u;
+    return (unsigned)(w >> 34) == epoch && flag != 0u;
+}
+__device__ __forceinline__ bool lb_try(const unsigned long long* state, int t, unsigned epoch, Int2& v, unsigned& flag) {
+    const unsigned long long a = lb_load(state + 2 * size_t(t)), b = lb_load(state + 2 * size_t(t) + 1);
+    v = Int2{int(unsigned(a)), int(unsigned(b))}; flag = unsigned(a >> 32) & 3u;
+    return (unsigned)(a >> 34) == epoch && (unsigned)(b >> 34) == epoch && flag != 0u && flag == (unsigned(b >> 32) & 3u);
+}
 template <typename V> constexpr int lb_words() { return int(sizeof(V) / sizeof(int)); }
 
 template <typename V, typename In, typename Out>
@@ -236,11 +249,11 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
     __shared__ V lds[kWaves];
     __shared__ V tile_prefix;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int base = tile * kScanTile;
-        V v[kScanItems];
+        const int base = tile * kLbTile;
+        V v[kLbItems];
         V sum = zero_of(V());
 #pragma unroll
-        for (int j = 0; j < kScanItems; j++) {
+        for (int j = 0; j < kLbItems; j++) {
             const int i = base + j * kBlock + threadIdx.x;
             v[j] = i < n ? in(i) : zero_of(V());
             sum = sum + v[j];
@@ -257,17 +270,40 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
                 if (carry_in) excl = *carry_in;
             } else {
                 if (lane_id() == 0) lb_publish(state, tile, epoch, kLbAggregate, agg);
+                // look back over kLbWindows x 64 predecessors per round (the status loads of a round are independent: one
+                // round trip for all of them), nearest first: add aggregates up to and including the nearest inclusive prefix
                 int p = tile - 1;
                 for (;;) {
-                    const int t = p - lane_id();
-                    V pv = zero_of(V());
-                    unsigned flag = kLbPrefix;                           // lanes before tile 0 end the search with a zero
-                    if (t >= 0) flag = lb_wait(state, t, epoch, pv);
-                    const unsigned long long is_prefix = __ballot(flag == kLbPrefix);
-                    const int first = __ffsll((long long)is_prefix) - 1;                 // nearest predecessor with an inclusive prefix
-                    if (first < 0 || lane_id() <= first) excl = excl + pv;
-                    if (first >= 0) break;
-                    p -= 64;
+                    V pv[kLbWindows];
+                    unsigned flag[kLbWindows];
+                    bool ok[kLbWindows];
+#pragma unroll
+                    for (int w = 0; w < kLbWindows; w++) {
+                        pv[w] = zero_of(V()); flag[w] = kLbPrefix;      // lanes before tile 0 end the search with a zero
+                        ok[w] = p - w * 64 - lane_id() < 0;
+                    }
+                    for (;;) {                                           // all outstanding looks of a trip are in flight together
+                        bool all = true;
+#pragma unroll
+                        for (int w = 0; w < kLbWindows; w++) {
+                            if (!ok[w]) ok[w] = lb_try(state, p - w * 64 - lane_id(), epoch, pv[w], flag[w]);
+                            all = all && ok[w];
+                        }
+                        if (all) break;
+                    }
+                    unsigned long long is_prefix[kLbWindows];
+#pragma unroll
+                    for (int w = 0; w < kLbWindows; w++) is_prefix[w] = __ballot(flag[w] == kLbPrefix);
+                    bool found = false;
+#pragma unroll
+                    for (int w = 0; w < kLbWindows; w++) {
+                        if (found) break;
+                        const int first = __ffsll((long long)is_prefix[w]) - 1;      // nearest predecessor of this window with a prefix
+                        if (first < 0 || lane_id() <= first) excl = excl + pv[w];
+                        found = first >= 0;
+                    }
+                    if (found) break;
+                    p -= 64 * kLbWindows;
                 }
                 // sum over the lanes
 #pragma unroll
@@ -282,9 +318,8 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
         __syncthreads();
         V running = tile_prefix;
 #pragma unroll
-        for (int j = 0; j < kScanItems; j++) {
+        for (int j = 0; j < kLbItems; j++) {                     // (no early exit: the loop must unroll, v[] lives in registers)
             const int i = base + j * kBlock + threadIdx.x;
-            if (base + j * kBlock >= n) break;
             const V incl = wave_inclusive_scan(v[j]);
             __syncthreads();
             if (lane_id() == 63) lds[wave_id()] = incl;
@@ -308,8 +343,15 @@ inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
 /// (hagrid_impl::lookback_state hands out both).
 template <typename V, typename In, typename Out>
 inline void device_scan_lookback(hipStream_t stream, int num_cus, In in, Out out, int n, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
-    const int tiles = scan_num_tiles(n);
-    const int blocks = std::max(1, std::min(tiles, std::max(num_cus, 1) * kLbBlocksPerCu));
+    // workgroups that are resident together: what the runtime reports for this instantiation, less one per CU (the report can
+    // be one too high, MI355X_MICROARCH.md "Residency and cooperative launch"), at most 8, at least 1
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_lookback<V, In, Out>, kBlock, 0) != hipSuccess) { (void)hipGetLastError(); n = 2; }
+        return std::max(1, std::min(n - 1, 8));
+    }();
+    const int tiles = (n + kLbTile - 1) / kLbTile;
+    const int blocks = std::max(1, std::min(tiles, std::max(num_cus, 1) * per_cu));
     scan_lookback<V, In, Out><<<blocks, kBlock, 0, stream>>>(in, out, n, tiles, state, epoch, carry_in, total_out);
 }
 
