@@ -300,7 +300,7 @@ def main():
                 "walk_achieved_image": round(ab["B_image_walk"] / (kernel_ms * 1e6), 1)},
             "roofline_build": build_block,
             "memory": {"cells": cells_b, "entries": 4 * grid.num_entries, "refs": 4 * grid.num_refs, "tris": 48 * n_tris,
-                       "traversal_image": image_b, "rays": 32 * n_rays, "hits": 16 * n_rays, "pool_now": mem.usage(), "pool_peak": mem.max_usage(),
+                       "traversal_image": image_b, "releasable_after_setup_traversal": cells_b + 4 * grid.num_entries, "rays": 32 * n_rays, "hits": 16 * n_rays, "pool_now": mem.usage(), "pool_peak": mem.max_usage(),
                        "unit": "bytes", "reference": "main.cpp:523-533"},
         }
         # ---- CPU baseline + parity check: the oracle on the SAME grid, rank 0, N = 1 only ---------------------------------

@@ -262,6 +262,13 @@ def setup_traversal(grid: Grid):
     _check(mem, mem._L.hagrid_setup_traversal(mem._ctx, C.byref(grid.pod)), "setup_traversal")
 
 
+def release_for_traversal(grid: Grid):
+    """Extension: frees grid.entries and grid.cells | small_cells once setup_traversal has built a self-contained traversal image;
+    traverse_grid keeps working (hagrid_grid_release_for_traversal)."""
+    mem = grid.mem or _current
+    _check(mem, mem._L.hagrid_grid_release_for_traversal(mem._ctx, C.byref(grid.pod)), "release_for_traversal")
+
+
 ANY_HIT, UVS = 1, 2      # hagrid_traverse_grid_ex flags
 
 

@@ -44,8 +44,8 @@ struct NullOut { __device__ void operator()(int, int) const {} };
 
 extern "C" int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     if (!ctx || !grid) return HAGRID_EINVAL;
-    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     if (!grid->cells || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "compress_grid: incomplete (or already compressed) grid");
+    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     for (int c = 0; c < 3; c++)
         if ((grid->dims[c] << grid->shift) >= (1 << 16)) return 0;          // compress.cu:41-44
     HG_HIP(ctx, hipSetDevice(ctx->device));

@@ -31,6 +31,8 @@ struct TravImageCache {
     bool valid = false;
     bool flat = false;              // records indexed by the voxel (no slot bytes)
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
+    bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
+    bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;

@@ -242,12 +242,12 @@ void listed_step(hipStream_t st, const ExpandK& k, const Entry* entries, const i
 
 extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void* tris_v, int iters) {
     if (!ctx || !grid) return HAGRID_EINVAL;
-    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     const bool subset_only = ctx->opt_expand_subset_only != 0;      // the reference's compiled setting (expand.cu:159) is true
     if (!subset_only && !tris_v && iters > 0) HG_FAIL(ctx, HAGRID_EINVAL, "expand_grid: the precise mode needs the triangles");
     const float4* tris = static_cast<const float4*>(tris_v);
     if (iters <= 0) return HAGRID_OK;
     if (!grid->cells || !grid->entries || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "expand_grid: incomplete (or compressed) grid");
+    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     HG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ExpandK k;

@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(kBlock) flatten_level(const uint32_t* __restri
 
 extern "C" int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     if (!ctx || !grid) return HAGRID_EINVAL;
-    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     if (!grid->entries || grid->num_offsets != grid->shift + 1) HG_FAIL(ctx, HAGRID_EINVAL, "flatten_grid: needs the un-flattened voxel map of build_grid/merge_grid");
+    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     HG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int shift = grid->shift, num_entries = grid->num_entries;

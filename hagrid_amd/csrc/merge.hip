@@ -223,8 +223,8 @@ __global__ void __launch_bounds__(kBlock) remap_entries_kernel(uint32_t* __restr
 
 extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha) {
     if (!ctx || !grid) return HAGRID_EINVAL;
-    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     if (!grid->cells || !grid->entries || !grid->ref_ids) HG_FAIL(ctx, HAGRID_EINVAL, "merge_grid: incomplete (or compressed) grid");
+    trav_image_drop(ctx);            // the traversal image of this context describes a grid that is about to change
     ctx->counts.merge_passes = 0;
     ctx->counts.merged_cells = grid->num_cells; ctx->counts.merged_refs = grid->num_refs;
     if (!(alpha > 0)) return HAGRID_OK;

@@ -381,6 +381,9 @@ void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
 
 bool hagrid_impl::trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* g) {
     const TravImageCache& img = ctx->image;
+    if (img.valid && img.detached)      // the descriptor of a released grid: no entries, no cells, everything else as at setup time
+        return !g->entries && !g->cells && !g->small_cells && g->ref_ids == img.refs && g->num_cells == img.num_cells && g->num_entries == img.num_entries &&
+               g->num_refs == img.num_refs && g->shift == img.shift && g->dims[0] == img.dims[0] && g->dims[1] == img.dims[1] && g->dims[2] == img.dims[2];
     return img.valid && g->entries == img.entries && (g->small_cells ? g->small_cells : g->cells) == img.cells && g->ref_ids == img.refs &&
            g->num_cells == img.num_cells && g->num_entries == img.num_entries && g->num_refs == img.num_refs && g->shift == img.shift &&
            g->dims[0] == img.dims[0] && g->dims[1] == img.dims[1] && g->dims[2] == img.dims[2];
@@ -392,7 +395,8 @@ void hagrid_impl::trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, si
     const char* lo = static_cast<const char*>(ptr);
     const char* hi = lo + (bytes ? bytes : 1);
     auto overlaps = [&](const void* p, size_t n) { const char* q = static_cast<const char*>(p); return q < hi && lo < q + n; };
-    if (overlaps(img.entries, size_t(img.num_entries) * 4) || overlaps(img.cells, size_t(img.num_cells) * size_t(img.cell_bytes)) || overlaps(img.refs, size_t(img.num_refs) * 4))
+    if ((img.entries && overlaps(img.entries, size_t(img.num_entries) * 4)) || (img.cells && overlaps(img.cells, size_t(img.num_cells) * size_t(img.cell_bytes))) ||
+        overlaps(img.refs, size_t(img.num_refs) * 4))
         trav_image_drop(ctx);
 }
 
@@ -435,10 +439,25 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.flat = flat;
     if (rc != HAGRID_OK) return rc;
     img.valid = img.table != nullptr;
+    img.standalone = flat && g->shift <= 6;            // blocks + nested blocks resolve six levels; only deeper grids keep `deep` links
     img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
     img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
     img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
     ctx->image = img;
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* grid) {
+    if (!ctx || !grid) return HAGRID_EINVAL;
+    TravImageCache& img = ctx->image;
+    if (!trav_image_matches(ctx, grid) || img.detached) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: call hagrid_setup_traversal for this grid first");
+    if (!img.standalone) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: the traversal image of this grid still refers to the voxel map (compact form, or more than six levels)");
+    void* entries = grid->entries;
+    void* cells = grid->cells ? grid->cells : grid->small_cells;
+    img.entries = nullptr; img.cells = nullptr; img.detached = true;      // the frees below must not take the image with them
+    HG_TRY(hagrid_mem_free(ctx, entries));
+    HG_TRY(hagrid_mem_free(ctx, cells));
+    grid->entries = nullptr; grid->cells = nullptr; grid->small_cells = nullptr;
     return HAGRID_OK;
 }

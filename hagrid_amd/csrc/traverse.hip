@@ -1068,7 +1068,8 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
 }
 
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
-    if (!g || !g->entries || !g->ref_ids || (!g->cells && !g->small_cells)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
+    const bool released = g && ctx->image.detached && trav_image_matches(ctx, g);     // hagrid_grid_release_for_traversal: the image stands for entries and cells
+    if (!g || !g->ref_ids || (!released && (!g->entries || (!g->cells && !g->small_cells)))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
     if (num_rays < 0 || (num_rays > 0 && (!rays || !hits || !tris))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: null buffer");
     if (g->shift < 0 || g->shift > 15) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: bad shift");
     // setup_traversal (traverse.cu:97-109)
@@ -1103,6 +1104,7 @@ extern "C" int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid) 
     if (!ctx) return HAGRID_EINVAL;
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a));
+    if (ctx->image.detached && trav_image_matches(ctx, grid)) return HAGRID_OK;      // a released grid: its image is all there is
     return trav_image_build(ctx, grid);     // "traverse.image" = 0: drops the image, traversal reads the construction format
 }
 
@@ -1160,7 +1162,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // latency-oriented v2 wins; large batches are throughput-bound and the persistent, vote-scheduled v3 wins (measured
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
     // hagrid_set_option("traverse.variant", 1|2|3|4) forces a kernel (tests, experiments).
-    const bool have_image = ctx->opt_image && trav_image_matches(ctx, grid);
+    const bool have_image = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
+    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant != 4) || (flags && !ctx->image.flat)))
+        HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal, only the traversal-image kernel can serve it");
     if (ctx->opt_variant == 4 && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
     const bool large = num_rays >= 24 * lanes;
@@ -1170,7 +1174,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                             ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
     // any-hit / barycentrics: the flat narrow image kernels and v2 have these variants
-    if (flags && !(variant == 4 && ctx->image.flat && img_narrow)) variant = 2;
+    if (flags && !(variant == 4 && ctx->image.flat && img_narrow)) {
+        if (ctx->image.detached && have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: any-hit / barycentrics on a released grid need the narrow image kernel (arrays below 4 GB)");
+        variant = 2;
+    }
     if (variant == 4) {
         a.img_table = static_cast<const uint2*>(ctx->image.table);
         a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
@@ -1258,6 +1265,7 @@ extern "C" int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* gr
                                           const void* rays, void* hits, int num_rays,
                                           void* steps, hagrid_traversal_stats* stats) {
     if (!ctx) return HAGRID_EINVAL;
+    if (grid && !grid->entries) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid_stats: the statistics walk the construction format (grid released for traversal)");
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (stats) memset(stats, 0, sizeof(*stats));

@@ -190,6 +190,12 @@ int hagrid_grid_broadcast(hagrid_ctx* ctx, void* comm, int rank, int root, hagri
  * a virtual resolution above 65535 per axis or for compressed grids deeper than six levels (three in the compact form).  Synchronous (one size read-back); 0.17 ms and 256 MB for
  * the 1M-triangle scene of BASELINE.md. */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
+/* Extension: after hagrid_setup_traversal built a self-contained image of `grid` (the flat form of a grid of at most six levels), the
+ * caller may give the construction format up: entries and cells | small_cells are released to the pool and set to NULL in the
+ * descriptor, the image answers for them (1M-triangle scene: 166 MB of 493 MB).  hagrid_traverse_grid[_ex] keep working with that
+ * descriptor; what reads the construction format (construction passes, hagrid_traverse_grid_stats, hagrid_grid_pack, forced kernel
+ * variants) is refused.  ref_ids and the triangles stay with the caller as before. */
+int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* grid);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
  * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
 int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,

@@ -681,3 +681,60 @@ def test_wave_time_diagnostic_does_not_change_hits(mem):
     finally:
         mem._L.hagrid_kat_wave_times(mem._ctx, None, None)
     mem.free(d_order); mem.free(d_times); mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
+def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
+    """Extension hagrid_grid_release_for_traversal: once setup_traversal has built a self-contained (flat) image, entries and cells
+    go back to the pool, traversal (nearest hit, any-hit, barycentrics, binned) gives the same hits from the image alone; what
+    needs the construction format is refused without harming the image."""
+    from hagrid_amd import api
+    tris = scene.make_soup(200_000)
+    mem = api.MemManager(keep=False)
+    d_tris = mem.upload(tris)
+    for compress in (False, True):
+        grid = api.build_all(mem, d_tris, tris.shape[0], compress=compress)
+        rays = np.concatenate([scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 256, 256),
+                               scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 150_000, 21)]).astype(np.float32)
+        n = rays.shape[0]
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+        api.setup_traversal(grid)
+        want = {}
+        for flags in (0, api.ANY_HIT, api.UVS):
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+            want[flags] = mem.download(d_hits, api.HIT_DTYPE, n)
+        before = mem.usage()
+        held = 4 * grid.num_entries + (16 if compress else 32) * grid.num_cells
+        api.release_for_traversal(grid)
+        assert not grid.entries and not grid.cells and not grid.small_cells and grid.ref_ids
+        assert before - mem.usage() >= held                       # keep = False: the buffers really went back
+        for binning in (0, 1):
+            mem.set_ray_binning(binning)
+            for flags in (0, api.ANY_HIT, api.UVS):
+                mem.zero(d_hits, 16 * n)
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                assert got.tobytes() == want[flags].tobytes(), (compress, binning, flags)
+        mem.set_ray_binning(0)
+        api.setup_traversal(grid)                                   # nothing to rebuild, nothing lost
+        with pytest.raises(api.HagridError):
+            api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n)
+        with pytest.raises(api.HagridError):
+            api.release_for_traversal(grid)                        # already released
+        if not compress:
+            with pytest.raises(api.HagridError):
+                api.expand_grid(mem, grid, d_tris, 1)
+        mem.set_option("traverse.variant", 2)
+        with pytest.raises(api.HagridError):
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        mem.set_option("traverse.variant", 0)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        assert mem.download(d_hits, api.HIT_DTYPE, n).tobytes() == want[0].tobytes()
+        mem.free(d_rays); mem.free(d_hits); grid.free()
+    # the compact image still walks the voxel map: not releasable
+    mem.set_option("traverse.image", 1)
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    api.setup_traversal(grid)
+    with pytest.raises(api.HagridError):
+        api.release_for_traversal(grid)
+    mem.set_option("traverse.image", 2)
+    grid.free(); mem.close()
