@@ -27,6 +27,8 @@ FLAGS = [
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
     "-Wall", "-Wno-unused-function",
 ] + os.environ.get("HAGRID_HIPCC_EXTRA", "").split()     # experiments only (tools/dev_flags.sh)
+if os.environ.get("HAGRID_DEBUG_SYNC", "0") not in ("", "0"):
+    FLAGS.append("-DHAGRID_DEBUG_SYNC")                    # per-kernel synchronisation + error check (ctx.h: HG_DBG); use with --force
 
 
 def _newer(target: str, deps: list[str]) -> bool:

@@ -465,8 +465,8 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     float* bb_part = tmp.get<float>(size_t(bb_blocks) * 6 + 8);
     if (!bb_part) return HAGRID_ENOMEM;
     float* bb_out = bb_part + size_t(bb_blocks) * 6;
-    bbox_partials<<<bb_blocks, kBlock, 0, st>>>(tris, num_tris, bb_part);
-    bbox_final<<<1, kBlock, 0, st>>>(bb_part, bb_blocks, bb_out);
+    bbox_partials<<<bb_blocks, kBlock, 0, st>>>(tris, num_tris, bb_part); HG_DBG(ctx);
+    bbox_final<<<1, kBlock, 0, st>>>(bb_part, bb_blocks, bb_out); HG_DBG(ctx);
     float hb[6];
     HG_TRY(read_back(ctx, bb_out, hb, sizeof(hb)));
     BBox gb(vec3(hb[0], hb[1], hb[2]), vec3(hb[3], hb[4], hb[5]));
@@ -490,9 +490,9 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     int* partials = tmp.get<int>(2 * size_t(scan_num_tiles(std::max(num_tris, num_top)) + 1));
     if (!counts || !start_emit || !refs_per_cell || !log_dims || !partials) return HAGRID_ENOMEM;
     HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
-    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, refs_per_cell);
+    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, refs_per_cell); HG_DBG(ctx);
     if (!ctx_scan<int>(ctx, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0)) return HAGRID_ENOMEM;
-    top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1);
+    top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1); HG_DBG(ctx);
     int h2[2];
     HG_TRY(read_back(ctx, dsc, h2, sizeof(h2)));
     const int R0 = h2[0], shift = h2[1];
@@ -514,8 +514,8 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
         L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
         if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
-        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids);
-        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k);
+        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids); HG_DBG(ctx);
+        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k); HG_DBG(ctx);
         HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(L.cell_counts, 0, size_t(num_top) * sizeof(int), st));
         levels.push_back(L);
@@ -530,11 +530,11 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         unsigned char* masks = tmp.get<unsigned char>(size_t(L.num_refs) + 1);
         if (!part || !masks) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
-            mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries);
+            mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries); HG_DBG(ctx);
         if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0)) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
             classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
-                                                                               masks, L.cell_counts, L.ranks, tot + 1);
+                                                                               masks, L.cell_counts, L.ranks, tot + 1); HG_DBG(ctx);
         int h3[3];
         HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
         const int num_new_cells = h3[0], num_children = h3[1];
@@ -555,8 +555,8 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
         emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
-                                                                             N.ref_ids, N.cell_ids, cursor);
-        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells);
+                                                                             N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
+        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells); HG_DBG(ctx);
         tmp.drop(masks);
         levels.push_back(N);
     }
@@ -592,12 +592,12 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     for (int l = 0, off = 0; l < num_levels; off += levels[l].num_cells, l++) {
         Level& L = levels[l];
         concat_level<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.cell_counts, L.start_cell, L.ref_begin,
-                                                                          L.num_cells, off, out_cells, out_entries);
+                                                                          L.num_cells, off, out_cells, out_entries); HG_DBG(ctx);
         if (L.num_refs > 0)
             scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.entries, L.ranks,
-                                                                                  L.ref_begin, out_refs);
+                                                                                  L.ref_begin, out_refs); HG_DBG(ctx);
     }
-    sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs);
+    sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs); HG_DBG(ctx);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);      // temporaries are released below
     if (e != hipSuccess) {

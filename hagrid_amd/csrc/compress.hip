@@ -58,15 +58,15 @@ extern "C" int hagrid_compress_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
     // the list lengths are known from the cells alone: total first (one small reduction + read-back), then
     // a single scan whose output functor writes the small cells and copies the lists
     int* total = ctx->dscratch;
-    scan_partials<int, SentinelIn><<<std::max(scan_num_tiles(n), 1), kBlock, 0, st>>>(SentinelIn{cells}, n, partials);
-    scan_spine<int><<<1, kBlock, 0, st>>>(partials, scan_num_tiles(n), nullptr, total);
+    scan_partials<int, SentinelIn><<<std::max(scan_num_tiles(n), 1), kBlock, 0, st>>>(SentinelIn{cells}, n, partials); HG_DBG(ctx);
+    scan_spine<int><<<1, kBlock, 0, st>>>(partials, scan_num_tiles(n), nullptr, total); HG_DBG(ctx);
     int h = 0;
     int rc = read_back(ctx, total, &h, sizeof(int));
     if (rc != HAGRID_OK || h < 0) { hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, small); return rc != HAGRID_OK ? rc : HAGRID_ERANGE; }
     int* srefs = pool_alloc<int>(ctx, size_t(h));
     if (!srefs) { hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, small); return HAGRID_ENOMEM; }
     scan_apply<int, SentinelIn, SmallCellOut><<<std::max(scan_num_tiles(n), 1), kBlock, 0, st>>>(
-        SentinelIn{cells}, SmallCellOut{cells, static_cast<const int*>(grid->ref_ids), small, srefs}, n, partials);
+        SentinelIn{cells}, SmallCellOut{cells, static_cast<const int*>(grid->ref_ids), small, srefs}, n, partials); HG_DBG(ctx);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hagrid_mem_free(ctx, partials);

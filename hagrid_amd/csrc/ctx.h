@@ -86,6 +86,8 @@ struct hagrid_ctx {
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
+    int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
+
     hagrid_impl::TravImageCache image;
     hagrid_build_counts counts = {};      // sizes of the last construction (hagrid_get_build_counts)
 
@@ -114,6 +116,16 @@ inline int fail(hagrid_ctx* ctx, int code, const char* file, int line, const cha
         int rc_ = (expr);                                                                         \
         if (rc_ < 0) return rc_;                                                                  \
     } while (0)
+
+// Debug build (HAGRID_DEBUG_SYNC=1 python hagrid_amd/build.py --force -> -DHAGRID_DEBUG_SYNC): after every kernel launch of a pass the
+// stream is drained and the runtime's error state checked; a failure prints "file(line): message" and aborts -- the reference's
+// DEBUG_SYNC of non-NDEBUG builds (common.h:95-108).  In a normal build the macro is empty.
+void debug_sync(hagrid_ctx* ctx, const char* file, int line);
+#ifdef HAGRID_DEBUG_SYNC
+#define HG_DBG(ctx) ::hagrid_impl::debug_sync((ctx), __FILE__, __LINE__)
+#else
+#define HG_DBG(ctx) do { } while (0)
+#endif
 
 // pool access for the passes (typed convenience over hagrid_mem_alloc)
 template <typename T>

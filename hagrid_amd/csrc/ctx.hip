@@ -267,11 +267,11 @@ extern "C" int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, 
         for (int it = 0; it < iters + 1 && rc == HAGRID_OK; it++) {           // the first round is a warm-up
             float ms = -1.0f;
             if (hagrid_profile_begin(ctx) != HAGRID_OK) { rc = HAGRID_EHIP; break; }
-            bw_copy_kernel<<<blocks, 256, 0, ctx->stream>>>(a, c, n);
+            bw_copy_kernel<<<blocks, 256, 0, ctx->stream>>>(a, c, n); HG_DBG(ctx);
             ms = hagrid_profile_end(ctx);
             if (ms > 0.0f && it) best_copy = std::max(best_copy, float(2.0 * double(n) * 16.0 / (double(ms) * 1e6)));
             if (hagrid_profile_begin(ctx) != HAGRID_OK) { rc = HAGRID_EHIP; break; }
-            bw_triad_kernel<<<blocks, 256, 0, ctx->stream>>>(a, b, c, n);
+            bw_triad_kernel<<<blocks, 256, 0, ctx->stream>>>(a, b, c, n); HG_DBG(ctx);
             ms = hagrid_profile_end(ctx);
             if (ms > 0.0f && it) best_triad = std::max(best_triad, float(3.0 * double(n) * 16.0 / (double(ms) * 1e6)));
         }
@@ -300,6 +300,23 @@ unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int 
     }
     *epoch = ++ctx->lb_epoch;
     return ctx->lb_state;
+}
+
+void hagrid_impl::debug_sync(hagrid_ctx* ctx, const char* file, int line) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "%s(%d): %s\n", file, line, hipGetErrorString(e));
+        abort();
+    }
+}
+
+extern "C" int hagrid_debug_sync_enabled(void) {
+#ifdef HAGRID_DEBUG_SYNC
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int hagrid_impl::read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes) {

@@ -286,13 +286,13 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
             continue;
         }
         if (subset_only) {
-            overlap_step<0, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
-            overlap_step<1, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
-            overlap_step<2, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<0, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
+            overlap_step<1, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
+            overlap_step<2, true><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
         } else {
-            overlap_step<0, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
-            overlap_step<1, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
-            overlap_step<2, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); std::swap(cells, other);
+            overlap_step<0, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
+            overlap_step<1, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
+            overlap_step<2, false><<<blocks, kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, n); HG_DBG(ctx); std::swap(cells, other);
         }
     }
     hipError_t e = hipGetLastError();

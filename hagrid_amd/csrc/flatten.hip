@@ -129,7 +129,7 @@ extern "C" int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid) {
 
     uint32_t* out = pool_alloc<uint32_t>(ctx, size_t(total_entries));
     if (!out) { release(); return HAGRID_ENOMEM; }
-    copy_top<<<grid_blocks(top_entries, kBlock), kBlock, 0, st>>>(entries, start, depths, out, top_entries);
+    copy_top<<<grid_blocks(top_entries, kBlock), kBlock, 0, st>>>(entries, start, depths, out, top_entries); HG_DBG(ctx);
     int new_offsets[HAGRID_MAX_LEVELS], num_new = 0;
     for (int i = 0, g = 0; i < shift; i += kFlatLevels, g++) {
         const int first = first_of(i), num = grid->offsets[i] - first;

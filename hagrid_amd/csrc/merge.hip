@@ -279,12 +279,12 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             Int2* tot = total + axis;
             const int* n_dev = (chain && axis) ? &total[axis - 1].a : nullptr;
             pass_tag++;
-            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
-            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev);
+            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev); HG_DBG(ctx);
+            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
             if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
-                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev);
-            remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries);
+                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev); HG_DBG(ctx);
+            remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
             std::swap(cells, cells_b);
             std::swap(refs, refs_b);
             if (axis == 2 || !chain) {

@@ -329,7 +329,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
         (void)hipMemsetAsync(total + 1, 0, sizeof(int), st);
         k.claim = claim; k.roots = roots; k.num_roots = total + 1;
     }
-    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr, 0);
+    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr, 0); HG_DBG(ctx);
     if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int h[2] = {0, 0};
     int rc = read_back(ctx, total, h, sizeof(h));
@@ -341,7 +341,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
         sizes1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
         depths1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
         if (!sizes1 || !depths1) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-        image_nested<false><<<num_roots, 64, 0, st>>>(k, num_roots, sizes1, depths1, nullptr, nullptr);
+        image_nested<false><<<num_roots, 64, 0, st>>>(k, num_roots, sizes1, depths1, nullptr, nullptr); HG_DBG(ctx);
         if (!ctx_scan<int>(ctx, SizeIn{sizes1}, SizeOut{sizes1}, num_roots, partials, (const int*)nullptr, total + 2)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
         rc = read_back(ctx, total + 2, &units1, sizeof(int));
         if (rc != HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return rc; }
@@ -359,7 +359,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     k.nested_off = sizes1; k.nested_d = depths1; k.nested_base = units;
     if (num_roots == 0) k.claim = nullptr;
-    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks, uniform ? 1 : 0);
+    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks, uniform ? 1 : 0); HG_DBG(ctx);
     if (num_roots > 0) image_nested<true><<<num_roots, 64, 0, st>>>(k, num_roots, nullptr, depths1, sizes1, blocks + size_t(units) * 128u);
     img.uniform = uniform;
     hipError_t e = hipGetLastError();

@@ -44,6 +44,7 @@ struct TraverseArgs {
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
     int num_rays;
+    int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
     int top_x, top_y;             // top-level resolution (x, y)
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
         }
     }
 
-    a.hits[id] = make_float4(__int_as_float(hit.id), hit.t, 0.0f, 0.0f);
+    a.hits[id] = make_float4(__int_as_float((STATS && a.id_is_steps) ? steps : hit.id), hit.t, 0.0f, 0.0f);
 
     if (STATS) {
         if (a.steps) a.steps[id] = steps;
@@ -1056,7 +1057,7 @@ bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform
 // kOriginMinRays rays and returns at once when the first criterion has already answered.
 constexpr int kOriginMinRays = 1 << 22;
 void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays) {
-    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0);
+    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0); HG_DBG(ctx);
     const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
     const float tau = length(ext) / 64.0f;
     if (!ctx->opt_detect_origins || num_rays < origin_min_rays || !(tau > 0.0f) || !(tau < 3.0e18f)) return;
@@ -1064,7 +1065,7 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
         if (hipMalloc((void**)&ctx->row_scores, (kRowCandidates + 8) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->row_scores = nullptr; return; }
         (void)hipMemsetAsync(ctx->row_scores, 0, (kRowCandidates + 8) * sizeof(int), ctx->stream);
     }
-    detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1);
+    detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1); HG_DBG(ctx);
 }
 
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
@@ -1087,7 +1088,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.num_rays = num_rays; a.shift = g->shift;
+    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -1121,6 +1122,18 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
     HG_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->opt_id_is_steps && flags == 0) {
+        // literal compatibility with the reference BINARY: its kernel overwrites Hit.id with the traversal step counter
+        // (traverse.cu:80,93) and its viewer colours by it (main.cpp:100-107).  Served by the reference-shaped kernel.
+        if (!grid->entries) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: traverse.id_is_steps needs the construction format (grid released for traversal)");
+        a.id_is_steps = 1;
+        const int blocks = grid_blocks(num_rays, 256);
+        if (grid->small_cells) traverse_kernel<true, true><<<blocks, 256, 0, ctx->stream>>>(a);
+        else                   traverse_kernel<false, true><<<blocks, 256, 0, ctx->stream>>>(a);
+        HG_DBG(ctx);
+        HG_HIP(ctx, hipGetLastError());
+        return HAGRID_OK;
+    }
     // binning buffers: released on every exit path.  The pool hands them to nobody else before the kernels below are done: in
     // keep mode free() only marks the slot (work of one context is stream-ordered), otherwise free() synchronises the stream first
     PoolTemps tmp(ctx);
@@ -1143,17 +1156,17 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));
             }
             launch_detect(ctx, a, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
-            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff);
+            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff); HG_DBG(ctx);
             (void)ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
-            ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag);
-            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag);
+            ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag); HG_DBG(ctx);
+            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag); HG_DBG(ctx);
             a.perm_flag = flag;
             if (ctx->opt_image_width == 0) a.row_len = row_len;
             else if (ctx->opt_image_width > 0) a.row_len_hint = ctx->opt_image_width;
         } else {
-            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr);
+            ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr); HG_DBG(ctx);
             (void)ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr);
-            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr);
+            ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr); HG_DBG(ctx);
         }
         a.perm = perm;
     }
@@ -1229,6 +1242,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (grid->small_cells) traverse_kernel_v3<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
         else                   traverse_kernel_v3<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, chunk, both, refill_at);
     }
+    HG_DBG(ctx);                                   // the traversal kernel launched by one of the helpers above
     HG_HIP(ctx, hipGetLastError());
     return HAGRID_OK;
 }
@@ -1244,6 +1258,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20}, {"traverse.detect_origins", &ctx->opt_detect_origins, 0, 1},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
+        {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
 
     };
     for (auto& t : table)
@@ -1375,7 +1390,7 @@ extern "C" int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, 
     for (int i = 0; i < n; i++) max_idx = std::max(max_idx, tri_index[i]);
     Staged t(ctx, tris, size_t(max_idx + 1) * 48), r(ctx, rays, size_t(n) * 32), ix(ctx, tri_index, size_t(n) * 4);
     Staged o0(ctx, nullptr, size_t(n) * 4), o1(ctx, nullptr, size_t(n) * 4), o2(ctx, nullptr, size_t(n) * 4);
-    kat_prim_ray<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d);
+    kat_prim_ray<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     HG_TRY(o0.fetch(ret)); HG_TRY(o1.fetch(hit_id)); HG_TRY(o2.fetch(hit_t));
     return HAGRID_OK;
@@ -1388,7 +1403,7 @@ extern "C" int hagrid_kat_intersect_prim_ray_uvs(hagrid_ctx* ctx, const void* tr
     for (int i = 0; i < n; i++) max_idx = std::max(max_idx, tri_index[i]);
     Staged t(ctx, tris, size_t(max_idx + 1) * 48), r(ctx, rays, size_t(n) * 32), ix(ctx, tri_index, size_t(n) * 4);
     Staged o0(ctx, nullptr, size_t(n) * 4), o1(ctx, nullptr, size_t(n) * 4), o2(ctx, nullptr, size_t(n) * 4), o3(ctx, nullptr, size_t(n) * 4), o4(ctx, nullptr, size_t(n) * 4);
-    kat_prim_ray_uvs<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d, (float*)o3.d, (float*)o4.d);
+    kat_prim_ray_uvs<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const Ray*)r.d, (const int*)ix.d, n, (int*)o0.d, (int*)o1.d, (float*)o2.d, (float*)o3.d, (float*)o4.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     HG_TRY(o0.fetch(ret)); HG_TRY(o1.fetch(hit_id)); HG_TRY(o2.fetch(hit_t)); HG_TRY(o3.fetch(hit_u)); HG_TRY(o4.fetch(hit_v));
     return HAGRID_OK;
@@ -1399,7 +1414,7 @@ extern "C" int hagrid_kat_intersect_prim_cell(hagrid_ctx* ctx, const void* tris,
     int max_idx = 0;
     for (int i = 0; i < n; i++) max_idx = std::max(max_idx, tri_index[i]);
     Staged t(ctx, tris, size_t(max_idx + 1) * 48), b(ctx, boxes, size_t(n) * 32), ix(ctx, tri_index, size_t(n) * 4), o(ctx, nullptr, size_t(n) * 4);
-    kat_prim_cell<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const BBox*)b.d, (const int*)ix.d, n, (int*)o.d);
+    kat_prim_cell<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Tri*)t.d, (const BBox*)b.d, (const int*)ix.d, n, (int*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(ret);
 }
@@ -1407,7 +1422,7 @@ extern "C" int hagrid_kat_intersect_prim_cell(hagrid_ctx* ctx, const void* tris,
 extern "C" int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* grid_bb, const void* obj_bb, int n, int32_t* out6) {
     if (!ctx || n <= 0) return HAGRID_EINVAL;
     Staged d(ctx, dims3, size_t(n) * 12), g(ctx, grid_bb, size_t(n) * 32), ob(ctx, obj_bb, size_t(n) * 32), o(ctx, nullptr, size_t(n) * 24);
-    kat_range<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const int*)d.d, (const BBox*)g.d, (const BBox*)ob.d, n, (int*)o.d);
+    kat_range<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const int*)d.d, (const BBox*)g.d, (const BBox*)ob.d, n, (int*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(out6);
 }
@@ -1415,7 +1430,7 @@ extern "C" int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, c
 extern "C" int hagrid_kat_compute_grid_dims(hagrid_ctx* ctx, const void* bb, const int32_t* num_prims, const float* density, int n, int32_t* out3) {
     if (!ctx || n <= 0) return HAGRID_EINVAL;
     Staged b(ctx, bb, size_t(n) * 32), np(ctx, num_prims, size_t(n) * 4), de(ctx, density, size_t(n) * 4), o(ctx, nullptr, size_t(n) * 12);
-    kat_grid_dims<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const BBox*)b.d, (const int*)np.d, (const float*)de.d, n, (int*)o.d);
+    kat_grid_dims<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const BBox*)b.d, (const int*)np.d, (const float*)de.d, n, (int*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(out3);
 }
@@ -1424,7 +1439,7 @@ extern "C" int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries,
                                        const int32_t* voxels3, int n, uint32_t* out) {
     if (!ctx || n <= 0 || num_entries <= 0) return HAGRID_EINVAL;
     Staged e(ctx, entries, size_t(num_entries) * 4), v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 4);
-    kat_lookup<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Entry*)e.d, shift, ivec3(top_dims3[0], top_dims3[1], top_dims3[2]), (const int*)v.d, n, (uint32_t*)o.d);
+    kat_lookup<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>((const Entry*)e.d, shift, ivec3(top_dims3[0], top_dims3[1], top_dims3[2]), (const int*)v.d, n, (uint32_t*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(out);
 }
@@ -1449,7 +1464,7 @@ extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len,
     a.num_rays = num_rays; a.row_len_hint = row_len; a.super_log2 = super_log2; a.xcd_chunk_log2 = xcd_chunk_log2;
     Staged o(ctx, nullptr, size_t(blocks) * 64 * 4);
     if (!o.d) return HAGRID_ENOMEM;
-    kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d);
+    kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(slots);
 }
@@ -1473,7 +1488,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }

@@ -369,11 +369,12 @@ inline void device_scan(hipStream_t stream, In in, Out out, int n, V* partials, 
 /// Returns false if the status words could not be allocated.
 template <typename V, typename In, typename Out>
 inline bool ctx_scan(hagrid_ctx* ctx, In in, Out out, int n, V* partials, const V* carry_in, V* total_out) {
-    if (!ctx->opt_lookback) { device_scan<V>(ctx->stream, in, out, n, partials, carry_in, total_out); return true; }
+    if (!ctx->opt_lookback) { device_scan<V>(ctx->stream, in, out, n, partials, carry_in, total_out); HG_DBG(ctx); return true; }
     unsigned epoch = 0;
     unsigned long long* state = lookback_state(ctx, scan_num_tiles(n), lb_words<V>(), &epoch);
     if (!state) return false;
     device_scan_lookback<V>(ctx->stream, ctx->num_cus, in, out, n, state, epoch, carry_in, total_out);
+    HG_DBG(ctx);
     return true;
 }
 

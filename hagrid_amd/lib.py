@@ -76,6 +76,7 @@ class BuildCounts(C.Structure):
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "hagrid_abi_version": (_i32, []),
+    "hagrid_debug_sync_enabled": (_i32, []),
     "hagrid_ctx_create": (_i32, [C.POINTER(_vp), _i32, _i32]),
     "hagrid_ctx_destroy": (None, [_vp]),
     "hagrid_ctx_set_stream": (_i32, [_vp, _vp]),

@@ -89,6 +89,9 @@ typedef struct hagrid_build_counts {
 /* ---- context ----------------------------------------------------------------------------------- */
 
 int hagrid_abi_version(void);
+/* 1 when the library was built with HAGRID_DEBUG_SYNC (every kernel launch of a pass is followed by a stream synchronisation and an
+ * error check that aborts with "file(line): message", the reference's DEBUG_SYNC of common.h:95-108), else 0. */
+int hagrid_debug_sync_enabled(void);
 
 /* Creates a context on HIP device `device`.  keep != 0 is MemManager's keep mode (mem_manager.h:40-42):
  * freed buffers stay allocated for reuse by later builds. */
@@ -238,9 +241,12 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * also from the origins alone -- bounce rays in the image order of their primary hits -- unless
  * "traverse.detect_origins" = 0), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
+ * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
+ * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
+ * ray.h:22 documents; t is the same either way);
  * "expand.subset_only" (1 = the reference's compiled setting, default; 0 = the precise expansion of
  * expand.cu:39-57,96-127 -- this one changes the grid, not the hits).  Returns HAGRID_EINVAL for an
- * unknown key or a value out of range.  Hits never depend on these settings. */
+ * unknown key or a value out of range.  Hits never depend on these settings ("traverse.id_is_steps" changes what Hit.id MEANS, not t). */
 int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 
 /* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */

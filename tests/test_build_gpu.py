@@ -281,3 +281,47 @@ def test_random_scenes_and_parameters(mem, seed):
         mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
     finally:
         mem.set_option("expand.subset_only", 1)
+
+
+def test_debug_sync_build_runs_the_whole_path(tmp_path):
+    """The HAGRID_DEBUG_SYNC build (per-kernel stream synchronisation + error check, the reference's DEBUG_SYNC of common.h:95-108)
+    compiles, reports itself and carries construction + traversal with unchanged results."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, shutil, importlib
+sys.path.insert(0, ROOT)
+import hagrid_amd.build as B
+B.OBJ = os.path.join(OUT, "obj"); B.LIB = os.path.join(OUT, "libhagrid_amd_debug.so")
+B.FLAGS.append("-DHAGRID_DEBUG_SYNC")
+B.build(force=True)
+import hagrid_amd.lib as L
+L.LIB_PATH = B.LIB
+import numpy as np
+from hagrid_amd import api, scene
+assert L.load().hagrid_debug_sync_enabled() == 1
+mem = api.MemManager(keep=True)
+tris = scene.make_soup(30000); d_tris = mem.upload(tris)
+grid = api.build_all(mem, d_tris, 30000, compress=True)
+rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 70000, 3)
+d_rays = mem.upload(rays); d_hits = mem.alloc(16 * 70000)
+api.setup_traversal(grid); mem.set_ray_binning(1)
+api.traverse_grid(grid, d_tris, d_rays, d_hits, 70000)
+h = mem.download(d_hits, api.HIT_DTYPE, 70000)
+print("SUMMARY", grid.num_cells, grid.num_refs, int((h["id"] >= 0).sum()), int(h["id"].astype(np.int64).sum()))
+'''.replace("ROOT", repr(root)).replace("OUT", repr(str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = [l for l in r.stdout.splitlines() if l.startswith("SUMMARY")][-1].split()[1:]
+    from hagrid_amd import api
+    mem = api.MemManager(keep=True)
+    assert mem._L.hagrid_debug_sync_enabled() == 0
+    tris = scene.make_soup(30000); d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, 30000, compress=True)
+    rays = scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 70000, 3)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * 70000)
+    api.setup_traversal(grid); mem.set_ray_binning(1)
+    api.traverse_grid(grid, d_tris, d_rays, d_hits, 70000)
+    h = mem.download(d_hits, api.HIT_DTYPE, 70000)
+    assert got == [str(grid.num_cells), str(grid.num_refs), str(int((h["id"] >= 0).sum())), str(int(h["id"].astype(np.int64).sum()))]
+    mem.close()

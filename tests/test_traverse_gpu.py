@@ -738,3 +738,31 @@ def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
         api.release_for_traversal(grid)
     mem.set_option("traverse.image", 2)
     grid.free(); mem.close()
+
+
+def test_hit_id_can_carry_the_reference_kernels_step_count():
+    """traverse.id_is_steps: Hit.id = the step count the reference kernel leaves there (traverse.cu:80,93: one per visited cell plus
+    one per reference of its list), t unchanged; the oracle's step counter is the witness."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(20_000)
+    mem = api.MemManager(keep=True)
+    d_tris = mem.upload(tris)
+    for compress in (False, True):
+        grid = api.build_all(mem, d_tris, tris.shape[0], compress=compress)
+        G = O.Grid.full(tris, compress=compress)
+        rays = np.concatenate([scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 128, 128), scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 30_000, 9)]).astype(np.float32)
+        n = rays.shape[0]
+        d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+        api.setup_traversal(grid)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        plain = mem.download(d_hits, api.HIT_DTYPE, n)
+        mem.set_option("traverse.id_is_steps", 1)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        stepped = mem.download(d_hits, api.HIT_DTYPE, n)
+        mem.set_option("traverse.id_is_steps", 0)
+        oh, _, osteps = G.traverse(tris, rays, want_steps=True)
+        assert (stepped["id"] == osteps).all() and (stepped["t"].view(np.uint32) == plain["t"].view(np.uint32)).all()
+        assert (plain["id"] == oh["id"]).all() and stepped["id"].max() > 3
+        mem.free(d_rays); mem.free(d_hits); grid.free()
+    mem.close()
