@@ -420,6 +420,12 @@ __device__ __forceinline__ bool intersect_prim_ray_uvs(const Tri& tri, const Ray
 // extension and a 64-bit add), index products are 24-bit multiplies (full rate; 32-bit multiplies are quarter rate) and the
 // range test is three unsigned compares.  The host selects it when every array it indexes is smaller than 4 GB and the
 // top-level resolution fits 23 bits per axis.
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {          // the median of three (one VALU instruction)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <typename T>
 __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
     return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
@@ -684,6 +690,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
         const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
+        const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
         int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
         uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
         uint4 ca, cb;
@@ -708,9 +715,10 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             const int nx = texit == tcell.x ? cx + bx : int(ev.x);
             const int ny = texit == tcell.y ? cy + by : int(ev.y);
             const int nz = texit == tcell.z ? cz + bz : int(ev.z);
-            vx = px ? max(nx, vx) : min(nx, vx);
-            vy = py ? max(ny, vy) : min(ny, vy);
-            vz = pz ? max(nz, vz) : min(nz, vz);
+            // never backwards: max with the current voxel along a positive direction, min along a negative one -- the median of
+            // (new, current, +-infinity), one instruction per axis
+            if (UNIFORM) { vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z); }
+            else { vx = px ? max(nx, vx) : min(nx, vx); vy = py ? max(ny, vy) : min(ny, vy); vz = pz ? max(nz, vz) : min(nz, vz); }   // (the table layouts have no registers to spare)
             const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
 
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
@@ -722,36 +730,48 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
             else record(tab, vx, vy, vz, na, nb);
 
-            // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two
-            // longest.  Inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
+            // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
             // than four ids, deep cells) fetches the id of the next test one test ahead, as v2 does.
             const bool by_index = int(ca.w) < 0;
             auto ref_at = [&](uint32_t i) -> int { return NARROW ? gather32<int>(a.refs, i << 2) : a.refs[i]; };
             uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;                       // inline: the ids still to test
             int ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
-            if (by_index) {                                                 // by index: q1 = index of the next id, q2 = end of the list
-                q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                ref = -1;
-                if (q1 < q2) ref = ref_at(q1);
-                q1++;
-            }
+            if (UNIFORM && __ballot(by_index) == 0ull) {
+                // shallow grids: lists of more than four ids are rare (1.5 % of the visited cells of the 1M-triangle soup), so a
+                // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
 #pragma unroll 1
-            while (ref >= 0) {
-                int next;
-                if (UNIFORM) {
-                    // shallow grids, long lists are rare: the fewest instructions for the inline form
-                    if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                    else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                while (ref >= 0) {
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    ref = (ANY && got) ? -1 : int(q1);
+                    q1 = q2; q2 = q3; q3 = ~0u;
                 }
-                int pre = -1;
-                if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
-                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                if (!UNIFORM) {
-                    if (by_index) { next = pre; q1++; }
-                    else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+            } else {
+                // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two longest.
+                if (by_index) {                                             // by index: q1 = index of the next id, q2 = end of the list
+                    q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
+                    ref = -1;
+                    if (q1 < q2) ref = ref_at(q1);
+                    q1++;
                 }
-                ref = (ANY && got) ? -1 : next;
+#pragma unroll 1
+                while (ref >= 0) {
+                    int next;
+                    if (UNIFORM) {
+                        // shallow grids, long lists are rare: the fewest instructions for the inline form
+                        if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                    }
+                    int pre = -1;
+                    if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    if (!UNIFORM) {
+                        if (by_index) { next = pre; q1++; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                    }
+                    ref = (ANY && got) ? -1 : next;
+                }
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhagrid_amd.so")
+LIB_PATH = os.environ.get("HAGRID_AMD_LIB") or os.path.join(HERE, "libhagrid_amd.so")     # the override serves A/B runs of two builds
 MAX_LEVELS = 32
 
 OK, EINVAL, EHIP, ENOMEM, ERANGE, ENODEV = 0, -1, -2, -3, -4, -5
