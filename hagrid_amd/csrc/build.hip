@@ -152,17 +152,24 @@ __global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ r
 // emit_new_refs (build.cu:69-136) + filter_refs (build.cu:139-157): every (primitive, top cell) pair of the
 // primitive's cell range in x-fastest order, with -1/-1 where the triangle misses the cell.  Large ranges are spread
 // over the wavefront as in count_top_refs (slot = start + linear cell index, so the order is the serial one).
+// A cell that receives a reference and still has levels to go is marked for splitting by whoever hands it the reference
+// (compute_dims, build.cu:286-302, does that in a pass of its own over the references): entry word 1 = make_entry(1, 0), the same
+// value from every writer.
 __device__ __forceinline__ void emit_one_top_ref(const BuildK& k, const Tri& tri, int prim, int x, int y, int z, int slot,
-                                                 int* __restrict__ ref_ids, int* __restrict__ cell_ids) {
+                                                 int* __restrict__ ref_ids, int* __restrict__ cell_ids,
+                                                 const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
     const int inc = 1 << k.shift;
     const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
     const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
+    const int cell = x + k.dims.x * (y + k.dims.y * z);
     ref_ids[slot] = hit ? prim : -1;
-    cell_ids[slot] = hit ? x + k.dims.x * (y + k.dims.y * z) : -1;
+    cell_ids[slot] = hit ? cell : -1;
+    if (hit && log_dims[cell] > 0) entries[cell] = 1u;
 }
 
 __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
-                                                        int* __restrict__ ref_ids, int* __restrict__ cell_ids) {
+                                                        int* __restrict__ ref_ids, int* __restrict__ cell_ids,
+                                                        const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     Range r(0, 0, 0, -1, -1, -1);
     int size = 0, start = 0;
@@ -178,7 +185,7 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
         int cur = start;
         for (int z = r.lz; z <= r.hz; z++)
             for (int y = r.ly; y <= r.hy; y++)
-                for (int x = r.lx; x <= r.hx; x++) emit_one_top_ref(k, tri, i, x, y, z, cur++, ref_ids, cell_ids);
+                for (int x = r.lx; x <= r.hx; x++) emit_one_top_ref(k, tri, i, x, y, z, cur++, ref_ids, cell_ids, log_dims, entries);
     }
     unsigned long long todo = __ballot(coop);
     while (todo) {
@@ -189,32 +196,23 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
         const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
         const Tri t = load_tri(tris, prim);                     // same address in every lane: one broadcast load
         for (int c = lane_id(); c < total; c += 64)
-            emit_one_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), first + c, ref_ids, cell_ids);
+            emit_one_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), first + c, ref_ids, cell_ids, log_dims, entries);
     }
 }
 
 // emit_top_cells (build.cu:332-351)
-__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k) {
+// + the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per level")
+__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims,
+                                                         unsigned char* __restrict__ depth_left) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_top) return;
+    depth_left[id] = (unsigned char)min(log_dims[id], 255);
     const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
     const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
     store_cell(cells, id, lo, 0, lo + ivec3(1 << k.shift), 0);
 }
 
 // ---- one subdivision level -----------------------------------------------------------------------------
-// compute_dims (build.cu:286-302) with update_log_dims (:273-278) folded in as max(0, log_dim0 - level)
-__global__ void __launch_bounds__(kBlock) mark_split_cells(const int* __restrict__ cell_ids, int num_refs, const Cell* __restrict__ cells,
-                                                           const int* __restrict__ log_dims, int level, BuildK k, uint32_t* __restrict__ entries) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_refs) return;
-    const int c = cell_ids[i];
-    if (c < 0) return;
-    const ivec3 m = load_cell_min(cells, c);
-    const int top = (m.x >> k.shift) + k.dims.x * ((m.y >> k.shift) + k.dims.y * (m.z >> k.shift));
-    if (log_dims[top] - level > 0) entries[c] = 1u;   // make_entry(1, 0); same value from every writer
-}
-
 // scan functors: 8 children per split cell (build.cu:557-559), then update_entries (build.cu:317-329)
 struct ChildCountIn {
     const uint32_t* entries;
@@ -298,6 +296,7 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
 constexpr int kEmitItems = 8;
 __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
                                                           const unsigned char* __restrict__ masks, const uint32_t* __restrict__ entries,
+                                                          const unsigned char* __restrict__ depth_left, uint32_t* __restrict__ new_entries,
                                                           int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
     __shared__ int lds[kWaves];
     __shared__ int tile_base;
@@ -326,12 +325,15 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
             if (mm) {
                 const int i = base + j * kBlock + threadIdx.x;
                 const int ref = ref_ids[i];
-                const int begin = int(entries[cell_ids[i]] >> 2);
+                const int cell = cell_ids[i];
+                const int begin = int(entries[cell] >> 2);
+                const bool splits_again = depth_left[cell] > 1;           // the children still have a level to go
                 while (mm) {
                     const int child = __ffs(mm) - 1;
                     mm &= mm - 1;
                     new_ref_ids[pos] = ref;
                     new_cell_ids[pos] = begin + child;
+                    if (splits_again) new_entries[begin + child] = 1u;
                     pos++;
                 }
             }
@@ -342,7 +344,8 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
 
 // emit_new_cells (build.cu:354-383): 8 cells x 32 B = 256 contiguous bytes per split cell
 __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, int num_cells,
-                                                           Cell* __restrict__ new_cells) {
+                                                           const unsigned char* __restrict__ depth_left, Cell* __restrict__ new_cells,
+                                                           unsigned char* __restrict__ new_depth_left) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int id = t >> 3, child = t & 7;     // 8 lanes per parent: each lane stores one child
     if (id >= num_cells) return;
@@ -353,6 +356,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __res
     const int inc = (b.x - a.x) >> 1;
     const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
     store_cell(new_cells, int(e >> 2) + child, lo, 0, lo + ivec3(inc), 0);
+    new_depth_left[int(e >> 2) + child] = (unsigned char)(depth_left[id] - 1);
 }
 
 // ---- concatenation ---------------------------------------------------------------------------------------
@@ -441,6 +445,7 @@ struct Level {
     Cell* cells = nullptr; uint32_t* entries = nullptr; int num_cells = 0;
     int* cell_counts = nullptr;                 // kept references per cell
     int* ranks = nullptr;                       // per kept reference: its slot inside its cell's list
+    unsigned char* depth = nullptr;             // per cell: levels it may still be split
     int* start_cell = nullptr; int* ref_begin = nullptr;
 };
 
@@ -513,11 +518,12 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         L.cells = tmp.get<Cell>(size_t(num_top)); L.entries = tmp.get<uint32_t>(size_t(num_top) + 1);
         L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
         L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
-        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
-        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids); HG_DBG(ctx);
-        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k); HG_DBG(ctx);
+        L.depth = tmp.get<unsigned char>(size_t(num_top));
+        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin || !L.depth) return HAGRID_ENOMEM;
         HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(L.cell_counts, 0, size_t(num_top) * sizeof(int), st));
+        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids, log_dims, L.entries); HG_DBG(ctx);
+        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims, L.depth); HG_DBG(ctx);
         levels.push_back(L);
     }
     tmp.drop(start_emit);
@@ -529,8 +535,6 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         int* part = tmp.get<int>(size_t(scan_num_tiles(L.num_cells)) + 1);
         unsigned char* masks = tmp.get<unsigned char>(size_t(L.num_refs) + 1);
         if (!part || !masks) return HAGRID_ENOMEM;
-        if (L.num_refs > 0)
-            mark_split_cells<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.cell_ids, L.num_refs, L.cells, log_dims, level, k, L.entries); HG_DBG(ctx);
         if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0)) return HAGRID_ENOMEM;
         if (L.num_refs > 0)
             classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
@@ -550,13 +554,14 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         N.cells = tmp.get<Cell>(size_t(num_new_cells)); N.entries = tmp.get<uint32_t>(size_t(num_new_cells) + 1);
         N.cell_counts = tmp.get<int>(size_t(num_new_cells)); N.ranks = tmp.get<int>(size_t(num_children));
         N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
-        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
+        N.depth = tmp.get<unsigned char>(size_t(num_new_cells));
+        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin || !N.depth) return HAGRID_ENOMEM;
         HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
         emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
-                                                                             N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
-        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells); HG_DBG(ctx);
+                                                                             L.depth, N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
+        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, L.depth, N.cells, N.depth); HG_DBG(ctx);
         tmp.drop(masks);
         levels.push_back(N);
     }

@@ -72,8 +72,8 @@ __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) 
 // Precise mode (expand.cu:39-57): a triangle the neighbour references and the cell does not limits the growth to the voxel layer
 // where its bounding box begins -- if the box overlaps the cell's cross-section at all.  `room` is the number of layers the face
 // may still move (a magnitude, whatever the direction).
-template <int AXIS, bool UP>
-__device__ __forceinline__ int room_before_prim(const ExpandK& k, const Tri& prim, const CellRec& cell, const BBox& cross, int room) {
+template <int AXIS>
+__device__ __forceinline__ int room_before_prim(const ExpandK& k, const Tri& prim, const CellRec& cell, const BBox& cross, int room, bool UP) {
     constexpr int A1 = (AXIS + 1) % 3, A2 = (AXIS + 2) % 3;
     const BBox pb = prim.bbox();
     const bool overlaps = get<A1>(pb.min) <= get<A1>(cross.max) && get<A1>(pb.max) >= get<A1>(cross.min) &&
@@ -89,9 +89,10 @@ __device__ __forceinline__ int room_before_prim(const ExpandK& k, const Tri& pri
 // The face is swept row by row in the order the reference sweeps it -- a neighbour's (possibly already expanded) box decides how
 // far the sweep jumps, so the set of neighbours looked at is part of the result.  Quantities are kept as magnitudes:
 //   reach = the least extent of a neighbour seen so far beyond the face, room = min(reach, limits from references).
-template <int AXIS, bool UP, bool SUBSET_ONLY>
+// The direction is a run-time argument: the two directions of a cell run in two neighbouring lanes, in lock step.
+template <int AXIS, bool SUBSET_ONLY>
 __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
-                                           const Cell* __restrict__ cells, const CellRec& cell, bool& again) {
+                                           const Cell* __restrict__ cells, const CellRec& cell, bool UP, bool& again) {
     constexpr int A1 = (AXIS + 1) % 3, A2 = (AXIS + 2) % 3;
     const int face = UP ? comp(cell.hi, AXIS) : comp(cell.lo, AXIS);
     const int extent = comp(k.dims, AXIS);
@@ -118,7 +119,7 @@ __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __rest
                 const int id = refs[nb.begin + j];
                 while (mine < own && refs[cell.begin + mine] < id) mine++;
                 if (mine < own && refs[cell.begin + mine] == id) continue;
-                room = room_before_prim<AXIS, UP>(k, load_tri(tris, id), cell, cross, room);
+                room = room_before_prim<AXIS>(k, load_tri(tris, id), cell, cross, room, UP);
             }
             if (room == 0) break;
         }
@@ -134,13 +135,19 @@ __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __rest
     return UP ? room : -room;
 }
 
+// A cell's two growth directions are independent walks of dependent gathers (voxel map -> neighbour cell -> its list): they
+// run in two neighbouring lanes (lane & 1 = direction), which halves the chain a thread has to wait through; the even lane
+// collects both results and writes the cell.  `id` and `flags` are the same in both lanes of a pair.
 template <int axis, bool SUBSET_ONLY>
 __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
-                                          const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags) {
+                                          const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags, bool up) {
     CellRec cell = load_cell(cells, id);
-    bool flag = false;
-    const int ov1 = face_growth<axis, false, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
-    const int ov2 = face_growth<axis, true, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, flag);
+    bool again = false;
+    const int mine = face_growth<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, up, again);
+    const int other = __shfl_xor(mine, 1, 64);
+    const bool flag = again | (__shfl_xor(int(again), 1, 64) != 0);
+    if (up) return;
+    const int ov1 = mine, ov2 = other;                               // this lane walked down, its neighbour up
     if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
     if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
     if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
@@ -155,10 +162,13 @@ template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                        int* __restrict__ cell_flags, int num_cells) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int id = t >> 1;                                         // two lanes per cell, one per direction
+    const bool up = (t & 1) != 0;
     if (id >= num_cells) return;
     const int flags = cell_flags[id];
     if ((flags & (1 << axis)) == 0) {      // copy through
+        if (up) return;
         const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
         int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
         const int4 a = p[0], b = p[1];
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
         if (flags & kChanged) cell_flags[id] = flags & ~kChanged;
         return;
     }
-    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags);
+    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags, up);
 }
 
 // ---- passes of the later iterations: dense over the cells that are still growing ------------------------------------
@@ -225,17 +235,18 @@ template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                         const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                         int* __restrict__ cell_flags, const int* __restrict__ list, const int* __restrict__ count) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int i = t >> 1;                                          // two lanes per listed cell, one per direction
     if (i >= *count) return;
     const int id = list[i];
-    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id]);
+    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id], (t & 1) != 0);
 }
 
 template <int axis, bool SUBSET_ONLY>
 void listed_step(hipStream_t st, const ExpandK& k, const Entry* entries, const int* refs, const float4* tris, const Cell* cells, Cell* other,
                  int* flags, int n, int* list, int* count) {
     expand_select<axis><<<grid_blocks(n, kSelectTile), kBlock, 0, st>>>(cells, other, flags, n, list, count);
-    expand_listed<axis, SUBSET_ONLY><<<grid_blocks(n, kBlock), kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, list, count);
+    expand_listed<axis, SUBSET_ONLY><<<grid_blocks(2ll * n, kBlock), kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, list, count);
 }
 
 } // namespace
@@ -266,7 +277,7 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     (void)hipMemsetAsync(flags, 0xFF, size_t(n) * sizeof(int), st);                     // expand.cu:206 (errors surface at the final check)
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
-    const int blocks = grid_blocks(n, kBlock);
+    const int blocks = grid_blocks(2ll * n, kBlock);      // overlap_step: two lanes per cell
     int* list = iters > 1 && ctx->opt_expand_listed ? pool_alloc<int>(ctx, size_t(n)) : nullptr;
     int* counts = ctx->dscratch + 160;             // one list length per listed pass
     const int max_listed = 48;
