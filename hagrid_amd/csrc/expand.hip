@@ -89,7 +89,7 @@ __device__ __forceinline__ int room_before_prim(const ExpandK& k, const Tri& pri
 // The face is swept row by row in the order the reference sweeps it -- a neighbour's (possibly already expanded) box decides how
 // far the sweep jumps, so the set of neighbours looked at is part of the result.  Quantities are kept as magnitudes:
 //   reach = the least extent of a neighbour seen so far beyond the face, room = min(reach, limits from references).
-// The direction is a run-time argument: the two directions of a cell run in two neighbouring lanes, in lock step.
+// The direction is a run-time argument: in the listed passes the two directions of a cell run in two neighbouring lanes, in lock step.
 template <int AXIS, bool SUBSET_ONLY>
 __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
                                            const Cell* __restrict__ cells, const CellRec& cell, bool UP, bool& again) {
@@ -135,19 +135,27 @@ __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __rest
     return UP ? room : -room;
 }
 
-// A cell's two growth directions are independent walks of dependent gathers (voxel map -> neighbour cell -> its list): they
-// run in two neighbouring lanes (lane & 1 = direction), which halves the chain a thread has to wait through; the even lane
-// collects both results and writes the cell.  `id` and `flags` are the same in both lanes of a pair.
-template <int axis, bool SUBSET_ONLY>
+// PAIRED: a cell's two growth directions are independent walks of dependent gathers (voxel map -> neighbour cell -> its list);
+// in the passes over the LISTED cells (few threads, every one a serial chain) they run in two neighbouring lanes (lane & 1 =
+// direction), the even lane collects both results and writes the cell: -10 % on those passes.  The pass over ALL cells is bound
+// by the gather rate, not by the chains (two lanes per cell: +12 %), and keeps one thread per cell.
+template <int axis, bool SUBSET_ONLY, bool PAIRED>
 __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
                                           const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags, bool up) {
     CellRec cell = load_cell(cells, id);
-    bool again = false;
-    const int mine = face_growth<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, up, again);
-    const int other = __shfl_xor(mine, 1, 64);
-    const bool flag = again | (__shfl_xor(int(again), 1, 64) != 0);
-    if (up) return;
-    const int ov1 = mine, ov2 = other;                               // this lane walked down, its neighbour up
+    bool flag = false;
+    int ov1, ov2;
+    if (PAIRED) {                                                      // `id` and `flags` are the same in both lanes of a pair
+        bool again = false;
+        const int mine = face_growth<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, up, again);
+        const int other = __shfl_xor(mine, 1, 64);
+        flag = again | (__shfl_xor(int(again), 1, 64) != 0);
+        if (up) return;
+        ov1 = mine; ov2 = other;                                       // this lane walked down, its neighbour up
+    } else {
+        ov1 = face_growth<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, false, flag);
+        ov2 = face_growth<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, cell, true, flag);
+    }
     if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
     if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
     if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
@@ -162,13 +170,10 @@ template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                        int* __restrict__ cell_flags, int num_cells) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    const int id = t >> 1;                                         // two lanes per cell, one per direction
-    const bool up = (t & 1) != 0;
+    const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_cells) return;
     const int flags = cell_flags[id];
     if ((flags & (1 << axis)) == 0) {      // copy through
-        if (up) return;
         const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
         int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
         const int4 a = p[0], b = p[1];
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
         if (flags & kChanged) cell_flags[id] = flags & ~kChanged;
         return;
     }
-    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags, up);
+    grow_cell<axis, SUBSET_ONLY, false>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags, false);
 }
 
 // ---- passes of the later iterations: dense over the cells that are still growing ------------------------------------
@@ -239,7 +244,7 @@ __global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* 
     const int i = t >> 1;                                          // two lanes per listed cell, one per direction
     if (i >= *count) return;
     const int id = list[i];
-    grow_cell<axis, SUBSET_ONLY>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id], (t & 1) != 0);
+    grow_cell<axis, SUBSET_ONLY, true>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id], (t & 1) != 0);
 }
 
 template <int axis, bool SUBSET_ONLY>
@@ -277,7 +282,7 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     (void)hipMemsetAsync(flags, 0xFF, size_t(n) * sizeof(int), st);                     // expand.cu:206 (errors surface at the final check)
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
-    const int blocks = grid_blocks(2ll * n, kBlock);      // overlap_step: two lanes per cell
+    const int blocks = grid_blocks(n, kBlock);
     int* list = iters > 1 && ctx->opt_expand_listed ? pool_alloc<int>(ctx, size_t(n)) : nullptr;
     int* counts = ctx->dscratch + 160;             // one list length per listed pass
     const int max_listed = 48;

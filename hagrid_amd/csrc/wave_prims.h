@@ -248,19 +248,27 @@ template <typename V, typename In, typename Out>
 __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
     __shared__ V lds[kWaves];
     __shared__ V tile_prefix;
+    constexpr int kWaveItems = kLbItems * 64;                           // a wavefront owns a contiguous run of the tile: rows of 64 items
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int base = tile * kLbTile;
+        const int base = tile * kLbTile + wave_id() * kWaveItems + lane_id();
+        // all loads of the tile first, then the scan of the wavefront's run entirely in registers (no workgroup barrier): after
+        // this v[j] is the exclusive prefix of item j inside the run and `run` the run's total
         V v[kLbItems];
-        V sum = zero_of(V());
 #pragma unroll
         for (int j = 0; j < kLbItems; j++) {
-            const int i = base + j * kBlock + threadIdx.x;
+            const int i = base + j * 64;
             v[j] = i < n ? in(i) : zero_of(V());
-            sum = sum + v[j];
         }
-        const V wsum = wave_inclusive_scan(sum);
+        V run = zero_of(V());
+#pragma unroll
+        for (int j = 0; j < kLbItems; j++) {
+            const V incl = wave_inclusive_scan(v[j]);
+            const V before = shfl_up_v(incl, 1);
+            v[j] = lane_id() > 0 ? run + before : run;
+            run = run + V(shfl_v(incl, 63));
+        }
         __syncthreads();                                                 // the previous tile's readers of lds / tile_prefix are done
-        if (lane_id() == 63) lds[wave_id()] = wsum;
+        if (lane_id() == 0) lds[wave_id()] = run;
         __syncthreads();
         if (wave_id() == 0) {
             V agg = lds[0];
@@ -316,22 +324,13 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
             }
         }
         __syncthreads();
-        V running = tile_prefix;
+        // what is left after the wait: one add and the output per item
+        V offset = tile_prefix;
+        for (int w = 0; w < wave_id(); w++) offset = offset + lds[w];
 #pragma unroll
-        for (int j = 0; j < kLbItems; j++) {                     // (no early exit: the loop must unroll, v[] lives in registers)
-            const int i = base + j * kBlock + threadIdx.x;
-            const V incl = wave_inclusive_scan(v[j]);
-            __syncthreads();
-            if (lane_id() == 63) lds[wave_id()] = incl;
-            __syncthreads();
-            V excl = running;
-            for (int w = 0; w < wave_id(); w++) excl = excl + lds[w];
-            const V prev = shfl_up_v(incl, 1);
-            if (lane_id() > 0) excl = excl + prev;
-            if (i < n) out(i, excl);
-            V t = running;
-            for (int w = 0; w < kWaves; w++) t = t + lds[w];
-            running = t;
+        for (int j = 0; j < kLbItems; j++) {
+            const int i = base + j * 64;
+            if (i < n) out(i, offset + v[j]);
         }
     }
     if (tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = carry_in ? *carry_in : zero_of(V());
