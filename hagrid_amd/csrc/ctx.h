@@ -86,10 +86,6 @@ struct hagrid_ctx {
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
-    int opt_stream = 0;         // image kernel as ONE launch of persistent wavefronts with in-launch compaction (traverse.hip: streaming generations)
-    int opt_stream_schedule = 8 | (8 << 6) | (16 << 12) | (32 << 18) | (63 << 24);   // cell steps per generation, 6 bits each
-    int opt_stream_min_rays = 1 << 16;
-    void* stream_entries = nullptr; void* stream_words = nullptr; size_t stream_entry_words = 0;
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
 
     hagrid_impl::TravImageCache image;

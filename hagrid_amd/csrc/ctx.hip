@@ -48,8 +48,6 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
     if (ctx->row_scores) (void)hipFree(ctx->row_scores);
     if (ctx->lb_state) (void)hipFree(ctx->lb_state);
-    if (ctx->stream_entries) (void)hipFree(ctx->stream_entries);
-    if (ctx->stream_words) (void)hipFree(ctx->stream_words);
     delete ctx;
 }
 

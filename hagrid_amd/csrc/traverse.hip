@@ -781,289 +781,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 }
 
 
-// ---- streaming generations: the image kernel with in-launch compaction ---------------------------------------------------
-// The one-pass kernel keeps its vector ALUs 76 % busy with 22 % of the lanes live per instruction: a wavefront lives as long as
-// its longest ray.  Here a wavefront advances the rays it holds by at most limit[g] cell steps (generation g), appends the
-// survivors -- compacted, 24 bytes of state each -- to the queue of generation g + 1 of its REGION and takes the next piece of
-// work: a full 64-entry chunk of the oldest generation that has one (or the last, partial chunk of a generation whose
-// producers are all done), else a fresh 8x8 tile.  One launch of persistent wavefronts, no barrier between generations: old
-// rays keep moving while young ones are still being started.  Per ray the arithmetic is that of the one-pass kernel step for
-// step (a ray's state at a hand-over is exactly: next voxel, hit), so hits are identical.
-// Protocol (all words agent-scope 64- or 32-bit atomics, one 128-byte line per control word; no fence needed):
-//   producer: tail += n (reserve) -> entry words (atomic stores) -> vmcnt(0) -> ready[chunk] += written -> vmcnt(0) -> finished[g]++
-//   consumer: head == h, ready[h] == 64 (or == the rest, once generation g - 1 is complete) -> CAS head -> entry words (atomic loads)
-//   generation g of a region is complete when g - 1 is and finished[g] == ceil(tail[g] / 64); completion cascades upwards.
-// Spins are bounded: a wavefront that waits too long raises the error word and leaves (the host reports it; nothing hangs).
-constexpr int kStreamRegions = 64;
-constexpr int kStreamGens = 6;
-constexpr int kStreamLine = 32;              // ints per control word (128 bytes)
-enum { kTail = 0, kHead = 1, kFinished = 2, kComplete = 3, kCtrlWords = 4 };
-
-struct StreamArgs {
-    unsigned long long* __restrict__ entries;     // [region][gen 1..][cap][3]
-    int* __restrict__ ctrl;                       // [region][gen][kCtrlWords][kStreamLine]
-    int* __restrict__ ready;                      // [region][gen 1..][cap / 64]
-    int* __restrict__ error;
-    int cap;                                      // entries per (region, generation), a multiple of 64
-    int num_tiles;                                // 64-ray blocks of the batch
-    int limit[kStreamGens];                       // cell steps per generation; the last one is ignored (runs to the end)
-    int spin_limit;
-};
-
-__device__ __forceinline__ int* stream_ctrl(const StreamArgs& q, int region, int gen, int word) {
-    return q.ctrl + ((size_t(region) * kStreamGens + gen) * kCtrlWords + word) * kStreamLine;
-}
-__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// generation g of `region` is complete when its predecessor is and every chunk of it has been processed; cascades upwards
-__device__ __forceinline__ void stream_try_complete(const StreamArgs& q, int region, int from, int tiles_of_region) {
-    for (int g = from; g < kStreamGens; g++) {
-        if (ld_agent(stream_ctrl(q, region, g, kComplete))) continue;
-        if (g > 0 && !ld_agent(stream_ctrl(q, region, g - 1, kComplete))) break;
-        const int items = g == 0 ? tiles_of_region : (ld_agent(stream_ctrl(q, region, g, kTail)) + 63) >> 6;
-        if (ld_agent(stream_ctrl(q, region, g, kFinished)) != items) break;
-        __hip_atomic_store(stream_ctrl(q, region, g, kComplete), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        drain_vmem();
-    }
-}
-
-template <bool UNIFORM>
-__global__ void __launch_bounds__(64, 8) traverse_kernel_stream(const TraverseArgs a, const StreamArgs* __restrict__ qp) {
-    const StreamArgs& q = *qp;          // in device memory: fetched where it is used instead of living in scalar registers through the walk
-    const int region = blockIdx.x & (kStreamRegions - 1);
-    const int tiles_of_region = (q.num_tiles - region + kStreamRegions - 1) / kStreamRegions;      // virtual blocks k * 64 + region < num_tiles
-    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
-    const int row_w = !perm ? tile_packet_row_len(a) : 0;
-    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
-    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
-    const size_t gens1 = kStreamGens - 1;
-    int spins = 0, polls = 0;
-#pragma unroll 1
-    for (;;) {
-        // ---- claim: the oldest generation with a ready chunk, else a fresh tile.  Lane g looks at generation g (lane 0: the tile
-        // cursor), so the control words of all generations travel in the same two round trips ----
-        int gen = -1, chunk = 0, count = 0;
-        {
-            const int g = int(threadIdx.x);
-            int h = 0, rest = 0;
-            bool ok = false, region_done = false;
-            if (g >= 1 && g < kStreamGens) {
-                h = ld_agent(stream_ctrl(q, region, g, kHead));
-                const int t = ld_agent(stream_ctrl(q, region, g, kTail));
-                const int prev_complete = ld_agent(stream_ctrl(q, region, g - 1, kComplete));
-                if (h * 64 < t) {
-                    rest = min(64, t - h * 64);
-                    const int rdy = ld_agent(q.ready + (size_t(region) * gens1 + (g - 1)) * size_t(q.cap >> 6) + h);
-                    ok = rdy == 64 || (rdy == rest && prev_complete && ld_agent(stream_ctrl(q, region, g, kTail)) == t);
-                }
-                if (g == kStreamGens - 1) region_done = ld_agent(stream_ctrl(q, region, g, kComplete)) != 0;
-            } else if (g == 0) {
-                h = ld_agent(stream_ctrl(q, region, 0, kHead));
-                ok = h < tiles_of_region; rest = 64;
-            }
-            const unsigned long long cand = __ballot(ok);
-            if (cand) {
-                const int pick = 63 - __clzll((long long)cand);                      // the oldest generation that has something
-                if (g == pick) {
-                    int* head = stream_ctrl(q, region, g, kHead);
-                    if (g == 0) {
-                        const int k = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (k < tiles_of_region) { gen = 0; chunk = k; count = 64; }
-                    } else {
-                        int expect = h;
-                        if (__hip_atomic_compare_exchange_strong(head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gen = g; chunk = h; count = rest; }
-                    }
-                }
-                gen = __shfl(gen, pick, 64); chunk = __shfl(chunk, pick, 64); count = __shfl(count, pick, 64);
-                if (gen < 0) continue;                                              // lost the race: look again at once
-            } else if (__ballot(region_done)) {
-                gen = -2;
-            }
-        }
-        gen = __builtin_amdgcn_readfirstlane(gen); chunk = __builtin_amdgcn_readfirstlane(chunk); count = __builtin_amdgcn_readfirstlane(count);
-        if (gen == -2) { if (threadIdx.x == 0 && polls) atomicAdd(q.error + 1, polls); return; }
-        if (gen < 0) {
-            if (++spins > q.spin_limit) { if (threadIdx.x == 0) atomicExch(q.error, 1); return; }
-            polls++;
-            // back off: the longer nothing turns up, the longer the nap (up to ~3 us), so that idle wavefronts do not flood the
-            // memory-side atomics the working ones depend on
-            for (int i = 0, n = min(spins, 16); i < n; i++) __builtin_amdgcn_s_sleep(64);
-            continue;
-        }
-
-        // ---- the rays of this piece of work ----
-        int id = -1, vx = 0, vy = 0, vz = 0;
-        Hit hit(-1, 0.0f, 0.0f, 0.0f);
-        bool alive = false;
-        if (gen == 0) {
-            const int vb = chunk * kStreamRegions + region;                                   // virtual block index
-            const int b = (row_w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(vb, q.num_tiles, a.xcd_chunk_log2) : xcd_split(vb, q.num_tiles);
-            const int slot = row_w ? tile_packet_slot(a, row_w, b, threadIdx.x) : b * 64 + threadIdx.x;
-            if (slot < a.num_rays) { id = perm ? perm[slot] : slot; alive = true; }
-        } else if (int(threadIdx.x) < count) {
-            const unsigned long long* e = q.entries + ((size_t(region) * gens1 + (gen - 1)) * size_t(q.cap) + size_t(chunk) * 64 + threadIdx.x) * 3;
-            const unsigned long long w0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long w1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long w2 = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            id = int(unsigned(w0)); hit.id = int(unsigned(w0 >> 32));
-            hit.t = __uint_as_float(unsigned(w1)); vz = int(unsigned(w1 >> 32));
-            vx = int(unsigned(w2) & 0xffffu); vy = int(unsigned(w2) >> 16);
-            alive = true;
-        }
-        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        if (alive) { r0 = nt_load4(a.rays + 2 * size_t(id)); r1 = nt_load4(a.rays + 2 * size_t(id) + 1); }
-        const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
-        const float tmin = r0.w, tmax = r1.w;
-        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-        const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
-        if (gen == 0 && alive) {
-            const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
-            const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
-            const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
-            const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
-            hit = Hit(-1, tmax, 0.0f, 0.0f);
-            if (tstart > tend) {
-                nt_store4(a.hits + id, __int_as_float(-1), tmax, 0.0f, 0.0f);          // misses the grid
-                alive = false;
-            } else {
-                const vec3 fv = (tstart * dir + org - gmin) * ginv;
-                vx = min(max(int(fv.x), 0), a.dims_x - 1);
-                vy = min(max(int(fv.y), 0), a.dims_y - 1);
-                vz = min(max(int(fv.z), 0), a.dims_z - 1);
-            }
-        }
-
-        if (alive) {
-            auto top_index = [&](int x, int y, int z) -> int {
-                return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
-            };
-            auto table_at = [&](int t) -> uint2 { return gather32<uint2>(a.img_table, uint32_t(t) << 3); };
-            uint32_t nest = ~0u;
-            int nest_x = 0, nest_y = 0, nest_z = 0;
-            auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
-                if (UNIFORM) {
-                    const int d = a.shift, m = (1 << d) - 1;
-                    const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-                    const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 5;
-                    const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                    ra = p[0]; rb = p[1];
-                } else {
-                    int d = int(tab.y & 3u), s = a.shift - d;
-                    uint32_t base = tab.x;
-                    if (nest != ~0u) {
-                        const int sr = a.shift - int(nest >> 27);
-                        if ((((x ^ nest_x) | (y ^ nest_y) | (z ^ nest_z)) >> sr) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
-                    }
-                    const int m = (1 << d) - 1;
-                    const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                    const uint32_t o = (base << 7) + (idx << 5);
-                    const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                    ra = p[0]; rb = p[1];
-                }
-            };
-            auto tri_at = [&](int ref) -> Tri {
-                uint32_t r3, o;
-                asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-                asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-                const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
-                const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-                return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-            };
-            auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
-
-            const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;
-            const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;
-            int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
-            uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
-            uint4 ca, cb;
-            record(tab, vx, vy, vz, ca, cb);
-            int steps_left = gen < kStreamGens - 1 ? q.limit[gen] : 0x7fffffff;
-            for (;;) {
-                if (!UNIFORM && ca.w >= 0xfffffffeu) {
-                    uint32_t off = ~0u, meta = 0u;
-                    image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
-                    if (off != ~0u) {
-                        nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;
-                        nest_x = vx; nest_y = vy; nest_z = vz;
-                    }
-                }
-                const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
-                const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
-                const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
-                const vec3 ev = (texit * dir + org - gmin) * ginv;
-                const int nx = texit == tcell.x ? cx + bx : int(ev.x);
-                const int ny = texit == tcell.y ? cy + by : int(ev.y);
-                const int nz = texit == tcell.z ? cz + bz : int(ev.z);
-                vx = px ? max(nx, vx) : min(nx, vx);
-                vy = py ? max(ny, vy) : min(ny, vy);
-                vz = pz ? max(nz, vz) : min(nz, vz);
-                const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
-                if (!UNIFORM) {
-                    const int ntop = outside ? top_idx : top_index(vx, vy, vz);
-                    if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
-                }
-                uint4 na, nb;
-                if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
-                else record(tab, vx, vy, vz, na, nb);
-
-                const bool by_index = int(ca.w) < 0;
-                uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;
-                int ref = int(cb.x);
-                if (by_index) {
-                    q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                    ref = -1;
-                    if (q1 < q2) ref = ref_at(q1);
-                    q1++;
-                }
-#pragma unroll 1
-                while (ref >= 0) {
-                    int next;
-                    if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                    else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
-                    intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    ref = next;
-                }
-                if (hit.t <= texit || outside) { alive = false; break; }
-                if (--steps_left == 0) break;
-                ca = na; cb = nb;
-            }
-            if (!alive) nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, 0.0f, 0.0f);
-        }
-
-        // ---- hand the survivors over, then account for the finished piece of work ----
-        const unsigned long long m = __ballot(alive);
-        if (m) {
-            const int n = __popcll(m);
-            int base = 0;
-            if (threadIdx.x == 0) base = __hip_atomic_fetch_add(stream_ctrl(q, region, gen + 1, kTail), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (alive) {
-                const int rank = __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0));
-                unsigned long long* e = q.entries + ((size_t(region) * gens1 + gen) * size_t(q.cap) + size_t(base + rank)) * 3;
-                __hip_atomic_store(e, (unsigned long long)uint32_t(id) | ((unsigned long long)uint32_t(hit.id) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(e + 1, (unsigned long long)__float_as_uint(hit.t) | ((unsigned long long)uint32_t(vz) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(e + 2, (unsigned long long)(uint32_t(vx) | (uint32_t(vy) << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            drain_vmem();
-            if (threadIdx.x == 0) {
-                int* ready = q.ready + (size_t(region) * gens1 + gen) * size_t(q.cap >> 6);
-                const int c0 = base >> 6, in0 = min(n, 64 - (base & 63));
-                __hip_atomic_fetch_add(ready + c0, in0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (n > in0) __hip_atomic_fetch_add(ready + c0 + 1, n - in0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            drain_vmem();
-        }
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(stream_ctrl(q, region, gen, kFinished), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            drain_vmem();
-            stream_try_complete(q, region, gen, tiles_of_region);
-        }
-        spins = 0;
-    }
-}
-
-
 // ---- v3: persistent wavefronts, lane refill, vote-scheduled phases -------------------------------------------------
 // Profile of v1/v2 on the 1M-ray batch (profiles/): the SIMDs issue ~80 % of the time while only ~19 % of the lanes
 // of an issued VALU instruction are live -- the kernel is instruction-issue bound and 4 of 5 lanes idle, because (a) a
@@ -1371,43 +1088,6 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
     detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1); HG_DBG(ctx);
 }
 
-// Launch of the streaming-generations kernel: control words and chunk counters are cleared on the stream, the grid is every
-// wavefront the part keeps resident; the error word is read back only by the debug build and by hagrid_kat_stream_error.
-int launch_stream(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, bool uniform) {
-    const int tiles = grid_blocks(num_rays, 64);
-    const int per_region = (tiles + kStreamRegions - 1) / kStreamRegions;
-    const size_t cap = size_t(per_region) * 64;
-    const size_t entry_words = size_t(kStreamRegions) * (kStreamGens - 1) * cap * 3;
-    const size_t ctrl_ints = size_t(kStreamRegions) * kStreamGens * kCtrlWords * kStreamLine + kStreamLine;
-    const size_t ready_ints = size_t(kStreamRegions) * (kStreamGens - 1) * (cap >> 6);
-    if (entry_words > ctx->stream_entry_words) {
-        HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->stream_entries) (void)hipFree(ctx->stream_entries);
-        if (ctx->stream_words) (void)hipFree(ctx->stream_words);
-        ctx->stream_entries = nullptr; ctx->stream_words = nullptr; ctx->stream_entry_words = 0;
-        HG_HIP(ctx, hipMalloc(&ctx->stream_entries, entry_words * sizeof(unsigned long long)));
-        HG_HIP(ctx, hipMalloc(&ctx->stream_words, (ctrl_ints + ready_ints + 64) * sizeof(int)));       // + the argument block
-        ctx->stream_entry_words = entry_words;
-    }
-    HG_HIP(ctx, hipMemsetAsync(ctx->stream_words, 0, (ctrl_ints + ready_ints) * sizeof(int), ctx->stream));
-    static_assert(sizeof(StreamArgs) <= 64 * sizeof(int), "StreamArgs slot");
-    StreamArgs q;
-    q.entries = static_cast<unsigned long long*>(ctx->stream_entries);
-    q.ctrl = static_cast<int*>(ctx->stream_words);
-    q.error = q.ctrl + ctrl_ints - kStreamLine;
-    q.ready = q.ctrl + ctrl_ints;
-    q.cap = int(cap); q.num_tiles = tiles; q.spin_limit = 1 << 20;
-    for (int g = 0; g < kStreamGens; g++) { const int l = (ctx->opt_stream_schedule >> (6 * g)) & 63; q.limit[g] = l ? l : 0x3fffffff; }    // 0: no limit (experiments)
-    const int blocks = std::min(tiles, ctx->num_cus * 32);
-    StreamArgs* dq = reinterpret_cast<StreamArgs*>(q.ctrl + ctrl_ints + ready_ints);
-    HG_HIP(ctx, hipMemcpyAsync(dq, &q, sizeof(q), hipMemcpyHostToDevice, ctx->stream));      // (pageable source: the copy is staged before the call returns)
-    if (uniform) traverse_kernel_stream<true><<<blocks, 64, 0, ctx->stream>>>(a, dq);
-    else         traverse_kernel_stream<false><<<blocks, 64, 0, ctx->stream>>>(a, dq);
-    HG_DBG(ctx);
-    HG_HIP(ctx, hipGetLastError());
-    return HAGRID_OK;
-}
-
 int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a) {
     const bool released = g && ctx->image.detached && trav_image_matches(ctx, g);     // hagrid_grid_release_for_traversal: the image stands for entries and cells
     if (!g || !g->ref_ids || (!released && (!g->entries || (!g->cells && !g->small_cells)))) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: incomplete grid");
@@ -1554,9 +1234,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             }
         }
     }
-    if (variant == 4 && ctx->opt_stream && flags == 0 && ctx->image.flat && img_narrow && num_rays >= ctx->opt_stream_min_rays && num_rays <= (1 << 24) && !ctx->kat_wave_times) {
-        HG_TRY(launch_stream(ctx, a, num_rays, ctx->image.uniform));
-    } else if (variant == 4) {
+    if (variant == 4) {
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
@@ -1601,8 +1279,6 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
         {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
-        {"traverse.stream", &ctx->opt_stream, 0, 1}, {"traverse.stream_schedule", &ctx->opt_stream_schedule, 0, (1 << 30) - 1},
-        {"traverse.stream_min_rays", &ctx->opt_stream_min_rays, 0, 1 << 30},
 
     };
     for (auto& t : table)
@@ -1811,17 +1487,6 @@ extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len,
     kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(slots);
-}
-
-extern "C" int hagrid_kat_stream_error(hagrid_ctx* ctx, int32_t* error) {
-    if (!ctx || !error) return HAGRID_EINVAL;
-    *error = 0;
-    if (!ctx->stream_words) return HAGRID_OK;
-    const size_t ctrl_ints = size_t(kStreamRegions) * kStreamGens * kCtrlWords * kStreamLine + kStreamLine;
-    int h[2] = {0, 0};
-    HG_TRY(read_back(ctx, static_cast<int*>(ctx->stream_words) + ctrl_ints - kStreamLine, h, sizeof(h)));
-    *error = h[0] | (h[1] << 1);                 // bit 0: failure; the rest: idle polls of the last launch (diagnostic)
-    return HAGRID_OK;
 }
 
 extern "C" int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_dev, const int* tile_order_dev) {

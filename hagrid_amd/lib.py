@@ -123,7 +123,6 @@ SIGNATURES = {
     "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
-    "hagrid_kat_stream_error": (_i32, [_vp, _vp]),
     "hagrid_kat_wave_times": (_i32, [_vp, _vp, _vp]),
     "hagrid_kat_tile_slots": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
 }

@@ -278,9 +278,6 @@ int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_
  * image-ordered batch then processes the 8x8 tile tile_order_dev[b] of the default order -- an experiment on dispatch order.
  * tools/dev_wave_timeline.py. */
 int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_dev, const int* tile_order_dev);
-/* "traverse.stream": 1 after a streaming-generations launch in which a wavefront gave up waiting for work (a protocol failure: the hits
- * of that launch are incomplete), else 0.  Synchronous. */
-int hagrid_kat_stream_error(hagrid_ctx* ctx, int32_t* error);
 /* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
  * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
  * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
