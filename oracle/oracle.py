@@ -56,7 +56,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build_oracle()
-        L = C.CDLL(os.path.join(_HERE, "libhagrid_oracle.so"))
+        # HAGRID_ORACLE_LIB: another build of the same source, e.g. the AddressSanitizer one of `make -C oracle asan`
+        L = C.CDLL(os.environ.get("HAGRID_ORACLE_LIB") or os.path.join(_HERE, "libhagrid_oracle.so"))
         vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
         L.orc_safe_rcp.restype = f32; L.orc_safe_rcp.argtypes = [f32]
         L.orc_prodsign.restype = f32; L.orc_prodsign.argtypes = [f32, f32]
