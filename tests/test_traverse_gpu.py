@@ -766,3 +766,48 @@ def test_hit_id_can_carry_the_reference_kernels_step_count():
         assert (plain["id"] == oh["id"]).all() and stepped["id"].max() > 3
         mem.free(d_rays); mem.free(d_hits); grid.free()
     mem.close()
+
+
+def test_image_of_a_voxel_map_with_non_box_regions(mem):
+    """A voxel map whose voxels of ONE cell do not form a box (hand-edited maps, grids uploaded from elsewhere): in many blocks the
+    three voxels (0,0,0), (1,0,0), (0,1,0) are redirected to one cell -- an L.  The compact image de-duplicates records through a
+    representative voxel per region; both image forms and the construction-format kernel must still agree with the oracle's
+    traversal of the very same arrays (the representative walk has to reach a fixed point)."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(30_000)
+    G0 = O.Grid.build(tris).flatten()                       # octree leaves, no merging, no expansion: every voxel its own cell
+    entries = G0.entries.copy(); cells = G0.cells.copy(); refs = G0.ref_ids.copy()
+    num_top = int(np.prod(G0.dims))
+    edited = 0
+    for T in range(num_top):
+        w = int(entries[T]); d = w & 3
+        if d == 0: continue
+        blk = w >> 2
+        block = entries[blk: blk + (1 << (3 * d))]
+        if (block & 3).any(): continue                      # only blocks that resolve fully
+        a = int(block[0]) >> 2
+        k100, k010 = 1, 1 << d
+        size = int(cells["max"][a][0] - cells["min"][a][0])
+        if any(int(cells["max"][int(block[k]) >> 2][0] - cells["min"][int(block[k]) >> 2][0]) != size for k in (k100, k010)): continue
+        # the L: two more voxels name cell a, whose box grows over the 2 x 2 x 1 corner; its list takes their references
+        merged = np.unique(np.concatenate([refs[cells["begin"][c]: cells["end"][c]] for c in (a, int(block[k100]) >> 2, int(block[k010]) >> 2)]))
+        cells["begin"][a] = refs.size; cells["end"][a] = refs.size + merged.size
+        refs = np.concatenate([refs, merged.astype(np.int32)])
+        cells["max"][a][0] += size; cells["max"][a][1] += size
+        entries[blk + k100] = block[0]; entries[blk + k010] = block[0]
+        edited += 1
+    assert edited > 100
+    G = O.Grid.from_arrays(entries, refs, cells, None, G0.bbox_min, G0.bbox_max, G0.dims, G0.shift, G0.offsets)
+    rays = np.concatenate([scene.make_rays_primary(G0.bbox_min, G0.bbox_max, 256, 256), scene.make_rays_incoherent(G0.bbox_min, G0.bbox_max, 100_000, 8)]).astype(np.float32)
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    d_tris = mem.upload(tris)
+    grid = api.Grid.upload(mem, entries, refs, cells, None, G0.bbox_min, G0.bbox_max, G0.dims, G0.shift, G0.offsets)
+    try:
+        for fmt, variant in ((1, 4), (2, 4), (0, 2), (0, 1)):
+            mem.set_option("traverse.image", fmt); mem.set_option("traverse.variant", variant)
+            got = gpu_traverse(mem, grid, d_tris, rays)
+            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (fmt, variant)
+    finally:
+        mem.set_option("traverse.image", 2); mem.set_option("traverse.variant", 0)
+        grid.free(); mem.free(d_tris)
