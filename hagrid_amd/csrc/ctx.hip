@@ -243,11 +243,22 @@ extern "C" float hagrid_profile_end(hagrid_ctx* ctx) {
 // ---- measured bandwidth peak (SURVEY.md 8(d) "BW_peak": a device copy / triad figure from the same run) ---------------------
 namespace {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// four 16-byte accesses per array in flight per lane, non-temporal (read once / written once), one pass over the arrays
 __global__ void __launch_bounds__(256) bw_copy_kernel(const f32x4_t* __restrict__ a, f32x4_t* __restrict__ c, size_t n) {
-    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) c[i] = a[i];
+    const size_t base = size_t(blockIdx.x) * 1024 + threadIdx.x;
+    f32x4_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j * 256 < n) v[j] = __builtin_nontemporal_load(a + base + j * 256);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j * 256 < n) __builtin_nontemporal_store(v[j], c + base + j * 256);
 }
 __global__ void __launch_bounds__(256) bw_triad_kernel(const f32x4_t* __restrict__ a, const f32x4_t* __restrict__ b, f32x4_t* __restrict__ c, size_t n) {
-    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) c[i] = a[i] + 3.0f * b[i];
+    const size_t base = size_t(blockIdx.x) * 1024 + threadIdx.x;
+    f32x4_t v[4], w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j * 256 < n) { v[j] = __builtin_nontemporal_load(a + base + j * 256); w[j] = __builtin_nontemporal_load(b + base + j * 256); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j * 256 < n) __builtin_nontemporal_store(v[j] + 3.0f * w[j], c + base + j * 256);
 }
 } // namespace
 
@@ -262,7 +273,7 @@ extern "C" int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, 
     if (!a || !b || !c) rc = HAGRID_ENOMEM;
     if (rc == HAGRID_OK) {
         (void)hipMemsetAsync(a, 0, n * 16, ctx->stream); (void)hipMemsetAsync(b, 0, n * 16, ctx->stream);
-        const int blocks = ctx->num_cus * 16;
+        const int blocks = int((n + 1023) / 1024);
         float best_copy = 0.0f, best_triad = 0.0f;
         for (int it = 0; it < iters + 1 && rc == HAGRID_OK; it++) {           // the first round is a warm-up
             float ms = -1.0f;
