@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
 // resident of this kernel (occupancy query minus one per CU, lb_resident_blocks), so all of them run concurrently, and
 // workgroup b owns the tiles b, b + G, b + 2G, ... in increasing order.  The lowest unfinished tile therefore always belongs to
 // a running workgroup that has nothing left to wait for.
+constexpr int kLbVec = 4;                            // consecutive items per lane and row
 constexpr int kLbItems = 8;                          // items per thread of the look-back scan
 constexpr int kLbWindows = 4;                        // predecessors examined per look-back round: 64 lanes x kLbWindows
 constexpr int kLbTile = kBlock * kLbItems;
@@ -248,23 +249,32 @@ template <typename V, typename In, typename Out>
 __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
     __shared__ V lds[kWaves];
     __shared__ V tile_prefix;
-    constexpr int kWaveItems = kLbItems * 64;                           // a wavefront owns a contiguous run of the tile: rows of 64 items
+    // A wavefront owns a contiguous run of the tile; a lane owns kLbVec CONSECUTIVE items per row (four 4-byte items = one 16-byte
+    // access per array: the streaming rate of the part needs wide accesses), a row is 64 x kLbVec items.
+    constexpr int kWaveItems = kLbItems * 64, kRows = kLbItems / kLbVec;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int base = tile * kLbTile + wave_id() * kWaveItems + lane_id();
+        const int base = tile * kLbTile + wave_id() * kWaveItems + lane_id() * kLbVec;
         // all loads of the tile first, then the scan of the wavefront's run entirely in registers (no workgroup barrier): after
         // this v[j] is the exclusive prefix of item j inside the run and `run` the run's total
         V v[kLbItems];
 #pragma unroll
-        for (int j = 0; j < kLbItems; j++) {
-            const int i = base + j * 64;
-            v[j] = i < n ? in(i) : zero_of(V());
-        }
+        for (int r = 0; r < kRows; r++)
+#pragma unroll
+            for (int c = 0; c < kLbVec; c++) {
+                const int i = base + r * 64 * kLbVec + c;
+                v[r * kLbVec + c] = i < n ? in(i) : zero_of(V());
+            }
         V run = zero_of(V());
 #pragma unroll
-        for (int j = 0; j < kLbItems; j++) {
-            const V incl = wave_inclusive_scan(v[j]);
+        for (int r = 0; r < kRows; r++) {
+            V mine = zero_of(V());                                       // the lane's own items first (serial), one wavefront scan per row
+#pragma unroll
+            for (int c = 0; c < kLbVec; c++) { const V x = v[r * kLbVec + c]; v[r * kLbVec + c] = mine; mine = mine + x; }
+            const V incl = wave_inclusive_scan(mine);
             const V before = shfl_up_v(incl, 1);
-            v[j] = lane_id() > 0 ? run + before : run;
+            const V lane_off = lane_id() > 0 ? run + before : run;
+#pragma unroll
+            for (int c = 0; c < kLbVec; c++) v[r * kLbVec + c] = v[r * kLbVec + c] + lane_off;
             run = run + V(shfl_v(incl, 63));
         }
         __syncthreads();                                                 // the previous tile's readers of lds / tile_prefix are done
@@ -328,10 +338,12 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
         V offset = tile_prefix;
         for (int w = 0; w < wave_id(); w++) offset = offset + lds[w];
 #pragma unroll
-        for (int j = 0; j < kLbItems; j++) {
-            const int i = base + j * 64;
-            if (i < n) out(i, offset + v[j]);
-        }
+        for (int r = 0; r < kRows; r++)
+#pragma unroll
+            for (int c = 0; c < kLbVec; c++) {
+                const int i = base + r * 64 * kLbVec + c;
+                if (i < n) out(i, offset + v[r * kLbVec + c]);
+            }
     }
     if (tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = carry_in ? *carry_in : zero_of(V());
 }
