@@ -195,7 +195,10 @@ int launch_ranks(char** argv, int world) {
         if (pid == 0) {
             setenv("HAGRID_CLI_RANK", std::to_string(rank).c_str(), 1);
             setenv("HAGRID_CLI_NCCL_ID", hex.c_str(), 1);
-            setenv("HAGRID_DEVICE", std::to_string(rank).c_str(), 1);
+            // one GPU per rank; HAGRID_CLI_DEVICES=n folds the ranks onto n devices (a test of the N > 1 logic on a smaller box --
+            // RCCL itself refuses two ranks on one device unless it is told otherwise)
+            const char* fold = getenv("HAGRID_CLI_DEVICES");
+            setenv("HAGRID_DEVICE", std::to_string(fold && atoi(fold) > 0 ? rank % atoi(fold) : rank).c_str(), 1);
             execv("/proc/self/exe", argv);
             _exit(127);
         }
@@ -232,7 +235,7 @@ int main(int argc, char** argv) {
         NcclId id;
         if (!rccl.load() || !hex || strlen(hex) != 256) { std::cerr << "rank " << rank << ": no RCCL / no id" << std::endl; return 1; }
         for (int i = 0; i < 128; i++) { unsigned v = 0; sscanf(hex + 2 * i, "%2x", &v); id.internal[i] = char(v); }
-        if (hipSetDeviceShim(rank) != 0 || rccl.comm_init_rank(&comm, world, id, rank) != 0) { std::cerr << "rank " << rank << ": ncclCommInitRank failed" << std::endl; return 1; }
+        if (hipSetDeviceShim(atoi(getenv("HAGRID_DEVICE") ? getenv("HAGRID_DEVICE") : "0")) != 0 || rccl.comm_init_rank(&comm, world, id, rank) != 0) { std::cerr << "rank " << rank << ": ncclCommInitRank failed" << std::endl; return 1; }
     }
 
     std::vector<Tri> host_tris;
