@@ -70,9 +70,7 @@ struct hagrid_ctx {
     int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
     int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
     int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
-    int opt_merge_chain = 1;     // merge_grid: the three axis passes of an iteration without host round trips in between
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
-    int opt_expand_listed = 1;   // expand_grid: iterations after the first run dense over the still-growing cells
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
@@ -80,7 +78,6 @@ struct hagrid_ctx {
     unsigned long long* kat_wave_times = nullptr;   // diagnostic: see hagrid_kat_wave_times
     const int* kat_tile_order = nullptr;
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
-    int opt_detect_origins = 1; // row length of image-ordered batches also from the origins (bounce rays)
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it

@@ -283,7 +283,7 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
-    int* list = iters > 1 && ctx->opt_expand_listed ? pool_alloc<int>(ctx, size_t(n)) : nullptr;
+    int* list = iters > 1 ? pool_alloc<int>(ctx, size_t(n)) : nullptr;      // (without it the later iterations fall back to the all-cells pass)
     int* counts = ctx->dscratch + 160;             // one list length per listed pass
     const int max_listed = 48;
     if (list) (void)hipMemsetAsync(counts, 0, max_listed * sizeof(int), st);

@@ -273,7 +273,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
         // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
         // read the real one.  One host round trip per iteration instead of three.
-        const bool chain = ctx->opt_merge_chain != 0;
+        constexpr bool chain = true;            // (false: one round trip per axis pass, the structure the passes were first written with)
         for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
             const int blocks = grid_blocks(num_cells, kBlock);
             Int2* tot = total + axis;

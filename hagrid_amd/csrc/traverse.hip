@@ -1080,7 +1080,7 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
     detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0); HG_DBG(ctx);
     const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
     const float tau = length(ext) / 64.0f;
-    if (!ctx->opt_detect_origins || num_rays < origin_min_rays || !(tau > 0.0f) || !(tau < 3.0e18f)) return;
+    if (num_rays < origin_min_rays || !(tau > 0.0f) || !(tau < 3.0e18f)) return;
     if (!ctx->row_scores) {
         if (hipMalloc((void**)&ctx->row_scores, (kRowCandidates + 8) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->row_scores = nullptr; return; }
         (void)hipMemsetAsync(ctx->row_scores, 0, (kRowCandidates + 8) * sizeof(int), ctx->stream);
@@ -1275,9 +1275,8 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
         {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},
-        {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20}, {"traverse.detect_origins", &ctx->opt_detect_origins, 0, 1},
-        {"traverse.narrow", &ctx->opt_narrow, 0, 1},          {"expand.listed", &ctx->opt_expand_listed, 0, 1},
-        {"build.lookback", &ctx->opt_lookback, 0, 1},          {"merge.chain", &ctx->opt_merge_chain, 0, 1},
+        {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
+        {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
 
     };

@@ -376,7 +376,7 @@ inline void device_scan(hipStream_t stream, In in, Out out, int n, V* partials, 
     if (tiles > 0) scan_apply<V, In, Out><<<tiles, kBlock, 0, stream>>>(in, out, n, partials);
 }
 
-/// The scan the construction passes call: look-back by default, the three-kernel form with "build.lookback" = 0.
+/// The scan the construction passes call: the look-back form (the three-kernel form is selected by hagrid_kat_scan only).
 /// Returns false if the status words could not be allocated.
 template <typename V, typename In, typename Out>
 inline bool ctx_scan(hagrid_ctx* ctx, In in, Out out, int n, V* partials, const V* carry_in, V* total_out) {

@@ -238,8 +238,7 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
  * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
- * also from the origins alone -- bounce rays in the image order of their primary hits -- unless
- * "traverse.detect_origins" = 0), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
+ * also from the origins alone -- bounce rays in the image order of their primary hits), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
  * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
