@@ -27,7 +27,7 @@ extern "C" int hagrid_ctx_create(hagrid_ctx** out, int device, int keep) {
     ctx->num_cus = prop.multiProcessorCount;
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
         hipHostMalloc((void**)&ctx->mailbox, 256 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void**)&ctx->dscratch, 512 * sizeof(int)) != hipSuccess) {
+        hipMalloc((void**)&ctx->dscratch, 256 * sizeof(int)) != hipSuccess) {
         hagrid_ctx_destroy(ctx);
         return HAGRID_EHIP;
     }

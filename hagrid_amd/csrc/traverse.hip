@@ -936,179 +936,6 @@ __global__ void __launch_bounds__(64) traverse_kernel_v3(const TraverseArgs a, i
 
 
 
-// ---- image kernel for LARGE batches: persistent wavefronts, lane refill in tile-packet order, vote-scheduled phases --------
-// A batch of many rays per resident lane is bound by VALU issue, not by the latency of its dependent gathers (counters of the
-// 4096^2 primary batch, profiles/pmc_r2k_traverse_img_16M.txt: VALU saturated, 39 % of the lanes of an issued instruction
-// live).  This kernel is v3's schedule on the image's records: a finished lane takes the next ray of the batch, and every
-// iteration the wavefront runs the phase -- CELL step (one record gather) or ONE triangle test -- most of its lanes wait for.
-// Rays are handed out in the order of the tile packets (blocks of 64 = 8 x 8 pixel tiles along the Z curve); groups of
-// 2^xcd_chunk blocks go round-robin to the XCDs exactly as traverse_kernel_img's workgroups do, a wavefront takes 2^take_log2
-// blocks per cursor atomic (one cursor per XCD, a cache line each; an XCD that runs dry continues with the next one's).
-// Every ray performs the operation sequence of traverse_kernel_img, so hits are identical.  FLAT + NARROW images, closest hit.
-constexpr int kCursorStride = 32;   // ints: one 128-byte line per cursor
-
-template <bool UNIFORM>
-__global__ void __launch_bounds__(64, 8) traverse_kernel_img_refill(const TraverseArgs a, int* __restrict__ cursors, int take_log2, int refill_at) {
-    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
-    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
-    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
-    const int w = perm ? 0 : tile_packet_row_len(a);
-    const int nblocks = (a.num_rays + 63) >> 6;
-    const int gl = a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4, pl = min(take_log2, gl), sl = gl - pl;
-
-    int xcd = blockIdx.x & 7, xcds_left = 8;
-    int pool_next = 0, pool_end = 0;
-    bool exhausted = false;
-
-    int ray_id = -1;                // -1: the lane carries no ray
-    bool done = false;              // the lane's ray is finished, its result waits in registers for the next refill
-    vec3 org(0.0f), dir(0.0f), inv_dir(0.0f);
-    float tmin = 0.0f, hit_t = 0.0f, texit = 0.0f;
-    int hit_id = -1;
-    int vx = 0, vy = 0, vz = 0;
-    int ref = -1;                   // the id of the next test, -1: the lane wants a cell step
-    uint32_t q1 = 0, q2 = 0, q3 = 0;// inline list: the ids after `ref`; list by index: q1 = index of the next id, q2 = end
-    bool by_index = false, outside = false;
-    uint32_t top_idx = ~0u; uint2 tab = make_uint2(0u, 0u);   // table layout: the ray's top-level cell and its table entry
-
-    auto top_index = [&](int x, int y, int z) -> uint32_t {
-        return uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
-    };
-    auto tri_at = [&](int r) -> Tri {
-        uint32_t r3, o;
-        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(r));
-        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
-        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-        return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-    };
-
-    uint4 na = make_uint4(0u, 0u, 0u, 0u), nb = make_uint4(0u, 0u, 0u, 0u);   // the record of voxel (vx, vy, vz), fetched ahead
-    int lx = 0, ly = 0, lz = 0;                                  // table layout: that voxel (links are resolved when the record is used)
-    auto fetch_record = [&]() {
-        if (UNIFORM) {
-            const int d = a.shift, m = (1 << d) - 1;
-            const uint32_t idx = uint32_t(vx & m) + (uint32_t((vy & m) + ((vz & m) << d)) << d);
-            const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + (((top_index(vx, vy, vz) << (3 * d)) + idx) << 5));
-            na = p[0]; nb = p[1];
-        } else {
-            const uint32_t t = top_index(vx, vy, vz);
-            if (t != top_idx) { tab = gather32<uint2>(a.img_table, t << 3); top_idx = t; }
-            const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
-            const uint32_t idx = uint32_t((vx >> s) & m) + (uint32_t(((vy >> s) & m) + (((vz >> s) & m) << d)) << d);
-            const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x << 7) + (idx << 5)));
-            na = p[0]; nb = p[1];
-            lx = vx; ly = vy; lz = vz;
-        }
-    };
-
-    for (;;) {
-        const bool has_ray = ray_id >= 0 && !done;
-        const bool want_tri = has_ray && ref >= 0;
-        const unsigned long long m_free = __ballot(!has_ray);
-        const int n_free = __popcll(m_free);
-        if (n_free == 64 && exhausted) break;
-
-        // ---- refill: finished lanes write their hits and take the next rays of the sequence --------------------------------
-        if (!exhausted && n_free >= refill_at) {
-            while (pool_next >= pool_end && !exhausted) {
-                int n = 0;
-                if (threadIdx.x == 0) n = atomicAdd(cursors + xcd * kCursorStride, 1);
-                n = __builtin_amdgcn_readfirstlane(n);
-                const int first = ((((n >> sl) << 3) + xcd) << gl) + ((n & ((1 << sl) - 1)) << pl);
-                if (first < nblocks) { pool_next = first << 6; pool_end = min(first + (1 << pl), nblocks) << 6; }
-                else { xcd = (xcd + 1) & 7; if (--xcds_left == 0) exhausted = true; }
-            }
-            const int take = min(n_free, pool_end - pool_next);
-            if (done) { nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f); done = false; ray_id = -1; }
-            if (!has_ray) {
-                const int rank = __builtin_amdgcn_mbcnt_hi(unsigned(m_free >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m_free), 0));
-                const int seq = pool_next + rank;
-                const int slot = w ? tile_packet_slot(a, w, seq >> 6, seq & 63) : seq;
-                if (rank < take && slot < a.num_rays) {
-                    const int id = perm ? perm[slot] : slot;
-                    const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
-                    org = vec3(r0.x, r0.y, r0.z); dir = vec3(r1.x, r1.y, r1.z);
-                    tmin = r0.w;
-                    const float tmax = r1.w;
-                    inv_dir = vec3(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-                    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
-                    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
-                    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
-                    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
-                    if (tstart > tend) {
-                        nt_store4(a.hits + id, __int_as_float(-1), tmax, 0.0f, 0.0f);     // misses the grid
-                    } else {
-                        const vec3 fv = (tstart * dir + org - gmin) * ginv;
-                        vx = min(max(int(fv.x), 0), a.dims_x - 1);
-                        vy = min(max(int(fv.y), 0), a.dims_y - 1);
-                        vz = min(max(int(fv.z), 0), a.dims_z - 1);
-                        hit_t = tmax; hit_id = -1; ref = -1; top_idx = ~0u;
-                        ray_id = id;
-                        fetch_record();
-                    }
-                }
-            }
-            pool_next += take;
-            continue;
-        }
-
-        // ---- phase vote: throughput mode runs the fuller phase only; once no rays are left to take every lane advances ------
-        const int n_tri = __popcll(__ballot(want_tri));
-        const int n_cell = 64 - n_free - n_tri;
-        const bool run_cell = n_cell > 0 && (exhausted || n_cell > n_tri);
-        const bool run_tri = n_tri > 0 && (exhausted || !run_cell);
-        bool finished = false;
-
-        if (run_cell) {
-            if (has_ray && !want_tri) {
-                uint4 ca = na, cb = nb;                          // fetched when the ray entered this voxel
-                if (!UNIFORM && ca.w >= 0xfffffffeu) { uint32_t off = ~0u, meta = 0u; image_resolve_links(a, lx, ly, lz, ca, cb, off, meta); }
-                const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
-                const int cx = int(__builtin_amdgcn_ubfe(ca.x, px ? 16u : 0u, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, py ? 16u : 0u, 16u)),
-                          cz = int(__builtin_amdgcn_ubfe(ca.z, pz ? 16u : 0u, 16u));
-                const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
-                texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
-                const vec3 ev = (texit * dir + org - gmin) * ginv;
-                const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
-                const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
-                const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
-                vx = px ? max(nx, vx) : min(nx, vx);
-                vy = py ? max(ny, vy) : min(ny, vy);
-                vz = pz ? max(nz, vz) : min(nz, vz);
-                outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
-                by_index = int(ca.w) < 0;
-                if (by_index) {
-                    q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                    ref = q1 < q2 ? gather32<int>(a.refs, q1 << 2) : -1;
-                    q1++;
-                } else {
-                    ref = int(cb.x); q1 = cb.y; q2 = cb.z; q3 = cb.w;
-                }
-                if (!outside) fetch_record();                   // the next voxel's record: in flight during this cell's tests
-                finished = ref < 0 && (hit_t <= texit || outside);
-            }
-        }
-        if (run_tri) {
-            // one test per lane that was waiting for one at the vote (a lane that just finished its cell step starts testing in
-            // the next iteration)
-            if (want_tri) {
-                int next;
-                if (by_index) { next = q1 < q2 ? gather32<int>(a.refs, q1 << 2) : -1; q1++; }
-                else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
-                Hit h(hit_id, hit_t, 0.0f, 0.0f);
-                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit_t), ref, h);
-                hit_id = h.id; hit_t = h.t;
-                ref = next;
-                finished = ref < 0 && (hit_t <= texit || outside);
-            }
-        }
-        if (finished) { done = true; ref = -1; }
-    }
-    if (done) nt_store4(a.hits + ray_id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-}
-
-
 // ---- ray binning (extension; north_star: "ray packets sorted ... to tame divergence") ----------------------------------
 // A batch without spatial order (random origins and directions) makes every load of a wavefront touch 64 unrelated cache
 // lines.  Measured on MI355X (tools/dev_sort_potential.py): ordering such a batch by a coarse Morton key of the ray's
@@ -1369,13 +1196,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // crossover on MI355X between 8M and 16M primary rays, i.e. ~24 rays per lane of a full machine).
     // hagrid_set_option("traverse.variant", 1|2|3|4) forces a kernel (tests, experiments).
     const bool have_image = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
-    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant < 4) || (flags && !ctx->image.flat)))
+    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant != 4) || (flags && !ctx->image.flat)))
         HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal, only the traversal-image kernel can serve it");
-    if ((ctx->opt_variant == 4 || ctx->opt_variant == 5) && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
+    if (ctx->opt_variant == 4 && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
     const long long lanes = (long long)ctx->num_cus * 32 * 64;
     const bool large = num_rays >= 24 * lanes;
     int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : (large ? 3 : 2));
-    if (perm && variant < 4) variant = 2;             // binned batches: the latency-oriented kernel wins at every size measured
+    if (perm && variant != 4) variant = 2;            // binned batches: the latency-oriented kernel wins at every size measured
     const bool img_narrow = have_image && ctx->opt_narrow && a.top_xy > 0 && grid->dims[2] < (1 << 23) && buffer_bytes_from(tris) < (size_t(1) << 32) &&
                             ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
@@ -1384,9 +1211,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (ctx->image.detached && have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: any-hit / barycentrics on a released grid need the narrow image kernel (arrays below 4 GB)");
         variant = 2;
     }
-    // variant 5: the refill form of the image kernel (flat narrow images, closest hit)
-    if (variant == 5 && !(ctx->image.flat && img_narrow && !flags)) variant = 4;
-    if (variant == 4 || variant == 5) {
+    if (variant == 4) {
         a.img_table = static_cast<const uint2*>(ctx->image.table);
         a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
     }
@@ -1394,7 +1219,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // (default) looks for one on the device, -1 switches the feature off.  The kernel reads the answer from device memory,
     // nobody waits for it -- except a large batch without a traversal image: image order + tiles + v2 beats v3
     // (4096^2 rays: 1.96 vs 2.55 ms), so there the kernel is chosen on the host after reading the row length back.
-    if (!perm && ctx->opt_image_width >= 0 && (variant == 2 || variant == 4 || variant == 5 || (!ctx->opt_variant && large))) {
+    if (!perm && ctx->opt_image_width >= 0 && (variant == 2 || variant == 4 || (!ctx->opt_variant && large))) {
         if (ctx->opt_image_width > 0) {
             a.row_len_hint = ctx->opt_image_width;
             if (variant == 3 && (a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
@@ -1414,14 +1239,6 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
         launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
-    } else if (variant == 5) {
-        const int blocks = std::min(grid_blocks(num_rays, 64), ctx->num_cus * ctx->opt_waves_per_cu);
-        int take_log2 = 2;                                   // blocks of 64 rays per cursor atomic
-        if (ctx->opt_chunk) { take_log2 = 0; while ((128 << take_log2) <= ctx->opt_chunk && take_log2 < 10) take_log2++; }
-        int* cursors = ctx->dscratch + 256;                  // 8 cursors, a cache line each
-        HG_HIP(ctx, hipMemsetAsync(cursors, 0, 8 * kCursorStride * sizeof(int), ctx->stream));
-        if (ctx->image.uniform) traverse_kernel_img_refill<true><<<blocks, 64, 0, ctx->stream>>>(a, cursors, take_log2, ctx->opt_refill_at);
-        else                    traverse_kernel_img_refill<false><<<blocks, 64, 0, ctx->stream>>>(a, cursors, take_log2, ctx->opt_refill_at);
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1453,7 +1270,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
 extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
-        {"traverse.variant", &ctx->opt_variant, 0, 5},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
+        {"traverse.variant", &ctx->opt_variant, 0, 4},        {"traverse.waves_per_cu", &ctx->opt_waves_per_cu, 1, 32},
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},

@@ -449,26 +449,17 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
         mem.set_option("traverse.image", fmt)
         for uniform in ((1, 0) if fmt == 2 else (1,)):          # flat blocks: table-free layout allowed / not allowed
             mem.set_option("traverse.image_uniform", uniform)
-            for variant in (4, 0, 2, 5):                             # 5: the refill form of the image kernel (flat images; else = 4)
+            for variant in (4, 0, 2):
                 mem.set_option("traverse.variant", variant)
                 for n in (rays.shape[0], 256 * 128, 65, 1):
                     got = gpu_traverse(mem, grid, d_tris, rays[:n])          # calls setup_traversal first
                     assert (got["id"] == want["id"][:n]).all() and (bits(got["t"]) == bits(want["t"][:n])).all(), (uniform, variant, n)
-            # the refill kernel with few resident wavefronts (every lane takes many rays), every refill threshold and take size
-            mem.set_option("traverse.variant", 5)
-            for waves, refill, chunk in ((1, 1, 64), (2, 64, 1024), (32, 24, 0), (4, 16, 256)):
-                mem.set_option("traverse.waves_per_cu", waves); mem.set_option("traverse.refill_at", refill); mem.set_option("traverse.chunk", chunk)
-                got = gpu_traverse(mem, grid, d_tris, rays)
-                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, waves, refill, chunk)
-            mem.set_option("traverse.waves_per_cu", 32); mem.set_option("traverse.refill_at", 24); mem.set_option("traverse.chunk", 0)
         mem.set_option("traverse.image_uniform", 1)
-        for variant in (4, 5):
-            mem.set_ray_binning(1); mem.set_option("traverse.variant", variant)
-            got = gpu_traverse(mem, grid, d_tris, rays)
-            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), variant
+        mem.set_ray_binning(1); mem.set_option("traverse.variant", 4)
+        got = gpu_traverse(mem, grid, d_tris, rays)
+        assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
         mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_uniform", 1)
-        mem.set_option("traverse.waves_per_cu", 32); mem.set_option("traverse.refill_at", 24); mem.set_option("traverse.chunk", 0)
     grid.free(); mem.free(d_tris)
 
 
