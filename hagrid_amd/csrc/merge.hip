@@ -168,16 +168,33 @@ __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restric
 // scans of merge.cu:310-311 fused; compute_ref_counts (merge.cu:173-186) folded into the input
 struct KeepIn {
     const int* cell_flags; const int* merge_counts; const int* n_dev;      // n_dev: the pass's cell count when only the device knows it
+    __device__ static Int2 item(int f, int m) { return Int2{ f ? 1 : 0, f ? (m >= 0 ? m : -(m + 1)) : 0 }; }
     __device__ Int2 operator()(int i) const {
         if (n_dev && i >= *n_dev) return Int2{0, 0};
-        const int f = cell_flags[i];
-        const int m = merge_counts[i];
-        return Int2{ f ? 1 : 0, f ? (m >= 0 ? m : -(m + 1)) : 0 };
+        return item(cell_flags[i], merge_counts[i]);
+    }
+    __device__ void load4(int i, int n, Int2* v) const {                   // i is a multiple of 4: one 16-byte access per array
+        const int lim = n_dev ? min(n, *n_dev) : n;
+        if (i + 4 <= lim) {
+            const int4 f = *reinterpret_cast<const int4*>(cell_flags + i), m = *reinterpret_cast<const int4*>(merge_counts + i);
+            v[0] = item(f.x, m.x); v[1] = item(f.y, m.y); v[2] = item(f.z, m.z); v[3] = item(f.w, m.w);
+        } else {
+            for (int c = 0; c < 4; c++) v[c] = i + c < lim ? item(cell_flags[i + c], merge_counts[i + c]) : Int2{0, 0};
+        }
     }
 };
 struct KeepOut {
     int* cell_scan; int* ref_scan; const int* n_dev;
     __device__ void operator()(int i, Int2 v) const { if (n_dev && i >= *n_dev) return; cell_scan[i] = v.a; ref_scan[i] = v.b; }
+    __device__ void store4(int i, int n, const Int2* v) const {
+        const int lim = n_dev ? min(n, *n_dev) : n;
+        if (i + 4 <= lim) {
+            *reinterpret_cast<int4*>(cell_scan + i) = make_int4(v[0].a, v[1].a, v[2].a, v[3].a);
+            *reinterpret_cast<int4*>(ref_scan + i) = make_int4(v[0].b, v[1].b, v[2].b, v[3].b);
+        } else {
+            for (int c = 0; c < 4; c++) if (i + c < lim) { cell_scan[i + c] = v[c].a; ref_scan[i + c] = v[c].b; }
+        }
+    }
 };
 
 // merge (merge.cu:189-278)

@@ -245,6 +245,19 @@ __device__ __forceinline__ bool lb_try(const unsigned long long* state, int t, u
 }
 template <typename V> constexpr int lb_words() { return int(sizeof(V) / sizeof(int)); }
 
+// A functor may offer the kLbVec consecutive items of a lane in one go (In::load4(i, n, v): items i .. i + 3, zero past n;
+// Out::store4(i, n, v)) so that it can use 16-byte accesses; the per-item call operator is the fallback.
+template <typename V, typename In> __device__ __forceinline__ auto lb_load_row(const In& in, int i, int n, V* v, int) -> decltype(in.load4(i, n, v), void()) { in.load4(i, n, v); }
+template <typename V, typename In> __device__ __forceinline__ void lb_load_row(const In& in, int i, int n, V* v, long) {
+#pragma unroll
+    for (int c = 0; c < kLbVec; c++) v[c] = i + c < n ? in(i + c) : zero_of(V());
+}
+template <typename V, typename Out> __device__ __forceinline__ auto lb_store_row(const Out& out, int i, int n, const V* v, int) -> decltype(out.store4(i, n, v), void()) { out.store4(i, n, v); }
+template <typename V, typename Out> __device__ __forceinline__ void lb_store_row(const Out& out, int i, int n, const V* v, long) {
+#pragma unroll
+    for (int c = 0; c < kLbVec; c++) if (i + c < n) out(i + c, v[c]);
+}
+
 template <typename V, typename In, typename Out>
 __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, const V* carry_in, V* total_out) {
     __shared__ V lds[kWaves];
@@ -258,12 +271,7 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
         // this v[j] is the exclusive prefix of item j inside the run and `run` the run's total
         V v[kLbItems];
 #pragma unroll
-        for (int r = 0; r < kRows; r++)
-#pragma unroll
-            for (int c = 0; c < kLbVec; c++) {
-                const int i = base + r * 64 * kLbVec + c;
-                v[r * kLbVec + c] = i < n ? in(i) : zero_of(V());
-            }
+        for (int r = 0; r < kRows; r++) lb_load_row<V>(in, base + r * 64 * kLbVec, n, v + r * kLbVec, 0);
         V run = zero_of(V());
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
@@ -338,12 +346,11 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
         V offset = tile_prefix;
         for (int w = 0; w < wave_id(); w++) offset = offset + lds[w];
 #pragma unroll
-        for (int r = 0; r < kRows; r++)
+        for (int r = 0; r < kRows; r++) {
 #pragma unroll
-            for (int c = 0; c < kLbVec; c++) {
-                const int i = base + r * 64 * kLbVec + c;
-                if (i < n) out(i, offset + v[r * kLbVec + c]);
-            }
+            for (int c = 0; c < kLbVec; c++) v[r * kLbVec + c] = offset + v[r * kLbVec + c];
+            lb_store_row<V>(out, base + r * 64 * kLbVec, n, v + r * kLbVec, 0);
+        }
     }
     if (tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = carry_in ? *carry_in : zero_of(V());
 }
