@@ -217,12 +217,27 @@ __global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cell
 struct ChildCountIn {
     const uint32_t* entries;
     __device__ int operator()(int i) const { return (entries[i] & 3u) ? 8 : 0; }
+    __device__ void load4(int i, int n, int* v) const {                 // a lane's four consecutive items: one 16-byte access
+        if (i + 4 <= n && lb_aligned16(entries + i)) {
+            const uint4 e = *reinterpret_cast<const uint4*>(entries + i);
+            v[0] = (e.x & 3u) ? 8 : 0; v[1] = (e.y & 3u) ? 8 : 0; v[2] = (e.z & 3u) ? 8 : 0; v[3] = (e.w & 3u) ? 8 : 0;
+        } else {
+            for (int c = 0; c < 4; c++) v[c] = i + c < n ? (*this)(i + c) : 0;
+        }
+    }
 };
 struct UpdateEntriesOut {
     uint32_t* entries;
-    __device__ void operator()(int i, int start) const {
-        const uint32_t ld = entries[i] & 3u;
-        entries[i] = ld | (uint32_t(ld ? start : i) << 2);
+    __device__ static uint32_t word(uint32_t e, int i, int start) { const uint32_t ld = e & 3u; return ld | (uint32_t(ld ? start : i) << 2); }
+    __device__ void operator()(int i, int start) const { entries[i] = word(entries[i], i, start); }
+    __device__ void store4(int i, int n, const int* v) const {
+        if (i + 4 <= n && lb_aligned16(entries + i)) {
+            uint4* p = reinterpret_cast<uint4*>(entries + i);
+            const uint4 e = *p;
+            *p = make_uint4(word(e.x, i, v[0]), word(e.y, i + 1, v[1]), word(e.z, i + 2, v[2]), word(e.w, i + 3, v[3]));
+        } else {
+            for (int c = 0; c < 4; c++) if (i + c < n) (*this)(i + c, v[c]);
+        }
     }
 };
 
@@ -363,14 +378,29 @@ __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __res
 // leaf flag + kept-reference count per cell, scanned over all levels in cell order
 struct LeafIn {
     const uint32_t* entries; const int* cell_counts;
-    __device__ Int2 operator()(int i) const {
-        const bool leaf = (entries[i] & 3u) == 0;
-        return Int2{ leaf ? 1 : 0, leaf ? cell_counts[i] : 0 };
+    __device__ static Int2 item(uint32_t e, int count) { const bool leaf = (e & 3u) == 0; return Int2{ leaf ? 1 : 0, leaf ? count : 0 }; }
+    __device__ Int2 operator()(int i) const { return item(entries[i], cell_counts[i]); }
+    __device__ void load4(int i, int n, Int2* v) const {
+        if (i + 4 <= n && lb_aligned16(entries + i) && lb_aligned16(cell_counts + i)) {
+            const uint4 e = *reinterpret_cast<const uint4*>(entries + i);
+            const int4 c = *reinterpret_cast<const int4*>(cell_counts + i);
+            v[0] = item(e.x, c.x); v[1] = item(e.y, c.y); v[2] = item(e.z, c.z); v[3] = item(e.w, c.w);
+        } else {
+            for (int k = 0; k < 4; k++) v[k] = i + k < n ? (*this)(i + k) : Int2{0, 0};
+        }
     }
 };
 struct LeafOut {
     int* start_cell; int* ref_begin;
     __device__ void operator()(int i, Int2 v) const { start_cell[i] = v.a; ref_begin[i] = v.b; }
+    __device__ void store4(int i, int n, const Int2* v) const {
+        if (i + 4 <= n && lb_aligned16(start_cell + i) && lb_aligned16(ref_begin + i)) {
+            *reinterpret_cast<int4*>(start_cell + i) = make_int4(v[0].a, v[1].a, v[2].a, v[3].a);
+            *reinterpret_cast<int4*>(ref_begin + i) = make_int4(v[0].b, v[1].b, v[2].b, v[3].b);
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n) (*this)(i + k, v[k]);
+        }
+    }
 };
 
 // copy_cells (build.cu:407-419) + copy_entries (:422-440) + compute_cell_ranges (:453-468)

@@ -175,7 +175,7 @@ struct KeepIn {
     }
     __device__ void load4(int i, int n, Int2* v) const {                   // i is a multiple of 4: one 16-byte access per array
         const int lim = n_dev ? min(n, *n_dev) : n;
-        if (i + 4 <= lim) {
+        if (i + 4 <= lim && lb_aligned16(cell_flags + i) && lb_aligned16(merge_counts + i)) {
             const int4 f = *reinterpret_cast<const int4*>(cell_flags + i), m = *reinterpret_cast<const int4*>(merge_counts + i);
             v[0] = item(f.x, m.x); v[1] = item(f.y, m.y); v[2] = item(f.z, m.z); v[3] = item(f.w, m.w);
         } else {
@@ -188,7 +188,7 @@ struct KeepOut {
     __device__ void operator()(int i, Int2 v) const { if (n_dev && i >= *n_dev) return; cell_scan[i] = v.a; ref_scan[i] = v.b; }
     __device__ void store4(int i, int n, const Int2* v) const {
         const int lim = n_dev ? min(n, *n_dev) : n;
-        if (i + 4 <= lim) {
+        if (i + 4 <= lim && lb_aligned16(cell_scan + i) && lb_aligned16(ref_scan + i)) {
             *reinterpret_cast<int4*>(cell_scan + i) = make_int4(v[0].a, v[1].a, v[2].a, v[3].a);
             *reinterpret_cast<int4*>(ref_scan + i) = make_int4(v[0].b, v[1].b, v[2].b, v[3].b);
         } else {

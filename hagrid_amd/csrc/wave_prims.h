@@ -247,6 +247,7 @@ template <typename V> constexpr int lb_words() { return int(sizeof(V) / sizeof(i
 
 // A functor may offer the kLbVec consecutive items of a lane in one go (In::load4(i, n, v): items i .. i + 3, zero past n;
 // Out::store4(i, n, v)) so that it can use 16-byte accesses; the per-item call operator is the fallback.
+__device__ __forceinline__ bool lb_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 template <typename V, typename In> __device__ __forceinline__ auto lb_load_row(const In& in, int i, int n, V* v, int) -> decltype(in.load4(i, n, v), void()) { in.load4(i, n, v); }
 template <typename V, typename In> __device__ __forceinline__ void lb_load_row(const In& in, int i, int n, V* v, long) {
 #pragma unroll
