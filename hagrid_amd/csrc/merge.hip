@@ -230,10 +230,17 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
 
 // remap_entries (merge.cu:281-290)
 __global__ void __launch_bounds__(kBlock) remap_entries_kernel(uint32_t* __restrict__ entries, const int* __restrict__ new_cell_ids, int num_entries) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    // four consecutive entries per thread: one 16-byte access each way
+    const int id = (blockIdx.x * kBlock + threadIdx.x) * 4;
     if (id >= num_entries) return;
-    const uint32_t e = entries[id];
-    if ((e & 3u) == 0) entries[id] = uint32_t(new_cell_ids[e >> 2]) << 2;
+    auto remap = [&](uint32_t e) { return (e & 3u) == 0 ? uint32_t(new_cell_ids[e >> 2]) << 2 : e; };
+    if (id + 4 <= num_entries && lb_aligned16(entries + id)) {
+        uint4* p = reinterpret_cast<uint4*>(entries + id);
+        const uint4 e = *p;
+        *p = make_uint4(remap(e.x), remap(e.y), remap(e.z), remap(e.w));
+    } else {
+        for (int i = id; i < min(id + 4, num_entries); i++) entries[i] = remap(entries[i]);
+    }
 }
 
 } // namespace
@@ -301,7 +308,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
                                                     merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev); HG_DBG(ctx);
-            remap_entries_kernel<<<grid_blocks(num_entries, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
+            remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
             std::swap(cells, cells_b);
             std::swap(refs, refs_b);
             if (axis == 2 || !chain) {
