@@ -151,11 +151,23 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
 // compute_cell_flags (merge.cu:145-170): chain heads mark every second cell of their chain as residue
 __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ has_prev, int pass_tag,
                                                             int* __restrict__ cell_flags, int num_cells, const int* __restrict__ n_dev) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= (n_dev ? *n_dev : num_cells)) return;
-    if (has_prev[id] != pass_tag) {
-        int next_id = nexts[id];
-        cell_flags[id] = 1;
+    // four consecutive cells per thread (16-byte loads; the arrays come from the pool); flags are stored one by one because the
+    // flag of a cell with a predecessor is written by its chain's head
+    const int id = (blockIdx.x * kBlock + threadIdx.x) * 4;
+    const int n = n_dev ? *n_dev : num_cells;
+    if (id >= n) return;
+    int hp[4], nx[4];
+    if (id + 4 <= n) {
+        const int4 h = *reinterpret_cast<const int4*>(has_prev + id), x = *reinterpret_cast<const int4*>(nexts + id);
+        hp[0] = h.x; hp[1] = h.y; hp[2] = h.z; hp[3] = h.w; nx[0] = x.x; nx[1] = x.y; nx[2] = x.z; nx[3] = x.w;
+    } else {
+        for (int c = 0; c < 4; c++) { hp[c] = id + c < n ? has_prev[id + c] : pass_tag; nx[c] = id + c < n ? nexts[id + c] : -1; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (hp[c] == pass_tag) continue;
+        int next_id = nx[c];
+        cell_flags[id + c] = 1;
         int count = 1;
         while (next_id >= 0) {
             cell_flags[next_id] = (count & 1) ? 0 : 1;
@@ -304,7 +316,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             const int* n_dev = (chain && axis) ? &total[axis - 1].a : nullptr;
             pass_tag++;
             merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev); HG_DBG(ctx);
-            cell_flags_kernel<<<blocks, kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
+            cell_flags_kernel<<<grid_blocks((num_cells + 3) / 4, kBlock), kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
             if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
                                                     merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev); HG_DBG(ctx);
