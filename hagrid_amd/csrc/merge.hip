@@ -33,17 +33,46 @@ struct MergeK {          // merge.cu:17-19
 
 struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
 
-__device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
-    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
-    const int4 a = p[0], b = p[1];
-    CellRec c; c.lo = ivec3(a.x, a.y, a.z); c.begin = a.w; c.hi = ivec3(b.x, b.y, b.z); c.end = b.w;
-    return c;
-}
-__device__ __forceinline__ void store_cell(Cell* cells, int i, ivec3 lo, int begin, ivec3 hi, int end) {
-    int4* p = reinterpret_cast<int4*>(cells) + 2 * size_t(i);
-    p[0] = make_int4(lo.x, lo.y, lo.z, begin);
-    p[1] = make_int4(hi.x, hi.y, hi.z, end);
-}
+// Between the passes the cells live in a 16-byte WORKING record: six u16 bounds + the first slot of the list.  The passes are
+// bound by the bytes they stream (6 % of the cells merge in a pass, the rest is copied to its new place), and the lists of
+// consecutive cells are contiguous in every array a pass writes -- a cell's list ends where the next one's begins, the record
+// after the last cell holds the number of references -- so `end` need not be stored.  The first pass reads the caller's 32-byte
+// cells, the last step converts back.  (Virtual resolutions of 65536 and more keep the 32-byte record throughout.)
+template <bool NARROW> struct CellFmt;
+template <> struct CellFmt<false> {
+    static __device__ __forceinline__ CellRec load(const void* cells, int i) {
+        const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+        const int4 a = p[0], b = p[1];
+        CellRec c; c.lo = ivec3(a.x, a.y, a.z); c.begin = a.w; c.hi = ivec3(b.x, b.y, b.z); c.end = b.w;
+        return c;
+    }
+    static __device__ __forceinline__ void finish(const void*, int, CellRec&) {}
+    static __device__ __forceinline__ void store(void* cells, int i, ivec3 lo, int begin, ivec3 hi, int end) {
+        int4* p = reinterpret_cast<int4*>(cells) + 2 * size_t(i);
+        p[0] = make_int4(lo.x, lo.y, lo.z, begin);
+        p[1] = make_int4(hi.x, hi.y, hi.z, end);
+    }
+    static __device__ __forceinline__ void store_end(void*, int, int) {}
+};
+template <> struct CellFmt<true> {
+    // box and begin; `end` is filled by finish() -- callers that only look at the box of a neighbour skip that second access
+    static __device__ __forceinline__ CellRec load(const void* cells, int i) {
+        const uint4 v = reinterpret_cast<const uint4*>(cells)[i];
+        CellRec c;
+        c.lo = ivec3(int(v.x & 0xffffu), int(v.x >> 16), int(v.y & 0xffffu));
+        c.hi = ivec3(int(v.y >> 16), int(v.z & 0xffffu), int(v.z >> 16));
+        c.begin = int(v.w); c.end = int(v.w);
+        return c;
+    }
+    static __device__ __forceinline__ void finish(const void* cells, int i, CellRec& c) { c.end = int(reinterpret_cast<const uint4*>(cells)[size_t(i) + 1].w); }
+    static __device__ __forceinline__ void store(void* cells, int i, ivec3 lo, int begin, ivec3 hi, int) {
+        reinterpret_cast<uint4*>(cells)[i] = make_uint4(uint32_t(lo.x) | uint32_t(lo.y) << 16, uint32_t(lo.z) | uint32_t(hi.x) << 16,
+                                                        uint32_t(hi.y) | uint32_t(hi.z) << 16, uint32_t(begin));
+    }
+    static __device__ __forceinline__ void store_end(void* cells, int num_cells, int num_refs) {      // the record after the last cell
+        reinterpret_cast<uint4*>(cells)[num_cells] = make_uint4(0u, 0u, 0u, uint32_t(num_refs));
+    }
+};
 __device__ __forceinline__ int comp(const ivec3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 __device__ __forceinline__ float comp(const vec3& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
@@ -111,21 +140,25 @@ __device__ __forceinline__ void write_union(const int* __restrict__ a, int na, c
 }
 
 // compute_merge_counts (merge.cu:91-142)
-__global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
+template <bool NARROW>
+__global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
                                                               const int* __restrict__ refs, int* __restrict__ merge_counts,
                                                               int* __restrict__ nexts, int* __restrict__ has_prev, int pass_tag, int empty_mask, int num_cells,
                                                               const int* __restrict__ n_dev) {
+    using F = CellFmt<NARROW>;
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= (n_dev ? *n_dev : num_cells)) return;
     const float unit_cost = 1.0f;
-    const CellRec c1 = load_cell(cells, id);
+    CellRec c1 = F::load(cells, id);
+    F::finish(cells, id, c1);
     const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
     int count = -(c1.end - c1.begin + 1);
     int next_id = -1;
     if (merge_allowed(k, empty_mask, comp(c1.lo, axis)) && comp(np, axis) < comp(k.dims, axis)) {
         next_id = int(lookup_entry(entries, k.shift, k.top, np));
-        const CellRec c2 = load_cell(cells, next_id);
+        CellRec c2 = F::load(cells, next_id);
         if (aligned(axis, c1, c2)) {
+            F::finish(cells, next_id, c2);
             const vec3 e1 = vec3(c1.hi - c1.lo) * k.cell_size;
             const vec3 e2 = vec3(c2.hi - c2.lo) * k.cell_size;
             const float a1 = e1.x * (e1.y + e1.z) + e1.y * e1.z;
@@ -210,15 +243,21 @@ struct KeepOut {
 };
 
 // merge (merge.cu:189-278)
-__global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const Cell* __restrict__ cells,
+template <bool IN_NARROW, bool OUT_NARROW>
+__global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
                                                        const int* __restrict__ refs, const int* __restrict__ cell_flags,
                                                        const int* __restrict__ cell_scan, const int* __restrict__ ref_scan,
                                                        const int* __restrict__ merge_counts, int* new_cell_ids /* holds nexts on entry */,
-                                                       Cell* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev) {
+                                                       void* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev,
+                                                       const Int2* __restrict__ totals) {
+    using FI = CellFmt<IN_NARROW>;
+    using FO = CellFmt<OUT_NARROW>;
     const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id == 0) FO::store_end(new_cells, totals->a, totals->b);
     if (id >= (n_dev ? *n_dev : num_cells) || !cell_flags[id]) return;
     const int new_id = cell_scan[id];
-    const CellRec cell = load_cell(cells, id);
+    CellRec cell = FI::load(cells, id);
+    FI::finish(cells, id, cell);
     const int mc = merge_counts[id];
     const int nb = ref_scan[id];
     // the array still holds `nexts` (compute_merge_counts' neighbour, = what lookup_entry would find again): only the second
@@ -227,17 +266,27 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     new_cell_ids[id] = new_id;
     const int n1 = cell.end - cell.begin;
     if (mc >= 0) {
-        const CellRec nc = load_cell(cells, next_id);
+        CellRec nc = FI::load(cells, next_id);
+        FI::finish(cells, next_id, nc);
         new_cell_ids[next_id] = new_id;
-        store_cell(new_cells, new_id, min(nc.lo, cell.lo), nb, max(nc.hi, cell.hi), nb + mc);
+        FO::store(new_cells, new_id, min(nc.lo, cell.lo), nb, max(nc.hi, cell.hi), nb + mc);
         if (nc.begin < nc.end) {
             write_union(refs + cell.begin, n1, refs + nc.begin, nc.end - nc.begin, new_refs + nb, mc);
             return;
         }
     } else {
-        store_cell(new_cells, new_id, cell.lo, nb, cell.hi, nb + n1);
+        FO::store(new_cells, new_id, cell.lo, nb, cell.hi, nb + n1);
     }
     for (int i = 0; i < n1; i++) new_refs[nb + i] = refs[cell.begin + i];
+}
+
+// working records -> the public 32-byte cells
+__global__ void __launch_bounds__(kBlock) widen_cells_kernel(const void* __restrict__ narrow, Cell* __restrict__ cells, const Int2* __restrict__ totals) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= totals->a) return;
+    CellRec c = CellFmt<true>::load(narrow, id);
+    CellFmt<true>::finish(narrow, id, c);
+    CellFmt<false>::store(cells, id, c.lo, c.begin, c.hi, c.end);
 }
 
 // remap_entries (merge.cu:281-290)
@@ -294,14 +343,18 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         return HAGRID_ENOMEM;
     }
 
-    Cell* cells = static_cast<Cell*>(grid->cells);
+    void* cells = grid->cells;
+    void* cells_other = cells_b;
     int* refs = static_cast<int*>(grid->ref_ids);
     uint32_t* entries = static_cast<uint32_t*>(grid->entries);
     int num_cells = grid->num_cells, num_refs = grid->num_refs;
     const int num_entries = grid->num_entries;
+    // 16-byte working records between the passes (CellFmt<true>) when the bounds fit 16 bits
+    const bool narrow = ctx->opt_merge_narrow && std::max(k.dims.x, std::max(k.dims.y, k.dims.z)) < 65536;
 
     int rc = HAGRID_OK;
     int prev_num_cells = 0, iter = 0, pass_tag = 0;
+    bool in_narrow = false;                                                // the caller's cells are 32-byte records
     (void)hipMemsetAsync(prevs, 0, nc0 * sizeof(int), st);                 // tag 0 = never had a predecessor
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
@@ -309,42 +362,51 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
         // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
         // read the real one.  One host round trip per iteration instead of three.
-        constexpr bool chain = true;            // (false: one round trip per axis pass, the structure the passes were first written with)
         for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
             const int blocks = grid_blocks(num_cells, kBlock);
             Int2* tot = total + axis;
-            const int* n_dev = (chain && axis) ? &total[axis - 1].a : nullptr;
+            const int* n_dev = axis ? &total[axis - 1].a : nullptr;
+            const Entry* ent = reinterpret_cast<const Entry*>(entries);
             pass_tag++;
-            merge_counts_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev); HG_DBG(ctx);
+            if (in_narrow) merge_counts_kernel<true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
+            else           merge_counts_kernel<false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
+            HG_DBG(ctx);
             cell_flags_kernel<<<grid_blocks((num_cells + 3) / 4, kBlock), kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
             if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
-            merge_kernel<<<blocks, kBlock, 0, st>>>(axis, k, reinterpret_cast<const Entry*>(entries), cells, refs, cell_flags, cell_scan, ref_scan,
-                                                    merge_counts, nexts /* new_cell_ids: nexts is dead after the flags */, cells_b, refs_b, num_cells, n_dev); HG_DBG(ctx);
+            // (new_cell_ids = nexts: dead after the flags)
+            if (in_narrow)   merge_kernel<true, true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else if (narrow) merge_kernel<false, true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else             merge_kernel<false, false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            HG_DBG(ctx);
+            in_narrow = narrow;
             remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
-            std::swap(cells, cells_b);
+            std::swap(cells, cells_other);
             std::swap(refs, refs_b);
-            if (axis == 2 || !chain) {
+            if (axis == 2) {
                 int h[6];
-                rc = read_back(ctx, total, h, sizeof(int) * 2 * size_t(axis + 1));
+                rc = read_back(ctx, total, h, sizeof(int) * 6);
                 if (rc != HAGRID_OK) break;
                 hagrid_build_counts& bc = ctx->counts;                     // sizes that entered the passes (diagnostics)
                 auto record = [&](int c, int r) {
                     if (bc.merge_passes < HAGRID_MAX_MERGE_PASSES) { bc.merge_cells[bc.merge_passes] = c; bc.merge_refs[bc.merge_passes] = r; bc.merge_passes++; }
                 };
-                record(num_cells, num_refs);
-                if (chain) { record(h[0], h[1]); record(h[2], h[3]); }
-                num_cells = h[2 * axis]; num_refs = h[2 * axis + 1];
+                record(num_cells, num_refs); record(h[0], h[1]); record(h[2], h[3]);
+                num_cells = h[4]; num_refs = h[5];
             }
         }
         iter++;
     } while (rc == HAGRID_OK && num_cells < alpha * prev_num_cells);
+    if (rc == HAGRID_OK && in_narrow) {                                    // back to the public record
+        widen_cells_kernel<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(cells, static_cast<Cell*>(cells_other), total + 2); HG_DBG(ctx);
+        std::swap(cells, cells_other);
+    }
 
     if (rc == HAGRID_OK) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e));
     }
     release();
-    hagrid_mem_free(ctx, cells_b);       // whichever buffers are not the live ones (merge.cu:375-376)
+    hagrid_mem_free(ctx, cells_other);   // whichever buffers are not the live ones (merge.cu:375-376)
     hagrid_mem_free(ctx, refs_b);
     grid->cells = cells; grid->ref_ids = refs;
     grid->num_cells = num_cells; grid->num_refs = num_refs;

@@ -1278,6 +1278,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
+        {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},
 
     };
     for (auto& t : table)

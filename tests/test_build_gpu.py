@@ -64,6 +64,26 @@ def test_build_config1_every_stage(mem):
     grid.free(); mem.free(d_tris)
 
 
+def test_merge_with_wide_working_cells(mem):
+    """merge.narrow_cells = 0 keeps the 32-byte record between the passes (the path of virtual resolutions >= 65536)."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(30000, seed=91)
+    d_tris = mem.upload(tris)
+    G = O.Grid.build(tris).merge(0.995)
+    try:
+        for narrow in (0, 1):
+            mem.set_option("merge.narrow_cells", narrow)
+            grid = api.Grid()
+            api.build_grid(mem, d_tris, tris.shape[0], grid, 0.12, 2.4)
+            api.merge_grid(mem, grid, 0.995)
+            assert_same_grid(grid.download(), G, ("merge", narrow))
+            grid.free()
+    finally:
+        mem.set_option("merge.narrow_cells", 1)
+    mem.free(d_tris)
+
+
 @pytest.mark.parametrize("n,td,sd", [(1, 0.12, 2.4), (2, 0.12, 2.4), (37, 0.12, 2.4), (3000, 0.15, 3.0), (50000, 0.12, 2.4), (20000, 0.5, 8.0)])
 def test_build_sizes_and_densities(mem, n, td, sd):
     tris = scene.make_soup(n, seed=1234 + n)
