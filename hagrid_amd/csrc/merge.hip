@@ -210,56 +210,61 @@ __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restric
     }
 }
 
-// scans of merge.cu:310-311 fused; compute_ref_counts (merge.cu:173-186) folded into the input
-struct KeepIn {
-    const int* cell_flags; const int* merge_counts; const int* n_dev;      // n_dev: the pass's cell count when only the device knows it
-    __device__ static Int2 item(int f, int m) { return Int2{ f ? 1 : 0, f ? (m >= 0 ? m : -(m + 1)) : 0 }; }
-    __device__ Int2 operator()(int i) const {
-        if (n_dev && i >= *n_dev) return Int2{0, 0};
-        return item(cell_flags[i], merge_counts[i]);
+// The two scans of merge.cu:310-311 (cells kept, references kept; compute_ref_counts of merge.cu:173-186 is the item) in three
+// steps that never write a scanned value per cell: one sum per TILE of 256 cells (a wavefront reads its tile with 16-byte
+// accesses), an exclusive scan over the tile sums (a few thousand items, in place), and the scan inside the tile by the
+// workgroup of the merge kernel that owns it.
+constexpr int kMergeTile = kBlock;                  // cells per workgroup of merge_kernel
+__device__ __forceinline__ Int2 keep_item(int flag, int count) { return Int2{ flag ? 1 : 0, flag ? (count >= 0 ? count : -(count + 1)) : 0 }; }
+
+__global__ void __launch_bounds__(kBlock) merge_tile_sums(const int* __restrict__ cell_flags, const int* __restrict__ merge_counts, int num_cells,
+                                                          const int* __restrict__ n_dev, Int2* __restrict__ sums, int num_tiles) {
+    static_assert(kMergeTile == 64 * 4, "a wavefront covers one tile with four cells per lane");
+    const int tile = blockIdx.x * kWaves + wave_id();
+    if (tile >= num_tiles) return;
+    const int n = n_dev ? min(num_cells, *n_dev) : num_cells;
+    const int i = tile * kMergeTile + lane_id() * 4;
+    Int2 s{0, 0};
+    if (i + 4 <= n) {
+        const int4 f = *reinterpret_cast<const int4*>(cell_flags + i), m = *reinterpret_cast<const int4*>(merge_counts + i);
+        s = keep_item(f.x, m.x) + keep_item(f.y, m.y) + keep_item(f.z, m.z) + keep_item(f.w, m.w);
+    } else {
+        for (int c = 0; c < 4; c++) if (i + c < n) s = s + keep_item(cell_flags[i + c], merge_counts[i + c]);
     }
-    __device__ void load4(int i, int n, Int2* v) const {                   // i is a multiple of 4: one 16-byte access per array
-        const int lim = n_dev ? min(n, *n_dev) : n;
-        if (i + 4 <= lim && lb_aligned16(cell_flags + i) && lb_aligned16(merge_counts + i)) {
-            const int4 f = *reinterpret_cast<const int4*>(cell_flags + i), m = *reinterpret_cast<const int4*>(merge_counts + i);
-            v[0] = item(f.x, m.x); v[1] = item(f.y, m.y); v[2] = item(f.z, m.z); v[3] = item(f.w, m.w);
-        } else {
-            for (int c = 0; c < 4; c++) v[c] = i + c < lim ? item(cell_flags[i + c], merge_counts[i + c]) : Int2{0, 0};
-        }
-    }
-};
-struct KeepOut {
-    int* cell_scan; int* ref_scan; const int* n_dev;
-    __device__ void operator()(int i, Int2 v) const { if (n_dev && i >= *n_dev) return; cell_scan[i] = v.a; ref_scan[i] = v.b; }
-    __device__ void store4(int i, int n, const Int2* v) const {
-        const int lim = n_dev ? min(n, *n_dev) : n;
-        if (i + 4 <= lim && lb_aligned16(cell_scan + i) && lb_aligned16(ref_scan + i)) {
-            *reinterpret_cast<int4*>(cell_scan + i) = make_int4(v[0].a, v[1].a, v[2].a, v[3].a);
-            *reinterpret_cast<int4*>(ref_scan + i) = make_int4(v[0].b, v[1].b, v[2].b, v[3].b);
-        } else {
-            for (int c = 0; c < 4; c++) if (i + c < lim) { cell_scan[i + c] = v[c].a; ref_scan[i + c] = v[c].b; }
-        }
-    }
-};
+    s = Int2{wave_sum(s.a), wave_sum(s.b)};
+    if (lane_id() == 0) sums[tile] = s;
+}
+struct SumsIn { const Int2* v; __device__ Int2 operator()(int i) const { return v[i]; } };
+struct SumsOut { Int2* v; __device__ void operator()(int i, Int2 s) const { v[i] = s; } };
 
 // merge (merge.cu:189-278)
 template <bool IN_NARROW, bool OUT_NARROW>
 __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
                                                        const int* __restrict__ refs, const int* __restrict__ cell_flags,
-                                                       const int* __restrict__ cell_scan, const int* __restrict__ ref_scan,
-                                                       const int* __restrict__ merge_counts, int* new_cell_ids /* holds nexts on entry */,
+                                                       const Int2* __restrict__ tile_prefix, const int* __restrict__ merge_counts,
+                                                       int* new_cell_ids /* holds nexts on entry */,
                                                        void* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev,
                                                        const Int2* __restrict__ totals) {
     using FI = CellFmt<IN_NARROW>;
     using FO = CellFmt<OUT_NARROW>;
+    __shared__ Int2 lds[kWaves];
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id == 0) FO::store_end(new_cells, totals->a, totals->b);
-    if (id >= (n_dev ? *n_dev : num_cells) || !cell_flags[id]) return;
-    const int new_id = cell_scan[id];
+    const bool inside = id < (n_dev ? min(num_cells, *n_dev) : num_cells);
+    const int flag = inside ? cell_flags[id] : 0;
+    const int mc = inside ? merge_counts[id] : 0;
+    // {new cell id, first slot of the list} = exclusive scan of the kept cells' items: inside the tile here, the tile's offset
+    // from the scan over the tile sums
+    const Int2 item = keep_item(flag, mc);
+    const Int2 incl = wave_inclusive_scan(item);
+    if (lane_id() == 63) lds[wave_id()] = incl;
+    __syncthreads();
+    if (!flag) return;
+    Int2 at = tile_prefix[blockIdx.x];
+    for (int w = 0; w < wave_id(); w++) at = at + lds[w];
+    const int new_id = at.a + incl.a - item.a, nb = at.b + incl.b - item.b;
     CellRec cell = FI::load(cells, id);
     FI::finish(cells, id, cell);
-    const int mc = merge_counts[id];
-    const int nb = ref_scan[id];
     // the array still holds `nexts` (compute_merge_counts' neighbour, = what lookup_entry would find again): only the second
     // cell of a merging pair is overwritten by another thread, and that cell is residue (flag 0) -- it never gets here
     const int next_id = new_cell_ids[id];
@@ -330,15 +335,15 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* nexts = pool_alloc<int>(ctx, nc0 + 1);
     int* prevs = pool_alloc<int>(ctx, nc0 + 1);
     int* cell_flags = pool_alloc<int>(ctx, nc0 + 1);
-    int* cell_scan = pool_alloc<int>(ctx, nc0 + 1);
-    int* ref_scan = pool_alloc<int>(ctx, nc0 + 1);
-    Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(grid->num_cells)) + 1);
+    const int max_tiles = grid_blocks(grid->num_cells, kMergeTile);
+    Int2* tile_sums = pool_alloc<Int2>(ctx, size_t(max_tiles) + 1);
+    Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(max_tiles)) + 1);
     Int2* total = reinterpret_cast<Int2*>(ctx->dscratch);
     auto release = [&]() {
         hagrid_mem_free(ctx, merge_counts); hagrid_mem_free(ctx, nexts); hagrid_mem_free(ctx, prevs); hagrid_mem_free(ctx, cell_flags);
-        hagrid_mem_free(ctx, cell_scan); hagrid_mem_free(ctx, ref_scan); hagrid_mem_free(ctx, partials);
+        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials);
     };
-    if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !cell_scan || !ref_scan || !partials) {
+    if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !tile_sums || !partials) {
         release(); hagrid_mem_free(ctx, cells_b); hagrid_mem_free(ctx, refs_b);
         return HAGRID_ENOMEM;
     }
@@ -372,11 +377,13 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             else           merge_counts_kernel<false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
             HG_DBG(ctx);
             cell_flags_kernel<<<grid_blocks((num_cells + 3) / 4, kBlock), kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
-            if (!ctx_scan<Int2>(ctx, KeepIn{cell_flags, merge_counts, n_dev}, KeepOut{cell_scan, ref_scan, n_dev}, num_cells, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
+            const int tiles = grid_blocks(num_cells, kMergeTile);
+            merge_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, merge_counts, num_cells, n_dev, tile_sums, tiles); HG_DBG(ctx);
+            if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
             // (new_cell_ids = nexts: dead after the flags)
-            if (in_narrow)   merge_kernel<true, true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else if (narrow) merge_kernel<false, true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else             merge_kernel<false, false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, cell_scan, ref_scan, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            if (in_narrow)   merge_kernel<true, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else if (narrow) merge_kernel<false, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else             merge_kernel<false, false><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
             HG_DBG(ctx);
             in_narrow = narrow;
             remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
