@@ -4,16 +4,23 @@
 // compute_merge_counts (:91-142), compute_cell_flags (:145-170), compute_ref_counts (:173-186), merge (:189-278),
 // remap_entries (:281-290).  Results are bit-identical to the CPU oracle's.
 //
-// Differences in structure: the axis is a kernel argument (one kernel instead of three instantiations); the two
-// scans of an iteration (cells kept, references kept) run as ONE scan over int pairs with the per-cell count
-// computed inside the scan's input functor (compute_ref_counts disappears); one host round trip per
-// axis-iteration; the reference's warp-cooperative copy of unmerged runs (written for 32-lane warps,
-// merge.cu:245-270) is replaced by per-cell copies -- lists hold one to two references on average.
+// Differences in structure: the axis is a kernel argument (one kernel instead of three instantiations); one host round trip per
+// iteration (the three axis passes chain through device-side counts); the reference's warp-cooperative copy of unmerged runs
+// (written for 32-lane warps, merge.cu:245-270) is replaced by per-cell copies -- lists hold one to two references on average.
+// The passes are bound by the bytes they stream -- about 6 % of the cells merge in a pass, the rest is copied to its new place --
+// so between the passes a cell is a 16-byte working record (CellFmt<true>), and the two scans of an iteration (cells kept,
+// references kept) never write a value per cell: sums per 256-cell tile, one small scan over the tile sums, the scan inside a
+// tile by the merge kernel's own workgroup (compute_ref_counts disappears into the item).
 //
 // Tried and rejected (round 1): merging in place (cells keep their index, absorbed cells become tombstones with a
 // redirect, merged lists bump-allocated by a chained scan, one compaction at the end).  Bit-identical, but slower:
 // 2.9 instead of 2.5 ms at 1M triangles, because every pass then runs over all 7.4M original slots while compacting
 // after each pass shrinks the population to 4.2M -- the compaction pays for itself.
+// Round 2, also measured and dropped (profiles/NOTES.md): the merge kernel as the output functor of the look-back scan (the
+// persistent, occupancy-limited scan is the wrong host for gather work: merge 2.43 -> 3.76 ms); trying the next few array
+// slots as the neighbour before walking the voxel map (+8 us per candidate and pass: the walk is cache-friendly, the extra
+// load is not free); two or four cells per thread carried through compute_merge_counts in lock step (+0.15 / +0.39 ms: the
+// pass is bound by gather throughput and bytes, not by the latency of one chain); {count, next} as one 8-byte record (+-0).
 #include "ctx.h"
 #include "wave_prims.h"
 

@@ -243,6 +243,8 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
  * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
  * ray.h:22 documents; t is the same either way);
+ * "merge.narrow_cells" (1, default = hagrid_merge_grid keeps 16-byte working cell records between its passes when the virtual
+ * resolution is below 65536; 0 = the 32-byte record throughout; the result is the same);
  * "expand.subset_only" (1 = the reference's compiled setting, default; 0 = the precise expansion of
  * expand.cu:39-57,96-127 -- this one changes the grid, not the hits).  Returns HAGRID_EINVAL for an
  * unknown key or a value out of range.  Hits never depend on these settings ("traverse.id_is_steps" changes what Hit.id MEANS, not t). */
