@@ -150,7 +150,7 @@ __device__ __forceinline__ void write_union(const int* __restrict__ a, int na, c
 template <bool NARROW>
 __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
                                                               const int* __restrict__ refs, int* __restrict__ merge_counts,
-                                                              int* __restrict__ nexts, int* __restrict__ has_prev, int pass_tag, int empty_mask, int num_cells,
+                                                              int* __restrict__ nexts, unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask, int num_cells,
                                                               const int* __restrict__ n_dev) {
     using F = CellFmt<NARROW>;
     const int id = blockIdx.x * kBlock + threadIdx.x;
@@ -185,20 +185,21 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
     nexts[id] = next_id;
     // merge.cu:141 stores the predecessor's id; only "has a predecessor" is ever read (compute_cell_flags, merge.cu:152), so the
     // array holds the tag of the pass that last gave the cell one: no clearing between the passes
-    if (next_id >= 0) has_prev[next_id] = pass_tag;
+    if (next_id >= 0) has_prev[next_id] = (unsigned char)pass_tag;
 }
 
 // compute_cell_flags (merge.cu:145-170): chain heads mark every second cell of their chain as residue
-__global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const int* __restrict__ has_prev, int pass_tag,
-                                                            int* __restrict__ cell_flags, int num_cells, const int* __restrict__ n_dev) {
-    // four consecutive cells per thread (16-byte loads; the arrays come from the pool); flags are stored one by one because the
-    // flag of a cell with a predecessor is written by its chain's head
+__global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restrict__ nexts, const unsigned char* __restrict__ has_prev, int pass_tag,
+                                                            unsigned char* __restrict__ cell_flags, int num_cells, const int* __restrict__ n_dev) {
+    // four consecutive cells per thread (one 16-byte and one 4-byte load; the arrays come from the pool); flags are bytes and are
+    // stored one by one because the flag of a cell with a predecessor is written by its chain's head
     const int id = (blockIdx.x * kBlock + threadIdx.x) * 4;
     const int n = n_dev ? *n_dev : num_cells;
     if (id >= n) return;
     int hp[4], nx[4];
     if (id + 4 <= n) {
-        const int4 h = *reinterpret_cast<const int4*>(has_prev + id), x = *reinterpret_cast<const int4*>(nexts + id);
+        const uchar4 h = *reinterpret_cast<const uchar4*>(has_prev + id);
+        const int4 x = *reinterpret_cast<const int4*>(nexts + id);
         hp[0] = h.x; hp[1] = h.y; hp[2] = h.z; hp[3] = h.w; nx[0] = x.x; nx[1] = x.y; nx[2] = x.z; nx[3] = x.w;
     } else {
         for (int c = 0; c < 4; c++) { hp[c] = id + c < n ? has_prev[id + c] : pass_tag; nx[c] = id + c < n ? nexts[id + c] : -1; }
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(kBlock) cell_flags_kernel(const int* __restric
 constexpr int kMergeTile = kBlock;                  // cells per workgroup of merge_kernel
 __device__ __forceinline__ Int2 keep_item(int flag, int count) { return Int2{ flag ? 1 : 0, flag ? (count >= 0 ? count : -(count + 1)) : 0 }; }
 
-__global__ void __launch_bounds__(kBlock) merge_tile_sums(const int* __restrict__ cell_flags, const int* __restrict__ merge_counts, int num_cells,
+__global__ void __launch_bounds__(kBlock) merge_tile_sums(const unsigned char* __restrict__ cell_flags, const int* __restrict__ merge_counts, int num_cells,
                                                           const int* __restrict__ n_dev, Int2* __restrict__ sums, int num_tiles) {
     static_assert(kMergeTile == 64 * 4, "a wavefront covers one tile with four cells per lane");
     const int tile = blockIdx.x * kWaves + wave_id();
@@ -233,7 +234,8 @@ __global__ void __launch_bounds__(kBlock) merge_tile_sums(const int* __restrict_
     const int i = tile * kMergeTile + lane_id() * 4;
     Int2 s{0, 0};
     if (i + 4 <= n) {
-        const int4 f = *reinterpret_cast<const int4*>(cell_flags + i), m = *reinterpret_cast<const int4*>(merge_counts + i);
+        const uchar4 f = *reinterpret_cast<const uchar4*>(cell_flags + i);
+        const int4 m = *reinterpret_cast<const int4*>(merge_counts + i);
         s = keep_item(f.x, m.x) + keep_item(f.y, m.y) + keep_item(f.z, m.z) + keep_item(f.w, m.w);
     } else {
         for (int c = 0; c < 4; c++) if (i + c < n) s = s + keep_item(cell_flags[i + c], merge_counts[i + c]);
@@ -247,7 +249,7 @@ struct SumsOut { Int2* v; __device__ void operator()(int i, Int2 s) const { v[i]
 // merge (merge.cu:189-278)
 template <bool IN_NARROW, bool OUT_NARROW>
 __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
-                                                       const int* __restrict__ refs, const int* __restrict__ cell_flags,
+                                                       const int* __restrict__ refs, const unsigned char* __restrict__ cell_flags,
                                                        const Int2* __restrict__ tile_prefix, const int* __restrict__ merge_counts,
                                                        int* new_cell_ids /* holds nexts on entry */,
                                                        void* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev,
@@ -340,8 +342,8 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* refs_b = pool_alloc<int>(ctx, nr0);
     int* merge_counts = pool_alloc<int>(ctx, nc0 + 1);
     int* nexts = pool_alloc<int>(ctx, nc0 + 1);
-    int* prevs = pool_alloc<int>(ctx, nc0 + 1);
-    int* cell_flags = pool_alloc<int>(ctx, nc0 + 1);
+    unsigned char* prevs = pool_alloc<unsigned char>(ctx, nc0 + 4);
+    unsigned char* cell_flags = pool_alloc<unsigned char>(ctx, nc0 + 4);
     const int max_tiles = grid_blocks(grid->num_cells, kMergeTile);
     Int2* tile_sums = pool_alloc<Int2>(ctx, size_t(max_tiles) + 1);
     Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(max_tiles)) + 1);
@@ -367,7 +369,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int rc = HAGRID_OK;
     int prev_num_cells = 0, iter = 0, pass_tag = 0;
     bool in_narrow = false;                                                // the caller's cells are 32-byte records
-    (void)hipMemsetAsync(prevs, 0, nc0 * sizeof(int), st);                 // tag 0 = never had a predecessor
+    (void)hipMemsetAsync(prevs, 0, nc0, st);                               // tag 0 = never had a predecessor
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
         const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
@@ -379,7 +381,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             Int2* tot = total + axis;
             const int* n_dev = axis ? &total[axis - 1].a : nullptr;
             const Entry* ent = reinterpret_cast<const Entry*>(entries);
-            pass_tag++;
+            if (++pass_tag == 256) { pass_tag = 1; (void)hipMemsetAsync(prevs, 0, nc0, st); }      // tags are bytes
             if (in_narrow) merge_counts_kernel<true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
             else           merge_counts_kernel<false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
             HG_DBG(ctx);
