@@ -18,7 +18,7 @@ using namespace hagrid_impl;
 namespace {
 
 struct ExpandK { ivec3 dims; ivec3 top; int shift; vec3 gmin, cell_size, grid_inv; };   // expand.cu:5-9
-constexpr int kChanged = 1 << 8;     // cell_flags: the cell's box changed in the previous pass (bits 0-2: expand.cu:145-182)
+constexpr int kChanged = 1 << 3;     // cell_flags (one byte per cell): the cell's box changed in the previous pass (bits 0-2: expand.cu:145-182)
 struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
 
 __device__ __forceinline__ CellRec load_cell(const Cell* cells, int i) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __rest
 // by the gather rate, not by the chains (two lanes per cell: +12 %), and keeps one thread per cell.
 template <int axis, bool SUBSET_ONLY, bool PAIRED>
 __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restrict__ entries, const int* __restrict__ refs, const float4* __restrict__ tris,
-                                          const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags, int id, int flags, bool up) {
+                                          const Cell* __restrict__ cells, Cell* __restrict__ new_cells, unsigned char* __restrict__ cell_flags, int id, int flags, bool up) {
     CellRec cell = load_cell(cells, id);
     bool flag = false;
     int ov1, ov2;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restr
     if (axis == 0) { cell.lo.x += ov1; cell.hi.x += ov2; }
     if (axis == 1) { cell.lo.y += ov1; cell.hi.y += ov2; }
     if (axis == 2) { cell.lo.z += ov1; cell.hi.z += ov2; }
-    cell_flags[id] = (flag ? 1 << axis : 0) | (flags & ~((1 << axis) | kChanged)) | ((ov1 | ov2) ? kChanged : 0);
+    cell_flags[id] = (unsigned char)((flag ? 1 << axis : 0) | (flags & ~((1 << axis) | kChanged)) | ((ov1 | ov2) ? kChanged : 0));
     int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
     out[0] = make_int4(cell.lo.x, cell.lo.y, cell.lo.z, cell.begin);
     out[1] = make_int4(cell.hi.x, cell.hi.y, cell.hi.z, cell.end);
@@ -169,7 +169,7 @@ __device__ __forceinline__ void grow_cell(const ExpandK& k, const Entry* __restr
 template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
-                                                       int* __restrict__ cell_flags, int num_cells) {
+                                                       unsigned char* __restrict__ cell_flags, int num_cells) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_cells) return;
     const int flags = cell_flags[id];
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* _
         int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
         const int4 a = p[0], b = p[1];
         out[0] = a; out[1] = b;
-        if (flags & kChanged) cell_flags[id] = flags & ~kChanged;
+        if (flags & kChanged) cell_flags[id] = (unsigned char)(flags & ~kChanged);
         return;
     }
     grow_cell<axis, SUBSET_ONLY, false>(k, entries, refs, tris, cells, new_cells, cell_flags, id, flags, false);
@@ -198,7 +198,7 @@ constexpr int kSelectItems = 16;                      // cells per thread
 constexpr int kSelectTile = kBlock * kSelectItems;    // cells per workgroup
 
 template <int axis>
-__global__ void __launch_bounds__(kBlock) expand_select(const Cell* __restrict__ cells, Cell* __restrict__ new_cells, int* __restrict__ cell_flags,
+__global__ void __launch_bounds__(kBlock) expand_select(const Cell* __restrict__ cells, Cell* __restrict__ new_cells, unsigned char* __restrict__ cell_flags,
                                                         int num_cells, int* __restrict__ list, int* __restrict__ count) {
     __shared__ int tile_list[kSelectTile];
     __shared__ int tile_count, tile_base;
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kBlock) expand_select(const Cell* __restrict__
             int4* out = reinterpret_cast<int4*>(new_cells) + 2 * size_t(id);
             const int4 a = p[0], b = p[1];
             out[0] = a; out[1] = b;
-            cell_flags[id] = flags & ~kChanged;
+            cell_flags[id] = (unsigned char)(flags & ~kChanged);
         }
     }
     __syncthreads();
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) expand_select(const Cell* __restrict__
 template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                         const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
-                                                        int* __restrict__ cell_flags, const int* __restrict__ list, const int* __restrict__ count) {
+                                                        unsigned char* __restrict__ cell_flags, const int* __restrict__ list, const int* __restrict__ count) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int i = t >> 1;                                          // two lanes per listed cell, one per direction
     if (i >= *count) return;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* 
 
 template <int axis, bool SUBSET_ONLY>
 void listed_step(hipStream_t st, const ExpandK& k, const Entry* entries, const int* refs, const float4* tris, const Cell* cells, Cell* other,
-                 int* flags, int n, int* list, int* count) {
+                 unsigned char* flags, int n, int* list, int* count) {
     expand_select<axis><<<grid_blocks(n, kSelectTile), kBlock, 0, st>>>(cells, other, flags, n, list, count);
     expand_listed<axis, SUBSET_ONLY><<<grid_blocks(2ll * n, kBlock), kBlock, 0, st>>>(k, entries, refs, tris, cells, other, flags, list, count);
 }
@@ -277,9 +277,9 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const int n = grid->num_cells;
     Cell* cells = static_cast<Cell*>(grid->cells);
     Cell* other = pool_alloc<Cell>(ctx, size_t(n));
-    int* flags = pool_alloc<int>(ctx, size_t(n));
+    unsigned char* flags = pool_alloc<unsigned char>(ctx, size_t(n));
     if (!other || !flags) { hagrid_mem_free(ctx, other); hagrid_mem_free(ctx, flags); return HAGRID_ENOMEM; }
-    (void)hipMemsetAsync(flags, 0xFF, size_t(n) * sizeof(int), st);                     // expand.cu:206 (errors surface at the final check)
+    (void)hipMemsetAsync(flags, 0xFF, size_t(n), st);                     // expand.cu:206 (errors surface at the final check)
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
