@@ -71,7 +71,6 @@ struct hagrid_ctx {
     int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
     int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
-    int opt_pairs = 0;           // traversal-image kernel with pooled (ray, triangle) tests per wavefront (experiment)
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller

@@ -781,174 +781,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 }
 
 
-#ifndef HG_PAIRS_MIN
-#define HG_PAIRS_MIN 2
-#endif
-// ---- image kernel with intra-wavefront (ray, triangle) PAIR expansion (uniform flat narrow image, closest hit) --------------
-// The address / L1 path of a CU takes a fixed ~12 cycles per wavefront load whatever the number of live lanes
-// (profiles/micro_r2l_vector_memory.txt), and in the plain kernel a cell step costs three loads per id of the LONGEST list among
-// the live lanes.  Here the lanes of a wavefront pool the triangle tests of a step: every live lane lists its (id, owner) pairs in
-// LDS, the pairs are dealt to ALL 64 lanes (finished lanes stay in the loop for this), each pair is tested against the owner's ray
-// (kept in LDS for the whole traversal) up to the comparison with the ray's current tmax, and the owners then take their candidates
-// in list order through that last comparison -- the arithmetic of intersect_prim_ray (prims.h:113-137) in the same order, so the
-// hits are the plain kernel's bit for bit.  Steps without a list of two or more ids, and steps where a lane holds a list by index,
-// run the plain loops.
-__global__ void __launch_bounds__(64, 8) traverse_kernel_img_pairs(const TraverseArgs a) {
-    __shared__ float4 s_ray[2 * 64];                    // [lane] = org, tmin; [64 + lane] = dir
-    __shared__ uint2 s_pair[4 * 64];                    // {triangle id, owner lane}; the lane that tests pair p overwrites slot p with
-    float2* s_res = reinterpret_cast<float2*>(s_pair);  // the result {t scaled by |det| (+inf: rejected), |det|}
-    const int lane = threadIdx.x;
-    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
-    const int w = !perm ? tile_packet_row_len(a) : 0;
-    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-    const int slot = w ? tile_packet_slot(a, w, b, lane) : b * 64 + lane;
-    const bool valid = slot < a.num_rays;
-    const int id = valid ? (perm ? perm[slot] : slot) : 0;
-
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 1.0f), r1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f);      // (an empty interval for lanes without a ray)
-    if (valid) { r0 = nt_load4(a.rays + 2 * size_t(id)); r1 = nt_load4(a.rays + 2 * size_t(id) + 1); }
-    s_ray[lane] = r0; s_ray[64 + lane] = make_float4(r1.x, r1.y, r1.z, 0.0f);
-    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
-    const float tmin = r0.w, tmax = r1.w;
-    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
-    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
-    const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
-    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
-    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
-    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
-    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
-    bool alive = valid && !(tstart > tend);
-    int hit_id = -1;
-    float hit_t = tmax;
-
-    auto top_index = [&](int x, int y, int z) -> int {
-        return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
-    };
-    auto record = [&](int x, int y, int z, uint4& ra, uint4& rb) {
-        const int d = a.shift, m = (1 << d) - 1;
-        const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-        const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + (((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 5));
-        ra = p[0]; rb = p[1];
-    };
-    auto tri_at = [&](int ref) -> Tri {
-        uint32_t r3, o;
-        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
-        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-        return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-    };
-    auto below = [&](unsigned long long m) -> int { return int(__builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u))); };
-
-    const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;
-    const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;
-    const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
-    int vx = 0, vy = 0, vz = 0;
-    uint4 ca = make_uint4(0u, 0u, 0u, 0u), cb = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (alive) {
-        const vec3 fv = (tstart * dir + org - gmin) * ginv;
-        vx = min(max(int(fv.x), 0), a.dims_x - 1);
-        vy = min(max(int(fv.y), 0), a.dims_y - 1);
-        vz = min(max(int(fv.z), 0), a.dims_z - 1);
-        record(vx, vy, vz, ca, cb);
-    }
-    __syncthreads();                                    // the rays are in LDS
-
-    while (__ballot(alive) != 0ull) {
-        float texit = 0.0f;
-        bool outside = false, by_index = false;
-        uint4 na = ca, nb = cb;
-        int k = 0;
-        if (alive) {
-            const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
-            const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
-            texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
-            const vec3 ev = (texit * dir + org - gmin) * ginv;
-            const int nx = texit == tcell.x ? cx + bx : int(ev.x);
-            const int ny = texit == tcell.y ? cy + by : int(ev.y);
-            const int nz = texit == tcell.z ? cz + bz : int(ev.z);
-            vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z);
-            outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
-            record(outside ? 0 : vx, outside ? 0 : vy, outside ? 0 : vz, na, nb);
-            by_index = int(ca.w) < 0;
-            k = by_index ? 0 : int(int(cb.x) >= 0) + int(int(cb.y) >= 0) + int(int(cb.z) >= 0) + int(int(cb.w) >= 0);
-        }
-        const unsigned long long m1 = __ballot(k > 1);
-        if (__ballot(alive && by_index) == 0ull && __ballot(k >= HG_PAIRS_MIN) != 0ull) {
-            // ---- pooled tests ----
-            const unsigned long long m0 = __ballot(k > 0), m2 = __ballot(k > 2), m3 = __ballot(k > 3);
-            const int base1 = __popcll(m0), base2 = base1 + __popcll(m1), base3 = base2 + __popcll(m2), pairs = base3 + __popcll(m3);
-            const int s0 = below(m0), s1 = base1 + below(m1), s2 = base2 + below(m2), s3 = base3 + below(m3);
-            if (k > 0) s_pair[s0] = make_uint2(cb.x, uint32_t(lane));
-            if (k > 1) s_pair[s1] = make_uint2(cb.y, uint32_t(lane));
-            if (k > 2) s_pair[s2] = make_uint2(cb.z, uint32_t(lane));
-            if (k > 3) s_pair[s3] = make_uint2(cb.w, uint32_t(lane));
-            __syncthreads();
-            for (int p0 = 0; p0 < pairs; p0 += 64) {
-                const int p = p0 + lane;
-                if (p < pairs) {
-                    const uint2 pr = s_pair[p];
-                    const float4 q0 = s_ray[pr.y], q1 = s_ray[64 + pr.y];
-                    const Tri tri = tri_at(int(pr.x));
-                    // intersect_prim_ray (prims.h:113-137) up to the comparison with tmax
-                    const vec3 o(q0.x, q0.y, q0.z), d(q1.x, q1.y, q1.z);
-                    const vec3 n = tri.normal();
-                    const vec3 c = tri.v0 - o;
-                    const vec3 r = cross(d, c);
-                    const float det = dot(n, d);
-                    const float abs_det = detail::fabs1(det);
-                    const float u = prodsign(dot(r, tri.e2), det);
-                    const float v = prodsign(dot(r, tri.e1), det);
-                    const float ww = abs_det - u - v;
-                    const float eps = 1e-9f;
-                    float t = __builtin_inff();
-                    if (u >= -eps && v >= -eps && ww >= -eps) {
-                        const float tt = prodsign(dot(n, c), det);
-                        if (tt >= abs_det * q0.w) t = tt;
-                    }
-                    s_res[p] = make_float2(t, abs_det);
-                }
-            }
-            __syncthreads();
-            // the owners take their candidates in list order: the rest of intersect_prim_ray
-            auto take = [&](int s, uint32_t ref) {
-                const float2 c = s_res[s];
-                if (c.y * hit_t > c.x) { const float inv_det = 1.0f / c.y; hit_t = c.x * inv_det; hit_id = int(ref); }
-            };
-            if (k > 0) take(s0, cb.x);
-            if (k > 1) take(s1, cb.y);
-            if (k > 2) take(s2, cb.z);
-            if (k > 3) take(s3, cb.w);
-        } else if (alive) {
-            // ---- the plain loops (traverse_kernel_img) ----
-            auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
-            uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;
-            int ref = int(cb.x);
-            if (by_index) {
-                q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                ref = -1;
-                if (q1 < q2) ref = ref_at(q1);
-                q1++;
-            }
-#pragma unroll 1
-            while (ref >= 0) {
-                int next;
-                if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
-                Hit h(hit_id, hit_t, 0.0f, 0.0f);
-                intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit_t), ref, h);
-                hit_id = h.id; hit_t = h.t;
-                ref = next;
-            }
-        }
-        if (alive && (hit_t <= texit || outside)) alive = false;
-        ca = na; cb = nb;
-    }
-    if (valid) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-}
-
-
 // ---- v3: persistent wavefronts, lane refill, vote-scheduled phases -------------------------------------------------
 // Profile of v1/v2 on the 1M-ray batch (profiles/): the SIMDs issue ~80 % of the time while only ~19 % of the lanes
 // of an issued VALU instruction are live -- the kernel is instruction-issue bound and 4 of 5 lanes idle, because (a) a
@@ -1406,8 +1238,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
-        if (ctx->opt_pairs && ctx->image.flat && ctx->image.uniform && narrow && !flags) traverse_kernel_img_pairs<<<blocks, 64, 0, ctx->stream>>>(a);
-        else launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
+        launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1448,7 +1279,6 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},
-        {"traverse.pairs", &ctx->opt_pairs, 0, 1},
 
     };
     for (auto& t : table)
