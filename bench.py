@@ -284,7 +284,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 # what binds according to the counters (profiles/): the working set is L2 / Infinity-Cache resident, the kernel is
                 # limited by instruction issue with partly idle wavefronts and by the line rate of the vector L1, NOT by HBM bandwidth
-                "binding_resource": "instruction issue + vector-L1 line rate (cache-resident working set); HBM itself runs at `hbm_measured`",
+                "binding_resource": "the CUs' vector-memory address/L1 path (~12 cycles per wavefront load + 1-10 per live lane and line: 84 % busy, profiles/micro_r2l_vector_memory.txt); working set cache-resident, HBM itself runs at `hbm_measured`",
                 "hbm_measured": None if traffic is None else round(traffic / (kernel_ms * 1e6), 1),
                 "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "l2_hit_rate": l2_hit,
