@@ -268,6 +268,8 @@ __device__ __forceinline__ int split_mask(const BuildK& k, ivec3 lo, ivec3 hi, c
     return mask;
 }
 
+constexpr int kNoRank = int(0x80000000);        // ranks[]: a reference without a cell
+
 // mark_kept_refs (build.cu:305-314) + compute_split_masks + the popcount reduction of build.cu:597, and the
 // per-cell reference count that replaces the final sort's histogram.  totals[0] += children, totals[1] += kept.
 __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
@@ -281,21 +283,24 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
     // would run into the ~88 atomics/us ceiling of a single L2 word)
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < num_refs; i += gridDim.x * kBlock) {
         const int c = cell_ids[i];
-        int m = 0;
+        int m = 0, r = kNoRank;
         if (c >= 0) {
-            if ((entries[c] & 3u) == 0) {
+            const uint32_t e = entries[c];
+            if ((e & 3u) == 0) {
                 kept++;
                 // the count and the reference's slot inside its cell's list in ONE atomic: random atomics run at ~26 per ns on this
                 // part whatever their scope or whether they return a value (tools/micro/atomic_scope.hip), so the scatter pass must
                 // not pay for a second one per reference
-                ranks[i] = atomicAdd(cell_counts + c, 1);
+                r = atomicAdd(cell_counts + c, 1);
             } else {
                 const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
                 const int4 a = p[0], b = p[1];
                 m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref_ids[i]));
                 children += __popc(m);
+                r = -int(e >> 2) - 1;                  // where the cell's children start: emit_child_refs need not look the entry up again
             }
         }
+        ranks[i] = r;                                  // >= 0: slot of a kept reference; < 0: not kept (scatter_kept_refs skips it unseen)
         masks[i] = (unsigned char)m;
     }
     children = block_sum(children, lds);
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
 // 2048 references: block-wide prefix over the per-thread child counts, one atomic per tile.
 constexpr int kEmitItems = 8;
 __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                          const unsigned char* __restrict__ masks, const uint32_t* __restrict__ entries,
+                                                          const unsigned char* __restrict__ masks, const int* __restrict__ ranks,
                                                           const unsigned char* __restrict__ depth_left, uint32_t* __restrict__ new_entries,
                                                           int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
     __shared__ int lds[kWaves];
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
                 const int i = base + j * kBlock + threadIdx.x;
                 const int ref = ref_ids[i];
                 const int cell = cell_ids[i];
-                const int begin = int(entries[cell] >> 2);
+                const int begin = -ranks[i] - 1;                           // classify_refs left the children's first cell here
                 const bool splits_again = depth_left[cell] > 1;           // the children still have a level to go
                 while (mm) {
                     const int child = __ffs(mm) - 1;
@@ -424,13 +429,12 @@ __global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restric
 // copy_refs + remap_refs + the scatter half of the sort (build.cu:634-647, :681, :691): the slot inside the cell's list is
 // the rank classify_refs drew for the reference
 __global__ void __launch_bounds__(kBlock) scatter_kept_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                            const uint32_t* __restrict__ entries, const int* __restrict__ ranks,
-                                                            const int* __restrict__ ref_begin, int* __restrict__ out_refs) {
+                                                            const int* __restrict__ ranks, const int* __restrict__ ref_begin, int* __restrict__ out_refs) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_refs) return;
-    const int c = cell_ids[i];
-    if (c < 0 || (entries[c] & 3u) != 0) return;
-    out_refs[ref_begin[c] + ranks[i]] = ref_ids[i];
+    const int r = ranks[i];
+    if (r < 0) return;                                 // split further or without a cell: classify_refs marked it
+    out_refs[ref_begin[cell_ids[i]] + r] = ref_ids[i];
 }
 
 } // namespace
@@ -443,13 +447,13 @@ struct PlainOut { int* v; __device__ void operator()(int i, int s) const { v[i] 
 // Puts every cell's reference list in ascending order (the canonical order: primitive ids within a cell
 // are distinct).  Lists are short -- a handful of references -- so each lane sorts its own cell in place:
 // insertion sort, preceded by Shell passes for the rare long list.
-__global__ void __launch_bounds__(kBlock) sort_cell_refs(const Cell* __restrict__ cells, int num_cells, int* __restrict__ refs) {
+// (one launch per level over the level's own 4-byte counts and list starts: a quarter of the bytes of the finished cells)
+__global__ void __launch_bounds__(kBlock) sort_cell_refs(const int* __restrict__ cell_counts, const int* __restrict__ ref_begin, int num_cells, int* __restrict__ refs) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_cells) return;
-    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
-    const int begin = p[0].w, n = p[1].w - begin;
+    const int n = cell_counts[i];                      // 0 for a cell that was split further
     if (n < 2) return;
-    int* r = refs + begin;
+    int* r = refs + ref_begin[i];
     if (n > 24) {
         const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
         for (int g = 0; g < 8; g++) {
@@ -589,7 +593,7 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
-        emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.entries,
+        emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.ranks,
                                                                              L.depth, N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
         emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, L.depth, N.cells, N.depth); HG_DBG(ctx);
         tmp.drop(masks);
@@ -629,10 +633,10 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         concat_level<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.cell_counts, L.start_cell, L.ref_begin,
                                                                           L.num_cells, off, out_cells, out_entries); HG_DBG(ctx);
         if (L.num_refs > 0)
-            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.entries, L.ranks,
-                                                                                  L.ref_begin, out_refs); HG_DBG(ctx);
+            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.ranks, L.ref_begin, out_refs); HG_DBG(ctx);
+        if (L.num_refs > 0)
+            sort_cell_refs<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.cell_counts, L.ref_begin, L.num_cells, out_refs); HG_DBG(ctx);
     }
-    sort_cell_refs<<<grid_blocks(new_total_cells, kBlock), kBlock, 0, st>>>(out_cells, new_total_cells, out_refs); HG_DBG(ctx);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);      // temporaries are released below
     if (e != hipSuccess) {
