@@ -202,14 +202,14 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
 
 // emit_top_cells (build.cu:332-351)
 // + the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per level")
-__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims,
-                                                         unsigned char* __restrict__ depth_left) {
+// While a level is under construction the `begin` word of its cells is free: it carries the number of levels the cell may still
+// be split, where classify_refs finds it in the record it loads anyway.
+__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_top) return;
-    depth_left[id] = (unsigned char)min(log_dims[id], 255);
     const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
     const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
-    store_cell(cells, id, lo, 0, lo + ivec3(1 << k.shift), 0);
+    store_cell(cells, id, lo, log_dims[id], lo + ivec3(1 << k.shift), 0);
 }
 
 // ---- one subdivision level -----------------------------------------------------------------------------
@@ -297,7 +297,9 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
                 const int4 a = p[0], b = p[1];
                 m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref_ids[i]));
                 children += __popc(m);
-                r = -int(e >> 2) - 1;                  // where the cell's children start: emit_child_refs need not look the entry up again
+                // where the cell's children start and whether they split again (a.w: levels left): emit_child_refs need not look
+                // anything up
+                r = -int(((e >> 2) << 1) | uint32_t(a.w > 1)) - 1;
             }
         }
         ranks[i] = r;                                  // >= 0: slot of a kept reference; < 0: not kept (scatter_kept_refs skips it unseen)
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
 constexpr int kEmitItems = 8;
 __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
                                                           const unsigned char* __restrict__ masks, const int* __restrict__ ranks,
-                                                          const unsigned char* __restrict__ depth_left, uint32_t* __restrict__ new_entries,
+                                                          uint32_t* __restrict__ new_entries,
                                                           int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
     __shared__ int lds[kWaves];
     __shared__ int tile_base;
@@ -345,9 +347,9 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
             if (mm) {
                 const int i = base + j * kBlock + threadIdx.x;
                 const int ref = ref_ids[i];
-                const int cell = cell_ids[i];
-                const int begin = -ranks[i] - 1;                           // classify_refs left the children's first cell here
-                const bool splits_again = depth_left[cell] > 1;           // the children still have a level to go
+                const int code = -ranks[i] - 1;                            // classify_refs left the children's first cell here
+                const int begin = code >> 1;
+                const bool splits_again = (code & 1) != 0;                 // the children still have a level to go
                 while (mm) {
                     const int child = __ffs(mm) - 1;
                     mm &= mm - 1;
@@ -364,8 +366,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
 
 // emit_new_cells (build.cu:354-383): 8 cells x 32 B = 256 contiguous bytes per split cell
 __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, int num_cells,
-                                                           const unsigned char* __restrict__ depth_left, Cell* __restrict__ new_cells,
-                                                           unsigned char* __restrict__ new_depth_left) {
+                                                           Cell* __restrict__ new_cells) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int id = t >> 3, child = t & 7;     // 8 lanes per parent: each lane stores one child
     if (id >= num_cells) return;
@@ -375,8 +376,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __res
     const int4 a = p[0], b = p[1];
     const int inc = (b.x - a.x) >> 1;
     const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
-    store_cell(new_cells, int(e >> 2) + child, lo, 0, lo + ivec3(inc), 0);
-    new_depth_left[int(e >> 2) + child] = (unsigned char)(depth_left[id] - 1);
+    store_cell(new_cells, int(e >> 2) + child, lo, a.w - 1, lo + ivec3(inc), 0);       // (a.w: levels left, see emit_top_cells)
 }
 
 // ---- concatenation ---------------------------------------------------------------------------------------
@@ -479,7 +479,6 @@ struct Level {
     Cell* cells = nullptr; uint32_t* entries = nullptr; int num_cells = 0;
     int* cell_counts = nullptr;                 // kept references per cell
     int* ranks = nullptr;                       // per kept reference: its slot inside its cell's list
-    unsigned char* depth = nullptr;             // per cell: levels it may still be split
     int* start_cell = nullptr; int* ref_begin = nullptr;
 };
 
@@ -552,12 +551,11 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         L.cells = tmp.get<Cell>(size_t(num_top)); L.entries = tmp.get<uint32_t>(size_t(num_top) + 1);
         L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
         L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
-        L.depth = tmp.get<unsigned char>(size_t(num_top));
-        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin || !L.depth) return HAGRID_ENOMEM;
+        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
         HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(L.cell_counts, 0, size_t(num_top) * sizeof(int), st));
         emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids, log_dims, L.entries); HG_DBG(ctx);
-        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims, L.depth); HG_DBG(ctx);
+        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims); HG_DBG(ctx);
         levels.push_back(L);
     }
     tmp.drop(start_emit);
@@ -588,14 +586,13 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         N.cells = tmp.get<Cell>(size_t(num_new_cells)); N.entries = tmp.get<uint32_t>(size_t(num_new_cells) + 1);
         N.cell_counts = tmp.get<int>(size_t(num_new_cells)); N.ranks = tmp.get<int>(size_t(num_children));
         N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
-        N.depth = tmp.get<unsigned char>(size_t(num_new_cells));
-        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin || !N.depth) return HAGRID_ENOMEM;
+        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
         HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
         HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
         emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.ranks,
-                                                                             L.depth, N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
-        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, L.depth, N.cells, N.depth); HG_DBG(ctx);
+                                                                             N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
+        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells); HG_DBG(ctx);
         tmp.drop(masks);
         levels.push_back(N);
     }
