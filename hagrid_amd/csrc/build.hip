@@ -204,9 +204,13 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
 // + the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per level")
 // While a level is under construction the `begin` word of its cells is free: it carries the number of levels the cell may still
 // be split, where classify_refs finds it in the record it loads anyway.
-__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims) {
+// The kernel that creates a level's cells also clears their voxel-map words and reference counts (it runs before the
+// references of the level are handed out): no fill launches.
+__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims,
+                                                         uint32_t* __restrict__ entries, int* __restrict__ cell_counts) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_top) return;
+    entries[id] = 0u; cell_counts[id] = 0;
     const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
     const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
     store_cell(cells, id, lo, log_dims[id], lo + ivec3(1 << k.shift), 0);
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict_
 
 // emit_new_cells (build.cu:354-383): 8 cells x 32 B = 256 contiguous bytes per split cell
 __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, int num_cells,
-                                                           Cell* __restrict__ new_cells) {
+                                                           Cell* __restrict__ new_cells, uint32_t* __restrict__ new_entries, int* __restrict__ new_cell_counts) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int id = t >> 3, child = t & 7;     // 8 lanes per parent: each lane stores one child
     if (id >= num_cells) return;
@@ -377,6 +381,7 @@ __global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __res
     const int inc = (b.x - a.x) >> 1;
     const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
     store_cell(new_cells, int(e >> 2) + child, lo, a.w - 1, lo + ivec3(inc), 0);       // (a.w: levels left, see emit_top_cells)
+    new_entries[int(e >> 2) + child] = 0u; new_cell_counts[int(e >> 2) + child] = 0;
 }
 
 // ---- concatenation ---------------------------------------------------------------------------------------
@@ -552,10 +557,8 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
         L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
         if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
-        HG_HIP(ctx, hipMemsetAsync(L.entries, 0, (size_t(num_top) + 1) * sizeof(uint32_t), st));
-        HG_HIP(ctx, hipMemsetAsync(L.cell_counts, 0, size_t(num_top) * sizeof(int), st));
+        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims, L.entries, L.cell_counts); HG_DBG(ctx);
         emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids, log_dims, L.entries); HG_DBG(ctx);
-        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims); HG_DBG(ctx);
         levels.push_back(L);
     }
     tmp.drop(start_emit);
@@ -587,12 +590,10 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
         N.cell_counts = tmp.get<int>(size_t(num_new_cells)); N.ranks = tmp.get<int>(size_t(num_children));
         N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
         if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
-        HG_HIP(ctx, hipMemsetAsync(N.entries, 0, (size_t(num_new_cells) + 1) * sizeof(uint32_t), st));
-        HG_HIP(ctx, hipMemsetAsync(N.cell_counts, 0, size_t(num_new_cells) * sizeof(int), st));
         int* cursor = tot + 3;                                              // zeroed above
+        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells, N.entries, N.cell_counts); HG_DBG(ctx);
         emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.ranks,
                                                                              N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
-        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells); HG_DBG(ctx);
         tmp.drop(masks);
         levels.push_back(N);
     }
