@@ -22,5 +22,5 @@ for _ in range(iters):
     grid = g
 for _ in range(iters):
     grid.free(); t.append(api.profile(lambda: api.build_all(mem, d_tris, n, grid=grid), mem))
-print(json.dumps({"tris": n, "build_ms_mean": round(float(np.mean(t)), 3), "min": round(min(t), 3),
+print(json.dumps({"tris": n, "build_ms_mean": round(float(np.mean(t)), 3), "median": round(float(np.median(t)), 3), "min": round(min(t), 3),
                   "stages_ms": {k: round(float(np.mean(v)), 3) for k, v in stages.items()}, "grid": grid.summary()}))
