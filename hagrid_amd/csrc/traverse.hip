@@ -610,6 +610,9 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
+#ifndef HG_SOLO
+#define HG_SOLO 1
+#endif
 template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
@@ -688,6 +691,20 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
 
+        // A round in which ONE lane is live (23 % of the triangle rounds of the 1M-ray batch, profiles/dev_r2_generations.txt item 10)
+        // still costs the CU's vector-memory path its fixed ~12 cycles per load: there the triangle comes through the scalar cache.
+        auto tri_solo = [&](int ref) -> Tri {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const char* base = reinterpret_cast<const char*>(a.tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u;
+            f4 p0, p1, p2;
+            asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(p0), "=&s"(p1), "=&s"(p2) : "s"(base) : "memory");
+            return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+        };
+        auto tri_for = [&](int ref) -> Tri {
+            if (HG_SOLO && UNIFORM && NARROW && __popcll(__ballot(true)) == 1) return tri_solo(ref);
+            return tri_at(ref);
+        };
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
         const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
         const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
@@ -741,8 +758,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
 #pragma unroll 1
                 while (ref >= 0) {
-                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                     ref = (ANY && got) ? -1 : int(q1);
                     q1 = q2; q2 = q3; q3 = ~0u;
                 }
@@ -764,8 +781,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                     }
                     int pre = -1;
                     if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
-                    const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                         : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                     if (!UNIFORM) {
                         if (by_index) { next = pre; q1++; }
                         else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
