@@ -695,10 +695,9 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         // still costs the CU's vector-memory path its fixed ~12 cycles per load: there the triangle comes through the scalar cache.
         auto tri_solo = [&](int ref) -> Tri {
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const char* base = reinterpret_cast<const char*>(a.tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u;
-            f4 p0, p1, p2;
-            asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(p0), "=&s"(p1), "=&s"(p2) : "s"(base) : "memory");
+            typedef const f4 __attribute__((address_space(4)))* const_f4;          // constant address space + a uniform address = scalar loads
+            const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(a.tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u);
+            const f4 p0 = p[0], p1 = p[1], p2 = p[2];
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
         auto tri_for = [&](int ref) -> Tri {

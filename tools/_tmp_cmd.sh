@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_traverse_gpu.py -x -q 2>&1 | tail -3
-timeout 600 python tools/dev_traverse_time.py 2>/dev/null
+for r in 1 2; do for v in asm as4; do echo "== $v"; HAGRID_AMD_LIB=$GRAFT_REPO_ROOT/tools/_ab/lib_$v.so timeout 600 python tools/dev_traverse_time.py 2>/dev/null | cut -c1-100; done; done
