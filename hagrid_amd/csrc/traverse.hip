@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
         auto tri_for = [&](int ref) -> Tri {
-            if (HG_SOLO && UNIFORM && NARROW && __popcll(__ballot(true)) == 1) return tri_solo(ref);
+            if (HG_SOLO && NARROW && __popcll(__ballot(true)) == 1) return tri_solo(ref);
             return tri_at(ref);
         };
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
