@@ -433,6 +433,20 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
 
 // MODE: HAGRID_TRAVERSE_ANY_HIT (the ray is done at its first accepted intersection: shadow rays) and / or
 // HAGRID_TRAVERSE_UVS (barycentrics stored with the hit) -- SURVEY.md 8(f) row 4; 0 is the reference's traversal.
+// A triangle round in which ONE lane is live (23 % of the rounds of the 1M-ray batch, profiles/dev_r2_generations.txt items 10-11) still
+// costs the CU's vector-memory path its fixed ~12 cycles per load instruction: there the triangle comes through the scalar cache
+// (constant address space + a uniform address = s_load), no vector-memory instruction at all.  HG_SOLO=0 compiles the path out.
+#ifndef HG_SOLO
+#define HG_SOLO 1
+#endif
+__device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const f4 __attribute__((address_space(4)))* const_f4;
+    const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u);
+    const f4 p0 = p[0], p1 = p[1], p2 = p[2];
+    return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+}
+
 template <bool SMALL, int BLOCK, bool NARROW, unsigned MODE>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
@@ -499,6 +513,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
         };
         auto tri_at = [&](int ref) -> Tri {
             if (!NARROW) return load_tri(a.tris, ref);
+            if (HG_SOLO && __popcll(__ballot(true)) == 1) return load_tri_scalar(a.tris, ref);
             // ref * 48 as two full-rate instructions (the compiler turns the shift-add back into a quarter-rate 32-bit multiply)
             uint32_t r3, o;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
@@ -610,9 +625,6 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-#ifndef HG_SOLO
-#define HG_SOLO 1
-#endif
 template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
@@ -691,17 +703,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
 
-        // A round in which ONE lane is live (23 % of the triangle rounds of the 1M-ray batch, profiles/dev_r2_generations.txt item 10)
-        // still costs the CU's vector-memory path its fixed ~12 cycles per load: there the triangle comes through the scalar cache.
-        auto tri_solo = [&](int ref) -> Tri {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            typedef const f4 __attribute__((address_space(4)))* const_f4;          // constant address space + a uniform address = scalar loads
-            const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(a.tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u);
-            const f4 p0 = p[0], p1 = p[1], p2 = p[2];
-            return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-        };
         auto tri_for = [&](int ref) -> Tri {
-            if (HG_SOLO && NARROW && __popcll(__ballot(true)) == 1) return tri_solo(ref);
+            if (HG_SOLO && NARROW && __popcll(__ballot(true)) == 1) return load_tri_scalar(a.tris, ref);
             return tri_at(ref);
         };
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
