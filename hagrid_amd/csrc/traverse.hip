@@ -433,9 +433,11 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
 
 // MODE: HAGRID_TRAVERSE_ANY_HIT (the ray is done at its first accepted intersection: shadow rays) and / or
 // HAGRID_TRAVERSE_UVS (barycentrics stored with the hit) -- SURVEY.md 8(f) row 4; 0 is the reference's traversal.
-// A triangle round in which ONE lane is live (23 % of the rounds of the 1M-ray batch, profiles/dev_r2_generations.txt items 10-11) still
-// costs the CU's vector-memory path its fixed ~12 cycles per load instruction: there the triangle comes through the scalar cache
-// (constant address space + a uniform address = s_load), no vector-memory instruction at all.  HG_SOLO=0 compiles the path out.
+// A triangle round in which every live lane tests the SAME triangle -- one live lane (23 % of the rounds of the 1M-ray batch,
+// profiles/dev_r2_generations.txt items 10-12), or neighbouring rays in the same cell at the same place of its list (common in dense
+// batches) -- still costs the CU's vector-memory path its fixed ~12 cycles per load instruction and a cycle per lane: there the
+// triangle comes through the scalar cache (constant address space + a uniform address = s_load), no vector-memory instruction at
+// all, and the test reads it from scalar registers.  HG_SOLO=0 compiles the path out.
 #ifndef HG_SOLO
 #define HG_SOLO 1
 #endif
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
         };
         auto tri_at = [&](int ref) -> Tri {
             if (!NARROW) return load_tri(a.tris, ref);
-            if (HG_SOLO && __popcll(__ballot(true)) == 1) return load_tri_scalar(a.tris, ref);
+            if (HG_SOLO && __ballot(ref != __builtin_amdgcn_readfirstlane(ref)) == 0ull) return load_tri_scalar(a.tris, ref);
             // ref * 48 as two full-rate instructions (the compiler turns the shift-add back into a quarter-rate 32-bit multiply)
             uint32_t r3, o;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
@@ -704,7 +706,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         };
 
         auto tri_for = [&](int ref) -> Tri {
-            if (HG_SOLO && NARROW && __popcll(__ballot(true)) == 1) return load_tri_scalar(a.tris, ref);
+            if (HG_SOLO && NARROW && __ballot(ref != __builtin_amdgcn_readfirstlane(ref)) == 0ull) return load_tri_scalar(a.tris, ref);
             return tri_at(ref);
         };
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
