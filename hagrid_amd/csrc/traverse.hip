@@ -706,7 +706,11 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         };
 
         auto tri_for = [&](int ref) -> Tri {
-            if (HG_SOLO && NARROW && __ballot(ref != __builtin_amdgcn_readfirstlane(ref)) == 0ull) return load_tri_scalar(a.tris, ref);
+            if (HG_SOLO && NARROW) {
+                const int r0 = __builtin_amdgcn_readfirstlane(ref);
+                const unsigned long long others = __ballot(ref != r0);
+                if (others == 0ull) return load_tri_scalar(a.tris, r0);
+            }
             return tri_at(ref);
         };
         const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
