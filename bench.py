@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-cores baseline sample")
     ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off, 1 compact, 2 flat (default)")
+    ap.add_argument("--opts", default="", help="experiments: comma-separated key=value pairs for hagrid_set_option, e.g. traverse.image_slim=0")
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 otherwise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
@@ -194,6 +195,8 @@ def main():
         rays_head = upload_generated(mem, d_rays, gen, first, n_rays, chunk=1 << 22, keep_host=keep)
     bin_rays = (cfg.get("bin_rays", 1 if ray_kind == "incoherent" else 0)) if args.bin_rays is None else args.bin_rays
     mem.set_option("traverse.image", args.image)
+    for kv in filter(None, args.opts.split(",")):                 # experiments: any hagrid_set_option key
+        k, v = kv.split("="); mem.set_option(k, int(v))
     api.setup_traversal(grid)                        # main.cpp:535; builds the traversal image (outside every timed region)
     setup_ms = api.profile(lambda: api.setup_traversal(grid), mem)
     if ray_kind == "bounce":
@@ -215,7 +218,8 @@ def main():
 
     # exact algorithmic byte counters of this batch (outside the timed region)
     stats = api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n_rays)
-    ab = api.algorithmic_bytes(stats, compressed)
+    record_bytes = mem.image_record_bytes(grid) if args.image else 32
+    ab = api.algorithmic_bytes(stats, compressed, record_bytes)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ------------------------------
     for _ in range(args.warmup):
@@ -271,7 +275,7 @@ def main():
                                    + (f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
                        "baseline_config": args.config, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
-                       "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: "flat blocks: one 32-byte record per voxel, built by setup_traversal"}[args.image],
+                       "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: f"flat blocks: one {record_bytes}-byte record per voxel, built by setup_traversal"}[args.image],
                        "ray_packets": "8x8 pixel tiles, row length detected on the device at every call (buffer stays in image order)",
                        "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",
                        "grid": grid.summary(), "device": info},

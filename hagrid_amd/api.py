@@ -130,6 +130,12 @@ class MemManager:
         _check(self, self._L.hagrid_bandwidth_probe(self._ctx, int(nbytes), int(iters), C.byref(c), C.byref(t)), "bandwidth_probe")
         return {"copy_GBps": float(c.value), "triad_GBps": float(t.value)}
 
+    def image_record_bytes(self, grid: "Grid") -> int:
+        """16 when the traversal image of `grid` holds slim records (table-free layout, one 16-byte record per voxel), else 32."""
+        d = grid.pod.dims
+        top = int(d[0]) * int(d[1]) * int(d[2])
+        return 16 if self.image_bytes(grid) == 16 * (top << (3 * grid.pod.shift)) + 8 * top else 32
+
     def image_bytes(self, grid: "Grid") -> int:
         """Size of the traversal image this manager holds for `grid` (0 when it holds none)."""
         b = C.c_int64(0)
@@ -321,15 +327,16 @@ def build_algorithmic_bytes(bc: dict) -> dict:
     return out
 
 
-def algorithmic_bytes(stats: dict, compressed: bool) -> dict:
-    """DESIGN.md / BASELINE.md section 4: bytes the algorithm must touch for a batch, from exact counters."""
+def algorithmic_bytes(stats: dict, compressed: bool, record_bytes: int = 32) -> dict:
+    """DESIGN.md / BASELINE.md section 4: bytes the algorithm must touch for a batch, from exact counters.  `record_bytes`: size of
+    a traversal-image record (32, or 16 for slim records: MemManager.image_record_bytes)."""
     s_cell = 16 if compressed else 32
     walk = 4 * stats["entry_words"] + s_cell * stats["cells"]
     total = 48 * stats["rays"] + walk + 52 * stats["refs"] + 4 * stats["sentinels"]
-    # what the traversal-image kernel gathers for the same walk: one 32-byte record per visited cell (bounds + list length +
-    # up to four ids inline), a 48-byte triangle per test, and a 4-byte id only for lists of more than four
-    image = 48 * stats["rays"] + 32 * stats["cells"] + 48 * stats["refs"] + 4 * stats.get("long_list_refs", 0)
-    return {"B_ray": int(total), "B_walk": int(walk), "B_image": int(image), "B_image_walk": int(32 * stats["cells"])}
+    # what the traversal-image kernel gathers for the same walk: one record per visited cell (bounds + up to four ids inline), a
+    # 48-byte triangle per test, and a 4-byte id only for lists of more than four
+    image = 48 * stats["rays"] + record_bytes * stats["cells"] + 48 * stats["refs"] + 4 * stats.get("long_list_refs", 0)
+    return {"B_ray": int(total), "B_walk": int(walk), "B_image": int(image), "B_image_walk": int(record_bytes * stats["cells"])}
 
 
 __all__ = ["MemManager", "Grid", "build_grid", "merge_grid", "flatten_grid", "expand_grid", "compress_grid", "build_all",

@@ -31,6 +31,7 @@ struct TravImageCache {
     bool valid = false;
     bool flat = false;              // records indexed by the voxel (no slot bytes)
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
+    int slim = 0;                   // uniform layout with 16-byte records: bits per inline reference id (20: four ids, 26: three), 0 = 32-byte records
     bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
     // identity of the source grid
@@ -81,6 +82,7 @@ struct hagrid_ctx {
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
+    int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
     int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 

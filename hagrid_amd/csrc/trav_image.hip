@@ -26,6 +26,14 @@
 // and every value the traversal arithmetic uses are copied unchanged: hits are identical to the traversal of the
 // construction format (tests/test_traverse_gpu.py).
 //
+// Slim records (uniform layout only, `traverse.image_slim`): 16 bytes per voxel instead of 32 -- ONE gather instruction per cell
+// step, half the lane-lines, half the image (it fits the 256 MB memory-side cache again).  The bounds travel as byte offsets
+// from the record's own voxel (voxel - lo, hi - voxel), the ids as packed fields of IDB bits:
+//   bits   0..47   lo.x hi.x lo.y hi.y lo.z hi.z offsets, one byte each (lo and hi of an axis in neighbouring bytes)
+//   bits  48..127  80 / IDB reference ids of IDB bits (IDB = 20: four, IDB = 26: three); unused = all ones
+//   by index       the LAST id field = all ones - 1; bits 48..79 first reference index, bits 80..99 list length
+// An image whose cells do not all fit (an offset above 255, a by-index list of 2^20 ids or more) is built with 32-byte records.
+//
 // Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal state), owned by
 // the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids and compressed grids of up to three levels, with a
 // virtual resolution below 65536 per axis; otherwise traversal reads the construction format.
@@ -303,6 +311,102 @@ __global__ void __launch_bounds__(64) image_nested(const ImgK k, int num_roots, 
     }
 }
 
+
+// ---- slim records -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_bits(uint32_t (&r)[4], int pos, int n, uint32_t v) {
+    for (int i = 0; i < n; i++) {
+        const int b = pos + i;
+        if ((v >> i) & 1u) r[b >> 5] |= 1u << (b & 31); else r[b >> 5] &= ~(1u << (b & 31));
+    }
+}
+
+// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
+// not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
+template <int D, int IDB>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status) {
+    constexpr int V = 1 << (3 * D), M = (1 << D) - 1, NI = 80 / IDB;
+    constexpr uint32_t NONE = (1u << IDB) - 1u;
+    const int T = blockIdx.x, lane = threadIdx.x;
+    const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
+    const uint32_t topw = k.entries[T];
+    if (lane == 0) table[T] = make_uint2(uint32_t(T) * uint32_t((16u << (3 * D)) >> 4), uint32_t(D) | 8u | 16u | (uint32_t(V) << 8));   // offset in 16-byte units; bit 4: slim
+    for (int f = lane; f < V; f += 64) {
+        const int rx = f & M, ry = (f >> D) & M, rz = f >> (2 * D);
+        uint32_t w = topw;
+        int depth = 0;
+        while (w & 3u) {
+            const int kk = int(w & 3u);
+            depth += kk;
+            const int s = D - depth, m = (1 << kk) - 1;
+            w = k.entries[int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk)];
+        }
+        const int c = int(w >> 2);
+        int lo[3], hi[3], begin, n;
+        if (k.small_cells) {
+            const uint4 sc = k.small_cells[c];
+            lo[0] = int(sc.x & 0xffffu); lo[1] = int(sc.x >> 16); lo[2] = int(sc.y & 0xffffu);
+            hi[0] = int(sc.y >> 16); hi[1] = int(sc.z & 0xffffu); hi[2] = int(sc.z >> 16);
+            begin = int(sc.w); n = 0;
+            if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
+            else begin = 0;
+        } else {
+            const int4 a = k.cells[2 * size_t(c)], b = k.cells[2 * size_t(c) + 1];
+            lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+            begin = a.w; n = b.w - a.w;
+        }
+        const int v[3] = {(tx << D) + rx, (ty << D) + ry, (tz << D) + rz};
+        uint32_t r[4] = {0u, 0u, ~0u, ~0u};
+        int bad = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            const int dl = v[ax] - lo[ax], dh = hi[ax] - v[ax];
+            if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
+            put_bits(r, 16 * ax, 8, uint32_t(dl) & 255u);
+            put_bits(r, 16 * ax + 8, 8, uint32_t(dh) & 255u);
+        }
+        r[1] |= 0xffff0000u;
+        // an id that does not fit the field (the kernel takes NONE for the end of a list, wherever the id came from): the whole image
+        // needs the wider field
+        bool wide = false;
+        for (int i = 0; i < n; i++) wide = wide || uint32_t(k.refs[begin + i]) >= NONE - 1u;
+        if (wide) atomicAdd(status + 1, 1);
+        if (n <= NI && !wide) {
+            for (int i = 0; i < n; i++) put_bits(r, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
+        } else {
+            if (n >= (1 << 20)) bad |= 2;
+            put_bits(r, 48, 32, uint32_t(begin));
+            put_bits(r, 80, 20, uint32_t(n));
+            put_bits(r, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
+        }
+        if (bad) atomicOr(status, bad);
+        recs[(size_t(T) << (3 * D)) + f] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+template <int D>
+int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table) {
+    const size_t bytes = (size_t(k.num_top) << (3 * D)) * 16u;
+    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
+    if (!recs) return HAGRID_ENOMEM;
+    int* status = ctx->dscratch + 228;
+    for (int idb : {20, 26}) {
+        if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
+        (void)hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream);
+        if (idb == 20) image_slim_fill<D, 20><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
+        else           image_slim_fill<D, 26><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
+        HG_DBG(ctx);
+        int h[2] = {0, 0};
+        const int rc = read_back(ctx, status, h, sizeof(h));
+        if (rc != HAGRID_OK) { hagrid_mem_free(ctx, recs); return rc; }
+        if (h[0]) break;                            // some cell does not fit a slim record: 32-byte records
+        if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
+        if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
+        img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
+        return HAGRID_OK;
+    }
+    hagrid_mem_free(ctx, recs);
+    return 1;
+}
+
 struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
 struct SizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
 
@@ -354,6 +458,11 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
+    if (uniform && ctx->opt_image_slim && !nest) {
+        const int rs = build_slim<D>(ctx, k, img, table);
+        if (rs == HAGRID_OK) { release(); img.uniform = true; img.table = table; return HAGRID_OK; }
+        if (rs != 1) { release(); hagrid_mem_free(ctx, table); return rs; }
+    }
     if ((long long)units + units1 >= (1ll << 31)) { release(); hagrid_mem_free(ctx, table); return 1; }
     unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, (size_t(units) + size_t(units1)) * 128u));
     if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }

@@ -627,9 +627,12 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false>
+// SLIM (with UNIFORM): 16-byte records, SLIM = bits per packed reference id (trav_image.hip, "Slim records"); 0 = 32-byte records
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
+    static_assert(SLIM == 0 || UNIFORM, "slim records exist in the uniform layout only");
+    constexpr int NONE = SLIM ? (1 << (SLIM ? SLIM : 1)) - 1 : -1;          // the id field of an unused list slot
     struct Stamp {
         unsigned long long* p;
         __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
@@ -675,9 +678,10 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             if (UNIFORM) {
                 const int d = a.shift, m = (1 << d) - 1;
                 const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-                const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 5;
+                const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << (SLIM ? 4 : 5);
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                ra = p[0]; rb = p[1];
+                ra = p[0];
+                if (!SLIM) rb = p[1];
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
@@ -713,12 +717,14 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             return tri_at(ref);
         };
-        const uint32_t ox = px ? 16u : 0u, oy = py ? 16u : 0u, oz = pz ? 16u : 0u;     // which half of a bounds word is the exit plane
+        // which half of a bounds word is the exit plane (slim records: which byte, and the direction the offset counts in)
+        const uint32_t ox = SLIM ? (px ? 8u : 0u) : (px ? 16u : 0u), oy = SLIM ? (py ? 24u : 16u) : (py ? 16u : 0u), oz = SLIM ? (pz ? 8u : 0u) : (pz ? 16u : 0u);
+        const int sgx = px ? 1 : -1, sgy = py ? 1 : -1, sgz = pz ? 1 : -1;
         const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
         const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
         int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
         uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
-        uint4 ca, cb;
+        uint4 ca, cb = make_uint4(0u, 0u, 0u, 0u);
         record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
@@ -733,7 +739,13 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 }
             }
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
-            const int cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)), cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)), cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u));
+            int cx, cy, cz;
+            if (SLIM) {     // byte offsets from the voxel the record belongs to
+                // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(sgy), "v"(__builtin_amdgcn_ubfe(ca.x, oy, 8u)), "v"(vy));
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(sgz), "v"(__builtin_amdgcn_ubfe(ca.y, oz, 8u)), "v"(vz));
+            } else { cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)); cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)); cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u)); }
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
             const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
             const vec3 ev = (texit * dir + org - gmin) * ginv;
@@ -751,51 +763,73 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 const int ntop = outside ? top_idx : top_index(vx, vy, vz);
                 if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
             }
-            uint4 na, nb;
+            uint4 na, nb = make_uint4(0u, 0u, 0u, 0u);
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
             else record(tab, vx, vy, vz, na, nb);
 
             // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
             // than four ids, deep cells) fetches the id of the next test one test ahead, as v2 does.
-            const bool by_index = int(ca.w) < 0;
             auto ref_at = [&](uint32_t i) -> int { return NARROW ? gather32<int>(a.refs, i << 2) : a.refs[i]; };
-            uint32_t q1 = cb.y, q2 = cb.z, q3 = cb.w;                       // inline: the ids still to test
-            int ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
+            bool by_index;
+            uint32_t q1, q2, q3, li_begin, li_count;
+            int ref;
+            if (SLIM) {
+                // id fields of SLIM bits from bit 48 on; the last field = NONE - 1 marks a list given by index
+                constexpr int NI = 80 / (SLIM ? SLIM : 80), LAST = 48 + (NI - 1) * SLIM;
+                auto field = [&](int pos, int n) -> uint32_t {              // pos, n are constants after inlining
+                    const uint32_t w[4] = {ca.x, ca.y, ca.z, ca.w};
+                    const int i = pos >> 5, o = pos & 31;
+                    uint32_t v = w[i] >> o;
+                    if (o + n > 32) v |= w[i + 1] << (32 - o);
+                    return n == 32 ? v : (v & ((1u << n) - 1u));
+                };
+                by_index = field(LAST, SLIM) == uint32_t(NONE - 1);
+                ref = int(field(48, SLIM));
+                q1 = NI > 1 ? field(48 + SLIM, SLIM) : uint32_t(NONE);
+                q2 = NI > 2 ? field(48 + 2 * SLIM, SLIM) : uint32_t(NONE);
+                q3 = NI > 3 ? field(48 + 3 * SLIM, SLIM) : uint32_t(NONE);
+                li_begin = field(48, 32); li_count = field(80, 20);
+            } else {
+                by_index = int(ca.w) < 0;
+                q1 = cb.y; q2 = cb.z; q3 = cb.w;                            // inline: the ids still to test
+                ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
+                li_begin = cb.x; li_count = ca.w & 0x7fffffffu;
+            }
             if (UNIFORM && __ballot(by_index) == 0ull) {
                 // shallow grids: lists of more than four ids are rare (1.5 % of the visited cells of the 1M-triangle soup), so a
                 // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
 #pragma unroll 1
-                while (ref >= 0) {
+                while (ref != NONE) {
                     const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
                                          : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
-                    ref = (ANY && got) ? -1 : int(q1);
-                    q1 = q2; q2 = q3; q3 = ~0u;
+                    ref = (ANY && got) ? NONE : int(q1);
+                    q1 = q2; q2 = q3; q3 = uint32_t(NONE);
                 }
             } else {
                 // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two longest.
                 if (by_index) {                                             // by index: q1 = index of the next id, q2 = end of the list
-                    q1 = cb.x; q2 = cb.x + (ca.w & 0x7fffffffu);
-                    ref = -1;
+                    q1 = li_begin; q2 = li_begin + li_count;
+                    ref = NONE;
                     if (q1 < q2) ref = ref_at(q1);
                     q1++;
                 }
 #pragma unroll 1
-                while (ref >= 0) {
+                while (ref != NONE) {
                     int next;
                     if (UNIFORM) {
                         // shallow grids, long lists are rare: the fewest instructions for the inline form
-                        if (by_index) { next = q1 < q2 ? ref_at(q1) : -1; q1++; }
-                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                        if (by_index) { next = q1 < q2 ? ref_at(q1) : NONE; q1++; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
                     }
-                    int pre = -1;
+                    int pre = NONE;
                     if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
                     const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
                                          : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                     if (!UNIFORM) {
                         if (by_index) { next = pre; q1++; }
-                        else { next = int(q1); q1 = q2; q2 = q3; q3 = ~0u; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
                     }
-                    ref = (ANY && got) ? -1 : next;
+                    ref = (ANY && got) ? NONE : next;
                 }
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
@@ -1078,8 +1112,14 @@ size_t buffer_bytes_from(const void* p) {
 
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
-bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, const TraverseArgs& a) {
-    if (flat && narrow && uniform && MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true><<<blocks, 64, 0, st>>>(a);
+bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, const TraverseArgs& a) {
+    if (flat && narrow && uniform && slim == 20) {
+        if (MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, st>>>(a);
+        else traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
+    }
+    else if (flat && narrow && uniform && slim == 26) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
+    else if (slim) return false;                    // slim records are read by the uniform narrow kernels only
+    else if (flat && narrow && uniform && MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow)       traverse_kernel_img<64, true, true, false, MODE><<<blocks, 64, 0, st>>>(a);
     else if (MODE != 0)            return false;
@@ -1088,12 +1128,12 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
     else                           traverse_kernel_img<64, false, false, false, 0><<<blocks, 64, 0, st>>>(a);
     return true;
 }
-bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, unsigned mode, const TraverseArgs& a) {
+bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, unsigned mode, const TraverseArgs& a) {
     switch (mode & 3u) {
-        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, a);
-        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, a);
-        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, a);
-        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, a);
+        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, slim, a);
+        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, slim, a);
+        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, slim, a);
+        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, slim, a);
     }
 }
 
@@ -1236,6 +1276,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (ctx->image.detached && have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: any-hit / barycentrics on a released grid need the narrow image kernel (arrays below 4 GB)");
         variant = 2;
     }
+    if (variant == 4 && ctx->image.slim && !img_narrow) {
+        // slim records are read by the narrow kernels only (arrays of 4 GB and more, "traverse.narrow" = 0): construction format
+        if (ctx->image.detached) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal and its slim traversal image needs the narrow kernel (arrays below 4 GB)");
+        variant = 2;
+    }
     if (variant == 4) {
         a.img_table = static_cast<const uint2*>(ctx->image.table);
         a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
@@ -1263,7 +1308,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
-        launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, flags, a);
+        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, flags, a))
+            HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
         if (grid->small_cells) traverse_kernel<true, false><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1299,7 +1345,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
@@ -1404,11 +1450,43 @@ __global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray a
     out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
 }
 
-__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat) {
+__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat, int slim) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
     const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
+    if (slim) {     // a slim record, brought into the form of the 32-byte record
+        const int d = a.shift, m = (1 << d) - 1;
+        const uint4 r = reinterpret_cast<const uint4*>(a.img_blocks)[(size_t(tab.x) + size_t((vx & m) + (((vy & m) + ((vz & m) << d)) << d)))];
+        const uint32_t w[5] = {r.x, r.y, r.z, r.w, 0u};
+        auto field = [&](int pos, int nb) -> uint32_t {
+            const int wi = pos >> 5, o = pos & 31;
+            unsigned long long v = (static_cast<unsigned long long>(w[wi + 1]) << 32 | w[wi]) >> o;
+            return nb == 32 ? uint32_t(v) : uint32_t(v) & ((1u << nb) - 1u);
+        };
+        const int ni = 80 / slim;
+        const uint32_t none = (1u << slim) - 1u;
+        uint32_t* o = out + 8 * size_t(i);
+        o[0] = uint32_t(vx - int(field(0, 8))) | uint32_t(vx + int(field(8, 8))) << 16;
+        o[1] = uint32_t(vy - int(field(16, 8))) | uint32_t(vy + int(field(24, 8))) << 16;
+        o[2] = uint32_t(vz - int(field(32, 8))) | uint32_t(vz + int(field(40, 8))) << 16;
+        if (field(48 + (ni - 1) * slim, slim) == none - 1u) {
+            const uint32_t cnt = field(80, 20);
+            // lists of at most four ids are inline in the 32-byte record: read them through the index
+            o[3] = cnt | (cnt > 4 ? 0x80000000u : 0u);
+            if (cnt > 4) { o[4] = field(48, 32); o[5] = o[6] = o[7] = 0u; }
+            else for (uint32_t j = 0; j < 4; j++) o[4 + j] = j < cnt ? uint32_t(a.refs[field(48, 32) + j]) : ~0u;
+        } else {
+            uint32_t cnt = 0;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t id = j < ni ? field(48 + j * slim, slim) : none;
+                o[4 + j] = id == none ? ~0u : id;
+                if (id != none) cnt++;
+            }
+            o[3] = cnt;
+        }
+        return;
+    }
     const uint4* rec = flat ? image_record<true>(a, tab, vx, vy, vz) : image_record<false>(a, tab, vx, vy, vz);
     uint4 ra = rec[0], rb = rec[1];
     if (ra.w >= 0xfffffffeu) { uint32_t off, meta; image_resolve_links(a, vx, vy, vz, ra, rb, off, meta); ra.w |= 0x40000000u; }     // bit 30: came through a nested block or a deep link
@@ -1533,7 +1611,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0); HG_DBG(ctx);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }

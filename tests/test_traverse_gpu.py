@@ -387,19 +387,34 @@ def _image_scenes():
             "compressed_long_lists": (np.concatenate([np.repeat(scene.make_soup(30, seed=15), 12, axis=0), scene.make_soup(6000, seed=16)]), dict(compress=True, top_density=0.3, snd_density=1.0))}
 
 
-@pytest.mark.parametrize("fmt", [1, 2])
+# (traverse.image, traverse.image_slim): compact blocks (slot bytes + de-duplicated records); flat (a record per voxel) with slim
+# 16-byte records where the layout is uniform and they fit; flat with 32-byte records only; flat with the 26-bit form of the slim record
+_IMAGE_FORMATS = {"compact": (1, 1), "flat": (2, 1), "flat_fat": (2, 0), "flat_slim26": (2, 2)}
+
+
+def _slim_expected(G, slim):
+    """Slim records are built for the table-free layout (every top-level cell at the full depth, at most three levels) when every
+    bound lies within 255 voxels of each of the cell's voxels."""
+    if not slim or not (1 <= G.shift <= 3):
+        return False
+    top = G.entries[:int(np.prod(G.dims))]
+    return bool(((top & 3) == G.shift).all())      # sufficient for "uniform" (the 25 % rule only matters for partly shallow grids)
+
+
+@pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
 @pytest.mark.parametrize("name", list(_image_scenes()))
-def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt):
+def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     """Every voxel of the virtual grid resolves, through the image's table / slot / record, to exactly the bounds, list
     length and reference ids that lookup_entry + cells + ref_ids give in the construction format."""
     from oracle import oracle as O
+    fmt, slim = _IMAGE_FORMATS[fmt_name]
     tris, params = _image_scenes()[name]
     G = O.Grid.full(tris, **params)
     grid = upload_oracle_grid(mem, G)
     from hagrid_amd import api
-    mem.set_option("traverse.image", fmt)          # 1: compact blocks (slot bytes + de-duplicated records), 2: flat (a record per voxel)
+    mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim)
     api.setup_traversal(grid)
-    mem.set_option("traverse.image", 2)
+    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_slim", 1)
     res = np.array(G.dims) << G.shift
     total = int(res[0]) * int(res[1]) * int(res[2])
     rng = np.random.default_rng(1)
@@ -414,6 +429,10 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt):
     assert rc == 0
     want, begin = _expected_records(G, vox.astype(np.int64))
     by_index, deep = _check_records(got, want, begin)
+    if fmt == 2 and _slim_expected(G, slim) and int(res.max()) <= 256:
+        assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims)), "slim records expected"
+    if fmt == 2 and not slim:
+        assert nbytes.value != 16 * total + 8 * int(np.prod(G.dims))
     assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
         assert (by_index & ~deep).any()
@@ -431,11 +450,12 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt):
     assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
 
 
-@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
 @pytest.mark.parametrize("name", list(_image_scenes()))
-def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
+def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
     from oracle import oracle as O
     from hagrid_amd import api
+    fmt, slim = _IMAGE_FORMATS[fmt_name]
     if name == "compressed_deep" and fmt == 1:
         pytest.skip("no compact image for compressed grids deeper than three levels")
     tris, params = _image_scenes()[name]
@@ -446,8 +466,8 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 60001, 17)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
-        mem.set_option("traverse.image", fmt)
-        for uniform in ((1, 0) if fmt == 2 else (1,)):          # flat blocks: table-free layout allowed / not allowed
+        mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim)
+        for uniform in ((1, 0) if fmt == 2 and slim == 1 else (1,)):          # flat blocks: table-free layout allowed / not allowed
             mem.set_option("traverse.image_uniform", uniform)
             for variant in (4, 0, 2):
                 mem.set_option("traverse.variant", variant)
@@ -460,6 +480,52 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt):
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
         mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_uniform", 1)
+        mem.set_option("traverse.image_slim", 1)
+    grid.free(); mem.free(d_tris)
+
+
+def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
+    """A cell that reaches more than 255 voxels away from one of its voxels does not fit the byte offsets of a slim record: the
+    image is then built with 32-byte records, and the hits stay the oracle's.  The 26-bit id form gives the same hits."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    a = scene.make_soup(2000, seed=31).copy(); b = scene.make_soup(2000, seed=32).copy()
+    b[:, 0] += np.float32(40.0)                                   # two clusters 40 units apart: long empty cells between them
+    tris = np.ascontiguousarray(np.concatenate([a, b]))
+    G = O.Grid.full(tris, top_density=0.5, snd_density=2.4)
+    assert G.shift == 3 and int((G.cells["max"].astype(int) - G.cells["min"].astype(int)).max()) > 255
+    total = int(np.prod(np.array(G.dims) << G.shift))
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 128, 64),
+                           scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 30000, 19)]).astype(np.float32)
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    nb = C.c_int64(0)
+    try:
+        mem.set_option("traverse.image_uniform", 2)              # the table-free layout whatever it costs: this grid is mostly empty
+        for slim in (1, 2, 0):
+            mem.set_option("traverse.image_slim", slim)
+            got = gpu_traverse(mem, grid, d_tris, rays)
+            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), slim
+            assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
+            assert nb.value >= 32 * total, "32-byte records expected"
+        # the same clusters close together: every cell fits, slim records in both id widths
+        b[:, 0] -= np.float32(39.0)
+        tris2 = np.ascontiguousarray(np.concatenate([a, b]))
+        G2 = O.Grid.full(tris2, top_density=0.5, snd_density=2.4)
+        total2 = int(np.prod(np.array(G2.dims) << G2.shift))
+        assert 1 <= G2.shift <= 3 and int((np.array(G2.dims) << G2.shift).max()) <= 256
+        d_tris2 = mem.upload(tris2); grid2 = upload_oracle_grid(mem, G2)
+        rays2 = scene.make_rays_incoherent(G2.bbox_min - 0.2, G2.bbox_max + 0.2, 30000, 19).astype(np.float32)
+        want2, _ = G2.traverse(tris2, rays2, nthreads=8)
+        for slim in (1, 2):
+            mem.set_option("traverse.image_slim", slim)
+            got = gpu_traverse(mem, grid2, d_tris2, rays2)
+            assert (got["id"] == want2["id"]).all() and (bits(got["t"]) == bits(want2["t"])).all(), slim
+            assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
+            assert nb.value == 16 * total2 + 8 * int(np.prod(G2.dims)), "slim records expected"
+        grid2.free(); mem.free(d_tris2)
+    finally:
+        mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1)
     grid.free(); mem.free(d_tris)
 
 
@@ -510,8 +576,10 @@ def test_image_lifetime(mem):
         nb = C.c_int64(0)
         api.setup_traversal(gb)
         assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value < (7 << 20)
-        mem.set_option("traverse.image_max_mb", 0); api.setup_traversal(gb)
+        mem.set_option("traverse.image_max_mb", 0); mem.set_option("traverse.image_slim", 0); api.setup_traversal(gb)
         assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value > (8 << 20)
+        mem.set_option("traverse.image_slim", 1); api.setup_traversal(gb)        # 16-byte records: half of it
+        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and (4 << 20) < nb.value < (5 << 20)
         gb.free(); mem.set_option("traverse.image", 1)
         # compressed grids get one as well (shift <= 3)
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
@@ -520,7 +588,7 @@ def test_image_lifetime(mem):
         grid.free()                                          # freeing a source array drops the image
         assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
     finally:
-        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 0)
+        mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 0); mem.set_option("traverse.image_slim", 1)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
 
 
