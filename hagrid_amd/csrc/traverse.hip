@@ -441,9 +441,6 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
 #ifndef HG_SOLO
 #define HG_SOLO 1
 #endif
-#ifndef HG_PF
-#define HG_PF 1         // inline-list loop of the table-free image kernel: first quarter of the next triangle fetched one round ahead
-#endif
 __device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef const f4 __attribute__((address_space(4)))* const_f4;
@@ -712,12 +709,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
 
-        auto tri_ptr = [&](int ref) -> const float4* {                        // NARROW: 32-bit offset off the scalar base
-            uint32_t r3, o;
-            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-            return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
-        };
         auto tri_for = [&](int ref) -> Tri {
             if (HG_SOLO && NARROW) {
                 const int r0 = __builtin_amdgcn_readfirstlane(ref);
@@ -807,47 +798,12 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             if (UNIFORM && __ballot(by_index) == 0ull) {
                 // shallow grids: lists of more than four ids are rare (1.5 % of the visited cells of the 1M-triangle soup), so a
                 // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
-                if (HG_PF && NARROW && SLIM != 0 && !UVS) {           // (the 32-byte-record and barycentric variants have no registers to spare)
-                    // The first 16 bytes of the NEXT triangle of the list are fetched while this one is tested (its id is in the record
-                    // already), so the line is on its way one round early at no extra load instruction -- only when that round will
-                    // take the vector path (some live lane wants a different triangle; uniform rounds go through the scalar cache).
-                    float4 pf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    bool pf_ok = false;                                     // wave-uniform: pf holds the first quarter of every live lane's triangle
-#pragma unroll 1
-                    while (ref != NONE) {
-                        const int r0 = __builtin_amdgcn_readfirstlane(ref);
-                        const bool uni = HG_SOLO && __ballot(ref != r0) == 0ull;
-                        const int nxt = int(q1);
-                        const unsigned long long mn = __ballot(nxt != NONE);
-                        const int n0 = mn ? __builtin_amdgcn_readlane(nxt, __builtin_ctzll(mn)) : NONE;
-                        const bool vec_next = __ballot(nxt != NONE && nxt != n0) != 0ull;
-                        Tri tri;
-                        float4 pn = pf;
-                        if (uni) {
-                            tri = load_tri_scalar(a.tris, r0);
-                            if (vec_next && nxt != NONE) pn = tri_ptr(nxt)[0];
-                        } else {
-                            const float4* p = tri_ptr(ref);
-                            float4 p0 = pf;
-                            if (!pf_ok) p0 = p[0];
-                            const float4 p1 = p[1], p2 = p[2];
-                            if (vec_next && nxt != NONE) pn = tri_ptr(nxt)[0];
-                            tri = Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
-                        }
-                        const bool got = UVS ? intersect_prim_ray_uvs(tri, Ray(org, tmin, dir, hit.t), ref, hit)
-                                             : intersect_prim_ray(tri, Ray(org, tmin, dir, hit.t), ref, hit);
-                        pf = pn; pf_ok = vec_next;
-                        ref = (ANY && got) ? NONE : nxt;
-                        q1 = q2; q2 = q3; q3 = uint32_t(NONE);
-                    }
-                } else {
 #pragma unroll 1
                 while (ref != NONE) {
                     const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
                                          : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                     ref = (ANY && got) ? NONE : int(q1);
                     q1 = q2; q2 = q3; q3 = uint32_t(NONE);
-                }
                 }
             } else {
                 // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two longest.
