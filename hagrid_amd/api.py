@@ -130,11 +130,16 @@ class MemManager:
         _check(self, self._L.hagrid_bandwidth_probe(self._ctx, int(nbytes), int(iters), C.byref(c), C.byref(t)), "bandwidth_probe")
         return {"copy_GBps": float(c.value), "triad_GBps": float(t.value)}
 
+    def image_format(self, grid: "Grid") -> dict:
+        """Layout of the traversal image held for `grid`: flat / uniform / slim id bits / bytes per record ({} without an image)."""
+        f = (C.c_int32 * 4)()
+        if self._L.hagrid_kat_image_format(self._ctx, C.byref(grid.pod), f) != 0:
+            return {}
+        return {"flat": bool(f[0]), "uniform": bool(f[1]), "slim_id_bits": int(f[2]), "record_bytes": int(f[3])}
+
     def image_record_bytes(self, grid: "Grid") -> int:
-        """16 when the traversal image of `grid` holds slim records (table-free layout, one 16-byte record per voxel), else 32."""
-        d = grid.pod.dims
-        top = int(d[0]) * int(d[1]) * int(d[2])
-        return 16 if self.image_bytes(grid) == 16 * (top << (3 * grid.pod.shift)) + 8 * top else 32
+        """16 when the traversal image of `grid` holds slim records, else 32."""
+        return self.image_format(grid).get("record_bytes", 32)
 
     def image_bytes(self, grid: "Grid") -> int:
         """Size of the traversal image this manager holds for `grid` (0 when it holds none)."""

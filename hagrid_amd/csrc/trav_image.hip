@@ -32,7 +32,10 @@
 //   bits   0..47   lo.x hi.x lo.y hi.y lo.z hi.z offsets, one byte each (lo and hi of an axis in neighbouring bytes)
 //   bits  48..127  80 / IDB reference ids of IDB bits (IDB = 20: four, IDB = 26: three); unused = all ones
 //   by index       the LAST id field = all ones - 1; bits 48..79 first reference index, bits 80..99 list length
-// An image whose cells do not all fit (an offset above 255, a by-index list of 2^20 ids or more) is built with 32-byte records.
+// Grids of at most three levels whose top-level cells differ in depth (table layout) get slim records as well: the block of a
+// top-level cell is (2^d)^3 records of 16 bytes, the table gives its offset in records, and the bound bytes are biased offsets from
+// the ORIGIN OF THE TOP-LEVEL CELL (bound - origin + 128: a coarse block voxel has no single finest-level voxel to count from).
+// An image whose cells do not all fit (an offset outside the byte, a by-index list of 2^20 ids or more) is built with 32-byte records.
 //
 // Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal state), owned by
 // the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids and compressed grids of up to three levels, with a
@@ -313,25 +316,33 @@ __global__ void __launch_bounds__(64) image_nested(const ImgK k, int num_roots, 
 
 
 // ---- slim records -------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void put_bits(uint32_t (&r)[4], int pos, int n, uint32_t v) {
-    for (int i = 0; i < n; i++) {
-        const int b = pos + i;
-        if ((v >> i) & 1u) r[b >> 5] |= 1u << (b & 31); else r[b >> 5] &= ~(1u << (b & 31));
-    }
+// bits [pos, pos + n) of the 128-bit record {lo, hi} := v   (n <= 32)
+__device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long long& hi, int pos, int n, uint32_t v) {
+    const unsigned long long m = n == 32 ? 0xffffffffull : ((1ull << n) - 1ull), x = v & m;
+    if (pos < 64) {
+        lo = (lo & ~(m << pos)) | (x << pos);
+        if (pos + n > 64) hi = (hi & ~(m >> (64 - pos))) | (x >> (64 - pos));
+    } else hi = (hi & ~(m << (pos - 64))) | (x << (pos - 64));
 }
 
 // One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
 // not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
-template <int D, int IDB>
-__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status) {
-    constexpr int V = 1 << (3 * D), M = (1 << D) - 1, NI = 80 / IDB;
+// TABLE: the block of top-level cell T has depth metas[T] & 3 and starts at record offsets[T]; its bound bytes count from the origin
+// of the top-level cell, biased by 128.
+template <int D, int IDB, bool TABLE>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
+                                                      const uint32_t* __restrict__ metas, const int* __restrict__ offsets) {
+    constexpr int NI = 80 / IDB;
     constexpr uint32_t NONE = (1u << IDB) - 1u;
     const int T = blockIdx.x, lane = threadIdx.x;
     const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
     const uint32_t topw = k.entries[T];
-    if (lane == 0) table[T] = make_uint2(uint32_t(T) * uint32_t((16u << (3 * D)) >> 4), uint32_t(D) | 8u | 16u | (uint32_t(V) << 8));   // offset in 16-byte units; bit 4: slim
+    const int d = TABLE ? int(metas[T] & 3u) : D, sd = D - d, V = 1 << (3 * d);
+    const size_t first = TABLE ? size_t(offsets[T]) : size_t(T) << (3 * D);
+    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(d) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
     for (int f = lane; f < V; f += 64) {
-        const int rx = f & M, ry = (f >> D) & M, rz = f >> (2 * D);
+        // block voxel f at depth d -> its lowest finest-level voxel inside the top-level cell
+        const int rx = (f & ((1 << d) - 1)) << sd, ry = ((f >> d) & ((1 << d) - 1)) << sd, rz = (f >> (2 * d)) << sd;
         uint32_t w = topw;
         int depth = 0;
         while (w & 3u) {
@@ -354,45 +365,63 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
             lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
             begin = a.w; n = b.w - a.w;
         }
-        const int v[3] = {(tx << D) + rx, (ty << D) + ry, (tz << D) + rz};
-        uint32_t r[4] = {0u, 0u, ~0u, ~0u};
+        const int v[3] = {(tx << D) + (TABLE ? 0 : rx), (ty << D) + (TABLE ? 0 : ry), (tz << D) + (TABLE ? 0 : rz)};
+        unsigned long long rl = ~0ull << 48, rh = ~0ull;               // every id field "unused"
         int bad = 0;
         for (int ax = 0; ax < 3; ax++) {
-            const int dl = v[ax] - lo[ax], dh = hi[ax] - v[ax];
+            const int dl = TABLE ? lo[ax] - v[ax] + 128 : v[ax] - lo[ax], dh = TABLE ? hi[ax] - v[ax] + 128 : hi[ax] - v[ax];
             if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
-            put_bits(r, 16 * ax, 8, uint32_t(dl) & 255u);
-            put_bits(r, 16 * ax + 8, 8, uint32_t(dh) & 255u);
+            rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
         }
-        r[1] |= 0xffff0000u;
         // an id that does not fit the field (the kernel takes NONE for the end of a list, wherever the id came from): the whole image
         // needs the wider field
         bool wide = false;
         for (int i = 0; i < n; i++) wide = wide || uint32_t(k.refs[begin + i]) >= NONE - 1u;
         if (wide) atomicAdd(status + 1, 1);
         if (n <= NI && !wide) {
-            for (int i = 0; i < n; i++) put_bits(r, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
+            for (int i = 0; i < n; i++) put_bits(rl, rh, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
         } else {
             if (n >= (1 << 20)) bad |= 2;
-            put_bits(r, 48, 32, uint32_t(begin));
-            put_bits(r, 80, 20, uint32_t(n));
-            put_bits(r, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
+            put_bits(rl, rh, 48, 32, uint32_t(begin));
+            put_bits(rl, rh, 80, 20, uint32_t(n));
+            put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
         }
         if (bad) atomicOr(status, bad);
-        recs[(size_t(T) << (3 * D)) + f] = make_uint4(r[0], r[1], r[2], r[3]);
+        recs[first + f] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
     }
 }
 
+struct SlimSizeIn { const uint32_t* m; __device__ int operator()(int i) const { return 1 << (3 * int(m[i] & 3u)); } };
+struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
+
+// uniform: every block has (2^D)^3 records, block T starts at T * (2^D)^3; otherwise `metas` holds the depth of every block and the
+// offsets come from a scan over the block sizes.  Returns 1 when some cell does not fit a slim record.
 template <int D>
-int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table) {
-    const size_t bytes = (size_t(k.num_top) << (3 * D)) * 16u;
+int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
+    long long records = (long long)k.num_top << (3 * D);
+    if (!uniform) {
+        int* total = ctx->dscratch + 227;
+        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
+        int h = 0;
+        const int rc = read_back(ctx, total, &h, sizeof(h));
+        if (rc != HAGRID_OK) return rc;
+        records = h;
+    }
+    if (records <= 0 || records >= (1ll << 28)) return 1;               // record offsets of the narrow kernels: 32-bit byte offsets
+    const size_t bytes = size_t(records) * 16u;
     uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
     if (!recs) return HAGRID_ENOMEM;
     int* status = ctx->dscratch + 228;
     for (int idb : {20, 26}) {
         if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
         (void)hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream);
-        if (idb == 20) image_slim_fill<D, 20><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
-        else           image_slim_fill<D, 26><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
+        if (uniform) {
+            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
+            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
+        } else {
+            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
+            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
+        }
         HG_DBG(ctx);
         int h[2] = {0, 0};
         const int rc = read_back(ctx, status, h, sizeof(h));
@@ -458,9 +487,14 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
-    if (uniform && ctx->opt_image_slim && !nest) {
-        const int rs = build_slim<D>(ctx, k, img, table);
-        if (rs == HAGRID_OK) { release(); img.uniform = true; img.table = table; return HAGRID_OK; }
+    if (FLAT && ctx->opt_image_slim && D == k.shift && D >= 1) {
+        // (three levels at most: every block resolves its cells, there are no links)  `sizes` is free again: the 32-byte fill below
+        // re-derives its offsets only in the non-uniform case, where the scan result is restored first
+        int* offs = nullptr;
+        if (!uniform) { offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1); if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; } }
+        const int rs = build_slim<D>(ctx, k, img, table, uniform, metas, offs, partials);
+        hagrid_mem_free(ctx, offs);
+        if (rs == HAGRID_OK) { release(); img.uniform = uniform; img.table = table; return HAGRID_OK; }
         if (rs != 1) { release(); hagrid_mem_free(ctx, table); return rs; }
     }
     if ((long long)units + units1 >= (1ll << 31)) { release(); hagrid_mem_free(ctx, table); return 1; }

@@ -627,11 +627,12 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
 // NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
 // UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-// SLIM (with UNIFORM): 16-byte records, SLIM = bits per packed reference id (trav_image.hip, "Slim records"); 0 = 32-byte records
+// SLIM (with FLAT and NARROW, grids of at most three levels): 16-byte records, SLIM = bits per packed reference id (trav_image.hip,
+// "Slim records"); 0 = 32-byte records.  UNIFORM: bounds as offsets from the voxel; table layout: from the top-level cell's origin.
 template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
-    static_assert(SLIM == 0 || UNIFORM, "slim records exist in the uniform layout only");
+    static_assert(SLIM == 0 || (FLAT && NARROW), "slim records are read by the flat narrow kernels only");
     constexpr int NONE = SLIM ? (1 << (SLIM ? SLIM : 1)) - 1 : -1;          // the id field of an unused list slot
     struct Stamp {
         unsigned long long* p;
@@ -682,6 +683,10 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
                 ra = p[0];
                 if (!SLIM) rb = p[1];
+            } else if (FLAT && NARROW && SLIM) {          // table layout, no links: block offset in records, depth of the block
+                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+                ra = *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
@@ -728,7 +733,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         record(tab, vx, vy, vz, ca, cb);
 
         for (;;) {
-            if (!UNIFORM && ca.w >= 0xfffffffeu) {                          // (the table-free layout needs shift <= 3: every block resolves its cell fully)
+            if (!UNIFORM && !SLIM && ca.w >= 0xfffffffeu) {                 // (the table-free layout and slim records need shift <= 3: every block resolves its cell fully)
                 // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
                 // cell the next records are fetched from it directly (one gather per step again)
                 uint32_t off = ~0u, meta = 0u;
@@ -740,7 +745,12 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
             int cx, cy, cz;
-            if (SLIM) {     // byte offsets from the voxel the record belongs to
+            if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell
+                const int org_mask = ~((1 << a.shift) - 1);
+                cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
+                cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
+                cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
+            } else if (SLIM) {     // byte offsets from the voxel the record belongs to
                 // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(sgy), "v"(__builtin_amdgcn_ubfe(ca.x, oy, 8u)), "v"(vy));
@@ -1113,12 +1123,14 @@ size_t buffer_bytes_from(const void* p) {
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, const TraverseArgs& a) {
-    if (flat && narrow && uniform && slim == 20) {
+    if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
+    if (slim == 20 && uniform) {
         if (MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, st>>>(a);
         else traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
     }
-    else if (flat && narrow && uniform && slim == 26) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
-    else if (slim) return false;                    // slim records are read by the uniform narrow kernels only
+    else if (slim == 26 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
+    else if (slim == 20)            traverse_kernel_img<64, true, true, false, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
+    else if (slim == 26)            traverse_kernel_img<64, true, true, false, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow && uniform && MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow)       traverse_kernel_img<64, true, true, false, MODE><<<blocks, 64, 0, st>>>(a);
@@ -1450,14 +1462,14 @@ __global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray a
     out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
 }
 
-__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat, int slim) {
+__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat, int slim, int slim_uniform) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
     const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
     if (slim) {     // a slim record, brought into the form of the 32-byte record
-        const int d = a.shift, m = (1 << d) - 1;
-        const uint4 r = reinterpret_cast<const uint4*>(a.img_blocks)[(size_t(tab.x) + size_t((vx & m) + (((vy & m) + ((vz & m) << d)) << d)))];
+        const int d = int(tab.y & 3u), sh = a.shift - d, m = (1 << d) - 1;             // (uniform layout: d == shift)
+        const uint4 r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(tab.x) + size_t(((vx >> sh) & m) + ((((vy >> sh) & m) + (((vz >> sh) & m) << d)) << d))];
         const uint32_t w[5] = {r.x, r.y, r.z, r.w, 0u};
         auto field = [&](int pos, int nb) -> uint32_t {
             const int wi = pos >> 5, o = pos & 31;
@@ -1467,9 +1479,16 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
         const int ni = 80 / slim;
         const uint32_t none = (1u << slim) - 1u;
         uint32_t* o = out + 8 * size_t(i);
-        o[0] = uint32_t(vx - int(field(0, 8))) | uint32_t(vx + int(field(8, 8))) << 16;
-        o[1] = uint32_t(vy - int(field(16, 8))) | uint32_t(vy + int(field(24, 8))) << 16;
-        o[2] = uint32_t(vz - int(field(32, 8))) | uint32_t(vz + int(field(40, 8))) << 16;
+        if (slim_uniform) {
+            o[0] = uint32_t(vx - int(field(0, 8))) | uint32_t(vx + int(field(8, 8))) << 16;
+            o[1] = uint32_t(vy - int(field(16, 8))) | uint32_t(vy + int(field(24, 8))) << 16;
+            o[2] = uint32_t(vz - int(field(32, 8))) | uint32_t(vz + int(field(40, 8))) << 16;
+        } else {
+            const int om = ~((1 << a.shift) - 1);
+            o[0] = uint32_t((vx & om) + int(field(0, 8)) - 128) | uint32_t((vx & om) + int(field(8, 8)) - 128) << 16;
+            o[1] = uint32_t((vy & om) + int(field(16, 8)) - 128) | uint32_t((vy & om) + int(field(24, 8)) - 128) << 16;
+            o[2] = uint32_t((vz & om) + int(field(32, 8)) - 128) | uint32_t((vz & om) + int(field(40, 8)) - 128) << 16;
+        }
         if (field(48 + (ni - 1) * slim, slim) == none - 1u) {
             const uint32_t cnt = field(80, 20);
             // lists of at most four ids are inline in the 32-byte record: read them through the index
@@ -1599,6 +1618,13 @@ extern "C" int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_
     return HAGRID_OK;
 }
 
+extern "C" int hagrid_kat_image_format(hagrid_ctx* ctx, const hagrid_grid* grid, int32_t* format4) {
+    if (!ctx || !grid || !format4) return HAGRID_EINVAL;
+    if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
+    format4[0] = ctx->image.flat ? 1 : 0; format4[1] = ctx->image.uniform ? 1 : 0; format4[2] = ctx->image.slim; format4[3] = ctx->image.slim ? 16 : 32;
+    return HAGRID_OK;
+}
+
 extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes) {
     if (!ctx || !grid || n < 0) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
@@ -1611,7 +1637,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim); HG_DBG(ctx);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim, ctx->image.uniform ? 1 : 0); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }

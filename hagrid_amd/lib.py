@@ -123,6 +123,7 @@ SIGNATURES = {
     "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "hagrid_kat_image_format": (_i32, [_vp, _vp, _vp]),
     "hagrid_kat_wave_times": (_i32, [_vp, _vp, _vp]),
     "hagrid_kat_tile_slots": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
 }

@@ -284,6 +284,9 @@ int hagrid_kat_wave_times(hagrid_ctx* ctx, unsigned long long* times_dev, const 
  * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
  * HAGRID_EINVAL when the context holds no image of this grid. */
 int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);
+/* Layout of the traversal image held for `grid`: format4 = { flat (a record per voxel), uniform (table-free), bits per packed
+ * reference id of slim 16-byte records (0: 32-byte records), bytes per record }.  HAGRID_EINVAL without an image of this grid. */
+int hagrid_kat_image_format(hagrid_ctx* ctx, const hagrid_grid* grid, int32_t* format4);
 
 #ifdef __cplusplus
 }

@@ -392,13 +392,11 @@ def _image_scenes():
 _IMAGE_FORMATS = {"compact": (1, 1), "flat": (2, 1), "flat_fat": (2, 0), "flat_slim26": (2, 2)}
 
 
-def _slim_expected(G, slim):
-    """Slim records are built for the table-free layout (every top-level cell at the full depth, at most three levels) when every
-    bound lies within 255 voxels of each of the cell's voxels."""
-    if not slim or not (1 <= G.shift <= 3):
-        return False
-    top = G.entries[:int(np.prod(G.dims))]
-    return bool(((top & 3) == G.shift).all())      # sufficient for "uniform" (the 25 % rule only matters for partly shallow grids)
+def _slim_must_fit(G, slim):
+    """Slim records are built for flat images of grids with one to three levels when every bound fits its byte: at most 255 voxels
+    from each of the cell's voxels (table-free layout), within [-128, 127] of the origin of each top-level cell the cell overlaps
+    (table layout).  Both hold for certain when the virtual resolution is at most 128."""
+    return bool(slim) and 1 <= G.shift <= 3 and int((np.array(G.dims) << G.shift).max()) <= 128
 
 
 @pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
@@ -429,10 +427,16 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     assert rc == 0
     want, begin = _expected_records(G, vox.astype(np.int64))
     by_index, deep = _check_records(got, want, begin)
-    if fmt == 2 and _slim_expected(G, slim) and int(res.max()) <= 256:
-        assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims)), "slim records expected"
-    if fmt == 2 and not slim:
-        assert nbytes.value != 16 * total + 8 * int(np.prod(G.dims))
+    info = mem.image_format(grid)
+    assert info["flat"] == (fmt == 2)
+    if fmt == 2 and _slim_must_fit(G, slim):
+        assert info["slim_id_bits"] == (26 if slim == 2 else 20) and info["record_bytes"] == 16, "slim records expected"
+    if fmt == 1 or not slim or not (1 <= G.shift <= 3):
+        assert info["slim_id_bits"] == 0 and info["record_bytes"] == 32
+    if info["slim_id_bits"] and info["uniform"]:
+        assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims))
+    if name == "soup30k_shift3" and fmt == 2 and slim:
+        assert info["slim_id_bits"] and not info["uniform"], "the table layout with slim records is exercised"
     assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
         assert (by_index & ~deep).any()
@@ -501,13 +505,17 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
     want, _ = G.traverse(tris, rays, nthreads=8)
     nb = C.c_int64(0)
     try:
-        mem.set_option("traverse.image_uniform", 2)              # the table-free layout whatever it costs: this grid is mostly empty
-        for slim in (1, 2, 0):
-            mem.set_option("traverse.image_slim", slim)
-            got = gpu_traverse(mem, grid, d_tris, rays)
-            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), slim
-            assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
-            assert nb.value >= 32 * total, "32-byte records expected"
+        for uniform in (2, 1):            # 2: the table-free layout whatever it costs (this grid is mostly empty); 1: the table layout here
+            mem.set_option("traverse.image_uniform", uniform)
+            for slim in (1, 2, 0):
+                mem.set_option("traverse.image_slim", slim)
+                got = gpu_traverse(mem, grid, d_tris, rays)
+                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim)
+                info = mem.image_format(grid)
+                assert info["flat"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
+                assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
+                assert uniform == 1 or nb.value >= 32 * total
+        mem.set_option("traverse.image_uniform", 2)
         # the same clusters close together: every cell fits, slim records in both id widths
         b[:, 0] -= np.float32(39.0)
         tris2 = np.ascontiguousarray(np.concatenate([a, b]))
@@ -523,6 +531,7 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
             assert (got["id"] == want2["id"]).all() and (bits(got["t"]) == bits(want2["t"])).all(), slim
             assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
             assert nb.value == 16 * total2 + 8 * int(np.prod(G2.dims)), "slim records expected"
+            assert mem.image_format(grid2) == {"flat": True, "uniform": True, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
         grid2.free(); mem.free(d_tris2)
     finally:
         mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1)
