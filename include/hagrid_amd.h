@@ -184,18 +184,21 @@ int hagrid_grid_broadcast(hagrid_ctx* ctx, void* comm, int rank, int root, hagri
  * of up to four inline -- so that a cell step is ONE dependent gather (the block's table entry is kept while the ray stays in
  * the top-level cell) instead of entry -> entry -> cell, and the reference-id gather disappears for short lists; blocks
  * resolve three levels, deeper subdivisions are links to nested blocks of the same form (three more levels each; below
- * six levels a link back into the construction format).  "traverse.image" = 1 is the compact
+ * six levels a link back into the construction format).  Grids of at most three levels get SLIM records of 16 bytes instead
+ * ("traverse.image_slim", on by default: bounds as byte offsets from the record's voxel -- from the top-level cell's origin in
+ * the table layout --, four reference ids of 20 bits or three of 26 bits; one gather instruction per cell step, half the
+ * image) unless a cell reaches further than a byte can say, in which case the 32-byte records are kept.  "traverse.image" = 1 is the compact
  * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.  A flat
  * image that would exceed max(1 GB, 8x the entries + cells it replaces) ("traverse.image_max_mb") is built in the compact form.
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
  * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
  * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for
- * a virtual resolution above 65535 per axis or for compressed grids deeper than six levels (three in the compact form).  Synchronous (one size read-back); 0.17 ms and 256 MB for
- * the 1M-triangle scene of BASELINE.md. */
+ * a virtual resolution above 65535 per axis or for compressed grids deeper than six levels (three in the compact form).  Synchronous (size / fit read-backs); 0.19 ms and 129 MB for
+ * the 1M-triangle scene of BASELINE.md (257 MB with 32-byte records). */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
 /* Extension: after hagrid_setup_traversal built a self-contained image of `grid` (the flat form of a grid of at most six levels), the
  * caller may give the construction format up: entries and cells | small_cells are released to the pool and set to NULL in the
- * descriptor, the image answers for them (1M-triangle scene: 166 MB of 493 MB).  hagrid_traverse_grid[_ex] keep working with that
+ * descriptor, the image answers for them (1M-triangle scene: 166 MB of 365 MB).  hagrid_traverse_grid[_ex] keep working with that
  * descriptor; what reads the construction format (construction passes, hagrid_traverse_grid_stats, hagrid_grid_pack, forced kernel
  * variants) is refused.  ref_ids and the triangles stay with the caller as before. */
 int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* grid);
@@ -232,7 +235,9 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
- * kernel, an error without an image), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing), "traverse.narrow" (1 = v2 uses 32-bit
+ * kernel, an error without an image), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing),
+ * "traverse.image_slim" (flat image of a grid of at most three levels: 1, default = 16-byte records where every cell fits them; 0 = 32-byte
+ * records; 2 = the 26-bit id form even where 20 bits would do), "traverse.narrow" (1 = v2 uses 32-bit
  * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
