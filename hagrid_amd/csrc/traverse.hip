@@ -850,6 +850,246 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 }
 
 
+// ---- image kernel with a tail mode ---------------------------------------------------------------------------------------
+// The 1M-ray launch ends when its longest rays end (half of it is the drain of wavefronts that hold a handful of live
+// rays, each lock-step iteration a serial chain of dependent instructions and one dependent gather), and a wavefront of few live rays
+// still pays a triangle round per id of its longest list.  Rays only finish, so the number of live rays of a wavefront only falls:
+// once it is at most 16 the wavefront COMPACTS -- live ray r moves to lanes 4r .. 4r + 3 (one LDS rendezvous, one ds_bpermute per
+// register, once per wavefront) -- and from then on a cell step tests the up to four inline ids of a list in ONE round, lane s of the
+// group taking id s.  The four lanes walk the voxels redundantly (same arithmetic, same record).  The reference's sequential rule
+// (every test sees the tmax the accepted tests before it left, prims.h:266-295) is kept exactly: a lane computes everything that
+// does not depend on tmax -- the barycentric test, t >= |det| * tmin, t and |det| -- and the group then replays the acceptance
+// `|det| * tmax > t` in list order on quad broadcasts (DPP), so hit ids and t stay bit-identical.  Table-free layout with slim
+// records, nearest hit, narrow addressing; everything else runs traverse_kernel_img.
+struct TriCand { float t, abs_det; bool ok; };
+__device__ __forceinline__ TriCand tri_candidate(const Tri& tri, const vec3& org, const vec3& dir, float tmin) {   // prims.h:266-283, up to the comparison with tmax
+    const vec3 n = tri.normal();
+    const vec3 c = tri.v0 - org;
+    const vec3 r = cross(dir, c);
+    const float det = dot(n, dir);
+    const float abs_det = detail::fabs1(det);
+    const float u = prodsign(dot(r, tri.e2), det);
+    const float v = prodsign(dot(r, tri.e1), det);
+    const float w = abs_det - u - v;
+    const float eps = 1e-9f;
+    TriCand cd; cd.t = 0.0f; cd.abs_det = abs_det; cd.ok = false;
+    if (u >= -eps && v >= -eps && w >= -eps) {
+        const float t = prodsign(dot(n, c), det);
+        if (t >= abs_det * tmin) { cd.t = t; cd.ok = true; }
+    }
+    return cd;
+}
+template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
+template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return __int_as_float(quad_bcast_i<K>(__float_as_int(x))); }
+
+constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
+
+template <int SLIM>
+__global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
+    constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
+    __shared__ int lanes_of[64];
+    const int lane = threadIdx.x;
+    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
+    const int w = !perm ? tile_packet_row_len(a) : 0;
+    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
+    const int slot = w ? tile_packet_slot(a, w, b, lane) : b * 64 + lane;
+    const bool valid = slot < a.num_rays;
+    int id = valid ? (perm ? perm[slot] : slot) : 0;
+    bool pending = valid;                                  // this lane still owes its ray's hit to the hit buffer
+
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+    if (valid) { r0 = nt_load4(a.rays + 2 * size_t(id)); r1 = nt_load4(a.rays + 2 * size_t(id) + 1); }
+    vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    float tmin = r0.w;
+    const float tmax = r1.w;
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+    float hit_t = tmax;
+    int hit_id = -1;
+    int vx = 0, vy = 0, vz = 0;
+    bool alive = false;
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+        const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+        const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+        const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+        if (valid && !(tstart > tend)) {
+            const vec3 fv = (tstart * dir + org - gmin) * ginv;
+            vx = min(max(int(fv.x), 0), a.dims_x - 1);
+            vy = min(max(int(fv.y), 0), a.dims_y - 1);
+            vz = min(max(int(fv.z), 0), a.dims_z - 1);
+            alive = true;
+        }
+    }
+    auto load_record = [&](int x, int y, int z) -> uint4 {
+        const int d = a.shift, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+        const uint32_t top = uint32_t(x >> d) + __umul24(uint32_t(a.top_x), uint32_t(y >> d)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> d));
+        return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+    };
+    auto tri_ptr = [&](int ref) -> const float4* {
+        uint32_t r3, o;
+        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+        return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
+    };
+    auto tri_vec = [&](int ref) -> Tri {
+        const float4* p = tri_ptr(ref);
+        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+        return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+    };
+    auto tri_for = [&](int ref) -> Tri {                   // every live lane the same triangle: through the scalar cache
+        const int f = __builtin_amdgcn_readfirstlane(ref);
+        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar(a.tris, f);
+        return tri_vec(ref);
+    };
+    auto field = [&](const uint4& rec, int pos, int n) -> uint32_t {
+        const uint32_t wd[4] = {rec.x, rec.y, rec.z, rec.w};
+        const int i = pos >> 5, o = pos & 31;
+        uint32_t v = wd[i] >> o;
+        if (o + n > 32) v |= wd[i + 1] << (32 - o);
+        return n == 32 ? v : (v & ((1u << n) - 1u));
+    };
+    auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
+
+    // One cell step of the ray in this lane (traverse.cu:61-78): exit plane of the cell `rec` describes, next voxel, next record.
+    float texit = 0.0f;
+    bool outside = false;
+    auto cell_step = [&](const uint4& rec, const vec3& inv_dir) -> uint4 {
+        const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+        int cx, cy, cz;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
+        const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+        texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+        const vec3 ev = (texit * dir + org - gmin) * ginv;
+        const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
+        const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
+        const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+        vx = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000));
+        vy = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000));
+        vz = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000));
+        outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
+        return load_record(outside ? 0 : vx, outside ? 0 : vy, outside ? 0 : vz);
+    };
+    // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
+    auto test_list = [&](const uint4& rec) {
+        const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1);
+        int ref = int(field(rec, 48, SLIM));
+        uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
+                 q3 = NI > 3 ? field(rec, 48 + 3 * SLIM, SLIM) : uint32_t(NONE);
+        if (__ballot(by_index) == 0ull) {
+#pragma unroll 1
+            while (ref != NONE) {
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                hit_t = h.t; hit_id = h.id;
+                ref = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE);
+            }
+        } else {
+            if (by_index) {
+                q1 = field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);
+                ref = NONE;
+                if (q1 < q2) ref = ref_at(q1);
+                q1++;
+            }
+#pragma unroll 1
+            while (ref != NONE) {
+                int next;
+                if (by_index) { next = q1 < q2 ? ref_at(q1) : NONE; q1++; }
+                else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                hit_t = h.t; hit_id = h.id;
+                ref = next;
+            }
+        }
+    };
+
+    uint4 ca = make_uint4(0u, 0u, 0u, 0u);
+    if (alive) ca = load_record(vx, vy, vz);
+    unsigned long long live = __ballot(alive);
+
+    // ---- phase 1: one ray per lane, while the wavefront holds more than kTailRays live rays -------------------------------
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        while (__popcll(live) > kTailRays) {
+            if (alive) {
+                const uint4 na = cell_step(ca, inv_dir);
+                test_list(ca);
+                if (hit_t <= texit || outside) alive = false;
+                ca = na;
+            }
+            live = __ballot(alive);
+        }
+    }
+    if (live == 0ull) {
+        if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+        return;
+    }
+
+    // ---- compaction: finished lanes hand in their hits; live ray r moves to lanes 4r .. 4r + 3 ----------------------------------
+    if (pending && !alive) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+    const int nlive = __popcll(live);
+    if (alive) lanes_of[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+    __syncthreads();
+    const int group = lane >> 2, sub = lane & 3;
+    alive = group < nlive;
+    pending = alive && sub == 0;
+    const int src4 = lanes_of[alive ? group : 0] << 2;
+    auto pull_i = [&](int v) -> int { return __builtin_amdgcn_ds_bpermute(src4, v); };
+    auto pull_f = [&](float v) -> float { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); };
+    org = vec3(pull_f(org.x), pull_f(org.y), pull_f(org.z));
+    dir = vec3(pull_f(dir.x), pull_f(dir.y), pull_f(dir.z));
+    tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
+    vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
+    ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
+
+    // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        live = __ballot(alive);
+        while (live) {
+            if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
+                const uint4 na = cell_step(ca, inv_dir);
+                const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
+                if (by_index) {
+                    // lists by index (more ids than a record holds): lane 0 of the group walks the list as in phase 1
+                    if (sub == 0) test_list(ca);
+                } else {
+                    const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
+                              i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
+                    const int mine = sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3));
+                    TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
+                    if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
+                    if (__ballot(cd.ok) != 0ull) {
+                        // replay the acceptance in list order; every lane of the group computes the same
+                        const int okv = cd.ok ? 1 : 0;
+                        auto accept = [&](int ok, float t, float ad, int ref) {
+                            if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
+                        };
+                        { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
+                        if (NI > 1) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
+                        if (NI > 2) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
+                        if (NI > 3) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
+                    }
+                }
+                if (__ballot(by_index) != 0ull) {                         // lane 0 of a by-index group tells the others
+                    const float t0 = quad_bcast_f<0>(hit_t); const int h0 = quad_bcast_i<0>(hit_id);
+                    if (by_index) { hit_t = t0; hit_id = h0; }
+                }
+                if (hit_t <= texit || outside) alive = false;
+                ca = na;
+            }
+            live = __ballot(alive);
+        }
+    }
+    if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+}
+
+
 // ---- v3: persistent wavefronts, lane refill, vote-scheduled phases -------------------------------------------------
 // Profile of v1/v2 on the 1M-ray batch (profiles/): the SIMDs issue ~80 % of the time while only ~19 % of the lanes
 // of an issued VALU instruction are live -- the kernel is instruction-issue bound and 4 of 5 lanes idle, because (a) a
@@ -1122,9 +1362,13 @@ size_t buffer_bytes_from(const void* p) {
 
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
-bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, const TraverseArgs& a) {
+bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
-    if (slim == 20 && uniform) {
+    if (tail && MODE == 0 && uniform && slim && !a.wave_times) {
+        if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, 0, st>>>(a);
+        else            traverse_kernel_tail<26><<<blocks, 64, 0, st>>>(a);
+    }
+    else if (slim == 20 && uniform) {
         if (MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, st>>>(a);
         else traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
     }
@@ -1140,12 +1384,12 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
     else                           traverse_kernel_img<64, false, false, false, 0><<<blocks, 64, 0, st>>>(a);
     return true;
 }
-bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, unsigned mode, const TraverseArgs& a) {
+bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
     switch (mode & 3u) {
-        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, slim, a);
-        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, slim, a);
-        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, slim, a);
-        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, slim, a);
+        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, slim, tail, a);
+        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, slim, tail, a);
+        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, slim, tail, a);
+        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, slim, tail, a);
     }
 }
 
@@ -1320,7 +1564,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
-        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, flags, a))
+        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
     } else if (variant == 1) {
         const int blocks = grid_blocks(num_rays, 256);
@@ -1357,7 +1601,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.tail", &ctx->opt_tail, 0, 1},
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},

@@ -39,3 +39,17 @@ for P in (1, 8, 2, 16, 4, 32, 9, 63):
                       "idle helper (dead or empty cell)": rounds2.max(axis=1).sum() / w.shape[0], "ratio2": round(rounds2.max(axis=1).sum() / base, 3)}), flush=True)
 # upper bound: every lane with a list of two or more always has a helper
 print(json.dumps({"every list halved": ((lw + 1) // 2).max(axis=1).sum() / w.shape[0], "ratio": round(((lw + 1) // 2).max(axis=1).sum() / base, 3)}))
+
+# ---- tail mode: once a wavefront holds at most 64 / G live rays, every live ray is spread over G lanes and its inline list is tested
+# G ids per round (rays only finish, so the switch is one-way); rounds of a step = max over the live rays of ceil(L / G)
+n_live = live.sum(axis=1)                                        # [waves, CAP]
+any_live = n_live > 0
+for thresholds in ((16,), (32, 16), (32, 16, 8), (32,), (8,)):
+    rounds = lw.max(axis=1)
+    for t in sorted(thresholds, reverse=True):
+        G = 64 // t
+        rounds = np.where(n_live <= t, ((lw + G - 1) // G).max(axis=1), rounds)
+    tail_steps = (any_live & (n_live <= max(thresholds))).sum()
+    print(json.dumps({"tail mode at live rays <=": thresholds, "tri_rounds/wave": rounds.sum() / w.shape[0], "ratio": round(rounds.sum() / base, 3),
+                      "cell steps in tail mode": round(float(tail_steps / any_live.sum()), 3),
+                      "iterations/wave": (cell_iters + rounds.sum()) / w.shape[0]}), flush=True)
