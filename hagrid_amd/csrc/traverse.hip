@@ -14,7 +14,6 @@
 
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
 
 #include "hagrid/grid.h"
 #include "hagrid/prims.h"
@@ -882,12 +881,6 @@ __device__ __forceinline__ TriCand tri_candidate(const Tri& tri, const vec3& org
 }
 template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
 template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return __int_as_float(quad_bcast_i<K>(__float_as_int(x))); }
-// lane K of every PAIR to both lanes of the pair: quad_perm (K, K, 2 + K, 2 + K)
-template <int K> __device__ __forceinline__ int pair_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, K | K << 2 | (2 + K) << 4 | (2 + K) << 6, 0xf, 0xf, false); }
-template <int K> __device__ __forceinline__ float pair_bcast_f(float x) { return __int_as_float(pair_bcast_i<K>(__float_as_int(x))); }
-#ifndef HG_TAIL2
-#define HG_TAIL2 1      // a two-lanes-per-ray stage between 32 and 16 live rays
-#endif
 
 constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
 
@@ -1022,7 +1015,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     // ---- phase 1: one ray per lane, while the wavefront holds more than kTailRays live rays -------------------------------
     {
         const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-        while (__popcll(live) > (HG_TAIL2 ? 2 * kTailRays : kTailRays)) {
+        while (__popcll(live) > kTailRays) {
             if (alive) {
                 const uint4 na = cell_step(ca, inv_dir);
                 test_list(ca);
@@ -1037,73 +1030,54 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         return;
     }
 
-    // ---- compaction + grouped phases: first two lanes per ray (at most 32 live rays), then four (at most 16) -----------------------
-    // compact<G>: finished rays hand in their hits; live ray r (its first lane) moves to lanes G r .. G r + G - 1
-    auto compact = [&](auto gc, bool leader) {
-        constexpr int G = decltype(gc)::value;
-        if (pending && !alive) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-        const unsigned long long leaders = __ballot(alive && leader);
-        const int nlive = __popcll(leaders);
-        __syncthreads();                                                   // (the previous compaction's reads of lanes_of are done)
-        if (alive && leader) lanes_of[__popcll(leaders & ((1ull << lane) - 1ull))] = lane;
-        __syncthreads();
-        const int group = lane / G;
-        alive = group < nlive;
-        pending = alive && (lane % G) == 0;
-        const int src4 = lanes_of[alive ? group : 0] << 2;
-        auto pull_i = [&](int v) -> int { return __builtin_amdgcn_ds_bpermute(src4, v); };
-        auto pull_f = [&](float v) -> float { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); };
-        org = vec3(pull_f(org.x), pull_f(org.y), pull_f(org.z));
-        dir = vec3(pull_f(dir.x), pull_f(dir.y), pull_f(dir.z));
-        tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
-        vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
-        ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
-    };
-    // grouped<G>: G lanes per ray until at most `until` rays are live (0: to the end).  Lane `sub` of a group tests ids sub, sub + G, ...
-    auto grouped = [&](auto gc, int until) {
-        constexpr int G = decltype(gc)::value;
-        const int sub = lane % G;
+    // ---- compaction: finished lanes hand in their hits; live ray r moves to lanes 4r .. 4r + 3 ----------------------------------
+    if (pending && !alive) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+    const int nlive = __popcll(live);
+    if (alive) lanes_of[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+    __syncthreads();
+    const int group = lane >> 2, sub = lane & 3;
+    alive = group < nlive;
+    pending = alive && sub == 0;
+    const int src4 = lanes_of[alive ? group : 0] << 2;
+    auto pull_i = [&](int v) -> int { return __builtin_amdgcn_ds_bpermute(src4, v); };
+    auto pull_f = [&](float v) -> float { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); };
+    org = vec3(pull_f(org.x), pull_f(org.y), pull_f(org.z));
+    dir = vec3(pull_f(dir.x), pull_f(dir.y), pull_f(dir.z));
+    tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
+    vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
+    ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
+
+    // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
+    {
         const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
         live = __ballot(alive);
-        while (__popcll(live) > until * G) {
-            if (alive) {                                                   // (whole groups: the lanes of a ray finish together)
+        while (live) {
+            if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint4 na = cell_step(ca, inv_dir);
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
                 if (by_index) {
-                    // lists by index (more ids than a record holds): the first lane of the group walks the list as in phase 1
+                    // lists by index (more ids than a record holds): lane 0 of the group walks the list as in phase 1
                     if (sub == 0) test_list(ca);
                 } else {
-                    const int ids[4] = {int(field(ca, 48, SLIM)), NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
-                                        NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE};
-#pragma unroll
-                    for (int r = 0; r * G < NI; r++) {
-                        int mine = NONE;
-#pragma unroll
-                        for (int k = 0; k < G; k++) if (r * G + k < 4 && sub == k) mine = ids[r * G + k];
-                        if (r > 0 && __ballot(mine != NONE) == 0ull) break;      // no list of the wavefront reaches this round
-                        TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
-                        if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
-                        if (__ballot(cd.ok) != 0ull) {
-                            // replay the acceptance in list order; every lane of the group computes the same
-                            const int okv = cd.ok ? 1 : 0;
-                            auto accept = [&](int ok, float t, float ad, int ref) {
-                                if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
-                            };
-                            if (G == 4) {
-                                { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, ids[0]); }
-                                { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, ids[1]); }
-                                { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, ids[2]); }
-                                { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, ids[3]); }
-                            } else {
-                                { const int ok = pair_bcast_i<0>(okv); const float t = pair_bcast_f<0>(cd.t), ad = pair_bcast_f<0>(cd.abs_det); accept(ok, t, ad, ids[(r * 2) & 3]); }
-                                { const int ok = pair_bcast_i<1>(okv); const float t = pair_bcast_f<1>(cd.t), ad = pair_bcast_f<1>(cd.abs_det); accept(ok, t, ad, ids[(r * 2 + 1) & 3]); }
-                            }
-                        }
+                    const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
+                              i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
+                    const int mine = sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3));
+                    TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
+                    if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
+                    if (__ballot(cd.ok) != 0ull) {
+                        // replay the acceptance in list order; every lane of the group computes the same
+                        const int okv = cd.ok ? 1 : 0;
+                        auto accept = [&](int ok, float t, float ad, int ref) {
+                            if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
+                        };
+                        { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
+                        if (NI > 1) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
+                        if (NI > 2) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
+                        if (NI > 3) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
                     }
                 }
-                if (__ballot(by_index) != 0ull) {                         // the first lane of a by-index group tells the others
-                    const float t0 = G == 4 ? quad_bcast_f<0>(hit_t) : pair_bcast_f<0>(hit_t);
-                    const int h0 = G == 4 ? quad_bcast_i<0>(hit_id) : pair_bcast_i<0>(hit_id);
+                if (__ballot(by_index) != 0ull) {                         // lane 0 of a by-index group tells the others
+                    const float t0 = quad_bcast_f<0>(hit_t); const int h0 = quad_bcast_i<0>(hit_id);
                     if (by_index) { hit_t = t0; hit_id = h0; }
                 }
                 if (hit_t <= texit || outside) alive = false;
@@ -1111,16 +1085,6 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             }
             live = __ballot(alive);
         }
-    };
-    bool leader = true;
-    if (HG_TAIL2 && __popcll(live) > kTailRays) {
-        compact(std::integral_constant<int, 2>(), leader);
-        grouped(std::integral_constant<int, 2>(), kTailRays);
-        leader = (lane & 1) == 0;
-    }
-    if (live != 0ull) {
-        compact(std::integral_constant<int, 4>(), leader);
-        grouped(std::integral_constant<int, 4>(), 0);
     }
     if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
 }
