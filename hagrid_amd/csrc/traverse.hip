@@ -884,15 +884,21 @@ template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return
 
 constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
 
-template <int SLIM>
+// TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
+template <int SLIM, bool TIMES = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
     const int lane = threadIdx.x;
+    struct Stamp {
+        unsigned long long* p;
+        __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
+        __device__ ~Stamp() { if (TIMES) { const unsigned long long t = wall_clock64(); atomicMax(p + 1, t); } }
+    } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = !perm ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-    const int slot = w ? tile_packet_slot(a, w, b, lane) : b * 64 + lane;
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, lane) : b * 64 + lane;
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
     bool pending = valid;                                  // this lane still owes its ray's hit to the hit buffer
@@ -1364,9 +1370,10 @@ size_t buffer_bytes_from(const void* p) {
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
-    if (tail && MODE == 0 && uniform && slim && !a.wave_times) {
-        if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, 0, st>>>(a);
-        else            traverse_kernel_tail<26><<<blocks, 64, 0, st>>>(a);
+    if (tail && MODE == 0 && uniform && slim && !(a.wave_times && slim != 20)) {
+        if (slim == 20 && a.wave_times) traverse_kernel_tail<20, true><<<blocks, 64, 0, st>>>(a);
+        else if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, 0, st>>>(a);
+        else                 traverse_kernel_tail<26><<<blocks, 64, 0, st>>>(a);
     }
     else if (slim == 20 && uniform) {
         if (MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, st>>>(a);

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hagrid_amd import api, scene
 N = int(os.environ.get("N", 1000000)); W = int(os.environ.get("W", 1024))
 mem = api.MemManager(keep=True)
+for kv in filter(None, os.environ.get("OPTS", "").split(",")):
+    k, v = kv.split("="); mem.set_option(k, int(v))
 tris = scene.make_soup(N); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, N)
 rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, W, W); n = rays.shape[0]
