@@ -270,7 +270,9 @@ def main():
                 traffic_source = "profiles/traffic_latest.json: " + tj.get("source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/gpu_round.sh), FETCH x2 per the gfx950 note; NOT measured in this run")
             except Exception:
                 traffic = None
-        kernel_name = "traverse_kernel_img" if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2")
+        fmt = mem.image_format(grid) if args.image else {}
+        tail = fmt.get("uniform") and fmt.get("slim_id_bits") and "traverse.tail=0" not in args.opts and "traverse.variant" not in args.opts
+        kernel_name = ("traverse_kernel_tail" if tail else "traverse_kernel_img") if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2")
         cells_b = grid.num_cells * (16 if compressed else 32)
         image_b = mem.image_bytes(grid)
         out = {
@@ -298,7 +300,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 # what binds according to the counters (profiles/): the working set is L2 / Infinity-Cache resident, the kernel is
                 # limited by instruction issue with partly idle wavefronts and by the line rate of the vector L1, NOT by HBM bandwidth
-                "binding_resource": "the CUs' vector-memory address/L1 path (~12 cycles per wavefront load + 1-10 per live lane and line: 84 % busy, profiles/micro_r2l_vector_memory.txt); working set cache-resident, HBM itself runs at `hbm_measured`",
+                "binding_resource": "instruction issue and the CUs' vector-memory address/L1 path (~12 cycles per wavefront load + 1-10 per live lane and line, profiles/micro_r2l_vector_memory.txt) while the machine is full, the dependent chains of the last wavefronts in the drain (profiles/dev_r2_wave_timeline_tail.txt); working set cache-resident, HBM itself runs at `hbm_measured`",
                 "hbm_measured": None if traffic is None else round(traffic / (kernel_ms * 1e6), 1),
                 "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "l2_hit_rate": l2_hit,
