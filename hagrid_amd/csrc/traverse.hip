@@ -1557,8 +1557,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             a.row_len_hint = ctx->opt_image_width;
             if (variant == 3 && (a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
         } else {
-            int* row_len = ctx->dscratch + 232;
-            launch_detect(ctx, a, num_rays, row_len);
+            // The row length only steers the lane <-> ray assignment (any value gives the same hits), so the answer found for a ray
+            // buffer is kept: calls with the same buffer and count reuse it and look again every 16th call ("traverse.row_cache" = 0:
+            // at every call).  A buffer refilled with rows of another length runs on the stale length until then -- slower, never wrong.
+            int* row_len = ctx->dscratch + 236;
+            const bool cached = ctx->opt_row_cache && variant != 3 && ctx->rowlen_rays == rays && ctx->rowlen_n == num_rays && ctx->rowlen_age < 15;
+            if (cached) ctx->rowlen_age++;
+            else { launch_detect(ctx, a, num_rays, row_len); ctx->rowlen_rays = rays; ctx->rowlen_n = num_rays; ctx->rowlen_age = 0; }
             a.row_len = row_len;
             if (variant == 3) {
                 int w = 0;
@@ -1608,7 +1613,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.tail", &ctx->opt_tail, 0, 1},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.tail", &ctx->opt_tail, 0, 1}, {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},

@@ -236,6 +236,8 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
  * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
  * kernel, an error without an image), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing),
+ * "traverse.tail" (1, default = the table-free slim image is traversed by the kernel with the tail mode: a wavefront that holds at most 16
+ * live rays spreads each over four lanes and tests a cell's inline list in one round; 0 = one ray per lane throughout),
  * "traverse.image_slim" (flat image of a grid of at most three levels: 1, default = 16-byte records where every cell fits them; 0 = 32-byte
  * records; 2 = the 26-bit id form even where 20 bits would do), "traverse.narrow" (1 = v2 uses 32-bit
  * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
@@ -243,7 +245,9 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
  * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
- * also from the origins alone -- bounce rays in the image order of their primary hits), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
+ * also from the origins alone -- bounce rays in the image order of their primary hits; the answer is kept per ray buffer and count and
+ * looked for again every 16th call, "traverse.row_cache" = 0: at every call -- it only steers the lane <-> ray assignment, hits never
+ * depend on it), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
  * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
