@@ -271,7 +271,7 @@ def main():
             except Exception:
                 traffic = None
         fmt = mem.image_format(grid) if args.image else {}
-        tail = fmt.get("uniform") and fmt.get("slim_id_bits") and "traverse.tail=0" not in args.opts and "traverse.variant" not in args.opts
+        tail = fmt.get("slim_id_bits") and "traverse.tail=0" not in args.opts and "traverse.variant" not in args.opts
         kernel_name = ("traverse_kernel_tail" if tail else "traverse_kernel_img") if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2")
         cells_b = grid.num_cells * (16 if compressed else 32)
         image_b = mem.image_bytes(grid)

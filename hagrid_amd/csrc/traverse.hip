@@ -885,7 +885,9 @@ template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return
 constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
 
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-template <int SLIM, bool TIMES = false>
+// UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
+// top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
+template <int SLIM, bool TIMES = false, bool UNIFORM = true>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
@@ -928,11 +930,22 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             alive = true;
         }
     }
+    uint32_t tab_off = 0u, tab_d = 0u;                     // table layout: block offset (records) and depth of the top-level cell the ray is in
+    int top_idx = -1;
     auto load_record = [&](int x, int y, int z) -> uint4 {
-        const int d = a.shift, m = (1 << d) - 1;
-        const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-        const uint32_t top = uint32_t(x >> d) + __umul24(uint32_t(a.top_x), uint32_t(y >> d)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> d));
-        return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+        const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
+        if (UNIFORM) {
+            const int d = a.shift, m = (1 << d) - 1;
+            const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+            return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+        }
+        if (int(top) != top_idx) {
+            const uint2 t = gather32<uint2>(a.img_table, top << 3);
+            tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+        }
+        const int d = int(tab_d), sh = a.shift - d, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t((x >> sh) & m) + (uint32_t(((y >> sh) & m) + (((z >> sh) & m) << d)) << d);
+        return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
     };
     auto tri_ptr = [&](int ref) -> const float4* {
         uint32_t r3, o;
@@ -965,9 +978,16 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     auto cell_step = [&](const uint4& rec, const vec3& inv_dir) -> uint4 {
         const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
         int cx, cy, cz;
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
+        if (UNIFORM) {
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
+        } else {
+            const int org_mask = ~((1 << a.shift) - 1);
+            cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
+            cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
+            cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
+        }
         const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
         texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
         const vec3 ev = (texit * dir + org - gmin) * ginv;
@@ -1052,6 +1072,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
     vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
     ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
+    if (!UNIFORM) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
 
     // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
     {
@@ -1370,7 +1391,11 @@ size_t buffer_bytes_from(const void* p) {
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
-    if (tail && MODE == 0 && uniform && slim && !(a.wave_times && slim != 20)) {
+    if (tail && MODE == 0 && slim && !a.wave_times && !uniform) {
+        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, 0, st>>>(a);
+        else            traverse_kernel_tail<26, false, false><<<blocks, 64, 0, st>>>(a);
+    }
+    else if (tail && MODE == 0 && uniform && slim && !(a.wave_times && slim != 20)) {
         if (slim == 20 && a.wave_times) traverse_kernel_tail<20, true><<<blocks, 64, 0, st>>>(a);
         else if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, 0, st>>>(a);
         else                 traverse_kernel_tail<26><<<blocks, 64, 0, st>>>(a);
