@@ -601,6 +601,50 @@ def test_image_lifetime(mem):
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
 
 
+# ---- tail mode (traverse_kernel_tail) ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("slim", [1, 2])
+def test_tail_mode_gives_the_oracle_hits(mem, slim):
+    """traverse_kernel_tail: a wavefront that holds at most 16 live rays compacts to four lanes per ray and tests a cell's inline list
+    in one round, replaying the acceptance in list order.  Hits must stay the oracle's bit for bit: wavefronts that are sparse from the
+    start (batches of 1 .. 17 rays, rays that miss the grid), that thin out on the way (64 coherent rays), lists longer than a record
+    holds (by index) met inside the tail phase, the 20- and 26-bit id forms, the table layout, binned batches -- and the kernel without
+    the tail mode for comparison."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    coincident = np.repeat(scene.make_soup(60, seed=41), 9, axis=0)          # nine copies of every triangle: equal t, lists of 9+ ids
+    scenes = {"soup": (scene.make_soup(30000, seed=42), {}),
+              "long_lists": (np.concatenate([coincident, scene.make_soup(4000, seed=43)]), dict(top_density=0.3, snd_density=1.0)),
+              "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0))}
+    try:
+        mem.set_option("traverse.image_slim", slim)
+        for name, (tris, params) in scenes.items():
+            G = O.Grid.full(tris, **params)
+            assert 1 <= G.shift <= 3
+            d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+            lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+            primary = scene.make_rays_primary(lo, hi, 64, 48)
+            rays = np.concatenate([primary, scene.make_rays_incoherent(lo - 0.3, hi + 0.3, 20011, 23)]).astype(np.float32)
+            want, _ = G.traverse(tris, rays, nthreads=8)
+            api.setup_traversal(grid)
+            info = mem.image_format(grid)
+            assert info["slim_id_bits"] == (26 if slim == 2 else 20), (name, info)
+            if name != "long_lists": assert info["uniform"] == (name == "soup"), (name, info)      # both slim layouts are exercised
+            for tail in (1, 0):
+                mem.set_option("traverse.tail", tail)
+                for binning in (0, 1):
+                    mem.set_ray_binning(binning)
+                    for first, n in ((0, rays.shape[0]), (0, 64 * 48), (0, 64), (5, 1), (7, 15), (0, 16), (3, 17), (64 * 48, 4099)):
+                        got = gpu_traverse(mem, grid, d_tris, rays[first:first + n])
+                        w = want[first:first + n]
+                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, binning, first, n)
+            if name == "long_lists":
+                assert (want["id"] >= 0).any()
+            grid.free(); mem.free(d_tris)
+    finally:
+        mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0)
+
+
 # ---- any-hit and barycentrics (SURVEY 8(f) row 4) ------------------------------------------------------------------------
 
 def test_intersect_prim_ray_with_uvs_matches_reference_header(mem, golden_dir):
