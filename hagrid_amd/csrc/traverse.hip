@@ -1349,16 +1349,55 @@ __global__ void __launch_bounds__(64) ray_bin_decide(const int* __restrict__ row
     if (threadIdx.x == 0) flag[0] = (*row_len == 0 && 2ll * d > num_rays) ? 1 : 0;
 }
 
+// The rays of a tile are first put in bin order inside LDS (local histogram -> local scan -> local rank), then written out: lanes
+// that are neighbours in LDS write neighbouring words of `perm`, so a store instruction touches the runs of a few bins instead of 64
+// unrelated lines (the lane-by-lane form moved 512 MB in 2.3 ms for 128M rays: bound by write transactions, not by bytes).
 __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* __restrict__ keys, const int* __restrict__ table_scan,
                                                           int num_rays, int* __restrict__ perm, const int* __restrict__ only_if) {
-    __shared__ int cursor[kBins];
+    static_assert(kBins == 2 * kBlock, "two bins per thread in the local scan");
+    __shared__ int count[kBins];               // rays of the tile per bin, then the cursor of the local ranks
+    __shared__ int lstart[kBins + 1];          // first LDS slot of every bin
+    __shared__ int gstart[kBins];              // first slot of the (bin, workgroup) run in perm
+    __shared__ int sorted_id[kBinTile];
+    __shared__ unsigned short sorted_key[kBinTile];
+    __shared__ int wsum[kWaves];
     if (only_if && *only_if == 0) return;
-    for (int i = threadIdx.x; i < kBins; i += kBlock) cursor[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x];
+    for (int i = threadIdx.x; i < kBins; i += kBlock) { count[i] = 0; gstart[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x]; }
     __syncthreads();
     const int base = blockIdx.x * kBinTile;
+    int key[kBinItems], rank[kBinItems];
+#pragma unroll
     for (int j = 0; j < kBinItems; j++) {
         const int id = base + j * kBlock + threadIdx.x;
-        if (id < num_rays) perm[atomicAdd(&cursor[keys[id]], 1)] = id;
+        key[j] = id < num_rays ? int(keys[id]) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kBinItems; j++) rank[j] = key[j] >= 0 ? atomicAdd(&count[key[j]], 1) : 0;
+    __syncthreads();
+    {   // exclusive scan of the 512 counts: two per thread, wavefront scan, wavefront sums through LDS
+        const int c0 = count[2 * threadIdx.x], c1 = count[2 * threadIdx.x + 1];
+        const int incl = wave_inclusive_scan(c0 + c1);
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave_id(); w++) before += wsum[w];
+        const int ex = before + incl - (c0 + c1);
+        lstart[2 * threadIdx.x] = ex; lstart[2 * threadIdx.x + 1] = ex + c0;
+        if (threadIdx.x == kBlock - 1) lstart[kBins] = ex + c0 + c1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kBinItems; j++)
+        if (key[j] >= 0) {
+            const int at = lstart[key[j]] + rank[j];
+            sorted_id[at] = base + j * kBlock + threadIdx.x;
+            sorted_key[at] = (unsigned short)key[j];
+        }
+    __syncthreads();
+    const int total = lstart[kBins];
+    for (int i = threadIdx.x; i < total; i += kBlock) {
+        const int k = sorted_key[i];
+        perm[gstart[k] + (i - lstart[k])] = sorted_id[i];
     }
 }
 
