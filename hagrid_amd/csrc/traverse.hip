@@ -1082,30 +1082,45 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint4 na = cell_step(ca, inv_dir);
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
-                if (by_index) {
-                    // lists by index (more ids than a record holds): lane 0 of the group walks the list as in phase 1
-                    if (sub == 0) test_list(ca);
-                } else {
-                    const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
-                              i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
-                    const int mine = sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3));
+                const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
+                          i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
+                const int inl = by_index ? NONE : (sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3)));
+                auto accept = [&](int ok, float t, float ad, int ref) {            // prims.h:284-292 with the tmax of this moment
+                    if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
+                };
+                if (__ballot(by_index) == 0ull) {
+                    // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
-                    if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
+                    if (inl != NONE) cd = tri_candidate(tri_for(inl), org, dir, tmin);
                     if (__ballot(cd.ok) != 0ull) {
                         // replay the acceptance in list order; every lane of the group computes the same
                         const int okv = cd.ok ? 1 : 0;
-                        auto accept = [&](int ok, float t, float ad, int ref) {
-                            if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
-                        };
                         { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
                         if (NI > 1) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
                         if (NI > 2) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
                         if (NI > 3) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
                     }
-                }
-                if (__ballot(by_index) != 0ull) {                         // lane 0 of a by-index group tells the others
-                    const float t0 = quad_bcast_f<0>(hit_t); const int h0 = quad_bcast_i<0>(hit_id);
-                    if (by_index) { hit_t = t0; hit_id = h0; }
+                } else {
+                    // some list of the wavefront is given by index (more ids than a record holds): four ids per round as well, lane s takes
+                    // ids s, s + 4, ...; the groups with inline lists take part in the first round
+                    const uint32_t li_begin = field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
+                    int mine = inl;
+                    if (uint32_t(sub) < li_count) mine = ref_at(li_begin + uint32_t(sub));
+#pragma unroll 1
+                    for (uint32_t next = 4u + uint32_t(sub); __ballot(mine != NONE) != 0ull; next += 4u) {
+                        int ahead = NONE;
+                        if (next < li_count) ahead = ref_at(li_begin + next);       // the id of the next round, in flight during this one
+                        TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
+                        if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
+                        if (__ballot(cd.ok) != 0ull) {
+                            const int okv = cd.ok ? 1 : 0;
+                            { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<0>(mine)); }
+                            { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<1>(mine)); }
+                            { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<2>(mine)); }
+                            { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<3>(mine)); }
+                        }
+                        mine = ahead;
+                    }
                 }
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
