@@ -55,7 +55,7 @@ struct hagrid_ctx {
     // profile()
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
-    // pinned mailbox for scalar read-backs (build passes) -- 256 ints
+    // pinned mailbox for scalar read-backs (build passes) -- 256 ints, + words 256.. for values the host only polls (word 300: row length)
     int* mailbox = nullptr;
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
@@ -83,7 +83,8 @@ struct hagrid_ctx {
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
-    const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0;
+    const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1;   // rowlen_known: the row length as the host has seen it (-1: not yet)
+    hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it

@@ -26,7 +26,7 @@ extern "C" int hagrid_ctx_create(hagrid_ctx** out, int device, int keep) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return HAGRID_ENODEV; }
     ctx->num_cus = prop.multiProcessorCount;
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->mailbox, 256 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->mailbox, 320 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&ctx->dscratch, 256 * sizeof(int)) != hipSuccess) {
         hagrid_ctx_destroy(ctx);
         return HAGRID_EHIP;
@@ -43,6 +43,7 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->rowlen_evt) (void)hipEventDestroy(ctx->rowlen_evt);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);

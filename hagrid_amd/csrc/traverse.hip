@@ -1564,6 +1564,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // binning buffers: released on every exit path.  The pool hands them to nobody else before the kernels below are done: in
     // keep mode free() only marks the slot (work of one context is stream-ordered), otherwise free() synchronises the stream first
     PoolTemps tmp(ctx);
+    bool publish_row_len = false;
     int* perm = nullptr;
     if (ctx->ray_binning && num_rays > kBinTile) {
         const int tiles = grid_blocks(num_rays, kBinTile);
@@ -1636,13 +1637,24 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             a.row_len_hint = ctx->opt_image_width;
             if (variant == 3 && (a.row_len_hint & 7) == 0 && num_rays / a.row_len_hint >= 8) variant = 2;
         } else {
-            // The row length only steers the lane <-> ray assignment (any value gives the same hits), so the answer found for a ray
+            // The row length only steers the lane <-> ray assignment (any value gives the same hits), so a row length FOUND for a ray
             // buffer is kept: calls with the same buffer and count reuse it and look again every 16th call ("traverse.row_cache" = 0:
-            // at every call).  A buffer refilled with rows of another length runs on the stale length until then -- slower, never wrong.
+            // at every call).  The host learns the answer without waiting (a 4-byte copy behind the traversal launch + an event it only
+            // polls) and never keeps "not image-ordered" once it has seen it, so a buffer that alternates between unordered rays and an
+            // image looks every time.  A buffer refilled with rows of another length runs on the stale length for at most 15 calls --
+            // slower, never wrong.
             int* row_len = ctx->dscratch + 236;
-            const bool cached = ctx->opt_row_cache && variant != 3 && ctx->rowlen_rays == rays && ctx->rowlen_n == num_rays && ctx->rowlen_age < 15;
-            if (cached) ctx->rowlen_age++;
-            else { launch_detect(ctx, a, num_rays, row_len); ctx->rowlen_rays = rays; ctx->rowlen_n = num_rays; ctx->rowlen_age = 0; }
+            const bool same = ctx->opt_row_cache && variant != 3 && ctx->rowlen_rays == rays && ctx->rowlen_n == num_rays;
+            if (same && ctx->rowlen_pending) {
+                if (hipEventQuery(ctx->rowlen_evt) == hipSuccess) { ctx->rowlen_known = ctx->mailbox[300]; ctx->rowlen_pending = false; }
+                else (void)hipGetLastError();                             // not ready yet: not an error
+            }
+            if (same && ctx->rowlen_known != 0 && ctx->rowlen_age < 15) ctx->rowlen_age++;
+            else {
+                launch_detect(ctx, a, num_rays, row_len);
+                ctx->rowlen_rays = rays; ctx->rowlen_n = num_rays; ctx->rowlen_age = 0; ctx->rowlen_known = -1;
+                publish_row_len = ctx->opt_row_cache && variant != 3;
+            }
             a.row_len = row_len;
             if (variant == 3) {
                 int w = 0;
@@ -1682,6 +1694,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     }
     HG_DBG(ctx);                                   // the traversal kernel launched by one of the helpers above
     HG_HIP(ctx, hipGetLastError());
+    if (publish_row_len) {                         // behind the traversal launch: nobody waits for it
+        if (!ctx->rowlen_evt) HG_HIP(ctx, hipEventCreateWithFlags(&ctx->rowlen_evt, hipEventDisableTiming));
+        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox + 300, ctx->dscratch + 236, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HG_HIP(ctx, hipEventRecord(ctx->rowlen_evt, ctx->stream));
+        ctx->rowlen_pending = true;
+    }
     return HAGRID_OK;
 }
 

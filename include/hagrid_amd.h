@@ -245,8 +245,8 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
  * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
  * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
- * also from the origins alone -- bounce rays in the image order of their primary hits; the answer is kept per ray buffer and count and
- * looked for again every 16th call, "traverse.row_cache" = 0: at every call -- it only steers the lane <-> ray assignment, hits never
+ * also from the origins alone -- bounce rays in the image order of their primary hits; a row length that was found is kept per ray buffer and count and
+ * looked for again every 16th call ("not image-ordered" is not kept once the host has seen it), "traverse.row_cache" = 0: at every call -- it only steers the lane <-> ray assignment, hits never
  * depend on it), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
