@@ -645,6 +645,36 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
         mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0)
 
 
+def test_row_length_cache_never_changes_hits(mem):
+    """The row length found for a ray buffer is reused by later calls with the same buffer and count; it only steers the lane <-> ray
+    assignment.  One buffer refilled in turn with images of two widths and with unordered rays: every call gives the oracle's hits."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(20000, seed=51)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+    n = 128 * 64
+    batches = [scene.make_rays_primary(lo, hi, 128, 64), scene.make_rays_primary(lo, hi, 64, 128),
+               scene.make_rays_incoherent(lo - 0.2, hi + 0.2, n, 29)]
+    batches = [np.ascontiguousarray(b, np.float32) for b in batches]
+    want = [G.traverse(tris, b, nthreads=8)[0] for b in batches]
+    api.setup_traversal(grid)
+    d_rays = mem.upload(batches[0]); d_hits = mem.alloc(16 * n)
+    try:
+        for cache in (1, 0):
+            mem.set_option("traverse.row_cache", cache)
+            for call in range(40):
+                k = (call * 7 + call // 5) % 3
+                mem.copy_h2d(d_rays, batches[k])
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                assert (got["id"] == want[k]["id"]).all() and (bits(got["t"]) == bits(want[k]["t"])).all(), (cache, call, k)
+    finally:
+        mem.set_option("traverse.row_cache", 1)
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
 # ---- any-hit and barycentrics (SURVEY 8(f) row 4) ------------------------------------------------------------------------
 
 def test_intersect_prim_ray_with_uvs_matches_reference_header(mem, golden_dir):
