@@ -280,6 +280,17 @@ def release_for_traversal(grid: Grid):
     _check(mem, mem._L.hagrid_grid_release_for_traversal(mem._ctx, C.byref(grid.pod)), "release_for_traversal")
 
 
+def share_traversal(dst: MemManager, grid: Grid) -> Grid:
+    """Extension (hagrid_share_traversal): a descriptor of `grid` for the context `dst` (another stream on the same device) that
+    traverses with the traversal image of grid.mem instead of a copy of its own -- independent batches in flight over one image.
+    The arrays and the image stay the property of grid.mem."""
+    src = grid.mem or _current
+    _check(dst, dst._L.hagrid_share_traversal(dst._ctx, src._ctx), "share_traversal")
+    g = Grid(); g.mem = dst
+    C.memmove(C.byref(g.pod), C.byref(grid.pod), C.sizeof(grid.pod))
+    return g
+
+
 ANY_HIT, UVS = 1, 2      # hagrid_traverse_grid_ex flags
 
 

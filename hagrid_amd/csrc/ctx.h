@@ -34,6 +34,7 @@ struct TravImageCache {
     int slim = 0;                   // uniform layout with 16-byte records: bits per inline reference id (20: four ids, 26: three), 0 = 32-byte records
     bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
+    bool borrowed = false;          // hagrid_share_traversal: table and blocks belong to another context's pool, never freed here
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;

@@ -516,7 +516,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
 
 void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
     TravImageCache& img = ctx->image;
-    void* t = img.table; void* b = img.blocks;
+    void* t = img.borrowed ? nullptr : img.table; void* b = img.borrowed ? nullptr : img.blocks;
     img = TravImageCache();
     if (t) hagrid_mem_free(ctx, t);
     if (b) hagrid_mem_free(ctx, b);
@@ -595,6 +595,7 @@ extern "C" int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* g
     if (!ctx || !grid) return HAGRID_EINVAL;
     TravImageCache& img = ctx->image;
     if (!trav_image_matches(ctx, grid) || img.detached) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: call hagrid_setup_traversal for this grid first");
+    if (img.borrowed) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: this context only borrows the traversal image (hagrid_share_traversal); release the grid in the context that built it");
     if (!img.standalone) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: the traversal image of this grid still refers to the voxel map (compact form, or more than six levels)");
     void* entries = grid->entries;
     void* cells = grid->cells ? grid->cells : grid->small_cells;
@@ -602,5 +603,17 @@ extern "C" int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* g
     HG_TRY(hagrid_mem_free(ctx, entries));
     HG_TRY(hagrid_mem_free(ctx, cells));
     grid->entries = nullptr; grid->cells = nullptr; grid->small_cells = nullptr;
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_share_traversal(hagrid_ctx* dst, hagrid_ctx* src) {
+    if (!dst || !src || dst == src) return HAGRID_EINVAL;
+    if (dst->device != src->device) HG_FAIL(dst, HAGRID_EINVAL, "share_traversal: the two contexts are on different devices");
+    if (!src->image.valid) HG_FAIL(dst, HAGRID_EINVAL, "share_traversal: the source context has no traversal image (hagrid_setup_traversal)");
+    HG_HIP(dst, hipSetDevice(src->device));
+    HG_HIP(dst, hipStreamSynchronize(src->stream));          // the image may still be under construction on the owner's stream
+    trav_image_drop(dst);
+    dst->image = src->image;
+    dst->image.borrowed = true;
     return HAGRID_OK;
 }

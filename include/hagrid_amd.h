@@ -202,6 +202,16 @@ int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
  * descriptor; what reads the construction format (construction passes, hagrid_traverse_grid_stats, hagrid_grid_pack, forced kernel
  * variants) is refused.  ref_ids and the triangles stay with the caller as before. */
 int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* grid);
+/* Extension: independent batches in flight.  A launch over a SMALL batch (1M rays) keeps the machine full for the first half of its
+ * time only; the second half is the drain of its last wavefronts.  A caller with independent batches (tiles of a frame, samples,
+ * frames) fills that drain by giving every batch in flight its own context = its own stream (hagrid_ctx_set_stream): contexts are
+ * independent.  This call lets `dst` traverse with the traversal image hagrid_setup_traversal built in `src` (same device) instead
+ * of building a copy of its own -- one image in the caches, however many streams.  The image stays the property of `src`: it
+ * must outlive its use in `dst`, and after the next hagrid_setup_traversal / construction pass / free of the grid in `src` the
+ * share must be renewed (hagrid_setup_traversal(dst, ...) or a construction pass in `dst` ends it too).  Waits for `src`'s stream.
+ * Measured, 1M-triangle scene, 1024 x 1024 primary rays: 0.192 ms per batch with one in flight, 0.128 ms with two
+ * (profiles/dev_r2_inflight.txt). */
+int hagrid_share_traversal(hagrid_ctx* dst, hagrid_ctx* src);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
  * hits[i].id = primitive id or -1, hits[i].t = distance (tmax on a miss), u = v = 0.  Asynchronous. */
 int hagrid_traverse_grid(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris,

@@ -97,3 +97,64 @@ def test_set_stream_drains_the_old_stream():
     assert (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
     mem.use_stream(None)
     mem.close()
+
+
+def test_shared_traversal_image_two_batches_in_flight():
+    """hagrid_share_traversal: a second context (own stream, own pool) traverses with the image the first one built.  Launches of
+    the two contexts interleave on the GPU; every hit buffer must equal the quiet single-context result, and the borrower must
+    neither free the image nor be allowed to release the grid."""
+    import torch
+    from hagrid_amd import api
+    tris = scene.make_soup(200_000)
+    a = api.MemManager(keep=True)
+    b = api.MemManager(keep=True)
+    with pytest.raises(api.HagridError):
+        api.share_traversal(b, _grid_stub(a))                      # nothing to share yet
+    d_tris = a.upload(tris)
+    grid = api.build_all(a, d_tris, tris.shape[0])
+    rays = [scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 768, 768),
+            scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 768, 768, sample=1, num_samples=2)]
+    n = rays[0].shape[0]
+    api.setup_traversal(grid)
+    # quiet results, context a alone
+    want = []
+    d_rays_a = a.upload(rays[0]); d_hits_a = a.alloc(16 * n)
+    for r in rays:
+        a.copy_h2d(d_rays_a, r)
+        api.traverse_grid(grid, d_tris, d_rays_a, d_hits_a, n)
+        want.append(a.download(d_hits_a, api.HIT_DTYPE, n).copy())
+    a.copy_h2d(d_rays_a, rays[0])
+    image_bytes = a.image_bytes(grid)
+    used_b = b.usage()
+    gb = api.share_traversal(b, grid)
+    assert b.usage() == used_b and b.image_bytes(gb) == image_bytes            # no copy of the image in b's pool
+    d_rays_b = b.upload(rays[1]); d_hits_b = b.alloc(16 * n)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    a.use_stream(sa.cuda_stream); b.use_stream(sb.cuda_stream)
+    for _ in range(50):
+        api.traverse_grid(grid, d_tris, d_rays_a, d_hits_a, n)
+        api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+    got_a = a.download(d_hits_a, api.HIT_DTYPE, n); got_b = b.download(d_hits_b, api.HIT_DTYPE, n)
+    for got, w in ((got_a, want[0]), (got_b, want[1])):
+        assert (got["id"] == w["id"]).all() and (got["t"].view(np.uint32) == w["t"].view(np.uint32)).all()
+    with pytest.raises(api.HagridError):
+        api.release_for_traversal(gb)                              # only the owner may give the construction format up
+    # the borrower builds an image of its own: the share ends, the owner's image is untouched
+    api.setup_traversal(gb)
+    assert b.usage() >= used_b + image_bytes
+    b.zero(d_hits_b, 16 * n)
+    api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+    got_b = b.download(d_hits_b, api.HIT_DTYPE, n)
+    assert (got_b["id"] == want[1]["id"]).all()
+    b.use_stream(None); b.close()
+    a.zero(d_hits_a, 16 * n)
+    api.traverse_grid(grid, d_tris, d_rays_a, d_hits_a, n)          # the owner still has its image after the borrower is gone
+    got_a = a.download(d_hits_a, api.HIT_DTYPE, n)
+    assert (got_a["id"] == want[0]["id"]).all() and a.image_bytes(grid) == image_bytes
+    a.use_stream(None); a.close()
+
+
+def _grid_stub(mem):
+    from hagrid_amd import api
+    g = api.Grid(); g.mem = mem
+    return g
