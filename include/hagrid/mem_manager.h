@@ -70,6 +70,9 @@ public:
 
     /// The C ABI handle (for hagrid_ctx_set_stream and friends).
     hagrid_ctx* context() const { return ctx_; }
+    /// Makes this manager the one the free functions (build_grid, traverse_grid, profile ...) work on; the last manager
+    /// constructed is current by default.  Several managers = several contexts / streams (traverse.h: share_traversal).
+    void make_current() { detail::current_ctx() = ctx_; }
 
 private:
     hagrid_ctx* ctx_;

@@ -97,6 +97,25 @@ int main(int argc, char** argv) {
         printf("%d mismatches in the any-hit / barycentric variants\n", bad_ext);
         bad += bad_ext;
     }
+    // a second manager (context, stream) traversing with the first one's traversal image
+    {
+        setup_traversal(grid);
+        MemManager mem2(false);
+        mem.make_current();
+        share_traversal(mem2, mem);
+        Hit* hits2 = mem2.alloc<Hit>(nrays);
+        traverse_grid(grid, tris, rays, hits, nrays);
+        traverse_grid(mem2, grid, tris, rays, hits2, nrays);
+        std::vector<Hit> h1(nrays), h2(nrays);
+        mem.copy<Copy::DEV_TO_HST>(h1.data(), hits, h1.size());
+        mem2.copy<Copy::DEV_TO_HST>(h2.data(), hits2, h2.size());
+        int bad_share = 0;
+        for (int i = 0; i < nrays; i++) if (h1[i].id != h2[i].id || h1[i].t != h2[i].t || h1[i].id != host_hits[i].id) bad_share++;
+        printf("%d mismatches with a shared traversal image\n", bad_share);
+        bad += bad_share;
+        mem2.free(hits2);
+    }
+    mem.make_current();
     mem.free(rays); mem.free(hits);
     mem.free(grid.entries); mem.free(grid.cells); mem.free(grid.ref_ids); mem.free(grid.small_cells); mem.free(tris);
     printf("peak usage %.1f MB, usage after free %zu\n", mem.max_usage() / 1048576.0, mem.usage());
