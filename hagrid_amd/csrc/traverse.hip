@@ -879,7 +879,7 @@ __device__ __forceinline__ TriCand tri_candidate(const Tri& tri, const vec3& org
     }
     return cd;
 }
-template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xf, 0xf, false); }
+template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(x, x, K * 0x55, 0xf, 0xf, true); }   // (every lane is written: no `old` value to set up)
 template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return __int_as_float(quad_bcast_i<K>(__float_as_int(x))); }
 
 constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
@@ -1092,13 +1092,15 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
                     if (inl != NONE) cd = tri_candidate(tri_for(inl), org, dir, tmin);
-                    if (__ballot(cd.ok) != 0ull) {
-                        // replay the acceptance in list order; every lane of the group computes the same
+                    const unsigned long long cand = __ballot(cd.ok);
+                    if (cand != 0ull) {
+                        // replay the acceptance in list order; every lane of the group computes the same.  A list position at which no
+                        // group of the wavefront holds a candidate is skipped (bit s of every nibble of `cand` = position s).
                         const int okv = cd.ok ? 1 : 0;
-                        { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
-                        if (NI > 1) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
-                        if (NI > 2) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
-                        if (NI > 3) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
+                        if (cand & 0x1111111111111111ull) { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
+                        if (NI > 1 && (cand & 0x2222222222222222ull)) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
+                        if (NI > 2 && (cand & 0x4444444444444444ull)) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
+                        if (NI > 3 && (cand & 0x8888888888888888ull)) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
                     }
                 } else {
                     // some list of the wavefront is given by index (more ids than a record holds): four ids per round as well, lane s takes
