@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
     {
         const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-        // Table-free layout: the cell step is split over the lanes of a group instead of being repeated by them.  Lane s owns axis
+        // The cell step is split over the lanes of a group instead of being repeated by them.  Lane s owns axis
         // min(s, 2) (lane 3 doubles z): it computes its axis' exit plane, the exit parameter is the minimum over the group, the lane
         // finds its own coordinate of the next voxel and its share of the record's address, and the shares are added over the group
         // (quad permutes [1,2,0,0] and [2,0,1,1]: every lane sees the other two axes).  The same operations on the same values as
@@ -1095,9 +1095,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         const uint32_t m_bit = (ax == 1 ? 16u : 0u) + (m_pos ? 8u : 0u);                       // where the record holds this axis' bound byte
         const uint32_t m_stride = ax == 0 ? 1u : (ax == 1 ? uint32_t(a.top_x) : uint32_t(a.top_xy)), m_lsh = uint32_t(ax * a.shift);
         int m_v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+        auto quad_sum = [&](uint32_t x) -> uint32_t { return x + uint32_t(quad_perm_i<9>(int(x))) + uint32_t(quad_perm_i<82>(int(x))); };
         auto quad_step = [&](const uint4& rec) -> uint4 {
             int c;
-            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(__builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u)), "v"(m_v));
+            const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
+            if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
+            else c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;             // table layout: bounds count from the top-level cell's origin
             const float tc = (float(c) * m_cs + m_gmin - m_org) * m_inv;
             texit = detail::fmin2(detail::fmin2(tc, quad_perm_f<9>(tc)), quad_perm_f<82>(tc));
             const float ev = (texit * m_dir + m_org - m_gmin) * m_ginv;
@@ -1105,15 +1108,24 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             m_v = med3_i32(n, m_v, m_pos ? 0x7fffffff : int(0x80000000));
             const int o = uint32_t(m_v) >= uint32_t(m_dims) ? 1 : 0;
             outside = (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0;
-            const uint32_t v = outside ? 0u : uint32_t(m_v), d = uint32_t(a.shift);
-            const uint32_t part = (__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh);
-            const uint32_t rec_idx = part + uint32_t(quad_perm_i<9>(int(part))) + uint32_t(quad_perm_i<82>(int(part)));
-            return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
+            const uint32_t v = outside ? 0u : uint32_t(m_v);
+            if (UNIFORM) {
+                const uint32_t d = uint32_t(a.shift);
+                const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh));
+                return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
+            }
+            const uint32_t top = quad_sum(__umul24(v >> uint32_t(a.shift), m_stride));
+            if (int(top) != top_idx) {
+                const uint2 t = gather32<uint2>(a.img_table, top << 3);
+                tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+            }
+            const uint32_t idx = quad_sum(((v >> (uint32_t(a.shift) - tab_d)) & ((1u << tab_d) - 1u)) << __umul24(uint32_t(ax), tab_d));
+            return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
         };
         live = __ballot(alive);
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
-                const uint4 na = UNIFORM ? quad_step(ca) : cell_step(ca, inv_dir);
+                const uint4 na = quad_step(ca);
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
