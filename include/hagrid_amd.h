@@ -209,7 +209,7 @@ int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* grid);
  * of building a copy of its own -- one image in the caches, however many streams.  The image stays the property of `src`: it
  * must outlive its use in `dst`, and after the next hagrid_setup_traversal / construction pass / free of the grid in `src` the
  * share must be renewed (hagrid_setup_traversal(dst, ...) or a construction pass in `dst` ends it too).  Waits for `src`'s stream.
- * Measured, 1M-triangle scene, 1024 x 1024 primary rays: 0.192 ms per batch with one in flight, 0.128 ms with two
+ * Measured, 1M-triangle scene, 1024 x 1024 primary rays: 0.177 ms per batch with one in flight, 0.118 ms with two
  * (profiles/dev_r2_inflight.txt). */
 int hagrid_share_traversal(hagrid_ctx* dst, hagrid_ctx* src);
 /* traverse_grid (traverse.cu:111-117): rays 32-byte Ray records, hits 16-byte Hit records.
