@@ -181,3 +181,19 @@ def test_bench_rccl_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["grid_broadcast_ms"] >= 0
+
+
+def test_bench_single_gpu_line_carries_the_pipelined_block():
+    """The default (single process) bench line: `pipelined` = the same steps with two calls in flight over one shared traversal image,
+    hits identical to the single-stream run; never part of `value`.  --inflight 0 leaves it out."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--tris", "100000",
+            "--width", "512", "--height", "512", "--build-iter", "1", "--no-cpu-baseline"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    p = out["pipelined"]
+    assert p and p["in_flight"] == 2 and p["hits_identical_to_single_stream"] is True and p["value"] > 0 and p["steps"] >= 6
+    assert out["value"] > 0 and out["n_gpus"] == 1
+    r = subprocess.run(base + ["--inflight", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["pipelined"] is None
