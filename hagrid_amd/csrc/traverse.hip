@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
 // still pays a triangle round per id of its longest list.  Rays only finish, so the number of live rays of a wavefront only falls:
 // once it is at most 16 the wavefront COMPACTS -- live ray r moves to lanes 4r .. 4r + 3 (one LDS rendezvous, one ds_bpermute per
 // register, once per wavefront) -- and from then on a cell step tests the up to four inline ids of a list in ONE round, lane s of the
-// group taking id s.  The four lanes walk the voxels redundantly (same arithmetic, same record).  The reference's sequential rule
+// group taking id s, and the cell step itself is split over the four lanes (one axis each, see phase 2 below).  The reference's sequential rule
 // (every test sees the tmax the accepted tests before it left, prims.h:266-295) is kept exactly: a lane computes everything that
 // does not depend on tmax -- the barycentric test, t >= |det| * tmin, t and |det| -- and the group then replays the acceptance
 // `|det| * tmax > t` in list order on quad broadcasts (DPP), so hit ids and t stay bit-identical.  Table-free layout with slim
@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         // min(s, 2) (lane 3 doubles z): it computes its axis' exit plane, the exit parameter is the minimum over the group, the lane
         // finds its own coordinate of the next voxel and its share of the record's address, and the shares are added over the group
         // (quad permutes [1,2,0,0] and [2,0,1,1]: every lane sees the other two axes).  The same operations on the same values as
-        // cell_step, a third of them per lane: ~35 instead of ~80 VALU instructions per step.
+        // cell_step, a third of them per lane: ~45 instead of ~100 VALU instructions per step, address included.
         const int ax = sub < 2 ? sub : 2;
         const float m_dir = ax == 0 ? dir.x : (ax == 1 ? dir.y : dir.z), m_org = ax == 0 ? org.x : (ax == 1 ? org.y : org.z);
         const float m_inv = ax == 0 ? inv_dir.x : (ax == 1 ? inv_dir.y : inv_dir.z);
