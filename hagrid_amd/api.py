@@ -73,6 +73,10 @@ class MemManager:
         """Enqueue all further work on a hipStream_t given as an integer (e.g. torch's cuda_stream)."""
         _check(self, self._L.hagrid_ctx_set_stream(self._ctx, C.c_void_p(stream or 0)), "set_stream")
 
+    def synchronize(self):
+        """Waits for everything queued on this manager's stream (hagrid_ctx_synchronize)."""
+        _check(self, self._L.hagrid_ctx_synchronize(self._ctx), "synchronize")
+
     def set_ray_binning(self, mode: int):
         """Extension: 1 = bin each ray batch by grid-entry position before traversal (for incoherent batches);
         2 = automatic: the device bins a batch only if it is neither image-ordered nor coherent (no host round trip)."""

@@ -64,6 +64,13 @@ extern "C" int hagrid_ctx_set_stream(hagrid_ctx* ctx, void* stream) {
     return HAGRID_OK;
 }
 
+extern "C" int hagrid_ctx_synchronize(hagrid_ctx* ctx) {
+    if (!ctx) return HAGRID_EINVAL;
+    HG_HIP(ctx, hipSetDevice(ctx->device));
+    HG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HAGRID_OK;
+}
+
 extern "C" int hagrid_get_build_counts(const hagrid_ctx* ctx, hagrid_build_counts* out) {
     if (!ctx || !out) return HAGRID_EINVAL;
     *out = ctx->counts;

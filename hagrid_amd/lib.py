@@ -110,6 +110,7 @@ SIGNATURES = {
     "hagrid_setup_traversal": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_grid_release_for_traversal": (_i32, [_vp, C.POINTER(GridPOD)]),
     "hagrid_share_traversal": (_i32, [_vp, _vp]),
+    "hagrid_ctx_synchronize": (_i32, [_vp]),
     "hagrid_traverse_grid": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32]),
     "hagrid_traverse_grid_ex": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, C.c_uint32]),
     "hagrid_traverse_grid_stats": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, _vp, C.POINTER(TraversalStats)]),

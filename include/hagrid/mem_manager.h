@@ -73,6 +73,8 @@ public:
     /// Makes this manager the one the free functions (build_grid, traverse_grid, profile ...) work on; the last manager
     /// constructed is current by default.  Several managers = several contexts / streams (traverse.h: share_traversal).
     void make_current() { detail::current_ctx() = ctx_; }
+    /// Waits for all work queued on this manager's stream.
+    void synchronize() { detail::check(ctx_, hagrid_ctx_synchronize(ctx_)); }
 
 private:
     hagrid_ctx* ctx_;

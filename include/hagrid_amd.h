@@ -99,6 +99,10 @@ int hagrid_ctx_create(hagrid_ctx** out, int device, int keep);
 void hagrid_ctx_destroy(hagrid_ctx* ctx);
 /* Launch all further work on `stream` (a hipStream_t; NULL = null stream). */
 int hagrid_ctx_set_stream(hagrid_ctx* ctx, void* stream);
+/* Waits until all work queued on the context's stream is done (hipStreamSynchronize): for callers that keep several contexts in
+ * flight and have no HIP of their own to wait with.  The reference synchronises with cudaDeviceSynchronize / event waits in
+ * its front-end (main.cpp:414-425, profile.cu:5-18). */
+int hagrid_ctx_synchronize(hagrid_ctx* ctx);
 const char* hagrid_last_error(const hagrid_ctx* ctx);
 /* Name / compute-unit count / memory of the context's device (diagnostics, bench records). */
 int hagrid_device_info(const hagrid_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem);

@@ -30,6 +30,17 @@ int run(const void* host_tris, int n, const void* host_rays, int nrays, void* ho
     if (rc == HAGRID_OK) rc = hagrid_set_option(ctx, "traverse.variant", 0);
     if (rc == HAGRID_OK) rc = hagrid_traverse_grid(ctx, &grid, tris, rays, hits, nrays);
     if (rc == HAGRID_OK) rc = hagrid_traverse_grid_stats(ctx, &grid, tris, rays, hits, nrays, NULL, &st);
+    if (rc == HAGRID_OK) {      /* a second context traversing with the first one's traversal image: same hits, written last */
+        hagrid_ctx* ctx2 = NULL;
+        rc = hagrid_ctx_create(&ctx2, 0, 0);
+        if (rc == HAGRID_OK) rc = hagrid_share_traversal(ctx2, ctx);
+        if (rc == HAGRID_OK) rc = hagrid_mem_zero(ctx, hits, (size_t)nrays * 16);
+        if (rc == HAGRID_OK) rc = hagrid_ctx_synchronize(ctx);
+        if (rc == HAGRID_OK) rc = hagrid_traverse_grid(ctx2, &grid, tris, rays, hits, nrays);
+        if (rc == HAGRID_OK) rc = hagrid_ctx_synchronize(ctx2);
+        if (rc != HAGRID_OK && ctx2) fprintf(stderr, "%s\n", hagrid_last_error(ctx2));
+        if (ctx2) hagrid_ctx_destroy(ctx2);
+    }
     if (rc == HAGRID_OK) rc = hagrid_mem_copy_d2h(ctx, host_hits, hits, (size_t)nrays * 16);
     if (rc != HAGRID_OK) fprintf(stderr, "%s\n", hagrid_last_error(ctx));
     hagrid_mem_free(ctx, grid.entries); hagrid_mem_free(ctx, grid.cells); hagrid_mem_free(ctx, grid.small_cells); hagrid_mem_free(ctx, grid.ref_ids);
