@@ -285,6 +285,8 @@ def main():
                 same = same and bool((other["id"] == hits["id"]).all() and (other["t"].view(np.uint32) == hits["t"].view(np.uint32)).all())
             pipelined = {"in_flight": k, "steps": launches, "ms_per_step": round(dt * 1e3 / launches, 5),
                          "value": round(n_rays * launches / dt / 1e6, 2), "unit": "Mrays/s", "hits_identical_to_single_stream": same,
+                         # the same algorithmic bytes per batch over the wall time per batch (not a kernel duration: launches overlap)
+                         "frac": round(ab["B_ray"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4), "walk_frac": round(ab["B_walk"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4),
                          "how": "one context (stream, hit buffer) per call in flight, all over the traversal image of context 0 (hagrid_share_traversal); "
                                 "the next launch fills the drain of the previous one.  NOT the headline: `value` is one call at a time"}
             for m, _g, h in lanes[1:]:
