@@ -1001,7 +1001,9 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         vy = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000));
         vz = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000));
         outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
-        return load_record(outside ? 0 : vx, outside ? 0 : vy, outside ? 0 : vz);
+        uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
+        if (!outside) next = load_record(vx, vy, vz);
+        return next;
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
     auto test_list = [&](const uint4& rec) {
