@@ -3,7 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,6 +37,9 @@ struct TravImageCache {
     bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
     bool borrowed = false;          // hagrid_share_traversal: table and blocks belong to another context's pool, never freed here
+    // Set by the context that built the image, cleared when THAT context drops it (new setup, construction pass, a source array
+    // freed, context destroyed).  Borrowers hold the same flag: a borrowed image whose flag is down is refused, not read.
+    std::shared_ptr<std::atomic<bool>> alive;
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;
@@ -63,6 +68,7 @@ struct hagrid_ctx {
     unsigned long long* lb_state = nullptr;   // status words of the look-back scans (wave_prims.h), never cleared: epochs
     size_t lb_words = 0;
     unsigned lb_epoch = 0;
+    unsigned lb_ticket_base = 0;              // value of the scans' ticket counter (first word of lb_state) once all queued scans are done
     int* row_scores = nullptr;           // row-length detection from origins: one score per candidate + a ticket counter
     int* bin_diff = nullptr;             // automatic ray binning: 64 partial counts of neighbouring rays in different bins
 
@@ -167,6 +173,7 @@ unsigned long long* lookback_state(hagrid_ctx* ctx, int tiles, int words_per_til
 int trav_image_build(hagrid_ctx* ctx, const hagrid_grid* grid);       // leaves the image invalid for grids it does not cover
 void trav_image_drop(hagrid_ctx* ctx);
 bool trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* grid);
+bool trav_image_stale(const hagrid_ctx* ctx);        // a borrowed image whose owner dropped it
 // a pool buffer is freed or overwritten: the image goes if it was derived from that buffer
 void trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, size_t bytes);
 

@@ -39,6 +39,8 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->rowlen_pending = false;                                       // (its copy and event are behind the synchronisation above)
+    if (!ctx->image.borrowed && ctx->image.alive) ctx->image.alive->store(false);      // borrowers of this context's image: refused from now on
     for (auto& s : ctx->slots)
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -303,7 +305,7 @@ extern "C" int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, 
 }
 
 unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int words_per_tile, unsigned* epoch) {
-    const size_t need = size_t(tiles > 0 ? tiles : 1) * size_t(words_per_tile);
+    const size_t need = size_t(tiles > 0 ? tiles : 1) * size_t(words_per_tile) + 16;     // + kLbTicketWords (wave_prims.h): the ticket counter in front
     if (need > ctx->lb_words || ctx->lb_epoch >= (1u << 30) - 2u) {
         // grow (or restart the epochs): the words must start out as "never published"
         (void)hipStreamSynchronize(ctx->stream);
@@ -316,6 +318,7 @@ unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int 
         }
         (void)hipMemsetAsync(ctx->lb_state, 0, ctx->lb_words * sizeof(unsigned long long), ctx->stream);
         ctx->lb_epoch = 0;
+        ctx->lb_ticket_base = 0;
     }
     *epoch = ++ctx->lb_epoch;
     return ctx->lb_state;

@@ -517,13 +517,20 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
 void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
     TravImageCache& img = ctx->image;
     void* t = img.borrowed ? nullptr : img.table; void* b = img.borrowed ? nullptr : img.blocks;
+    if (!img.borrowed && img.alive) img.alive->store(false);          // every borrower sees it before the memory is handed on
     img = TravImageCache();
     if (t) hagrid_mem_free(ctx, t);
     if (b) hagrid_mem_free(ctx, b);
 }
 
+bool hagrid_impl::trav_image_stale(const hagrid_ctx* ctx) {
+    const TravImageCache& img = ctx->image;
+    return img.valid && img.borrowed && !(img.alive && img.alive->load());
+}
+
 bool hagrid_impl::trav_image_matches(const hagrid_ctx* ctx, const hagrid_grid* g) {
     const TravImageCache& img = ctx->image;
+    if (trav_image_stale(ctx)) return false;
     if (img.valid && img.detached)      // the descriptor of a released grid: no entries, no cells, everything else as at setup time
         return !g->entries && !g->cells && !g->small_cells && g->ref_ids == img.refs && g->num_cells == img.num_cells && g->num_entries == img.num_entries &&
                g->num_refs == img.num_refs && g->shift == img.shift && g->dims[0] == img.dims[0] && g->dims[1] == img.dims[1] && g->dims[2] == img.dims[2];
@@ -587,6 +594,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
     img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
+    if (img.valid) img.alive = std::make_shared<std::atomic<bool>>(true);
     ctx->image = img;
     return HAGRID_OK;
 }
@@ -609,7 +617,7 @@ extern "C" int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* g
 extern "C" int hagrid_share_traversal(hagrid_ctx* dst, hagrid_ctx* src) {
     if (!dst || !src || dst == src) return HAGRID_EINVAL;
     if (dst->device != src->device) HG_FAIL(dst, HAGRID_EINVAL, "share_traversal: the two contexts are on different devices");
-    if (!src->image.valid) HG_FAIL(dst, HAGRID_EINVAL, "share_traversal: the source context has no traversal image (hagrid_setup_traversal)");
+    if (!src->image.valid || trav_image_stale(src)) HG_FAIL(dst, HAGRID_EINVAL, "share_traversal: the source context has no traversal image (hagrid_setup_traversal)");
     HG_HIP(dst, hipSetDevice(src->device));
     HG_HIP(dst, hipStreamSynchronize(src->stream));          // the image may still be under construction on the owner's stream
     trav_image_drop(dst);

@@ -1595,6 +1595,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     if (!ctx) return HAGRID_EINVAL;
     if (flags & ~uint32_t(HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS)) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid_ex: unknown flag");
     TraverseArgs a;
+    if (trav_image_stale(ctx))
+        HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image this context borrows (hagrid_share_traversal) was dropped by its owner; renew the share or call hagrid_setup_traversal here");
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
     if (num_rays == 0) return HAGRID_OK;
     HG_HIP(ctx, hipSetDevice(ctx->device));

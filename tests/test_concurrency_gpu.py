@@ -158,3 +158,130 @@ def _grid_stub(mem):
     from hagrid_amd import api
     g = api.Grid(); g.mem = mem
     return g
+
+
+def test_borrowed_traversal_image_is_refused_once_its_owner_drops_it():
+    """hagrid_share_traversal hands out the owner's image: once the owner sets traversal up again, runs a construction
+    pass, frees a grid array or goes away, the borrower's next traverse_grid must fail with an error instead of reading pool memory
+    that has been handed on; renewing the share (or an own setup_traversal) makes it work again."""
+    from hagrid_amd import api
+    tris = scene.make_soup(50_000)
+    a = api.MemManager(keep=True)
+    b = api.MemManager(keep=True)
+    d_tris = a.upload(tris)
+    grid = api.build_all(a, d_tris, tris.shape[0])
+    rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 256, 256)
+    n = rays.shape[0]
+    d_rays_a = a.upload(rays); d_hits_a = a.alloc(16 * n)
+    d_rays_b = b.upload(rays); d_hits_b = b.alloc(16 * n)
+    api.setup_traversal(grid)
+    api.traverse_grid(grid, d_tris, d_rays_a, d_hits_a, n)
+    want = a.download(d_hits_a, api.HIT_DTYPE, n).copy()
+
+    def borrower_ok(gb):
+        b.zero(d_hits_b, 16 * n)
+        api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+        got = b.download(d_hits_b, api.HIT_DTYPE, n)
+        return (got["id"] == want["id"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+
+    gb = api.share_traversal(b, grid)
+    assert borrower_ok(gb)
+    # 1. the owner sets traversal up again: a new image, the old one is back in the owner's pool
+    api.setup_traversal(grid)
+    with pytest.raises(api.HagridError, match="dropped by its owner"):
+        api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+    gb = api.share_traversal(b, grid)                              # renewed
+    assert borrower_ok(gb)
+    # 2. a construction pass in the owner's context
+    api.expand_grid(a, grid, d_tris, 1)
+    with pytest.raises(api.HagridError, match="dropped by its owner"):
+        api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+    with pytest.raises(api.HagridError):
+        api.share_traversal(b, grid)                               # the owner has no image now
+    api.setup_traversal(grid)
+    api.traverse_grid(grid, d_tris, d_rays_a, d_hits_a, n)
+    want = a.download(d_hits_a, api.HIT_DTYPE, n).copy()           # (same hits: expansion never changes them)
+    gb = api.share_traversal(b, grid)
+    assert borrower_ok(gb)
+    # 3. the borrower's own setup ends the share and is not affected by the owner any more
+    api.setup_traversal(gb)
+    api.setup_traversal(grid)
+    assert borrower_ok(gb)
+    # 4. the owner goes away altogether while a share is live
+    gb = api.share_traversal(b, grid)
+    assert borrower_ok(gb)
+    a.close()
+    with pytest.raises(api.HagridError, match="dropped by its owner"):
+        api.traverse_grid(gb, d_tris, d_rays_b, d_hits_b, n)
+    b.close()
+
+
+def test_large_scans_of_two_contexts_while_traversal_keeps_the_cus_busy():
+    """the single-pass scan must make progress when its launch is only partly resident -- two threads build
+    large scenes (scans over millions of cells) while a third context keeps every CU busy with traversal launches."""
+    import torch
+    from hagrid_amd import api
+    big = [scene.make_soup(1_000_000), scene.make_soup(800_000, seed=7)]
+    quiet = []
+    for t in big:
+        m = api.MemManager(keep=True)
+        g = api.build_all(m, m.upload(t), t.shape[0])
+        d = g.download()
+        quiet.append((g.summary(), int(d["entries"].astype(np.int64).sum()), int(d["ref_ids"].astype(np.int64).sum())))
+        m.close()
+    # the traffic: a context of its own traversing 2048^2 rays over and over on its own stream
+    tm = api.MemManager(keep=True)
+    small = scene.make_soup(200_000, seed=3)
+    d_small = tm.upload(small)
+    tg = api.build_all(tm, d_small, small.shape[0])
+    api.setup_traversal(tg)
+    rays = scene.make_rays_primary(tg.bbox_min, tg.bbox_max, 2048, 2048)
+    d_rays = tm.upload(rays); d_hits = tm.alloc(16 * rays.shape[0])
+    api.traverse_grid(tg, d_small, d_rays, d_hits, rays.shape[0])
+    want = tm.download(d_hits, api.HIT_DTYPE, rays.shape[0]).copy()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    tm.use_stream(streams[2].cuda_stream)
+    stop = threading.Event()
+    out = {}
+
+    def traffic():
+        try:
+            while not stop.is_set():
+                for _ in range(8):
+                    api.traverse_grid(tg, d_small, d_rays, d_hits, rays.shape[0])
+                tm.synchronize()
+            out["t"] = True
+        except Exception as e:
+            out["t"] = e
+
+    def builder(i):
+        try:
+            m = api.MemManager(keep=True)
+            m.use_stream(streams[i].cuda_stream)
+            d_t = m.upload(big[i])
+            res = []
+            for _ in range(3):
+                g = api.build_all(m, d_t, big[i].shape[0])
+                d = g.download()
+                res.append((g.summary(), int(d["entries"].astype(np.int64).sum()), int(d["ref_ids"].astype(np.int64).sum())))
+                g.free()
+            m.use_stream(None); m.close()
+            out[i] = res
+        except Exception as e:
+            out[i] = e
+
+    th = [threading.Thread(target=traffic)] + [threading.Thread(target=builder, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th[1:]:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a construction did not finish while the device was shared: scan without forward progress?"
+    stop.set(); th[0].join(timeout=60)
+    assert not th[0].is_alive() and out["t"] is True, out.get("t")
+    for i in range(2):
+        assert not isinstance(out[i], Exception), out[i]
+        for r in out[i]:
+            assert r == quiet[i]
+    got = tm.download(d_hits, api.HIT_DTYPE, rays.shape[0])
+    assert (got["id"] == want["id"]).all()
+    tm.use_stream(None); tm.close()

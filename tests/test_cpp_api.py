@@ -8,6 +8,8 @@ import tempfile
 
 import pytest
 
+import _subproc
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INC = os.path.join(ROOT, "include")
 
@@ -115,15 +117,15 @@ def test_cpp_program_through_the_headers_on_gpu():
         subprocess.run(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DHOST=", "-DDEVICE=", "-I", INC, os.path.join(ROOT, "tests", "cpp", "api_drop_in.cpp"),
                         "-o", exe, "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-L", hip_lib, "-lamdhip64",
                         "-Wl,-rpath," + os.path.join(ROOT, "hagrid_amd"), "-Wl,-rpath," + hip_lib, "-Wl,--allow-shlib-undefined"], check=True)
-        r = subprocess.run([exe, "20000", "4096"], capture_output=True, text=True, timeout=300)
+        r = _subproc.check([exe, "20000", "4096"], timeout=120)
         sys.stdout.write(r.stdout)
-        assert r.returncode == 0, r.stdout + r.stderr
         assert " 0 mismatches vs host" in r.stdout and "\n0 mismatches in the any-hit" in r.stdout, r.stdout
 
 
-def _build_cli(d):
-    import torch
-    hip_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+def _build_cli(d, hip_lib=None):
+    if hip_lib is None:
+        import torch
+        hip_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
     exe = os.path.join(d, "hagrid_cli")
     subprocess.run(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DHOST=", "-DDEVICE=", "-I", INC, os.path.join(ROOT, "tools", "hagrid_cli.cpp"),
                     "-o", exe, "-L", os.path.join(ROOT, "hagrid_amd"), "-lhagrid_amd", "-L", hip_lib, "-lamdhip64", "-ldl",
@@ -144,9 +146,11 @@ def test_cli_usage_and_option_errors_need_no_gpu():
         assert r.returncode == 1 and "No model specified" in r.stderr
 
 
-@pytest.mark.gpu
-def test_cli_obj_scene_and_ray_file_benchmark():
-    """SURVEY 8(f) rows 1-2: OBJ scene + .rays file through the CLI; the intersection count equals the Python API's."""
+@pytest.fixture(scope="module")
+def cli_case():
+    """hagrid_cli built once, an OBJ scene (absolute, v/vt/vn and negative index forms mixed), a .rays file, and the number of
+    intersections the Python API finds for them.  The parent keeps its context alive while the CLI runs, as a renderer's
+    host process would."""
     import numpy as np
     from hagrid_amd import api, scene
     tris = scene.make_soup(5000)
@@ -160,7 +164,6 @@ def test_cli_obj_scene_and_ray_file_benchmark():
                 for p in (a, b, c):
                     f.write("v %r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
             for i in range(tris.shape[0]):
-                # mix absolute, v/vt/vn and negative (relative to the END of the vertex list) index forms
                 if i % 3 == 0: f.write(f"f {3*i+1} {3*i+2} {3*i+3}\n")
                 elif i % 3 == 1: f.write(f"f {3*i+1}/1/1 {3*i+2}/1/1 {3*i+3}/1/1\n")
                 else: f.write(f"f {3*i+1-3*5000-1} {3*i+2-3*5000-1} {3*i+3-3*5000-1}\n")
@@ -176,38 +179,70 @@ def test_cli_obj_scene_and_ray_file_benchmark():
         d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
         api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
         want = int((mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])["id"] >= 0).sum())
-        r = subprocess.run([exe, obj, "-r", rfile, "-n", "3", "-w", "1", "-k", "-nb", "2"], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert "5000 triangle(s)" in r.stdout and "Grid built in " in r.stdout and "Entering benchmark mode" in r.stdout
-        assert f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
-        assert f"{want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout and "# Median: " in r.stdout
-        # synthetic scene + compression + one traced frame written as an image
-        img = os.path.join(d, "frame.pgm")
-        r = subprocess.run([exe, "soup:20000", "-z", "-sx", "256", "-sy", "128", "-o", img], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "20000 triangle(s)" in r.stdout and "Tracing one 256x128 frame" in r.stdout
-        assert os.path.getsize(img) == len("P5\n256 128\n255\n") + 256 * 128
-        # occlusion rays give the same intersection count (a ray is occluded iff it has a nearest hit),
-        # and the step-count heat map of the viewer (main.cpp:100-107) is written from the statistics entry point
-        heat = os.path.join(d, "steps.pgm")
-        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--any-hit"], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and f"{want} intersection(s)." in r.stdout
-        r = subprocess.run([exe, "soup:20000", "-sx", "128", "-sy", "64", "-s", heat], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "Steps per ray: max " in r.stdout, r.stdout + r.stderr
-        assert os.path.getsize(heat) == len("P5\n128 64\n255\n") + 128 * 64
-        # the grid as a file: --save-grid, then --load-grid instead of a scene gives the same grid and the same intersections
-        gfile = os.path.join(d, "soup.grid")
-        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--save-grid", gfile], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and f"{want} intersection(s)." in r.stdout and os.path.getsize(gfile) % 128 == 0
-        r = subprocess.run([exe, "--load-grid", gfile, "-r", rfile], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert "5000 triangle(s)" in r.stdout and "Grid loaded (" in r.stdout and f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
-        assert f"{want} intersection(s)." in r.stdout
-        # one process per GPU, the grid broadcast from C++ with RCCL (here: one rank, all this box has)
-        r = subprocess.run([exe, obj, "-r", rfile, "-k", "--gpus", "1", "-n", "2"], capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert "1 rank(s), grid broadcast in " in r.stdout and f"{grid.num_cells} cells, {grid.num_refs} references)" in r.stdout
-        assert f"{want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout
+
+        class Case: pass
+        c = Case()
+        c.dir, c.exe, c.obj, c.rays, c.want, c.cells, c.refs = d, exe, obj, rfile, want, grid.num_cells, grid.num_refs
+        yield c
         mem.close()
+
+
+@pytest.mark.gpu
+def test_cli_obj_scene_and_ray_file_benchmark(cli_case):
+    """SURVEY 8(f) rows 1-2: OBJ scene + .rays file through the CLI; the intersection count equals the Python API's."""
+    c = cli_case
+    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-n", "3", "-w", "1", "-k", "-nb", "2"])
+    assert "5000 triangle(s)" in r.stdout and "Grid built in " in r.stdout and "Entering benchmark mode" in r.stdout
+    assert f"{c.cells} cells, {c.refs} references)" in r.stdout
+    assert f"{c.want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout and "# Median: " in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_synthetic_scene_compressed_frame_image(cli_case):
+    c = cli_case
+    img = os.path.join(c.dir, "frame.pgm")
+    r = _subproc.check([c.exe, "soup:20000", "-z", "-sx", "256", "-sy", "128", "-o", img])
+    assert "20000 triangle(s)" in r.stdout and "Tracing one 256x128 frame" in r.stdout
+    assert os.path.getsize(img) == len("P5\n256 128\n255\n") + 256 * 128
+
+
+@pytest.mark.gpu
+def test_cli_any_hit_counts_the_same_intersections(cli_case):
+    """a ray is occluded iff it has a nearest hit."""
+    c = cli_case
+    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-k", "--any-hit"])
+    assert f"{c.want} intersection(s)." in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_step_count_heat_map(cli_case):
+    """The step-count picture of the viewer (main.cpp:100-107), written from the statistics entry point."""
+    c = cli_case
+    heat = os.path.join(c.dir, "steps.pgm")
+    r = _subproc.check([c.exe, "soup:20000", "-sx", "128", "-sy", "64", "-s", heat])
+    assert "Steps per ray: max " in r.stdout, r.stdout + r.stderr
+    assert os.path.getsize(heat) == len("P5\n128 64\n255\n") + 128 * 64
+
+
+@pytest.mark.gpu
+def test_cli_save_grid_then_load_grid(cli_case):
+    """The grid as a file: --save-grid, then --load-grid instead of a scene gives the same grid and the same intersections."""
+    c = cli_case
+    gfile = os.path.join(c.dir, "soup.grid")
+    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-k", "--save-grid", gfile])
+    assert f"{c.want} intersection(s)." in r.stdout and os.path.getsize(gfile) % 128 == 0
+    r = _subproc.check([c.exe, "--load-grid", gfile, "-r", c.rays])
+    assert "5000 triangle(s)" in r.stdout and "Grid loaded (" in r.stdout and f"{c.cells} cells, {c.refs} references)" in r.stdout
+    assert f"{c.want} intersection(s)." in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_one_process_per_gpu_rccl_broadcast(cli_case):
+    """One process per GPU, the grid broadcast from C++ with RCCL (here: one rank, all this box has)."""
+    c = cli_case
+    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-k", "--gpus", "1", "-n", "2"], timeout=120)
+    assert "1 rank(s), grid broadcast in " in r.stdout and f"{c.cells} cells, {c.refs} references)" in r.stdout
+    assert f"{c.want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout
 
 
 @pytest.mark.gpu
