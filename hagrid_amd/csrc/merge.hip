@@ -424,6 +424,15 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     release();
     hagrid_mem_free(ctx, cells_other);   // whichever buffers are not the live ones (merge.cu:375-376)
     hagrid_mem_free(ctx, refs_b);
+    if (rc != HAGRID_OK) {
+        // A pass failed half way: the voxel map may already point at the new cell numbers and the cells may be 16-byte working
+        // records.  Nothing of that is a grid (the reference aborts here, common.h:103-108): cells and references go back to the
+        // pool and the descriptor says so; entries stay the caller's to free.
+        (void)hipStreamSynchronize(st);
+        hagrid_mem_free(ctx, cells); hagrid_mem_free(ctx, refs);
+        grid->cells = nullptr; grid->ref_ids = nullptr; grid->num_cells = 0; grid->num_refs = 0;
+        return rc;
+    }
     grid->cells = cells; grid->ref_ids = refs;
     grid->num_cells = num_cells; grid->num_refs = num_refs;
     ctx->counts.merged_cells = num_cells; ctx->counts.merged_refs = num_refs;

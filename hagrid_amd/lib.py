@@ -14,6 +14,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAGRID_AMD_LIB") or os.path.join(HERE, "libhagrid_amd.so")     # the override serves A/B runs of two builds
 MAX_LEVELS = 32
+ABI_VERSION = 2             # HAGRID_ABI_VERSION of include/hagrid_amd.h this loader was written against
 
 OK, EINVAL, EHIP, ENOMEM, ERANGE, ENODEV = 0, -1, -2, -3, -4, -5
 
@@ -169,7 +170,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.hagrid_abi_version() != 1:
+    if lib.hagrid_abi_version() != ABI_VERSION:
         raise HagridError("ABI version mismatch")
     _lib = lib
     return lib

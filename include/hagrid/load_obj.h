@@ -19,9 +19,8 @@
 //     command; "usemtl", "mtllib" are recorded, "s" is ignored, anything else is an error;
 //   * errors do not stop the reading, but load_obj returns false if there was any (:238) and the front-end then refuses
 //     the scene (main.cpp:249-250).
-// Deviations: a vertex index beyond the end of the list is an error here (the reference stores it and reads out of bounds
-// later, main.cpp:256); load_mtl reads nothing and reports failure, which load_scene tolerates exactly as the reference
-// tolerates a missing material file (load_obj.h:86-89) -- materials do not take part in the hot path.
+// Deviation: a vertex index beyond the end of the list is an error here (the reference stores it and reads out of bounds
+// later, main.cpp:256).  load_mtl (load_obj.cpp:241-361) is pinned the same way: tests/golden/mtl_golden.npz.
 #ifndef HAGRID_LOAD_OBJ_H
 #define HAGRID_LOAD_OBJ_H
 
@@ -54,11 +53,11 @@ public:
     struct Object { std::vector<Group> groups; };
 
     struct Material {
-        vec3 ka, kd, ks, ke;
-        float ns, ni;
-        vec3 tf;
-        float tr, d;
-        int illum;
+        vec3 ka = vec3(0.0f), kd = vec3(0.0f), ks = vec3(0.0f), ke = vec3(0.0f);
+        float ns = 0.0f, ni = 0.0f;
+        vec3 tf = vec3(0.0f);
+        float tr = 0.0f, d = 0.0f;
+        int illum = 0;
         std::string map_ka, map_kd, map_ks, map_ke, map_bump, map_d;
     };
 
@@ -173,8 +172,77 @@ public:
         return errors == 0;
     }
 
-    /// Materials do not take part in the construction / traversal path: nothing is read, failure is reported (and tolerated).
-    static bool load_mtl(const std::string&, MaterialLib&) { return false; }
+    /// Material library reader with the observable behaviour of load_obj.cpp:241-361 (materials take no part in the grid path;
+    /// the viewer and load_scene's callers get what the reference would give them):
+    ///   * a material exists from its first ATTRIBUTE on (a "newmtl" without attributes leaves no entry), zero-initialised;
+    ///     attributes before any "newmtl" belong to the material named "";
+    ///   * "newmtl name" for a name the library already holds counts as an error but still selects that material;
+    ///   * Ka Kd Ks Ke Tf take three numbers, Ns Ni Tr d one, illum one (read as a float, stored as int); missing numbers are 0;
+    ///   * map_Ka map_Kd map_Ks map_Ke map_bump bump map_d take the rest of the line; anything else is an error;
+    ///   * errors do not stop the reading; the return value says whether there was none.  Lines as in load_obj (1024-byte buffer).
+    static bool load_mtl(const std::string& path, MaterialLib& mtl_lib) {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return false;
+        std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        int errors = 0;
+        std::string name;
+        const size_t line_capacity = 1023;
+        size_t at = 0;
+        while (at < text.size()) {
+            size_t end = text.find('\n', at);
+            const bool last = end == std::string::npos;
+            if (last) end = text.size();
+            if (end - at > line_capacity) break;
+            std::string line = text.substr(at, end - at);
+            at = last ? end : end + 1;
+            const size_t nul = line.find('\0');
+            if (nul != std::string::npos) line.resize(nul);
+
+            Cursor c(line);
+            c.skip_space();
+            if (c.done() || c.peek() == '#') continue;
+            c.trim_right();
+            auto three = [&](vec3& v) { v.x = c.number(); v.y = c.number(); v.z = c.number(); };
+            const char k0 = c.peek(), k1 = c.peek(1);
+            const bool arg2 = is_space(c.peek(2));                          // a two-letter command followed by white space
+            if (c.keyword("newmtl")) {
+                c.advance(1);
+                name = c.word();
+                if (mtl_lib.find(name) != mtl_lib.end()) errors++;
+            } else if (k0 == 'K') {
+                if (!arg2 || (k1 != 'a' && k1 != 'd' && k1 != 's' && k1 != 'e')) { errors++; continue; }
+                Material& m = mtl_lib[name];
+                c.advance(3);
+                three(k1 == 'a' ? m.ka : (k1 == 'd' ? m.kd : (k1 == 's' ? m.ks : m.ke)));
+            } else if (k0 == 'N') {
+                if (!arg2 || (k1 != 's' && k1 != 'i')) { errors++; continue; }
+                Material& m = mtl_lib[name];
+                c.advance(3);
+                (k1 == 's' ? m.ns : m.ni) = c.number();
+            } else if (k0 == 'T') {
+                if (!arg2 || (k1 != 'f' && k1 != 'r')) { errors++; continue; }
+                Material& m = mtl_lib[name];
+                c.advance(3);
+                if (k1 == 'f') three(m.tf); else m.tr = c.number();
+            } else if (k0 == 'd' && is_space(k1)) {
+                Material& m = mtl_lib[name];
+                c.advance(2);
+                m.d = c.number();
+            } else if (c.keyword("illum")) {
+                Material& m = mtl_lib[name];
+                c.advance(1);
+                m.illum = int(c.number());
+            } else if (c.keyword("map_Ka")) { mtl_lib[name].map_ka = c.rest(); }
+            else if (c.keyword("map_Kd")) { mtl_lib[name].map_kd = c.rest(); }
+            else if (c.keyword("map_Ks")) { mtl_lib[name].map_ks = c.rest(); }
+            else if (c.keyword("map_Ke")) { mtl_lib[name].map_ke = c.rest(); }
+            else if (c.keyword("map_bump")) { mtl_lib[name].map_bump = c.rest(); }
+            else if (c.keyword("bump")) { mtl_lib[name].map_bump = c.rest(); }
+            else if (c.keyword("map_d")) { mtl_lib[name].map_d = c.rest(); }
+            else errors++;
+        }
+        return errors == 0;
+    }
 
     static bool load_scene(const Path& path, File& file, MaterialLib& mtl_lib) {
         if (!load_obj(path, file)) return false;
@@ -230,6 +298,11 @@ private:
             if (s.compare(p, n, w) != 0 || !is_space(peek(n))) return false;
             advance(n);
             return true;
+        }
+        std::string rest() {                       // behind the separator that follows a keyword: leading white space cut, up to the line's end
+            advance(1);
+            skip_space();
+            return s.substr(p);
         }
         std::string word() {                       // the next run of non-space characters
             skip_space();

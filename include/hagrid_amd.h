@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HAGRID_ABI_VERSION 1
+#define HAGRID_ABI_VERSION 2   /* 2: hagrid_traversal_stats grew by long_list_refs (64 bytes); hagrid_grid_broadcast checks the communicator */
 #define HAGRID_MAX_LEVELS 32
 
 enum {
@@ -140,7 +140,8 @@ float hagrid_profile_end(hagrid_ctx* ctx);
 /* build_grid (build.cu:718-760).  tris: 48-byte Tri records on the device.  grid is overwritten. */
 int hagrid_build_grid(hagrid_ctx* ctx, const void* tris, int num_tris, hagrid_grid* grid,
                       float top_density, float snd_density);
-/* merge_grid (merge.cu:331-377) */
+/* merge_grid (merge.cu:331-377).  On an error the grid is gone: cells and ref_ids are released and NULL in the descriptor
+ * (the voxel map may already name the new cells); entries stay the caller's to free. */
 int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha);
 /* flatten_grid (flatten.cu:109-175) */
 int hagrid_flatten_grid(hagrid_ctx* ctx, hagrid_grid* grid);

@@ -6,7 +6,8 @@ oracle/_ref/libhagrid_ref_obj.so):
 
     make -C oracle && python tests/golden/make_golden_obj.py
 
-Output: tests/golden/obj/*.obj (fixtures written by this script, not taken from anywhere) and tests/golden/obj_golden.npz
+Output: tests/golden/obj/*.obj and *.mtl (fixtures written by this script, not taken from anywhere), tests/golden/mtl_golden.npz
+(per .mtl fixture the material library the reference's load_mtl reads, as the text ref_load_mtl prints) and tests/golden/obj_golden.npz
 with, per fixture, `<name>_ok` (did the reference accept the file) and `<name>_tris` (float32 [n, 12]).  tests/test_obj_loader.py
 compares include/hagrid/load_obj.h against them bit for bit.
 """
@@ -55,6 +56,23 @@ def fixtures():
     return f
 
 
+def mtl_fixtures():
+    """Material libraries for load_mtl (load_obj.cpp:241-361): every command, attributes before any newmtl, a material without
+    attributes (leaves no entry), a redefinition (an error that still selects the material), missing numbers, texture names with
+    blanks, CRLF, unknown / malformed commands, the 1024-byte line buffer."""
+    f = {}
+    f["plain"] = "\n".join(["# two materials", "newmtl red", "Ka 0.1 0.2 0.3", "Kd 1 0 0", "Ks 0.5 0.5 0.5", "Ke 0 0 0.25", "Ns 96.078431", "Ni 1.45",
+                            "Tf 1 1 1", "Tr 0.25", "d 0.75", "illum 2", "map_Ka amb.png", "map_Kd tex/red diffuse.png", "map_Ks spec.png", "map_Ke glow.png",
+                            "map_bump bump.png", "map_d alpha.png", "", "newmtl blue", "Kd 0 0 1", "bump other_bump.png", "illum 7.9"]) + "\n"
+    f["forms"] = "\r\n".join(["Kd 0.25 0.5 0.75", "  \t newmtl   first   ignored words  ", "Ka 1", "Kd\t0.5\t0.25", "Ns", "newmtl empty_one", "newmtl second",
+                              "d\t0.5", "map_Kd    spaced name.png   ", "newmtl first", "Ks 1 2 3", "illum -3"]) + "\r\n"
+    f["errors"] = "\n".join(["newmtl a", "Kd 1 1 1", "Kx 1 2 3", "Ka", "Nq 3", "Ns5", "Tx 1", "dissolve 1", "illumination 2", "map_Ka", "map_Kz x.png", "foo", "newmtl a", "Kd 0 1 0", "d 1"]) + "\n"
+    f["long_line"] = "\n".join(["newmtl a", "Kd 1 2 3", "# " + "x" * 1100, "newmtl b", "Kd 3 2 1"]) + "\n"
+    f["no_final_newline"] = "newmtl last\nKd 0.125 0.25 0.5"
+    f["empty"] = "# nothing\n\n"
+    return f
+
+
 def main():
     os.makedirs(OBJ, exist_ok=True)
     R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhagrid_ref_obj.so"))
@@ -71,6 +89,22 @@ def main():
         out[name + "_tris"] = buf[:max(n, 0)].copy()
         print(f"{name:18s} reference: {'refused' if n < 0 else str(n) + ' triangles'}")
     np.savez_compressed(os.path.join(HERE, "obj_golden.npz"), **out)
+    R.ref_load_mtl.restype = C.c_int
+    R.ref_load_mtl.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    out = {}
+    for name, text in mtl_fixtures().items():
+        path = os.path.join(OBJ, name + ".mtl")
+        with open(path, "wb") as fh:
+            fh.write(text.encode("ascii"))
+        buf = C.create_string_buffer(1 << 16)
+        n = R.ref_load_mtl(path.encode(), buf, len(buf))
+        assert n >= 0
+        out[name] = np.frombuffer(buf.raw[:n], dtype=np.uint8).copy()
+        print(f"{name:18s} reference: {buf.raw[:5].decode()} {buf.raw[:n].count(b'name=')} material(s)")
+    buf = C.create_string_buffer(1 << 16)
+    n = R.ref_load_mtl(os.path.join(OBJ, "does_not_exist.mtl").encode(), buf, len(buf))
+    out["missing_file"] = np.frombuffer(buf.raw[:n], dtype=np.uint8).copy()
+    np.savez_compressed(os.path.join(HERE, "mtl_golden.npz"), **out)
 
 
 if __name__ == "__main__":

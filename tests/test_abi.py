@@ -28,7 +28,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/hagrid_amd.h but not exported"
     assert sorted(built.SIGNATURES) == names, "hagrid_amd/lib.py signature table out of sync with the header"
-    assert L.hagrid_abi_version() == 1
+    assert L.hagrid_abi_version() == lib.ABI_VERSION == 2
 
 
 def test_struct_layout_matches_header(built):
