@@ -26,6 +26,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -34,6 +35,8 @@
 #include "hagrid/mem_manager.h"
 #include "hagrid/multi_gpu.h"
 #include "hagrid/traverse.h"
+
+#include "cli_report.h"
 
 using namespace hagrid;
 
@@ -51,7 +54,7 @@ struct Options {
 };
 
 enum Kind { FLAG, INT, FLOAT, STRING };
-struct OptDesc { const char* s; const char* l; Kind kind; void* dst; const char* text; };
+struct OptDesc { const char* s; const char* l; Kind kind; void* dst; const char* text; const char* section; };   // section: a heading printed before this option (usage)
 
 bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
     table = {
@@ -60,7 +63,7 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
         {"-sy", "--height", INT, &o.height, "Sets the viewport height"},
         {"-c", "--clip", FLOAT, &o.clip, "Sets the clipping distance"},
         {"-f", "--fov", FLOAT, &o.fov, "Sets the field of view"},
-        {"-td", "--top-density", FLOAT, &o.top_density, "Sets the top-level density"},
+        {"-td", "--top-density", FLOAT, &o.top_density, "Sets the top-level density", " Construction parameters:"},
         {"-sd", "--snd-density", FLOAT, &o.snd_density, "Sets the second-level density"},
         {"-a", "--alpha", FLOAT, &o.alpha, "Sets the cell merging threshold"},
         {"-e", "--expansion", INT, &o.exp_iters, "Sets the number of expansion iterations"},
@@ -68,12 +71,12 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
         {"-wb", "--build-warmup", INT, &o.build_warmup, "Sets the number of warmup build iterations"},
         {"-k", "--keep-alive", FLAG, &o.keep_alive, "Keep the buffers alive during construction"},
         {"-z", "--compress", FLAG, &o.compress, "Compress the cells after construction"},
-        {"-r", "--ray-file", STRING, &o.ray_file, "Loads rays from a file and enters benchmark mode"},
+        {"-r", "--ray-file", STRING, &o.ray_file, "Loads rays from a file and enters benchmark mode", " Benchmarking:"},
         {"-tmin", "--tmin", FLOAT, &o.tmin, "Sets the minimum distance along every ray"},
         {"-tmax", "--tmax", FLOAT, &o.tmax, "Sets the maximum distance along every ray"},
         {"-n", "--bench-iter", INT, &o.bench_iter, "Sets the number of benchmarking iterations"},
         {"-w", "--bench-warmup", INT, &o.bench_warmup, "Sets the number of benchmarking warmup iterations"},
-        {"-o", "--out", STRING, &o.out_image, "(extension) writes the traced frame as a PGM depth image"},
+        {"-o", "--out", STRING, &o.out_image, "(extension) writes the traced frame as a PGM depth image", " Extensions of this front-end:"},
         {"-s", "--steps-image", STRING, &o.steps_image, "(extension) writes the per-pixel traversal step count as a PGM heat map"},
         {"-ah", "--any-hit", FLAG, &o.any_hit, "(extension) occlusion rays: a ray stops at its first intersection"},
         {"-g", "--gpus", INT, &o.gpus, "(extension) one process per GPU: the grid is built once and broadcast (RCCL), the rays are sharded"},
@@ -104,7 +107,12 @@ bool parse(int argc, char** argv, Options& o, std::vector<OptDesc>& table) {
 
 void usage(const std::vector<OptDesc>& table) {
     std::cout << "Usage: hagrid [options] file\nOptions:\n";
-    for (const auto& t : table) printf("  %-7s %-15s %s\n", t.s, t.l, t.text);
+    for (const auto& t : table) {                      // the reference's text (main.cpp:373-396), then the extensions
+        if (t.section) std::cout << t.section << "\n";
+        char line[256];
+        snprintf(line, sizeof(line), "  %-7s %-15s %s\n", t.s, t.l, t.text);
+        std::cout << line;
+    }
     std::cout << std::endl;
 }
 
@@ -145,15 +153,16 @@ bool load_rays(const std::string& name, std::vector<Ray>& rays, float tmin, floa
     return true;
 }
 
-void report_timings(std::vector<double> t, size_t rays_per_iter, int intr) {    // main.cpp:434-444
-    std::sort(t.begin(), t.end());
-    const double sum = std::accumulate(t.begin(), t.end(), 0.0);
-    std::cout << intr << " intersection(s)." << std::endl;
-    std::cout << sum << "ms for " << t.size() << " iteration(s)." << std::endl;
-    std::cout << rays_per_iter * t.size() / (1000.0 * sum) << " Mrays/sec." << std::endl;
-    std::cout << "# Average: " << sum / t.size() << " ms" << std::endl;
-    std::cout << "# Median: " << t[t.size() / 2] << " ms" << std::endl;
-    std::cout << "# Min: " << t.front() << " ms" << std::endl;
+// SIGALRM during teardown: async-signal-safe calls only
+constexpr unsigned kTeardownSeconds = 30;
+void teardown_overdue(int) {
+    static const char msg[] = "hagrid_cli: device teardown did not finish within 30 s; the results above are complete, ending the process\n";
+    ssize_t r = write(2, msg, sizeof(msg) - 1); (void)r;
+    _exit(0);
+}
+void arm_teardown_watchdog() {
+    signal(SIGALRM, teardown_overdue);
+    alarm(kTeardownSeconds);
 }
 
 extern "C" int hipSetDevice(int);      // the one HIP runtime call of this front-end (the process links libamdhip64 for the library's sake)
@@ -251,13 +260,13 @@ int main(int argc, char** argv) {
             std::cerr << "Scene cannot be loaded (file not present or contains errors)" << std::endl;
             return 1;
         }
-        std::cout << host_tris.size() << " triangle(s)" << std::endl;
+        hagrid_cli::report_scene(std::cout, host_tris.size());
         num_tris = int(host_tris.size());
         tris = mem.alloc<Tri>(host_tris.size());
         mem.copy<Copy::HST_TO_DEV>(tris, host_tris.data(), host_tris.size());
     } else if (root) {
         if (!load_grid(mem, opts.load_grid, grid, tris, num_tris)) { std::cerr << "Grid file cannot be loaded" << std::endl; return 1; }
-        std::cout << num_tris << " triangle(s)" << std::endl;
+        hagrid_cli::report_scene(std::cout, size_t(num_tris));
     }
 
     auto construct = [&] {
@@ -285,19 +294,9 @@ int main(int argc, char** argv) {
 
     if (root) {
         const ivec3 dims = grid.dims << grid.shift;
-        if (build_here) std::cout << "Grid built in " << total_time / opts.build_iter << " ms (";
-        else std::cout << "Grid loaded (";
-        std::cout << dims.x << "x" << dims.y << "x" << dims.z << ", " << grid.num_cells << " cells, " << grid.num_refs << " references)" << std::endl;
-        const size_t cells_mem = size_t(grid.num_cells) * (grid.small_cells ? sizeof(SmallCell) : sizeof(Cell));
-        const size_t entries_mem = size_t(grid.num_entries) * sizeof(int), refs_mem = size_t(grid.num_refs) * sizeof(int);
-        const size_t tris_mem = size_t(num_tris) * sizeof(Tri);
-        const double mb = 1024.0 * 1024.0;
-        std::cout << "Total memory: " << (cells_mem + entries_mem + refs_mem + tris_mem) / mb << " MB" << std::endl;
-        std::cout << "Cells: " << cells_mem / mb << " MB" << std::endl;
-        std::cout << "Entries: " << entries_mem / mb << " MB" << std::endl;
-        std::cout << "References: " << refs_mem / mb << " MB" << std::endl;
-        std::cout << "Triangles: " << tris_mem / mb << " MB" << std::endl;
-        std::cout << "Peak usage: " << mem.max_usage() / mb << " MB" << std::endl;
+        hagrid_cli::report_grid(std::cout, build_here ? total_time / opts.build_iter : -1.0, dims.x, dims.y, dims.z, grid.num_cells, grid.num_refs);
+        hagrid_cli::report_memory(std::cout, size_t(grid.num_cells) * (grid.small_cells ? sizeof(SmallCell) : sizeof(Cell)), size_t(grid.num_entries) * sizeof(int),
+                                  size_t(grid.num_refs) * sizeof(int), size_t(num_tris) * sizeof(Tri), mem.max_usage());
     }
 
     setup_traversal(grid);
@@ -353,7 +352,12 @@ int main(int argc, char** argv) {
         mem.copy<Copy::DEV_TO_HST>(&intr, d_n, 1);
         mem.free(d_t); mem.free(d_n);
     }
-    if (root) report_timings(std::vector<double>(timings.begin(), timings.end()), all_rays, intr);
+    if (root) hagrid_cli::report_timings(std::cout, std::vector<double>(timings.begin(), timings.end()), all_rays, intr);
+    // Everything the caller asked for is on stdout.  What follows returns device memory and takes the runtime down; a runtime that
+    // does not come back from that (seen once in the round-2 driver run: the report printed, the process never exited) must not
+    // hold the caller: after kTeardownSeconds the process says so on stderr and ends with the status of its work.
+    std::cout.flush();
+    arm_teardown_watchdog();
 
     if (!opts.out_image.empty() && opts.ray_file.empty() && world == 1) {
         std::ofstream img(opts.out_image, std::ofstream::binary);
