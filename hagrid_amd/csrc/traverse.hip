@@ -44,6 +44,8 @@ struct TraverseArgs {
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
     int num_rays;
+    int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
+    int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
@@ -902,8 +904,22 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = !perm ? tile_packet_row_len(a) : 0;
-    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, lane) : b * 64 + lane;
+    // The last tiles in dispatch order are traversed with four lanes per ray from their first cell on (phase 2 below): a tile is then
+    // four blocks of 16 rays (its 4 x 4 pixel quadrants).  They are the wavefronts that start when the machine begins to drain, where
+    // wavefront slots are free and what counts is how long the longest ray of a wavefront takes.
+    const bool quad_start = int(blockIdx.x) >= a.quad_first_block;
+    const int group = lane >> 2, sub = lane & 3;
+    int b, lane_in_tile = lane;
+    if (quad_start) {
+        const int q = int(blockIdx.x) - a.quad_first_block, nq = int(gridDim.x) - a.quad_first_block;
+        const int lq = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(q, nq, a.xcd_chunk_log2 + 2) : xcd_split(q, nq);
+        b = a.quad_first_block + (lq >> 2);
+        lane_in_tile = ((((lq >> 1) & 1) << 2) + (group >> 2)) * 8 + ((lq & 1) << 2) + (group & 3);
+    } else {
+        const int nb = min(int(gridDim.x), a.quad_first_block);
+        b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, nb, a.xcd_chunk_log2) : xcd_split(blockIdx.x, nb);
+    }
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, lane_in_tile) : b * 64 + lane_in_tile;
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
     bool pending = valid;                                  // this lane still owes its ray's hit to the hit buffer
@@ -1043,6 +1059,8 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     if (alive) ca = load_record(vx, vy, vz);
     unsigned long long live = __ballot(alive);
 
+    if (quad_start) pending = valid && sub == 0;           // (the four lanes of a group hold the same ray: one of them stores its hit)
+    else {
     // ---- phase 1: one ray per lane, while the wavefront holds more than kTailRays live rays -------------------------------
     {
         const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
@@ -1066,7 +1084,6 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     const int nlive = __popcll(live);
     if (alive) lanes_of[__popcll(live & ((1ull << lane) - 1ull))] = lane;
     __syncthreads();
-    const int group = lane >> 2, sub = lane & 3;
     alive = group < nlive;
     pending = alive && sub == 0;
     const int src4 = lanes_of[alive ? group : 0] << 2;
@@ -1078,6 +1095,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
     ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
     if (!UNIFORM) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
+    }
 
     // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
     {
@@ -1495,13 +1513,13 @@ template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
     if (tail && MODE == 0 && slim && !a.wave_times && !uniform) {
-        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, 0, st>>>(a);
-        else            traverse_kernel_tail<26, false, false><<<blocks, 64, 0, st>>>(a);
+        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+        else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
     }
     else if (tail && MODE == 0 && uniform && slim && !(a.wave_times && slim != 20)) {
         if (slim == 20 && a.wave_times) traverse_kernel_tail<20, true><<<blocks, 64, 0, st>>>(a);
-        else if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, 0, st>>>(a);
-        else                 traverse_kernel_tail<26><<<blocks, 64, 0, st>>>(a);
+        else if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, a.lds_pad, st>>>(a);
+        else                 traverse_kernel_tail<26><<<blocks, 64, a.lds_pad, st>>>(a);
     }
     else if (slim == 20 && uniform) {
         if (MODE == 0 && a.wave_times) traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, st>>>(a);
@@ -1564,7 +1582,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0;
+    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -1715,8 +1733,23 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
     }
     if (variant == 4) {
-        const int blocks = grid_blocks(num_rays, 64);
+        int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
+        // Tail kernel: "traverse.quad_tail" per cent of the tiles, the last in dispatch order, start with four lanes per ray.  -1 (default):
+        // a quarter of the tiles when the launch is between one and two rounds of the resident wavefronts (1024^2 rays on 256 CUs) --
+        // there the last wavefronts to start are what the launch waits for (1024^2: 0.179 -> 0.175 ms; 6 / 12 / 37 / 50 %: 0.180 /
+        // 0.181 / 0.189 / 0.204 ms).  Larger launches are throughput-bound and lose (2048^2 at 12 %: +3 %, 4096^2: +10 %), binned
+        // batches too; an unordered 1M batch gains up to 20 % at 100 (profiles/dev_r3_quad_tail.txt).  Hits do not depend on it.
+        int quad_pct = ctx->opt_quad_tail;
+        if (quad_pct < 0) {
+            const long long slots = (long long)ctx->num_cus * 32;
+            quad_pct = (!perm && blocks > slots && 4ll * blocks <= 9 * slots) ? 25 : 0;
+        }
+        if (quad_pct > 0 && ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow) {
+            const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
+            const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
+            if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
+        }
         a.wave_times = ctx->kat_wave_times; a.tile_order = ctx->kat_tile_order;
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
@@ -1761,7 +1794,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.chunk", &ctx->opt_chunk, 0, 1 << 20},      {"traverse.both_phases", &ctx->opt_both_phases, 0, 1},
         {"traverse.refill_at", &ctx->opt_refill_at, 1, 64},   {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1},
         {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},
-        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.tail", &ctx->opt_tail, 0, 1}, {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},
+        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16}, {"traverse.image", &ctx->opt_image, 0, 2},             {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2}, {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.tail", &ctx->opt_tail, 0, 1}, {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100}, {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536}, {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},
         {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
         {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},

@@ -119,5 +119,6 @@ int main(int argc, char** argv) {
     mem.free(rays); mem.free(hits);
     mem.free(grid.entries); mem.free(grid.cells); mem.free(grid.ref_ids); mem.free(grid.small_cells); mem.free(tris);
     printf("peak usage %.1f MB, usage after free %zu\n", mem.max_usage() / 1048576.0, mem.usage());
+    fflush(stdout);
     return bad == 0 && intr > 0 ? 0 : 1;
 }

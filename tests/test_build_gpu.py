@@ -330,7 +330,9 @@ api.traverse_grid(grid, d_tris, d_rays, d_hits, 70000)
 h = mem.download(d_hits, api.HIT_DTYPE, 70000)
 print("SUMMARY", grid.num_cells, grid.num_refs, int((h["id"] >= 0).sum()), int(h["id"].astype(np.int64).sum()))
 '''.replace("ROOT", repr(root)).replace("OUT", repr(str(tmp_path)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    import _subproc
+    r = _subproc.run([sys.executable, "-c", code], timeout=600)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     got = [l for l in r.stdout.splitlines() if l.startswith("SUMMARY")][-1].split()[1:]
     from hagrid_amd import api

@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+import _subproc
+
 from hagrid_amd import scene
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +28,8 @@ def test_bench_two_ranks_share_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--tris", "100000", "--width", "512", "--height", "512", "--backend", "gloo", "--device", "0", "--build-iter", "1"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = _subproc.run(cmd, timeout=300, cwd=ROOT)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
@@ -42,7 +45,8 @@ def test_bench_strong_scaling_two_ranks(config, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(config),
            "--tris", "100000", "--backend", "gloo", "--device", "0", "--build-iter", "1"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = _subproc.run(cmd, timeout=300, cwd=ROOT)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     total = 300001 if config == 4 else int(extra[1]) * int(extra[3])
@@ -177,7 +181,8 @@ def test_bench_rccl_path_with_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--tris", "100000",
            "--width", "512", "--height", "512", "--build-iter", "1", "--force-dist", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    r = _subproc.run(cmd, timeout=300, cwd=ROOT, env=env)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["grid_broadcast_ms"] >= 0
@@ -188,12 +193,14 @@ def test_bench_single_gpu_line_carries_the_pipelined_block():
     hits identical to the single-stream run; never part of `value`.  --inflight 0 leaves it out."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--tris", "100000",
             "--width", "512", "--height", "512", "--build-iter", "1", "--no-cpu-baseline"]
-    r = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = _subproc.run(base, timeout=300, cwd=ROOT)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     p = out["pipelined"]
     assert p and p["in_flight"] == 2 and p["hits_identical_to_single_stream"] is True and p["value"] > 0 and p["steps"] >= 6
     assert out["value"] > 0 and out["n_gpus"] == 1
-    r = subprocess.run(base + ["--inflight", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = _subproc.run(base + ["--inflight", "0"], timeout=300, cwd=ROOT)
+    assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["pipelined"] is None

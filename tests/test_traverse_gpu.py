@@ -606,7 +606,8 @@ def test_image_lifetime(mem):
 @pytest.mark.parametrize("slim", [1, 2])
 def test_tail_mode_gives_the_oracle_hits(mem, slim):
     """traverse_kernel_tail: a wavefront that holds at most 16 live rays compacts to four lanes per ray and tests a cell's inline list
-    in one round, replaying the acceptance in list order.  Hits must stay the oracle's bit for bit: wavefronts that are sparse from the
+    in one round, replaying the acceptance in list order; the last tiles of a launch may start in that form ("traverse.quad_tail": four blocks
+    of 16 rays per tile, a 4 x 4 pixel quadrant each).  Hits must stay the oracle's bit for bit: wavefronts that are sparse from the
     start (batches of 1 .. 17 rays, rays that miss the grid), that thin out on the way (64 coherent rays), lists longer than a record
     holds (by index) met inside the tail phase, the 20- and 26-bit id forms, the table layout, binned batches -- and the kernel without
     the tail mode for comparison."""
@@ -630,19 +631,20 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             info = mem.image_format(grid)
             assert info["slim_id_bits"] == (26 if slim == 2 else 20), (name, info)
             if name != "long_lists": assert info["uniform"] == (name == "soup"), (name, info)      # both slim layouts are exercised
-            for tail in (1, 0):
-                mem.set_option("traverse.tail", tail)
+            # (tail mode, per cent of the tiles that START with four lanes per ray -- "traverse.quad_tail", 16 rays per wavefront)
+            for tail, quad in ((1, -1), (1, 0), (1, 30), (1, 100), (0, 0)):
+                mem.set_option("traverse.tail", tail); mem.set_option("traverse.quad_tail", quad)
                 for binning in (0, 1):
                     mem.set_ray_binning(binning)
                     for first, n in ((0, rays.shape[0]), (0, 64 * 48), (0, 64), (5, 1), (7, 15), (0, 16), (3, 17), (64 * 48, 4099)):
                         got = gpu_traverse(mem, grid, d_tris, rays[first:first + n])
                         w = want[first:first + n]
-                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, binning, first, n)
+                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, quad, binning, first, n)
             if name == "long_lists":
                 assert (want["id"] >= 0).any()
             grid.free(); mem.free(d_tris)
     finally:
-        mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0)
+        mem.set_option("traverse.tail", 1); mem.set_option("traverse.quad_tail", -1); mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0)
 
 
 def test_row_length_cache_never_changes_hits(mem):

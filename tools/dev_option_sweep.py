@@ -1,0 +1,43 @@
+"""DEV TOOL: one traversal option swept in ONE process on ONE grid (same box, same clocks): per value the median / min of event-timed
+launches in steady state (launches back to back for `settle` ms first) and a checksum of the hits, which must not move.
+
+usage: python tools/dev_option_sweep.py KEY v0,v1,... [--batch "primary 1024^2"] [--reps 3] [OPTS=k=v,... in the environment]
+"""
+import json, os, sys, time, zlib
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hagrid_amd import api, scene
+
+key = sys.argv[1]; values = [int(v) for v in sys.argv[2].split(",")]
+arg = lambda name, default: (sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default)
+batch = arg("--batch", "primary 1024^2"); reps = int(arg("--reps", "3")); launches = int(arg("--launches", "200"))
+mem = api.MemManager(keep=True)
+for kv in filter(None, os.environ.get("OPTS", "").split(",")):
+    k, v = kv.split("="); mem.set_option(k, int(v))
+td, sd = (0.15, 3.0) if "config3" in batch else (0.12, 2.4)
+tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
+grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
+api.setup_traversal(grid)
+gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
+        "primary 2048^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 2048, 2048),
+        "primary 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
+        "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
+        "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
+        "incoherent 1M": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4)}
+rays = gens[batch](); n = rays.shape[0]
+d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+if "binned" in batch: mem.set_ray_binning(1)
+go = lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+for rep in range(reps):
+    for v in values:
+        mem.set_option(key, v)
+        t0 = time.time()
+        while time.time() - t0 < 0.15:
+            for _ in range(20): go()
+            mem.synchronize()
+        mem.zero(d_hits, 16 * n)
+        # steady state: K launches between one pair of events
+        ms = sorted(api.profile(lambda: [go() for _ in range(launches // 10)], mem) / (launches // 10) for _ in range(10))
+        h = mem.download(d_hits, api.HIT_DTYPE, n)
+        print(json.dumps({"rep": rep, key: v, "batch": batch, "ms_median": round(ms[5], 5), "ms_min": round(ms[0], 5),
+                          "hits_crc": zlib.crc32(h.tobytes())}), flush=True)
