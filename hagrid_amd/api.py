@@ -137,7 +137,7 @@ class MemManager:
     def image_format(self, grid: "Grid") -> dict:
         """Layout of the traversal image held for `grid`: flat / uniform / slim id bits / bytes per record ({} without an image)."""
         f = (C.c_int32 * 4)()
-        if self._L.hagrid_kat_image_format(self._ctx, C.byref(grid.pod), f) != 0:
+        if self._L.hagrid_traversal_image_info(self._ctx, C.byref(grid.pod), f, None) != 0:
             return {}
         return {"flat": bool(f[0]), "uniform": bool(f[1]), "slim_id_bits": int(f[2]), "record_bytes": int(f[3])}
 
@@ -148,8 +148,13 @@ class MemManager:
     def image_bytes(self, grid: "Grid") -> int:
         """Size of the traversal image this manager holds for `grid` (0 when it holds none)."""
         b = C.c_int64(0)
-        rc = self._L.hagrid_kat_image_records(self._ctx, C.byref(grid.pod), None, 0, None, C.byref(b))
+        rc = self._L.hagrid_traversal_image_info(self._ctx, C.byref(grid.pod), None, C.byref(b))
         return int(b.value) if rc == 0 else 0
+
+    @property
+    def _K(self):
+        """libhagrid_amd_kat.so: known-answer hooks and timed diagnostic kernels (tests and dev tools only)."""
+        return _lib.load_kat()
 
     def build_counts(self) -> dict:
         """Sizes the construction passes of this manager went through since its last build_grid."""

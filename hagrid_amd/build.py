@@ -1,6 +1,8 @@
 """Builds hagrid_amd/libhagrid_amd.so in-tree: every csrc/*.hip is compiled for gfx950 with hipcc and
 the objects are linked WITHOUT naming a HIP runtime, so the library binds to whichever libamdhip64 the
 process already holds (PyTorch's when loaded from Python, /opt/rocm's when linked into a C++ program).
+csrc/kat/*.hip -- known-answer hooks and diagnostic instantiations, used by tests/ and tools/dev_*.py only --
+become a second library, hagrid_amd/libhagrid_amd_kat.so, which links against the first.
 
 Floating-point policy: no contraction, no fast-math, correctly rounded divide/sqrt -- the
 kernels must agree bit for bit with the CPU oracle.
@@ -18,6 +20,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "obj")
 LIB = os.path.join(HERE, "libhagrid_amd.so")
+KAT_LIB = os.path.join(HERE, "libhagrid_amd_kat.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -38,18 +41,36 @@ def _newer(target: str, deps: list[str]) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 over the sources the libraries are built from (csrc/, include/, this recipe): what a profile or a traffic
+    figure has to name to say which kernels it measured (bench.py: roofline.traffic_source)."""
+    import hashlib
+    files = sorted(glob.glob(os.path.join(CSRC, "**", "*.hip"), recursive=True) + glob.glob(os.path.join(CSRC, "**", "*.h"), recursive=True) +
+                   glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True) + [os.path.abspath(__file__)])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode()); h.update(b"\0")
+        h.update(open(f, "rb").read()); h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True)
+    hdrs = glob.glob(os.path.join(CSRC, "**", "*.h"), recursive=True) + glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True)
     hdrs.append(os.path.abspath(__file__))
     jobs = []
-    objs = []
-    for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
-        objs.append(o)
-        if force or not _newer(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+
+    def objects(srcs, prefix=""):
+        objs = []
+        for s in srcs:
+            o = os.path.join(OBJ, prefix + os.path.basename(s)[:-4] + ".o")
+            objs.append(o)
+            if force or not _newer(o, [s] + hdrs):
+                jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+        return objs
+
+    objs = objects(sorted(glob.glob(os.path.join(CSRC, "*.hip"))))
+    kat_objs = objects(sorted(glob.glob(os.path.join(CSRC, "kat", "*.hip"))), "kat_")
 
     def run(cmd):
         if verbose:
@@ -64,6 +85,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     if jobs or force or not _newer(LIB, objs):
         run(["g++", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread", "-ldl"])
+    if jobs or force or not _newer(KAT_LIB, kat_objs + [LIB]):
+        run(["g++", "-shared", "-fPIC", "-o", KAT_LIB, *kat_objs, "-L" + HERE, "-lhagrid_amd", "-Wl,-rpath,$ORIGIN", "-lpthread"])
     return LIB
 
 

@@ -74,18 +74,13 @@ struct hagrid_ctx {
 
     // traversal options (hagrid_set_ray_binning, hagrid_set_option)
     int ray_binning = 0;
-    int opt_variant = 0;        // 0 = choose by batch size, 1 / 2 / 3 = force that kernel
-    int opt_waves_per_cu = 32;  // persistent kernel: resident wavefronts per CU
-    int opt_chunk = 0;          // persistent kernel: rays per cursor atomic (0 = derive from the batch)
-    int opt_both_phases = 0;    // persistent kernel: run both phases every iteration
+    int opt_variant = 0;        // 0 = the image kernel when the grid has an image, else v2; 1 / 2 / 4 = force the reference-shaped kernel / v2 / the image kernel
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
     int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
-    unsigned long long* kat_wave_times = nullptr;   // diagnostic: see hagrid_kat_wave_times
-    const int* kat_tile_order = nullptr;
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
@@ -97,7 +92,6 @@ struct hagrid_ctx {
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
-    int opt_refill_at = 24;     // persistent kernel: free lanes that trigger a refill (sweep: tools/dev_v3_tune.py)
 
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
 

@@ -1,0 +1,51 @@
+/* hagrid_amd_kat.h -- C ABI of libhagrid_amd_kat.so: known-answer hooks for the device code (tests/) and diagnostic instantiations
+ * (tools/dev_*.py).  TEST INFRASTRUCTURE -- not part of the drop-in boundary (include/hagrid_amd.h) and not in the product library.
+ * The hooks work on contexts of the product library (the two libraries share one process and one HIP runtime). */
+#ifndef HAGRID_AMD_KAT_H
+#define HAGRID_AMD_KAT_H
+
+#include "hagrid_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- known-answer hooks for the L0 device functions (tests only; tiny launches) ---------------------- */
+/* Each evaluates the named device function for n inputs (host arrays in, host arrays out). */
+int hagrid_kat_intersect_prim_ray(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
+                                  int n, int32_t* ret, int32_t* hit_id, float* hit_t);
+/* the same with COMPUTE_UVS: additionally the barycentrics */
+int hagrid_kat_intersect_prim_ray_uvs(hagrid_ctx* ctx, const void* tris, const void* rays, const int32_t* tri_index,
+                                      int n, int32_t* ret, int32_t* hit_id, float* hit_t, float* hit_u, float* hit_v);
+int hagrid_kat_intersect_prim_cell(hagrid_ctx* ctx, const void* tris, const void* boxes, const int32_t* tri_index,
+                                   int n, int32_t* ret);
+int hagrid_kat_compute_range(hagrid_ctx* ctx, const int32_t* dims3, const void* grid_bb, const void* obj_bb, int n, int32_t* out6);
+int hagrid_kat_compute_grid_dims(hagrid_ctx* ctx, const void* bb, const int32_t* num_prims, const float* density, int n, int32_t* out3);
+int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_entries, int shift, const int32_t* top_dims3,
+                            const int32_t* voxels3, int n, uint32_t* out);
+/* The device-wide ordered exclusive scan the construction passes use in place of cub::DeviceScan::ExclusiveSum (parallel.cuh:31-42):
+ * out[i] = carry + sum of values[0..i), total = carry + sum of all; words = 1 (int) or 2 (pairs of ints, interleaved); carry_in =
+ * `words` ints or NULL; lookback != 0 runs the single-pass decoupled look-back form, 0 the three-kernel reduce-then-scan form. */
+int hagrid_kat_scan(hagrid_ctx* ctx, const int32_t* values, int n, int words, const int32_t* carry_in, int lookback,
+                    int32_t* out, int32_t* total);
+/* Tile packets (see "traverse.image_width"): the row length the device finds for a ray buffer in device memory (0 = not
+ * image-ordered), and the ray slot every lane of every 64-lane block gets for a batch of num_rays rays with rows of
+ * row_len rays, in block dispatch order (slots: 64 * ceil(num_rays / 64) ints; values >= num_rays mark idle lanes). */
+int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev, int num_rays, float bbox_diag, int32_t* row_len);
+int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots);
+/* One launch of the headline kernel (table-free image with 20-bit slim records, nearest hit) in its timed instantiation: per block b
+ * (64 rays) the 100 MHz wall clock at its start in times_dev[2b] and when its last lane left in times_dev[2b + 1] (the caller zeroes
+ * the buffer).  row_len = image width of the batch; tail = 0 times the plain slim kernel instead; tile_order_dev (or null): block b
+ * traverses the 8x8 tile tile_order_dev[b] of the default order -- an experiment on dispatch order.  tools/dev_wave_timeline.py. */
+int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris, const void* rays, void* hits, int num_rays,
+                              int row_len, int tail, unsigned long long* times_dev, const int* tile_order_dev);
+/* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
+ * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
+ * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
+ * HAGRID_EINVAL when the context holds no image of this grid. */
+int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAGRID_AMD_KAT_H */

@@ -3,8 +3,9 @@
 // The scans replace cub::DeviceScan::ExclusiveSum of the reference (parallel.cuh:31-42); the construction passes only ever
 // exercise them indirectly, so tests/test_scan_gpu.py drives them directly: tile-boundary sizes, the device carry chain and
 // the two-word (Int2) publish of the look-back form.
-#include "ctx.h"
-#include "wave_prims.h"
+#include "../ctx.h"
+#include "../wave_prims.h"
+#include "hagrid_amd_kat.h"
 
 using namespace hagrid_impl;
 

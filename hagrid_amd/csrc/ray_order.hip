@@ -1,0 +1,324 @@
+// ray_order.hip -- how a batch meets the lanes: the row length of an image-ordered batch, found on the device (it steers the tile
+// packets of trav_common.h), and ray binning, the counting sort of an unordered batch on 512 Morton bins of the rays' entry points
+// (north_star: "per-wavefront ray packets sorted in LDS to tame divergence").  Neither changes a hit: both only choose which lane
+// traverses which ray.  No reference counterpart (the reference traverses rays in buffer order, traverse.cu:35-38).
+#include "trav_common.h"
+#include "wave_prims.h"
+
+using namespace hagrid;
+using namespace hagrid_impl;
+using namespace hagrid_trav;
+
+namespace {
+
+// Row length of an image-ordered batch, or 0: the (origin, direction) of consecutive rays advances by a constant step
+// s = ray[1] - ray[0] along a row (perspective: the direction; orthographic: the origin) and jumps at a row break.
+// w = index of the first break; accepted if it is a multiple of 8, the second row starts with the same step and, when
+// there is a third row, ray 2w is a break too.  One workgroup; the answer stays on the device (no host round trip).
+// A wrong answer can only cost speed: any row length gives a valid lane <-> ray assignment.
+constexpr int kDetectBlock = 1024;
+constexpr int kDetectLimit = 1 << 16;
+
+__device__ __forceinline__ float ray_step_dev2(const float4* __restrict__ rays, int i, const float (&s)[6]) {
+    // squared distance between (ray[i+1] - ray[i]) and s over origin and direction
+    const float4 a0 = rays[2 * size_t(i)], a1 = rays[2 * size_t(i) + 1], b0 = rays[2 * size_t(i) + 2], b1 = rays[2 * size_t(i) + 3];
+    const float d[6] = {b0.x - a0.x - s[0], b0.y - a0.y - s[1], b0.z - a0.z - s[2], b1.x - a1.x - s[3], b1.y - a1.y - s[4], b1.z - a1.z - s[5]};
+    return d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+}
+
+// Second criterion, for image-ordered batches whose directions are not a function of the pixel (bounce rays leaving the
+// primary hit points): the ORIGINS of vertically neighbouring pixels are close.  Every candidate row length w = 64, 72, ...
+// gets the clamped mean squared distance |org[i + w] - org[i]|^2 / tau^2 over 256 sampled i (tau = 1/64 of the grid
+// diagonal); the true row length is the minimum (one pixel apart; w +- 8 is eight pixels apart, 2w two rows).  Accepted if
+// it stands out from the mean over all candidates and horizontally neighbouring origins are as close (but not all identical).  Blocks 1.. of the same
+// launch do the scoring, the block that finishes last picks -- no extra launch, nothing waits; used only when the first
+// criterion found nothing.  Like the first one it can only cost speed if it is wrong.
+constexpr int kRowCandidates = 2048;                 // w = 8 * (c + 8): 64 .. 16440
+constexpr int kRowSamples = 256;
+
+__global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __restrict__ rays, int n, int* __restrict__ out,
+                                                                int* __restrict__ scores, float inv_tau2, int origins_only) {
+    __shared__ int first_break;
+    __shared__ int lds_score[kDetectBlock / 64];
+    __shared__ int ticket;
+    __shared__ unsigned long long best[kDetectBlock / 64];
+    __shared__ long long sums[kDetectBlock / 64];
+    __shared__ int counts[kDetectBlock / 64];
+    // origins_only: a second launch after the first criterion; nothing to do if that one found the row length
+    if (origins_only && __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) return;
+    if (blockIdx.x == 0 && !origins_only) {
+        if (threadIdx.x == 0) { first_break = 0x7fffffff; out[0] = 0; }
+        int w1 = 0;
+        if (n >= 128) {
+            const float4 a0 = rays[0], a1 = rays[1], b0 = rays[2], b1 = rays[3];
+            const float s[6] = {b0.x - a0.x, b0.y - a0.y, b0.z - a0.z, b1.x - a1.x, b1.y - a1.y, b1.z - a1.z};
+            const float s2 = s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+            if ((s2 > 0.0f) && (s2 < 3.0e38f)) {
+                const float tol = 0.25f * s2;
+                const int limit = min(n - 1, kDetectLimit);              // pairs (i, i + 1) with i < limit
+                __syncthreads();
+                for (int base = 1; base < limit; base += kDetectBlock) {
+                    const int i = base + int(threadIdx.x);
+                    if (i < limit && !(ray_step_dev2(rays, i, s) <= tol)) atomicMin(&first_break, i + 1);
+                    __syncthreads();
+                    const int found = first_break;
+                    __syncthreads();
+                    if (found != 0x7fffffff) break;
+                }
+                if (threadIdx.x == 0) {
+                    const int w = first_break;
+                    bool ok = w != 0x7fffffff && w >= 8 && (w & 7) == 0 && n / w >= 8;
+                    if (ok) ok = ray_step_dev2(rays, w, s) <= tol;                                   // second row advances like the first
+                    if (ok && n > 2 * w) ok = !(ray_step_dev2(rays, 2 * w - 1, s) <= tol);            // and ends where the first did
+                    w1 = ok ? w : 0;
+                }
+            }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(out, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.x == 1) return;
+    } else if (blockIdx.x != 0) {
+        // four candidates per block, one per group of 256 threads; candidate kRowCandidates is the horizontal neighbour (w = 1)
+        const int c = (int(blockIdx.x) - 1) * 4 + int(threadIdx.x >> 8);
+        const int w = c < kRowCandidates ? 8 * (c + 8) : 1;
+        int v = 1024;
+        if (c <= kRowCandidates && n - w > 0) {
+            uint32_t h = uint32_t(c) * 2654435761u + (threadIdx.x & 255u) * 40503u + 12345u;
+            h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+            const int i = int(h % uint32_t(n - w));
+            const float4 p = rays[2 * size_t(i)], q = rays[2 * size_t(i + w)];
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            const float d2 = (dx * dx + dy * dy + dz * dz) * inv_tau2;
+            v = d2 < 1.0f ? int(d2 * 1024.0f) : 1024;            // NaN -> 1024
+        }
+        v = wave_sum(v);
+        if (lane_id() == 0) lds_score[wave_id()] = v;
+        __syncthreads();
+        if ((threadIdx.x & 255) == 0 && c <= kRowCandidates) {
+            const int g = int(threadIdx.x >> 8) * 4;
+            __hip_atomic_store(scores + c, lds_score[g] + lds_score[g + 1] + lds_score[g + 2] + lds_score[g + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the block that finishes last picks.  Scores and out[0] travel as agent-scope atomics (a __threadfence per thread costs an
+    // L2 write-back each on this part: 150 us for the launch); the ticket is the release / acquire point.
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(scores + kRowCandidates + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != int(gridDim.x) - 1) return;
+    unsigned long long m = ~0ull;                                    // (score << 32 | w), minimum
+    long long total = 0; int counted = 0;                            // mean score of the candidates
+    for (int c = int(threadIdx.x); c < kRowCandidates; c += kDetectBlock) {
+        const int w = 8 * (c + 8);
+        if (n / w >= 8) {
+            const unsigned sc = (unsigned)__hip_atomic_load(scores + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long key = ((unsigned long long)sc << 32) | unsigned(w);
+            m = key < m ? key : m;
+            total += sc; counted++;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(m, d, 64); m = o < m ? o : m;
+        total += __shfl_xor(total, d, 64); counted += __shfl_xor(counted, d, 64);
+    }
+    if (lane_id() == 0) { best[wave_id()] = m; sums[wave_id()] = total; counts[wave_id()] = counted; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kDetectBlock / 64; i++) { m = best[i] < m ? best[i] : m; total += sums[i]; counted += counts[i]; }
+        // The row length stands out: its score lies clearly (8 % of the clamp) below the mean of all candidates, and so does the
+        // score of horizontally neighbouring origins.  Unrelated origins score ~1.0 everywhere; rows of hit points with
+        // silhouettes and rays that left the scene 0.2-0.9.  horizontal == 0: all origins coincide (a pinhole camera) -- no information.
+        const int full = kRowSamples * 1024;
+        const long long mean = counted ? total / counted : 0;
+        const int horizontal = __hip_atomic_load(scores + kRowCandidates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int w1 = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long bar = mean - full * 8 / 100;
+        if (w1 == 0 && m != ~0ull && (long long)(m >> 32) < bar && horizontal < bar && horizontal > 0) out[0] = int(unsigned(m));
+        scores[kRowCandidates + 1] = 0;                              // ready for the next batch
+    }
+}
+
+// ---- ray binning (extension; north_star: "ray packets sorted ... to tame divergence") ----------------------------------
+// A batch without spatial order (random origins and directions) makes every load of a wavefront touch 64 unrelated cache
+// lines.  Measured on MI355X (tools/dev_sort_potential.py): ordering such a batch by a coarse Morton key of the ray's
+// position -- 8 x 8 x 8 bins are enough, the direction octant does not matter -- lifts traversal from 1.0 to 2.3-2.6
+// Grays/s.  So the device does a counting sort on 512 bins, not a general sort:
+//   ray_bin_count   : key = Morton3(entry point of the ray into the grid box, 3 bits per axis); per-workgroup histogram in
+//                     LDS, written to table[bin][workgroup]
+//   device_scan     : exclusive scan of the table in (bin, workgroup) order = first slot of every (bin, workgroup) run
+//   ray_bin_scatter : slot = run start + rank inside the run (LDS atomic), perm[slot] = ray index
+// The order inside a bin is irrelevant.  No global atomics; one extra 4-byte word per ray.
+constexpr int kBinBits = 3;
+constexpr int kBins = 1 << (3 * kBinBits);
+constexpr int kBinItems = 16;                       // rays per thread
+constexpr int kBinTile = kBlock * kBinItems;        // rays per workgroup
+
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {   // 3 bits -> every third bit
+    return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4);
+}
+
+__device__ __forceinline__ int ray_bin_key(const TraverseArgs& a, int id) {
+    const float4 r0 = a.rays[2 * size_t(id)], r1 = a.rays[2 * size_t(id) + 1];
+    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+    const vec3 t0 = min(ta, tb);
+    float ts = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), r0.w);
+    if (!(ts == ts) || ts > 3.0e38f || ts < -3.0e38f) ts = 0.0f;
+    const vec3 p = (ts * dir + org - gmin) / (gmax - gmin) * float(1 << kBinBits);
+    const int m = (1 << kBinBits) - 1;
+    const int x = min(max(int(detail::fmin2(detail::fmax2(p.x, 0.0f), float(m))), 0), m);
+    const int y = min(max(int(detail::fmin2(detail::fmax2(p.y, 0.0f), float(m))), 0), m);
+    const int z = min(max(int(detail::fmin2(detail::fmax2(p.z, 0.0f), float(m))), 0), m);
+    return int(spread3(uint32_t(x)) | (spread3(uint32_t(y)) << 1) | (spread3(uint32_t(z)) << 2));
+}
+
+// auto mode: `skip_if` (the row length found by detect_ray_rows) > 0 means the batch is image-ordered and is left alone;
+// `diff` (64 words) receives the number of neighbouring rays (i, i + 1) whose keys differ -- the coherence estimate
+__global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, unsigned short* __restrict__ keys, int* __restrict__ table,
+                                                        const int* __restrict__ skip_if, int* __restrict__ diff) {
+    __shared__ int hist[kBins];
+    __shared__ unsigned short tile_keys[kBinTile];
+    __shared__ int lds[kWaves];
+    if (skip_if && *skip_if > 0) return;
+    for (int i = threadIdx.x; i < kBins; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kBinTile;
+    for (int j = 0; j < kBinItems; j++) {
+        const int id = base + j * kBlock + threadIdx.x;
+        if (id < a.num_rays) {
+            const int k = ray_bin_key(a, id);
+            keys[id] = (unsigned short)k;
+            if (diff) tile_keys[j * kBlock + threadIdx.x] = (unsigned short)k;
+            atomicAdd(&hist[k], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBins; i += kBlock) table[size_t(i) * gridDim.x + blockIdx.x] = hist[i];
+    if (diff) {
+        int d = 0;
+        for (int j = 0; j < kBinItems; j++) {
+            const int i = j * kBlock + threadIdx.x;
+            if (base + i + 1 < a.num_rays && i + 1 < kBinTile) d += tile_keys[i] != tile_keys[i + 1];
+        }
+        d = block_sum(d, lds);
+        if (threadIdx.x == 0 && d) atomicAdd(diff + (blockIdx.x & 63), d);
+    }
+}
+
+// auto mode: bin the batch iff it is not image-ordered and more than half of its neighbouring rays fall into different bins
+__global__ void __launch_bounds__(64) ray_bin_decide(const int* __restrict__ row_len, int* __restrict__ diff, int num_rays, int* __restrict__ flag) {
+    int d = diff[threadIdx.x];
+    diff[threadIdx.x] = 0;                       // ready for the next batch
+    d = wave_sum(d);
+    if (threadIdx.x == 0) flag[0] = (*row_len == 0 && 2ll * d > num_rays) ? 1 : 0;
+}
+
+// The rays of a tile are first put in bin order inside LDS (local histogram -> local scan -> local rank), then written out: lanes
+// that are neighbours in LDS write neighbouring words of `perm`, so a store instruction touches the runs of a few bins instead of 64
+// unrelated lines (the lane-by-lane form moved 512 MB in 2.3 ms for 128M rays: bound by write transactions, not by bytes).
+__global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* __restrict__ keys, const int* __restrict__ table_scan,
+                                                          int num_rays, int* __restrict__ perm, const int* __restrict__ only_if) {
+    static_assert(kBins == 2 * kBlock, "two bins per thread in the local scan");
+    __shared__ int count[kBins];               // rays of the tile per bin, then the cursor of the local ranks
+    __shared__ int lstart[kBins + 1];          // first LDS slot of every bin
+    __shared__ int gstart[kBins];              // first slot of the (bin, workgroup) run in perm
+    __shared__ int sorted_id[kBinTile];
+    __shared__ unsigned short sorted_key[kBinTile];
+    __shared__ int wsum[kWaves];
+    if (only_if && *only_if == 0) return;
+    for (int i = threadIdx.x; i < kBins; i += kBlock) { count[i] = 0; gstart[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x]; }
+    __syncthreads();
+    const int base = blockIdx.x * kBinTile;
+    int key[kBinItems], rank[kBinItems];
+#pragma unroll
+    for (int j = 0; j < kBinItems; j++) {
+        const int id = base + j * kBlock + threadIdx.x;
+        key[j] = id < num_rays ? int(keys[id]) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kBinItems; j++) rank[j] = key[j] >= 0 ? atomicAdd(&count[key[j]], 1) : 0;
+    __syncthreads();
+    {   // exclusive scan of the 512 counts: two per thread, wavefront scan, wavefront sums through LDS
+        const int c0 = count[2 * threadIdx.x], c1 = count[2 * threadIdx.x + 1];
+        const int incl = wave_inclusive_scan(c0 + c1);
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave_id(); w++) before += wsum[w];
+        const int ex = before + incl - (c0 + c1);
+        lstart[2 * threadIdx.x] = ex; lstart[2 * threadIdx.x + 1] = ex + c0;
+        if (threadIdx.x == kBlock - 1) lstart[kBins] = ex + c0 + c1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kBinItems; j++)
+        if (key[j] >= 0) {
+            const int at = lstart[key[j]] + rank[j];
+            sorted_id[at] = base + j * kBlock + threadIdx.x;
+            sorted_key[at] = (unsigned short)key[j];
+        }
+    __syncthreads();
+    const int total = lstart[kBins];
+    for (int i = threadIdx.x; i < total; i += kBlock) {
+        const int k = sorted_key[i];
+        perm[gstart[k] + (i - lstart[k])] = sorted_id[i];
+    }
+}
+
+struct TableIn { const int* t; __device__ int operator()(int i) const { return t[i]; } };
+struct TableOut { int* t; __device__ void operator()(int i, int s) const { t[i] = s; } };
+
+} // namespace
+
+// row length of an image-ordered batch -> row_len[0] on the device.  The origin criterion costs ~17 us (2049 candidates x 256
+// sampled pairs) and only pays where tile packets pay for bounce rays: it runs as a second launch for batches of at least
+// kOriginMinRays rays and returns at once when the first criterion has already answered.
+void hagrid_trav::launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays) {
+    detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0); HG_DBG(ctx);
+    const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
+    const float tau = length(ext) / 64.0f;
+    if (num_rays < origin_min_rays || !(tau > 0.0f) || !(tau < 3.0e18f)) return;
+    if (!ctx->row_scores) {
+        if (hipMalloc((void**)&ctx->row_scores, (kRowCandidates + 8) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->row_scores = nullptr; return; }
+        (void)hipMemsetAsync(ctx->row_scores, 0, (kRowCandidates + 8) * sizeof(int), ctx->stream);
+    }
+    detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1); HG_DBG(ctx);
+}
+
+
+int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
+    a.perm = nullptr;
+    if (!ctx->ray_binning || num_rays <= kBinTile) return HAGRID_OK;
+    const int tiles = grid_blocks(num_rays, kBinTile);
+    const int table_n = kBins * tiles;
+    int* perm = tmp.get<int>(size_t(num_rays));
+    unsigned short* bin_keys = tmp.get<unsigned short>(size_t(num_rays));
+    int* bin_table = tmp.get<int>(size_t(table_n));
+    int* bin_partials = tmp.get<int>(size_t(scan_num_tiles(table_n)) + 1);
+    if (!perm || !bin_keys || !bin_table || !bin_partials) return HAGRID_ENOMEM;
+    if (ctx->ray_binning == 2) {
+        // automatic: everything is decided on the device, nobody waits.  row length (image-ordered batches are left to the
+        // tile packets) -> keys + coherence estimate -> scan -> decision -> scatter; the traversal kernel reads the decision.
+        int* row_len = ctx->dscratch + 232;
+        int* flag = ctx->dscratch + 233;
+        if (!ctx->bin_diff) {
+            HG_HIP(ctx, hipMalloc((void**)&ctx->bin_diff, 64 * sizeof(int)));
+            HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));
+        }
+        launch_detect(ctx, a, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
+        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff); HG_DBG(ctx);
+        if (!ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
+        ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag); HG_DBG(ctx);
+        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag); HG_DBG(ctx);
+        a.perm_flag = flag;
+        if (ctx->opt_image_width == 0) a.row_len = row_len;
+        else if (ctx->opt_image_width > 0) a.row_len_hint = ctx->opt_image_width;
+    } else {
+        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr); HG_DBG(ctx);
+        if (!ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
+        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr); HG_DBG(ctx);
+    }
+    a.perm = perm;
+    return HAGRID_OK;
+}

@@ -1,0 +1,273 @@
+// trav_common.h -- what the traversal translation units share: the kernel argument block, record / triangle loads, the tile
+// packets (lane <-> ray assignment), small device helpers, and the host entry points each unit offers the others.
+//   traverse.hip    the C ABI (setup_traversal, traverse_grid[_ex|_stats], options) and the traversal-image kernels (trav_kernels.h)
+//   trav_plain.hip  the kernels that walk the construction format: the reference-shaped one (statistics, Hit.id = steps) and v2
+//   ray_order.hip   row-length detection of image-ordered batches and the counting sort of unordered ones (ray binning)
+//   kat/kat.hip     known-answer hooks and timed diagnostic instantiations: a separate library, libhagrid_amd_kat.so (tests, dev tools)
+#pragma once
+
+#include "ctx.h"
+
+#include "hagrid/grid.h"
+#include "hagrid/prims.h"
+#include "hagrid/ray.h"
+
+namespace hagrid_trav {
+
+using namespace hagrid;
+using namespace hagrid_impl;
+
+struct TraverseArgs {
+    const uint32_t* __restrict__ entries;
+    const void* __restrict__ cells;
+    const int* __restrict__ refs;
+    const float4* __restrict__ tris;
+    const float4* __restrict__ rays;
+    float4* __restrict__ hits;
+    int* __restrict__ steps;                 // optional per-ray step counter
+    unsigned long long* __restrict__ stats;  // optional 8 batch counters
+    const int* __restrict__ perm;            // optional traversal order (ray binning): slot i processes ray perm[i]
+    const int* __restrict__ perm_flag;       // optional, device: 0 = ignore perm (automatic binning decided against it)
+    const int* __restrict__ row_len;         // optional, device: row length found by detect_ray_rows (0 = none)
+    int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
+    int super_log2;                          // tile packets: tiles per super-tile edge, log2
+    int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
+    const int* __restrict__ tile_order;      // TIMES instantiations only (kat/kat.hip): packet b processes tile tile_order[b]
+    unsigned long long* __restrict__ wave_times; // TIMES instantiations only: start / end of every wavefront, 100 MHz wall clock
+    const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
+    const unsigned char* __restrict__ img_blocks;
+    int num_rays;
+    int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
+    int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
+    int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
+    int shift;
+    int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
+    int top_x, top_y;             // top-level resolution (x, y)
+    int top_xy;                   // top_x * top_y when it fits 24 bits (NARROW kernels), else 0
+    float min_x, min_y, min_z;    // grid box
+    float max_x, max_y, max_z;
+    float cs_x, cs_y, cs_z;       // cell size
+    float inv_x, inv_y, inv_z;    // 1 / cell size (as dims / extents)
+};
+
+struct CellBox { int lx, ly, lz, hx, hy, hz, begin, end; };
+
+template <bool SMALL>
+__device__ __forceinline__ CellBox load_cell_box(const void* __restrict__ cells, uint32_t index) {
+    CellBox c;
+    if (SMALL) {
+        const uint4 w = reinterpret_cast<const uint4*>(cells)[index];
+        c.lx = int(w.x & 0xffffu); c.ly = int(w.x >> 16); c.lz = int(w.y & 0xffffu);
+        c.hx = int(w.y >> 16); c.hy = int(w.z & 0xffffu); c.hz = int(w.z >> 16);
+        c.begin = int(w.w); c.end = 0;
+    } else {
+        const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(index);
+        const int4 a = p[0], b = p[1];
+        c.lx = a.x; c.ly = a.y; c.lz = a.z; c.begin = a.w;
+        c.hx = b.x; c.hy = b.y; c.hz = b.z; c.end = b.w;
+    }
+    return c;
+}
+
+__device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int ref) {
+    const float4* p = tris + 3 * size_t(ref);
+    const float4 a = p[0], b = p[1], c = p[2];
+    return Tri(vec3(a.x, a.y, a.z), a.w, vec3(b.x, b.y, b.z), b.w, vec3(c.x, c.y, c.z), c.w);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// streaming (read-once / write-once) accesses for rays and hits: keep them out of the way of the grid in L2
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float x, float y, float z, float w) {
+    f32x4 v; v.x = x; v.y = y; v.z = z; v.w = w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
+
+// ---- tile packets ---------------------------------------------------------------------------------------------------
+// A batch of camera rays arrives in image order (gen_rays, main.cpp:55-66: ray y * w + x), so 64 consecutive rays are
+// a 64 x 1 pixel strip: the lanes of a wavefront fan out over 64 pixel columns and share few cells.  An 8 x 8 pixel
+// tile per wavefront keeps the packet compact in both image directions (the vector L1 serves fewer distinct lines per
+// load instruction), and listing the tiles along a Z curve inside super-tiles keeps neighbouring wavefronts -- and the
+// contiguous block range each XCD receives -- compact as well (L2).  Measured on MI355X, soup-1M, unchanged kernel,
+// rays reordered on the host (tools/dev_tile_order.py): 1024^2 rays 0.406 -> 0.355 ms, 4096^2 rays 3.36 -> 2.10 ms.
+// The ray buffer stays in the reference's order and every hit goes to its ray's slot: only the lane <-> ray assignment
+// changes, so results are identical.  The row length w comes from the caller ("traverse.image_width") or from
+// detect_ray_rows below; w must be a multiple of 8; rows beyond the last multiple of 8 and rays beyond the last full
+// row keep the identity assignment.
+__device__ __forceinline__ uint32_t compact1by1(uint32_t v) {   // even bits of v, packed
+    v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
+    return (v | (v >> 8)) & 0x0000ffffu;
+}
+
+// Blocks are dispatched round-robin over the 8 XCDs (private L2 each).  split: XCD x runs the x-th eighth of the logical
+// block range (bands of a batch in buffer order).  chunked: XCD x runs the logical chunks x, x + 8, x + 16, ... of
+// 2^k blocks each -- along the Z curve an aligned run of 4^j tiles is a compact square, so every L2 serves compact
+// squares while the 8 XCDs work side by side on neighbouring ones: an image whose cost is concentrated in one region
+// (scene in the middle, sky around it) still loads them evenly.
+__device__ __forceinline__ int xcd_split(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+__device__ __forceinline__ int xcd_chunked(int b, int nb, int chunk_log2) {
+    const int full = (nb >> (chunk_log2 + 3)) << (chunk_log2 + 3);       // blocks in complete groups of 8 chunks
+    if (b >= full) return full + xcd_split(b - full, nb - full);
+    const int xcd = b & 7, j = b >> 3;
+    return ((((j >> chunk_log2) << 3) + xcd) << chunk_log2) + (j & ((1 << chunk_log2) - 1));
+}
+
+__device__ __forceinline__ int tile_packet_row_len(const TraverseArgs& a) {      // 0: buffer order
+    const int w = a.row_len_hint > 0 ? a.row_len_hint : (a.row_len ? __builtin_amdgcn_readfirstlane(*a.row_len) : 0);
+    return (w < 8 || (w & 7) || a.num_rays / w < 8) ? 0 : w;
+}
+
+__device__ __forceinline__ int tile_packet_slot(const TraverseArgs& a, int w, int b, int lane) {
+    const int identity = b * 64 + lane;
+    if (!w) return identity;
+    const int tiles_x = w >> 3, tiles_y = (a.num_rays / w) >> 3;
+    if (b >= tiles_x * tiles_y) return identity;             // ragged rows at the bottom, rays past the last full row
+    const int S = 1 << a.super_log2;
+    const int band = b / (tiles_x * S), in_band = b - band * tiles_x * S;
+    const int hb = min(S, tiles_y - band * S);               // tile rows in this band of super-tiles
+    const int col = in_band / (S * hb), in_super = in_band - col * S * hb;
+    const int wc = min(S, tiles_x - col * S);                // tile columns in this super-tile
+    int tx, ty;
+    if (wc == S && hb == S) { tx = int(compact1by1(uint32_t(in_super))); ty = int(compact1by1(uint32_t(in_super) >> 1)); }
+    else                    { ty = in_super / wc; tx = in_super - ty * wc; }
+    const int px = ((col * S + tx) << 3) + (lane & 7), py = ((band * S + ty) << 3) + (lane >> 3);
+    return py * w + px;
+}
+
+// intersect_prim_ray as the reference compiles it with COMPUTE_UVS (prims.h:266-295, :285-288): same test, the accepted
+// hit also stores its barycentrics.  (include/hagrid/prims.h has the same code behind the same macro; the kernels need both
+// forms in one translation unit.)
+__device__ __forceinline__ bool intersect_prim_ray_uvs(const Tri& tri, const Ray& ray, int id, Hit& hit) {
+    const vec3 n = tri.normal();
+    const vec3 c = tri.v0 - ray.org;
+    const vec3 r = cross(ray.dir, c);
+    const float det = dot(n, ray.dir);
+    const float abs_det = detail::fabs1(det);
+    const float u = prodsign(dot(r, tri.e2), det);
+    const float v = prodsign(dot(r, tri.e1), det);
+    const float w = abs_det - u - v;
+    const float eps = 1e-9f;
+    if (u >= -eps && v >= -eps && w >= -eps) {
+        const float t = prodsign(dot(n, c), det);
+        if (t >= abs_det * ray.tmin && abs_det * ray.tmax > t) {
+            const float inv_det = 1.0f / abs_det;
+            hit.t = t * inv_det;
+            hit.u = u * inv_det;
+            hit.v = v * inv_det;
+            hit.id = id;
+            return true;
+        }
+    }
+    return false;
+}
+
+// NARROW: every gather is base (scalar registers) + unsigned 32-bit byte offset (one VALU shift instead of a sign
+// extension and a 64-bit add), index products are 24-bit multiplies (full rate; 32-bit multiplies are quarter rate) and the
+// range test is three unsigned compares.  The host selects it when every array it indexes is smaller than 4 GB and the
+// top-level resolution fits 23 bits per axis.
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {          // the median of three (one VALU instruction)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
+    return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_offset);
+}
+
+// MODE: HAGRID_TRAVERSE_ANY_HIT (the ray is done at its first accepted intersection: shadow rays) and / or
+// HAGRID_TRAVERSE_UVS (barycentrics stored with the hit) -- SURVEY.md 8(f) row 4; 0 is the reference's traversal.
+// A triangle round in which every live lane tests the SAME triangle -- one live lane (23 % of the rounds of the 1M-ray batch,
+// profiles/dev_r2_generations.txt items 10-12), or neighbouring rays in the same cell at the same place of its list (common in dense
+// batches) -- still costs the CU's vector-memory path its fixed ~12 cycles per load instruction and a cycle per lane: there the
+// triangle comes through the scalar cache (constant address space + a uniform address = s_load), no vector-memory instruction at
+// all, and the test reads it from scalar registers.  HG_SOLO=0 compiles the path out.
+#ifndef HG_SOLO
+#define HG_SOLO 1
+#endif
+__device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const f4 __attribute__((address_space(4)))* const_f4;
+    const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u);
+    const f4 p0 = p[0], p1 = p[1], p2 = p[2];
+    return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+}
+
+// ---- records of the traversal image (trav_image.hip) ----------------------------------------------------------------------
+// Same ray arithmetic as v1 / v2 / the oracle; the cell comes from the traversal image (trav_image.hip): the table entry
+// of the top-level cell (kept in registers while the ray stays inside it), one slot byte, one 32-byte record that carries
+// the bounds and -- for lists of up to four -- the reference ids themselves.  The next cell's slot + record are fetched
+// before the current cell's triangles are tested, as in v2.
+template <bool FLAT>
+__device__ __forceinline__ const uint4* image_record(const TraverseArgs& a, uint2 tab, int vx, int vy, int vz) {
+    const uint32_t meta = tab.y;
+    const int d = int(meta & 3u), w = int((meta >> 2) & 1u);
+    const unsigned char* base = a.img_blocks + size_t(tab.x) * 128u;
+    const int s = a.shift - d, m = (1 << d) - 1;
+    const int idx = ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << d)) << d);   // 0 when d == 0
+    if (FLAT) return reinterpret_cast<const uint4*>(base + uint32_t(idx) * 32u);             // the record itself: one gather per step
+    uint32_t slot = base[idx << w];                                                           // d == 0: a byte of the record, ignored
+    if (w) slot |= uint32_t(base[(idx << 1) + 1]) << 8;
+    uint32_t ebytes = (1u << (3 * d)) << w;
+    ebytes = d ? (ebytes < 32u ? 32u : ebytes) : 0u;
+    if (!d) slot = 0;
+    return reinterpret_cast<const uint4*>(base + ebytes + slot * 32u);
+}
+
+// A `deep` record: the block does not resolve this voxel; continue the walk of the construction format at the entry the
+// record names and bring the cell into record form (list by index, never inline).
+__device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb) {
+    uint32_t w = a.entries[cb.x];
+    int depth = int(cb.y);
+    while (w & 3u) {
+        const int k = int(w & 3u);
+        depth += k;
+        const int s = a.shift - depth, m = (1 << k) - 1;
+        w = a.entries[(w >> 2) + ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << k)) << k)];
+    }
+    const int4* p = reinterpret_cast<const int4*>(a.cells) + 2 * size_t(w >> 2);
+    const int4 lo = p[0], hi = p[1];
+    ca.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
+    ca.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
+    ca.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
+    ca.w = uint32_t(hi.w - lo.w) | 0x80000000u;
+    cb.x = uint32_t(lo.w);
+}
+
+// Records that are links: 0xfffffffe = nested block (three more levels of the same flat form), 0xffffffff = deep (construction
+// format).  Dense spots of very non-uniform scenes only; the common record never gets here.
+__device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb, uint32_t& nest_off, uint32_t& nest_meta) {
+    while (ca.w == 0xfffffffeu) {
+        nest_off = cb.x; nest_meta = cb.y;
+        const int d = int(cb.y & 3u), s = a.shift - int(cb.y >> 8) - d, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t((vx >> s) & m) + (uint32_t(((vy >> s) & m) + (((vz >> s) & m) << d)) << d);
+        const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + size_t(cb.x) * 128u + size_t(idx) * 32u);
+        ca = p[0]; cb = p[1];
+    }
+    if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
+}
+
+
+// ---- host entry points of the translation units ------------------------------------------------------------------------------
+// traverse.hip: the argument block of a grid (setup_traversal's constants, traverse.cu:97-109); tris / rays / hits may be null when num_rays == 0
+int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const void* rays, void* hits, int num_rays, TraverseArgs& a);
+// bytes from p to the end of the device allocation that holds it (all bits set if the runtime does not know the pointer)
+size_t buffer_bytes_from(const void* p);
+// trav_plain.hip: 256 threads per block (reference-shaped kernel), one wavefront per block (v2)
+void launch_plain(hipStream_t st, int num_rays, bool small, bool stats, const TraverseArgs& a);
+void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a);
+// ray_order.hip: row length of an image-ordered batch -> row_len[0] on the device (0: none); nobody waits for it
+constexpr int kOriginMinRays = 1 << 22;
+void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays);
+// ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the
+// automatic mode) from buffers of `tmp`, or leaves a.perm null for batches too small to bin
+int bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp);
+
+} // namespace hagrid_trav

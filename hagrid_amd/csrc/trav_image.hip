@@ -625,3 +625,12 @@ extern "C" int hagrid_share_traversal(hagrid_ctx* dst, hagrid_ctx* src) {
     dst->image.borrowed = true;
     return HAGRID_OK;
 }
+
+extern "C" int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* grid, int32_t* format4, int64_t* image_bytes) {
+    if (!ctx || !grid) return HAGRID_EINVAL;
+    if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
+    const TravImageCache& img = ctx->image;
+    if (format4) { format4[0] = img.flat ? 1 : 0; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
+    if (image_bytes) *image_bytes = (int64_t)img.block_bytes + 8ll * grid->dims[0] * grid->dims[1] * grid->dims[2];
+    return HAGRID_OK;
+}

@@ -1,0 +1,584 @@
+// trav_kernels.h -- the kernels that traverse the traversal image: traverse_kernel_img (every layout, any-hit / barycentric variants)
+// and traverse_kernel_tail (slim records, nearest hit: the default of every BASELINE configuration).  Templates, instantiated by
+// traverse.hip (the product) and, with TIMES = true, by kat/kat.hip (wavefront timelines for tools/dev_wave_timeline.py).
+#pragma once
+
+#include "trav_common.h"
+
+namespace hagrid_trav {
+
+// NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
+// UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
+// TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
+// SLIM (with FLAT and NARROW, grids of at most three levels): 16-byte records, SLIM = bits per packed reference id (trav_image.hip,
+// "Slim records"); 0 = 32-byte records.  UNIFORM: bounds as offsets from the voxel; table layout: from the top-level cell's origin.
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0>
+__global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
+    constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
+    static_assert(SLIM == 0 || (FLAT && NARROW), "slim records are read by the flat narrow kernels only");
+    constexpr int NONE = SLIM ? (1 << (SLIM ? SLIM : 1)) - 1 : -1;          // the id field of an unused list slot
+    struct Stamp {
+        unsigned long long* p;
+        __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
+        __device__ ~Stamp() { if (TIMES) { const unsigned long long t = wall_clock64(); atomicMax(p + 1, t); } }   // the last lane to leave
+    } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
+    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
+    const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
+    const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, threadIdx.x) : b * BLOCK + threadIdx.x;
+    if (slot >= a.num_rays) return;
+    const int id = perm ? perm[slot] : slot;
+
+    const float4 r0 = nt_load4(a.rays + 2 * size_t(id)), r1 = nt_load4(a.rays + 2 * size_t(id) + 1);
+    const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    const float tmin = r0.w, tmax = r1.w;
+    const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+    const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+
+    const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+    const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+    const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+    const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+
+    Hit hit(-1, tmax, 0.0f, 0.0f);
+
+    if (!(tstart > tend)) {
+        const vec3 fv = (tstart * dir + org - gmin) * ginv;
+        int vx = min(max(int(fv.x), 0), a.dims_x - 1);
+        int vy = min(max(int(fv.y), 0), a.dims_y - 1);
+        int vz = min(max(int(fv.z), 0), a.dims_z - 1);
+
+        auto top_index = [&](int x, int y, int z) -> int {
+            if (NARROW) return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
+            return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
+        };
+        auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
+        uint32_t nest = ~0u;                                                    // innermost nested block the ray is inside (FLAT + NARROW, table layout)
+        int nest_x = 0, nest_y = 0, nest_z = 0;                                 // ... and the voxel that led there
+        // record of a voxel: FLAT + NARROW is one address computation off the scalar base
+        auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
+            if (UNIFORM) {
+                const int d = a.shift, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+                const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << (SLIM ? 4 : 5);
+                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
+                ra = p[0];
+                if (!SLIM) rb = p[1];
+            } else if (FLAT && NARROW && SLIM) {          // table layout, no links: block offset in records, depth of the block
+                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+                ra = *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
+            } else if (FLAT && NARROW) {
+                int d = int(tab.y & 3u), s = a.shift - d;
+                uint32_t base = tab.x;
+                if (nest != ~0u) {
+                    const int sr = a.shift - int(nest >> 27);               // finest-level voxels per root cell of the nested block, log2
+                    if ((((x ^ nest_x) | (y ^ nest_y) | (z ^ nest_z)) >> sr) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
+                }
+                const int m = (1 << d) - 1;
+                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+                const uint32_t o = (base << 7) + (idx << 5);
+                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
+                ra = p[0]; rb = p[1];
+            } else {
+                const uint4* p = image_record<FLAT>(a, tab, x, y, z);
+                ra = p[0]; rb = p[1];
+            }
+        };
+        auto tri_at = [&](int ref) -> Tri {
+            if (!NARROW) return load_tri(a.tris, ref);
+            uint32_t r3, o;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
+            const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+            return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+        };
+
+        auto tri_for = [&](int ref) -> Tri {
+            if (HG_SOLO && NARROW) {
+                const int r0 = __builtin_amdgcn_readfirstlane(ref);
+                const unsigned long long others = __ballot(ref != r0);
+                if (others == 0ull) return load_tri_scalar(a.tris, r0);
+            }
+            return tri_at(ref);
+        };
+        // which half of a bounds word is the exit plane (slim records: which byte, and the direction the offset counts in)
+        const uint32_t ox = SLIM ? (px ? 8u : 0u) : (px ? 16u : 0u), oy = SLIM ? (py ? 24u : 16u) : (py ? 16u : 0u), oz = SLIM ? (pz ? 8u : 0u) : (pz ? 16u : 0u);
+        const int sgx = px ? 1 : -1, sgy = py ? 1 : -1, sgz = pz ? 1 : -1;
+        const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
+        const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
+        int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
+        uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
+        uint4 ca, cb = make_uint4(0u, 0u, 0u, 0u);
+        record(tab, vx, vy, vz, ca, cb);
+
+        for (;;) {
+            if (!UNIFORM && !SLIM && ca.w >= 0xfffffffeu) {                 // (the table-free layout and slim records need shift <= 3: every block resolves its cell fully)
+                // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
+                // cell the next records are fetched from it directly (one gather per step again)
+                uint32_t off = ~0u, meta = 0u;
+                image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
+                if (!UNIFORM && FLAT && NARROW && off != ~0u) {
+                    nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;        // offset < 2^25 units (NARROW), depth of the block, depth of its root
+                    nest_x = vx; nest_y = vy; nest_z = vz;
+                }
+            }
+            // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
+            int cx, cy, cz;
+            if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell
+                const int org_mask = ~((1 << a.shift) - 1);
+                cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
+                cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
+                cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
+            } else if (SLIM) {     // byte offsets from the voxel the record belongs to
+                // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(sgy), "v"(__builtin_amdgcn_ubfe(ca.x, oy, 8u)), "v"(vy));
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(sgz), "v"(__builtin_amdgcn_ubfe(ca.y, oz, 8u)), "v"(vz));
+            } else { cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)); cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)); cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u)); }
+            const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+            const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+            const vec3 ev = (texit * dir + org - gmin) * ginv;
+            const int nx = texit == tcell.x ? cx + bx : int(ev.x);
+            const int ny = texit == tcell.y ? cy + by : int(ev.y);
+            const int nz = texit == tcell.z ? cz + bz : int(ev.z);
+            // never backwards: max with the current voxel along a positive direction, min along a negative one -- the median of
+            // (new, current, +-infinity), one instruction per axis
+            if (UNIFORM) { vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z); }
+            else { vx = px ? max(nx, vx) : min(nx, vx); vy = py ? max(ny, vy) : min(ny, vy); vz = pz ? max(nz, vz) : min(nz, vz); }   // (the table layouts have no registers to spare)
+            const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
+
+            // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
+            if (!UNIFORM) {
+                const int ntop = outside ? top_idx : top_index(vx, vy, vz);
+                if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
+            }
+            uint4 na, nb = make_uint4(0u, 0u, 0u, 0u);
+            if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
+            else record(tab, vx, vy, vz, na, nb);
+
+            // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
+            // than four ids, deep cells) fetches the id of the next test one test ahead, as v2 does.
+            auto ref_at = [&](uint32_t i) -> int { return NARROW ? gather32<int>(a.refs, i << 2) : a.refs[i]; };
+            bool by_index;
+            uint32_t q1, q2, q3, li_begin, li_count;
+            int ref;
+            if (SLIM) {
+                // id fields of SLIM bits from bit 48 on; the last field = NONE - 1 marks a list given by index
+                constexpr int NI = 80 / (SLIM ? SLIM : 80), LAST = 48 + (NI - 1) * SLIM;
+                auto field = [&](int pos, int n) -> uint32_t {              // pos, n are constants after inlining
+                    const uint32_t w[4] = {ca.x, ca.y, ca.z, ca.w};
+                    const int i = pos >> 5, o = pos & 31;
+                    uint32_t v = w[i] >> o;
+                    if (o + n > 32) v |= w[i + 1] << (32 - o);
+                    return n == 32 ? v : (v & ((1u << n) - 1u));
+                };
+                by_index = field(LAST, SLIM) == uint32_t(NONE - 1);
+                ref = int(field(48, SLIM));
+                q1 = NI > 1 ? field(48 + SLIM, SLIM) : uint32_t(NONE);
+                q2 = NI > 2 ? field(48 + 2 * SLIM, SLIM) : uint32_t(NONE);
+                q3 = NI > 3 ? field(48 + 3 * SLIM, SLIM) : uint32_t(NONE);
+                li_begin = field(48, 32); li_count = field(80, 20);
+            } else {
+                by_index = int(ca.w) < 0;
+                q1 = cb.y; q2 = cb.z; q3 = cb.w;                            // inline: the ids still to test
+                ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
+                li_begin = cb.x; li_count = ca.w & 0x7fffffffu;
+            }
+            if (UNIFORM && __ballot(by_index) == 0ull) {
+                // shallow grids: lists of more than four ids are rare (1.5 % of the visited cells of the 1M-triangle soup), so a
+                // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
+#pragma unroll 1
+                while (ref != NONE) {
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    ref = (ANY && got) ? NONE : int(q1);
+                    q1 = q2; q2 = q3; q3 = uint32_t(NONE);
+                }
+            } else {
+                // One loop for both list forms, so a wavefront whose lanes hold both pays the longest list, not the sum of the two longest.
+                if (by_index) {                                             // by index: q1 = index of the next id, q2 = end of the list
+                    q1 = li_begin; q2 = li_begin + li_count;
+                    ref = NONE;
+                    if (q1 < q2) ref = ref_at(q1);
+                    q1++;
+                }
+#pragma unroll 1
+                while (ref != NONE) {
+                    int next;
+                    if (UNIFORM) {
+                        // shallow grids, long lists are rare: the fewest instructions for the inline form
+                        if (by_index) { next = q1 < q2 ? ref_at(q1) : NONE; q1++; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
+                    }
+                    int pre = NONE;
+                    if (!UNIFORM && by_index && q1 < q2) pre = ref_at(q1);      // in flight during the test; nothing reads it before
+                    const bool got = UVS ? intersect_prim_ray_uvs(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit)
+                                         : intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                    if (!UNIFORM) {
+                        if (by_index) { next = pre; q1++; }
+                        else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
+                    }
+                    ref = (ANY && got) ? NONE : next;
+                }
+            }
+            if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
+            ca = na; cb = nb;
+        }
+    }
+    nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
+}
+
+
+// ---- image kernel with a tail mode ---------------------------------------------------------------------------------------
+// The 1M-ray launch ends when its longest rays end (half of it is the drain of wavefronts that hold a handful of live
+// rays, each lock-step iteration a serial chain of dependent instructions and one dependent gather), and a wavefront of few live rays
+// still pays a triangle round per id of its longest list.  Rays only finish, so the number of live rays of a wavefront only falls:
+// once it is at most 16 the wavefront COMPACTS -- live ray r moves to lanes 4r .. 4r + 3 (one LDS rendezvous, one ds_bpermute per
+// register, once per wavefront) -- and from then on a cell step tests the up to four inline ids of a list in ONE round, lane s of the
+// group taking id s, and the cell step itself is split over the four lanes (one axis each, see phase 2 below).  The reference's sequential rule
+// (every test sees the tmax the accepted tests before it left, prims.h:266-295) is kept exactly: a lane computes everything that
+// does not depend on tmax -- the barycentric test, t >= |det| * tmin, t and |det| -- and the group then replays the acceptance
+// `|det| * tmax > t` in list order on quad broadcasts (DPP), so hit ids and t stay bit-identical.  Table-free layout with slim
+// records, nearest hit, narrow addressing; everything else runs traverse_kernel_img.
+struct TriCand { float t, abs_det; bool ok; };
+__device__ __forceinline__ TriCand tri_candidate(const Tri& tri, const vec3& org, const vec3& dir, float tmin) {   // prims.h:266-283, up to the comparison with tmax
+    const vec3 n = tri.normal();
+    const vec3 c = tri.v0 - org;
+    const vec3 r = cross(dir, c);
+    const float det = dot(n, dir);
+    const float abs_det = detail::fabs1(det);
+    const float u = prodsign(dot(r, tri.e2), det);
+    const float v = prodsign(dot(r, tri.e1), det);
+    const float w = abs_det - u - v;
+    const float eps = 1e-9f;
+    TriCand cd; cd.t = 0.0f; cd.abs_det = abs_det; cd.ok = false;
+    if (u >= -eps && v >= -eps && w >= -eps) {
+        const float t = prodsign(dot(n, c), det);
+        if (t >= abs_det * tmin) { cd.t = t; cd.ok = true; }
+    }
+    return cd;
+}
+template <int K> __device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(x, x, K * 0x55, 0xf, 0xf, true); }   // (every lane is written: no `old` value to set up)
+template <int K> __device__ __forceinline__ float quad_bcast_f(float x) { return __int_as_float(quad_bcast_i<K>(__float_as_int(x))); }
+// lane s of a quad reads lane (CTRL >> 2s) & 3 of the same quad: 9 = [1,2,0,0], 82 = [2,0,1,1]
+template <int CTRL> __device__ __forceinline__ int quad_perm_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float quad_perm_f(float x) { return __int_as_float(quad_perm_i<CTRL>(__float_as_int(x))); }
+
+constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
+
+// TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
+// UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
+// top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
+template <int SLIM, bool TIMES = false, bool UNIFORM = true>
+__global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
+    constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
+    __shared__ int lanes_of[64];
+    const int lane = threadIdx.x;
+    struct Stamp {
+        unsigned long long* p;
+        __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
+        __device__ ~Stamp() { if (TIMES) { const unsigned long long t = wall_clock64(); atomicMax(p + 1, t); } }
+    } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
+    const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
+    const int w = !perm ? tile_packet_row_len(a) : 0;
+    // The last tiles in dispatch order are traversed with four lanes per ray from their first cell on (phase 2 below): a tile is then
+    // four blocks of 16 rays (its 4 x 4 pixel quadrants).  They are the wavefronts that start when the machine begins to drain, where
+    // wavefront slots are free and what counts is how long the longest ray of a wavefront takes.
+    const bool quad_start = int(blockIdx.x) >= a.quad_first_block;
+    const int group = lane >> 2, sub = lane & 3;
+    int b, lane_in_tile = lane;
+    if (quad_start) {
+        const int q = int(blockIdx.x) - a.quad_first_block, nq = int(gridDim.x) - a.quad_first_block;
+        const int lq = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(q, nq, a.xcd_chunk_log2 + 2) : xcd_split(q, nq);
+        b = a.quad_first_block + (lq >> 2);
+        lane_in_tile = ((((lq >> 1) & 1) << 2) + (group >> 2)) * 8 + ((lq & 1) << 2) + (group & 3);
+    } else {
+        const int nb = min(int(gridDim.x), a.quad_first_block);
+        b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, nb, a.xcd_chunk_log2) : xcd_split(blockIdx.x, nb);
+    }
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, lane_in_tile) : b * 64 + lane_in_tile;
+    const bool valid = slot < a.num_rays;
+    int id = valid ? (perm ? perm[slot] : slot) : 0;
+    bool pending = valid;                                  // this lane still owes its ray's hit to the hit buffer
+
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+    if (valid) { r0 = nt_load4(a.rays + 2 * size_t(id)); r1 = nt_load4(a.rays + 2 * size_t(id) + 1); }
+    vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
+    float tmin = r0.w;
+    const float tmax = r1.w;
+    const vec3 gmin(a.min_x, a.min_y, a.min_z), gmax(a.max_x, a.max_y, a.max_z);
+    const vec3 csize(a.cs_x, a.cs_y, a.cs_z), ginv(a.inv_x, a.inv_y, a.inv_z);
+    float hit_t = tmax;
+    int hit_id = -1;
+    int vx = 0, vy = 0, vz = 0;
+    bool alive = false;
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
+        const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
+        const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
+        const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), tmax);
+        if (valid && !(tstart > tend)) {
+            const vec3 fv = (tstart * dir + org - gmin) * ginv;
+            vx = min(max(int(fv.x), 0), a.dims_x - 1);
+            vy = min(max(int(fv.y), 0), a.dims_y - 1);
+            vz = min(max(int(fv.z), 0), a.dims_z - 1);
+            alive = true;
+        }
+    }
+    uint32_t tab_off = 0u, tab_d = 0u;                     // table layout: block offset (records) and depth of the top-level cell the ray is in
+    int top_idx = -1;
+    auto load_record = [&](int x, int y, int z) -> uint4 {
+        const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
+        if (UNIFORM) {
+            const int d = a.shift, m = (1 << d) - 1;
+            const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+            return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+        }
+        if (int(top) != top_idx) {
+            const uint2 t = gather32<uint2>(a.img_table, top << 3);
+            tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+        }
+        const int d = int(tab_d), sh = a.shift - d, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t((x >> sh) & m) + (uint32_t(((y >> sh) & m) + (((z >> sh) & m) << d)) << d);
+        return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
+    };
+    auto tri_ptr = [&](int ref) -> const float4* {
+        uint32_t r3, o;
+        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+        return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
+    };
+    auto tri_vec = [&](int ref) -> Tri {
+        const float4* p = tri_ptr(ref);
+        const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+        return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
+    };
+    auto tri_for = [&](int ref) -> Tri {                   // every live lane the same triangle: through the scalar cache
+        const int f = __builtin_amdgcn_readfirstlane(ref);
+        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar(a.tris, f);
+        return tri_vec(ref);
+    };
+    auto field = [&](const uint4& rec, int pos, int n) -> uint32_t {
+        const uint32_t wd[4] = {rec.x, rec.y, rec.z, rec.w};
+        const int i = pos >> 5, o = pos & 31;
+        uint32_t v = wd[i] >> o;
+        if (o + n > 32) v |= wd[i + 1] << (32 - o);
+        return n == 32 ? v : (v & ((1u << n) - 1u));
+    };
+    auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
+
+    // One cell step of the ray in this lane (traverse.cu:61-78): exit plane of the cell `rec` describes, next voxel, next record.
+    float texit = 0.0f;
+    bool outside = false;
+    auto cell_step = [&](const uint4& rec, const vec3& inv_dir) -> uint4 {
+        const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+        int cx, cy, cz;
+        if (UNIFORM) {
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
+        } else {
+            const int org_mask = ~((1 << a.shift) - 1);
+            cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
+            cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
+            cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
+        }
+        const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
+        texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
+        const vec3 ev = (texit * dir + org - gmin) * ginv;
+        const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
+        const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
+        const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+        vx = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000));
+        vy = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000));
+        vz = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000));
+        outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
+        uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
+        if (!outside) next = load_record(vx, vy, vz);
+        return next;
+    };
+    // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
+    auto test_list = [&](const uint4& rec) {
+        const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1);
+        int ref = int(field(rec, 48, SLIM));
+        uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
+                 q3 = NI > 3 ? field(rec, 48 + 3 * SLIM, SLIM) : uint32_t(NONE);
+        if (__ballot(by_index) == 0ull) {
+#pragma unroll 1
+            while (ref != NONE) {
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                hit_t = h.t; hit_id = h.id;
+                ref = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE);
+            }
+        } else {
+            if (by_index) {
+                q1 = field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);
+                ref = NONE;
+                if (q1 < q2) ref = ref_at(q1);
+                q1++;
+            }
+#pragma unroll 1
+            while (ref != NONE) {
+                int next;
+                if (by_index) { next = q1 < q2 ? ref_at(q1) : NONE; q1++; }
+                else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                hit_t = h.t; hit_id = h.id;
+                ref = next;
+            }
+        }
+    };
+
+    uint4 ca = make_uint4(0u, 0u, 0u, 0u);
+    if (alive) ca = load_record(vx, vy, vz);
+    unsigned long long live = __ballot(alive);
+
+    if (quad_start) pending = valid && sub == 0;           // (the four lanes of a group hold the same ray: one of them stores its hit)
+    else {
+    // ---- phase 1: one ray per lane, while the wavefront holds more than kTailRays live rays -------------------------------
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        while (__popcll(live) > kTailRays) {
+            if (alive) {
+                const uint4 na = cell_step(ca, inv_dir);
+                test_list(ca);
+                if (hit_t <= texit || outside) alive = false;
+                ca = na;
+            }
+            live = __ballot(alive);
+        }
+    }
+    if (live == 0ull) {
+        if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+        return;
+    }
+
+    // ---- compaction: finished lanes hand in their hits; live ray r moves to lanes 4r .. 4r + 3 ----------------------------------
+    if (pending && !alive) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+    const int nlive = __popcll(live);
+    if (alive) lanes_of[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+    __syncthreads();
+    alive = group < nlive;
+    pending = alive && sub == 0;
+    const int src4 = lanes_of[alive ? group : 0] << 2;
+    auto pull_i = [&](int v) -> int { return __builtin_amdgcn_ds_bpermute(src4, v); };
+    auto pull_f = [&](float v) -> float { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); };
+    org = vec3(pull_f(org.x), pull_f(org.y), pull_f(org.z));
+    dir = vec3(pull_f(dir.x), pull_f(dir.y), pull_f(dir.z));
+    tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
+    vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
+    ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
+    if (!UNIFORM) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
+    }
+
+    // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
+    {
+        const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
+        // The cell step is split over the lanes of a group instead of being repeated by them.  Lane s owns axis
+        // min(s, 2) (lane 3 doubles z): it computes its axis' exit plane, the exit parameter is the minimum over the group, the lane
+        // finds its own coordinate of the next voxel and its share of the record's address, and the shares are added over the group
+        // (quad permutes [1,2,0,0] and [2,0,1,1]: every lane sees the other two axes).  The same operations on the same values as
+        // cell_step, a third of them per lane: ~45 instead of ~100 VALU instructions per step, address included.
+        const int ax = sub < 2 ? sub : 2;
+        const float m_dir = ax == 0 ? dir.x : (ax == 1 ? dir.y : dir.z), m_org = ax == 0 ? org.x : (ax == 1 ? org.y : org.z);
+        const float m_inv = ax == 0 ? inv_dir.x : (ax == 1 ? inv_dir.y : inv_dir.z);
+        const float m_cs = ax == 0 ? a.cs_x : (ax == 1 ? a.cs_y : a.cs_z), m_gmin = ax == 0 ? a.min_x : (ax == 1 ? a.min_y : a.min_z);
+        const float m_ginv = ax == 0 ? a.inv_x : (ax == 1 ? a.inv_y : a.inv_z);
+        const int m_dims = ax == 0 ? a.dims_x : (ax == 1 ? a.dims_y : a.dims_z);
+        const bool m_pos = m_dir >= 0.0f;
+        const uint32_t m_bit = (ax == 1 ? 16u : 0u) + (m_pos ? 8u : 0u);                       // where the record holds this axis' bound byte
+        const uint32_t m_stride = ax == 0 ? 1u : (ax == 1 ? uint32_t(a.top_x) : uint32_t(a.top_xy)), m_lsh = uint32_t(ax * a.shift);
+        int m_v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+        auto quad_sum = [&](uint32_t x) -> uint32_t { return x + uint32_t(quad_perm_i<9>(int(x))) + uint32_t(quad_perm_i<82>(int(x))); };
+        auto quad_step = [&](const uint4& rec) -> uint4 {
+            int c;
+            const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
+            if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
+            else c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;             // table layout: bounds count from the top-level cell's origin
+            const float tc = (float(c) * m_cs + m_gmin - m_org) * m_inv;
+            texit = detail::fmin2(detail::fmin2(tc, quad_perm_f<9>(tc)), quad_perm_f<82>(tc));
+            const float ev = (texit * m_dir + m_org - m_gmin) * m_ginv;
+            const int n = texit == tc ? c + (m_pos ? 0 : -1) : int(ev);
+            m_v = med3_i32(n, m_v, m_pos ? 0x7fffffff : int(0x80000000));
+            const int o = uint32_t(m_v) >= uint32_t(m_dims) ? 1 : 0;
+            outside = (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0;
+            const uint32_t v = outside ? 0u : uint32_t(m_v);
+            if (UNIFORM) {
+                const uint32_t d = uint32_t(a.shift);
+                const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh));
+                return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
+            }
+            const uint32_t top = quad_sum(__umul24(v >> uint32_t(a.shift), m_stride));
+            if (int(top) != top_idx) {
+                const uint2 t = gather32<uint2>(a.img_table, top << 3);
+                tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+            }
+            const uint32_t idx = quad_sum(((v >> (uint32_t(a.shift) - tab_d)) & ((1u << tab_d) - 1u)) << __umul24(uint32_t(ax), tab_d));
+            return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
+        };
+        live = __ballot(alive);
+        while (live) {
+            if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
+                const uint4 na = quad_step(ca);
+                const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
+                const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
+                          i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
+                const int inl = by_index ? NONE : (sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3)));
+                auto accept = [&](int ok, float t, float ad, int ref) {            // prims.h:284-292 with the tmax of this moment
+                    if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
+                };
+                if (__ballot(by_index) == 0ull) {
+                    // the common step: inline lists only, one round
+                    TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
+                    if (inl != NONE) cd = tri_candidate(tri_for(inl), org, dir, tmin);
+                    const unsigned long long cand = __ballot(cd.ok);
+                    if (cand != 0ull) {
+                        // replay the acceptance in list order; every lane of the group computes the same.  A list position at which no
+                        // group of the wavefront holds a candidate is skipped (bit s of every nibble of `cand` = position s).
+                        const int okv = cd.ok ? 1 : 0;
+                        if (cand & 0x1111111111111111ull) { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, i0); }
+                        if (NI > 1 && (cand & 0x2222222222222222ull)) { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, i1); }
+                        if (NI > 2 && (cand & 0x4444444444444444ull)) { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, i2); }
+                        if (NI > 3 && (cand & 0x8888888888888888ull)) { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, i3); }
+                    }
+                } else {
+                    // some list of the wavefront is given by index (more ids than a record holds): four ids per round as well, lane s takes
+                    // ids s, s + 4, ...; the groups with inline lists take part in the first round
+                    const uint32_t li_begin = field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
+                    int mine = inl;
+                    if (uint32_t(sub) < li_count) mine = ref_at(li_begin + uint32_t(sub));
+#pragma unroll 1
+                    for (uint32_t next = 4u + uint32_t(sub); __ballot(mine != NONE) != 0ull; next += 4u) {
+                        int ahead = NONE;
+                        if (next < li_count) ahead = ref_at(li_begin + next);       // the id of the next round, in flight during this one
+                        TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
+                        if (mine != NONE) cd = tri_candidate(tri_for(mine), org, dir, tmin);
+                        if (__ballot(cd.ok) != 0ull) {
+                            const int okv = cd.ok ? 1 : 0;
+                            { const int ok = quad_bcast_i<0>(okv); const float t = quad_bcast_f<0>(cd.t), ad = quad_bcast_f<0>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<0>(mine)); }
+                            { const int ok = quad_bcast_i<1>(okv); const float t = quad_bcast_f<1>(cd.t), ad = quad_bcast_f<1>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<1>(mine)); }
+                            { const int ok = quad_bcast_i<2>(okv); const float t = quad_bcast_f<2>(cd.t), ad = quad_bcast_f<2>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<2>(mine)); }
+                            { const int ok = quad_bcast_i<3>(okv); const float t = quad_bcast_f<3>(cd.t), ad = quad_bcast_f<3>(cd.abs_det); accept(ok, t, ad, quad_bcast_i<3>(mine)); }
+                        }
+                        mine = ahead;
+                    }
+                }
+                if (hit_t <= texit || outside) alive = false;
+                ca = na;
+            }
+            live = __ballot(alive);
+        }
+    }
+    if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+}
+
+
+
+} // namespace hagrid_trav

@@ -117,6 +117,12 @@ SIGNATURES = {
     "hagrid_traverse_grid_stats": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, _vp, C.POINTER(TraversalStats)]),
     "hagrid_set_ray_binning": (_i32, [_vp, _i32]),
     "hagrid_set_option": (_i32, [_vp, C.c_char_p, _i32]),
+    "hagrid_traversal_image_info": (_i32, [_vp, C.POINTER(GridPOD), _vp, C.POINTER(_i64)]),
+}
+
+# libhagrid_amd_kat.so (hagrid_amd/csrc/kat/hagrid_amd_kat.h): known-answer hooks and diagnostic instantiations -- tests/ and tools/ only
+KAT_LIB_PATH = os.path.join(HERE, "libhagrid_amd_kat.so")
+KAT_SIGNATURES = {
     "hagrid_kat_intersect_prim_ray": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "hagrid_kat_intersect_prim_ray_uvs": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "hagrid_kat_intersect_prim_cell": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
@@ -126,12 +132,12 @@ SIGNATURES = {
     "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
-    "hagrid_kat_image_format": (_i32, [_vp, _vp, _vp]),
-    "hagrid_kat_wave_times": (_i32, [_vp, _vp, _vp]),
     "hagrid_kat_tile_slots": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
+    "hagrid_kat_traverse_timed": (_i32, [_vp, C.POINTER(GridPOD), _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None
+_kat = None
 
 
 def _preload_hip_runtime() -> None:
@@ -173,4 +179,24 @@ def load() -> C.CDLL:
     if lib.hagrid_abi_version() != ABI_VERSION:
         raise HagridError("ABI version mismatch")
     _lib = lib
+    return lib
+
+
+def load_kat() -> C.CDLL:
+    """The test library (known-answer hooks); needs the product library in the process first.  Tests and dev tools only."""
+    global _kat
+    if _kat is not None:
+        return _kat
+    load()
+    if not os.path.exists(KAT_LIB_PATH):
+        raise HagridError(f"{KAT_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        lib = C.CDLL(KAT_LIB_PATH)
+    except OSError as e:
+        raise HagridError(f"cannot load {KAT_LIB_PATH}: {e}") from e
+    for name, (res, args) in KAT_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _kat = lib
     return lib

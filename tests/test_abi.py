@@ -15,8 +15,8 @@ def built():
     return lib
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hagrid_amd.h")).read()
+def declared_symbols(header=os.path.join(ROOT, "include", "hagrid_amd.h")):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hagrid_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,7 +28,20 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/hagrid_amd.h but not exported"
     assert sorted(built.SIGNATURES) == names, "hagrid_amd/lib.py signature table out of sync with the header"
-    assert L.hagrid_abi_version() == lib.ABI_VERSION == 2
+    assert L.hagrid_abi_version() == built.ABI_VERSION == 2
+    # the product library carries no test hooks (they live in libhagrid_amd_kat.so)
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hagrid_kat_" not in exported and "hagrid_kat_" not in open(os.path.join(ROOT, "include", "hagrid_amd.h")).read()
+
+
+def test_kat_library_exports_its_header(built):
+    """libhagrid_amd_kat.so (known-answer hooks, tests and dev tools only) against hagrid_amd/csrc/kat/hagrid_amd_kat.h."""
+    K = built.load_kat()
+    names = [n for n in declared_symbols(os.path.join(ROOT, "hagrid_amd", "csrc", "kat", "hagrid_amd_kat.h")) if n.startswith("hagrid_kat_")]
+    assert len(names) >= 10 and sorted(built.KAT_SIGNATURES) == names
+    for n in names:
+        assert hasattr(K, n), n
 
 
 def test_struct_layout_matches_header(built):

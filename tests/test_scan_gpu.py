@@ -25,7 +25,7 @@ def scan(mem, values, words, carry, lookback):
     n = values.size // words
     out = np.empty_like(values); total = np.zeros(words, np.int32)
     c = None if carry is None else np.ascontiguousarray(carry, dtype=np.int32)
-    api._check(mem, mem._L.hagrid_kat_scan(mem._ctx, values.ctypes.data_as(C.c_void_p), n, words, None if c is None else c.ctypes.data_as(C.c_void_p),
+    api._check(mem, mem._K.hagrid_kat_scan(mem._ctx, values.ctypes.data_as(C.c_void_p), n, words, None if c is None else c.ctypes.data_as(C.c_void_p),
                                            lookback, out.ctypes.data_as(C.c_void_p), total.ctypes.data_as(C.c_void_p)), "kat_scan")
     return out, total
 

@@ -47,7 +47,7 @@ def gpu_traverse(mem, grid, d_tris, rays, stats=False):
 def test_l0_device_functions_match_golden(mem, golden_dir):
     """The DEVICE versions of the L0 functions against the reference-header golden vectors."""
     kat = np.load(os.path.join(golden_dir, "l0_kat.npz"))
-    L, ctx = mem._L, mem._ctx
+    L, ctx = mem._K, mem._ctx
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     tris = np.ascontiguousarray(kat["tris"])
     n = kat["ipr_rays"].shape[0]
@@ -188,9 +188,9 @@ def test_ray_binning_gives_identical_hits(mem):
 
 @pytest.mark.parametrize("compressed", [False, True])
 def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
-    """The three kernels (plain v1, latency-oriented v2, persistent vote-scheduled v3) and v3's tuning knobs: forced through
-    hagrid_set_option, each must reproduce the oracle bit for bit -- including batches that are not a multiple of the
-    wavefront size and batches smaller than the persistent grid."""
+    """The kernels that walk the construction format (the reference-shaped one and the latency-oriented v2, with and without 32-bit
+    addressing), forced through hagrid_set_option: each must reproduce the oracle bit for bit -- including batches that are not a
+    multiple of the wavefront size.  (The traversal-image kernels: the tests further down.)"""
     from oracle import oracle as O
     from hagrid_amd import api
     tris = scene.make_soup(80000)
@@ -200,11 +200,8 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
     rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 640, 480),
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 200003, 31)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
-    settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 2, "traverse.narrow": 0}, {"traverse.variant": 3},
-                {"traverse.variant": 3, "traverse.both_phases": 1}, {"traverse.variant": 3, "traverse.refill_at": 1, "traverse.chunk": 64},
-                {"traverse.variant": 3, "traverse.refill_at": 64, "traverse.waves_per_cu": 2, "traverse.chunk": 1024}]
-    defaults = {"traverse.variant": 0, "traverse.both_phases": 0, "traverse.refill_at": 24, "traverse.chunk": 0, "traverse.waves_per_cu": 32,
-                "traverse.narrow": 1}
+    settings = [{"traverse.variant": 1}, {"traverse.variant": 2}, {"traverse.variant": 2, "traverse.narrow": 0}]
+    defaults = {"traverse.variant": 0, "traverse.narrow": 1}
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():
@@ -215,17 +212,20 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
     finally:
         for k, v in defaults.items():
             mem.set_option(k, v)
-    with pytest.raises(api.HagridError):
-        mem.set_option("traverse.variant", 9)
+    for bad in (9, 3):                                       # (3 was the persistent kernel of rounds 1-2: gone)
+        with pytest.raises(api.HagridError):
+            mem.set_option("traverse.variant", bad)
     with pytest.raises(api.HagridError):
         mem.set_option("no.such.key", 1)
+    with pytest.raises(api.HagridError):
+        mem.set_option("traverse.refill_at", 24)
     grid.free(); mem.free(d_tris)
 
 
 def _tile_slots(mem, n, w, super_log2=5, chunked=6):
     """slot of every lane, blocks in dispatch order"""
     out = np.full(64 * ((n + 63) // 64), -1, np.int32)
-    assert mem._L.hagrid_kat_tile_slots(mem._ctx, n, w, super_log2, chunked, out.ctypes.data_as(C.c_void_p)) == 0
+    assert mem._K.hagrid_kat_tile_slots(mem._ctx, n, w, super_log2, chunked, out.ctypes.data_as(C.c_void_p)) == 0
     return out
 
 
@@ -252,7 +252,7 @@ def test_row_length_detection(mem):
     lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
     def detect(rays, diag=1.7320508):
         d = mem.upload(np.ascontiguousarray(rays, np.float32)); w = C.c_int32(-1)
-        assert mem._L.hagrid_kat_detect_ray_rows(mem._ctx, C.c_void_p(d), rays.shape[0], C.c_float(diag), C.byref(w)) == 0
+        assert mem._K.hagrid_kat_detect_ray_rows(mem._ctx, C.c_void_p(d), rays.shape[0], C.c_float(diag), C.byref(w)) == 0
         mem.free(d)
         return w.value
     assert detect(scene.make_rays_primary(lo, hi, 1024, 512)) == 1024
@@ -419,7 +419,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     flat = np.arange(total) if total <= 400000 else rng.choice(total, 400000, replace=False)
     vox = np.stack([flat % res[0], (flat // res[0]) % res[1], flat // (res[0] * res[1])], axis=1).astype(np.int32)
     got = np.zeros((len(vox), 8), np.uint32); nbytes = C.c_int64(0)
-    rc = mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), vox.ctypes.data_as(C.c_void_p), len(vox), got.ctypes.data_as(C.c_void_p), C.byref(nbytes))
+    rc = mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), vox.ctypes.data_as(C.c_void_p), len(vox), got.ctypes.data_as(C.c_void_p), C.byref(nbytes))
     if name == "compressed_deep" and fmt == 1:         # the compact form would need deep links, which resolve through 32-byte cells only
         assert rc != 0
         grid.free()
@@ -451,7 +451,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
         key = (top[:, 0] + G.dims[0] * (top[:, 1] + G.dims[1] * top[:, 2])).astype(np.int64) * (G.num_cells + 1) + _np_lookup(G, vox.astype(np.int64))
         assert np.bincount(np.unique(key) // (G.num_cells + 1)).max() > 255        # the u16 slot form is exercised
     grid.free()
-    assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
+    assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
 
 
 @pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
@@ -513,7 +513,7 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
                 assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim)
                 info = mem.image_format(grid)
                 assert info["flat"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
-                assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
+                assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
                 assert uniform == 1 or nb.value >= 32 * total
         mem.set_option("traverse.image_uniform", 2)
         # the same clusters close together: every cell fits, slim records in both id widths
@@ -529,7 +529,7 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
             mem.set_option("traverse.image_slim", slim)
             got = gpu_traverse(mem, grid2, d_tris2, rays2)
             assert (got["id"] == want2["id"]).all() and (bits(got["t"]) == bits(want2["t"])).all(), slim
-            assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
+            assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
             assert nb.value == 16 * total2 + 8 * int(np.prod(G2.dims)), "slim records expected"
             assert mem.image_format(grid2) == {"flat": True, "uniform": True, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
         grid2.free(); mem.free(d_tris2)
@@ -549,7 +549,7 @@ def test_image_lifetime(mem):
     rays = scene.make_rays_incoherent(G.bbox_min, G.bbox_max, 20000, 4)
     want, _ = G.traverse(tris, rays, nthreads=4)
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * rays.shape[0])
-    has_image = lambda g: mem._L.hagrid_kat_image_records(mem._ctx, C.byref(g.pod), None, 0, None, None) == 0
+    has_image = lambda g: mem._K.hagrid_kat_image_records(mem._ctx, C.byref(g.pod), None, 0, None, None) == 0
     def check():
         api.traverse_grid(grid, d_tris, d_rays, d_hits, rays.shape[0])
         got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
@@ -584,18 +584,18 @@ def test_image_lifetime(mem):
         big = O.Grid.full(scene.make_soup(40000, seed=22)); gb = upload_oracle_grid(mem, big)
         nb = C.c_int64(0)
         api.setup_traversal(gb)
-        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value < (7 << 20)
+        assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value < (7 << 20)
         mem.set_option("traverse.image_max_mb", 0); mem.set_option("traverse.image_slim", 0); api.setup_traversal(gb)
-        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value > (8 << 20)
+        assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value > (8 << 20)
         mem.set_option("traverse.image_slim", 1); api.setup_traversal(gb)        # 16-byte records: half of it
-        assert mem._L.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and (4 << 20) < nb.value < (5 << 20)
+        assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and (4 << 20) < nb.value < (5 << 20)
         gb.free(); mem.set_option("traverse.image", 1)
         # compressed grids get one as well (shift <= 3)
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
         api.setup_traversal(gc); assert has_image(gc) == (Gc.shift <= 3); gc.free()
         api.setup_traversal(grid); assert has_image(grid)
         grid.free()                                          # freeing a source array drops the image
-        assert not mem._L.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
+        assert not mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
     finally:
         mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 0); mem.set_option("traverse.image_slim", 1)
     mem.free(d_rays); mem.free(d_hits); mem.free(d_tris)
@@ -686,7 +686,7 @@ def test_intersect_prim_ray_with_uvs_matches_reference_header(mem, golden_dir):
     tris = np.ascontiguousarray(kat["tris"]); rays = np.ascontiguousarray(kat["ipr_rays"]); tid = np.ascontiguousarray(kat["ipr_tid"])
     n = rays.shape[0]
     ret = np.zeros(n, np.int32); hid = np.zeros(n, np.int32); ht = np.zeros(n, np.float32); hu = np.zeros(n, np.float32); hv = np.zeros(n, np.float32)
-    assert mem._L.hagrid_kat_intersect_prim_ray_uvs(mem._ctx, p(tris), p(rays), p(tid), n, p(ret), p(hid), p(ht), p(hu), p(hv)) == 0
+    assert mem._K.hagrid_kat_intersect_prim_ray_uvs(mem._ctx, p(tris), p(rays), p(tid), n, p(ret), p(hid), p(ht), p(hu), p(hv)) == 0
     assert (ret == uv["ret"]).all() and (hid == uv["id"]).all() and (bits(ht) == bits(uv["t"])).all()
     assert (bits(hu) == bits(uv["u"])).all() and (bits(hv) == bits(uv["v"])).all()
 
@@ -809,8 +809,9 @@ def test_automatic_ray_binning(mem):
 
 
 def test_wave_time_diagnostic_does_not_change_hits(mem):
-    """hagrid_kat_wave_times: the stamped instantiation gives the same hits, every wavefront has start <= end, and a tile order
-    (here: reversed) only changes which wavefront takes which tile."""
+    """hagrid_kat_traverse_timed (libhagrid_amd_kat.so): the stamped instantiations of the headline kernel and of the plain slim
+    kernel give the product's hits, every wavefront has start <= end, and a tile order (here: reversed) only changes which wavefront
+    takes which tile."""
     from hagrid_amd import api
     tris = scene.make_soup(30000, seed=3)
     d_tris = mem.upload(tris)
@@ -819,20 +820,18 @@ def test_wave_time_diagnostic_does_not_change_hits(mem):
     n = rays.shape[0]; nw = n // 64
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n); d_times = mem.alloc(16 * nw)
     api.setup_traversal(grid)
+    assert mem.image_format(grid) == {"flat": True, "uniform": True, "slim_id_bits": 20, "record_bytes": 16}
     api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
     ref = mem.download(d_hits, api.HIT_DTYPE, n)
     d_order = mem.upload(np.arange(nw, dtype=np.int32)[::-1].copy())
-    try:
+    for tail in (1, 0):
         for order in (None, d_order):
             mem.zero(d_times, 16 * nw); mem.zero(d_hits, 16 * n)
-            assert mem._L.hagrid_kat_wave_times(mem._ctx, d_times, order) == 0
-            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            api._check(mem, mem._K.hagrid_kat_traverse_timed(mem._ctx, C.byref(grid.pod), d_tris, d_rays, d_hits, n, 256, tail, d_times, order), "kat_traverse_timed")
             got = mem.download(d_hits, api.HIT_DTYPE, n)
             t = mem.download(d_times, np.uint64, 2 * nw).reshape(nw, 2)
             assert (got["id"] == ref["id"]).all() and (bits(got["t"]) == bits(ref["t"])).all()
             assert (t[:, 0] > 0).all() and (t[:, 1] >= t[:, 0]).all()
-    finally:
-        mem._L.hagrid_kat_wave_times(mem._ctx, None, None)
     mem.free(d_order); mem.free(d_times); mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 

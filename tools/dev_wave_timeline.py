@@ -1,4 +1,4 @@
-"""DEV TOOL: timeline of the wavefronts of one traversal launch (table-free image kernel, hagrid_kat_wave_times): when every
+"""DEV TOOL: timeline of the wavefronts of one traversal launch (table-free image kernel, hagrid_kat_traverse_timed of libhagrid_amd_kat.so): when every
 wavefront starts and ends (100 MHz wall clock), how many are resident over time, which ones end last."""
 import os, sys, json
 import numpy as np
@@ -23,9 +23,9 @@ def run(order=None, label=""):
     out = None
     for rep in range(3):
         mem.zero(d_times, 16 * nw)
-        assert mem._L.hagrid_kat_wave_times(mem._ctx, d_times, d_order) == 0
-        ms = api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n))
-        mem._L.hagrid_kat_wave_times(mem._ctx, None, None)
+        import ctypes as C
+        tail = 0 if "traverse.tail=0" in os.environ.get("OPTS", "") else 1
+        ms = api.profile(lambda: api._check(mem, mem._K.hagrid_kat_traverse_timed(mem._ctx, C.byref(grid.pod), d_tris, d_rays, d_hits, n, W, tail, d_times, d_order), "kat_traverse_timed"))
         t = mem.download(d_times, np.uint64, 2 * nw).reshape(nw, 2).astype(np.int64)
         t0 = t[:, 0].min(); s = (t[:, 0] - t0) / 100.0; e = (t[:, 1] - t0) / 100.0        # microseconds
         dur = e - s
