@@ -286,7 +286,8 @@ def main():
             pipelined = {"in_flight": k, "steps": launches, "ms_per_step": round(dt * 1e3 / launches, 5),
                          "value": round(n_rays * launches / dt / 1e6, 2), "unit": "Mrays/s", "hits_identical_to_single_stream": same,
                          # the same algorithmic bytes per batch over the wall time per batch (not a kernel duration: launches overlap)
-                         "frac": round(ab["B_ray"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4), "walk_frac": round(ab["B_walk"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4),
+                         "frac": round(ab["B_image"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4), "frac_contract": round(ab["B_ray"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4),
+                         "walk_frac": round(ab["B_walk"] / (dt / launches * 1e9) / HBM_PEAK_GBPS, 4),
                          "how": "one context (stream, hit buffer) per call in flight, all over the traversal image of context 0 (hagrid_share_traversal); "
                                 "the next launch fills the drain of the previous one.  NOT the headline: `value` is one call at a time"}
             for m, _g, h in lanes[1:]:
@@ -305,17 +306,30 @@ def main():
         achieved_img = ab["B_image"] / (kernel_ms * 1e6)           # GB/s of the bytes the image kernel gathers for the same walk
         peak = mem.bandwidth_probe(1 << 30, 5)                     # measured in this process: float4 copy / triad over 1 GiB arrays
         traffic = None; traffic_source = None; l2_hit = None
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command
+        # (tools/gpu_round.sh) and committed as profiles/traffic_latest.json together with the hash of the kernel sources it
+        # measured.  A file measured on other sources is refused: traffic = null, traffic_source says "stale".
+        from hagrid_amd import build as _build
+        src_hash = _build.source_hash()
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and world == 1 and args.config == 2 and args.image == 2 and n_tris == 1_000_000 and (width, height) == (1024, 1024):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate")
-                traffic_source = "profiles/traffic_latest.json: " + tj.get("source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/gpu_round.sh), FETCH x2 per the gfx950 note; NOT measured in this run")
-            except Exception:
-                traffic = None
+                if tj.get("source_hash") == src_hash:
+                    traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate")
+                    traffic_source = f"profiles/traffic_latest.json (kernel sources {src_hash}, commit {tj.get('commit', '?')}): " + tj.get("source", "")
+                else:
+                    traffic_source = f"stale: profiles/traffic_latest.json measured kernel sources {tj.get('source_hash', 'unknown')}, this run has {src_hash}"
+            except Exception as e:
+                traffic = None; traffic_source = f"unreadable: {e}"
         fmt = mem.image_format(grid) if args.image else {}
         tail = fmt.get("slim_id_bits") and "traverse.tail=0" not in args.opts and "traverse.variant" not in args.opts
-        kernel_name = ("traverse_kernel_tail" if tail else "traverse_kernel_img") if args.image else ("traverse_kernel_v3" if n_rays >= 24 * info["compute_units"] * 32 * 64 and not bin_rays else "traverse_kernel_v2")
+        kernel_name = ("traverse_kernel_tail" if tail else "traverse_kernel_img") if args.image else "traverse_kernel_v2"
+        # what the roofline is quoted on: with a traversal image the bytes the image kernel gathers for the walk (B_image: 48 per ray +
+        # record bytes per cell + 48 per test + 4 per id of a by-index list) -- `frac` then cannot exceed what a copy reaches; the
+        # SURVEY 8(d) formula on the CONSTRUCTION format (entries + cells + ids + triangles, which this kernel never reads) is
+        # carried next to it as `*_contract`.  Without an image the two are the same thing.
+        ach = achieved_img if args.image else achieved
         cells_b = grid.num_cells * (16 if compressed else 32)
         image_b = mem.image_bytes(grid)
         out = {
@@ -338,8 +352,9 @@ def main():
             "setup_traversal_ms": round(setup_ms, 3),
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
             "roofline": {
-                # the contract's figure: ALGORITHMIC bytes (SURVEY.md 8(d) formula on the construction format) / launch duration / HBM peak
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "bytes": "B_image: what the traversal-image kernel gathers (DESIGN.md 4.2)" if args.image else "B_ray: SURVEY.md 8(d) on the construction format",
+                "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / HBM_PEAK_GBPS, 4),     # SURVEY.md 8(d) formula, construction format
                 "traffic": traffic, "traffic_source": traffic_source,
                 # what binds according to the counters (profiles/): the working set is L2 / Infinity-Cache resident, the kernel is
                 # limited by instruction issue with partly idle wavefronts and by the line rate of the vector L1, NOT by HBM bandwidth
@@ -348,11 +363,10 @@ def main():
                 "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "l2_hit_rate": l2_hit,
                 "peak_measured": {"copy": round(peak["copy_GBps"], 1), "triad": round(peak["triad_GBps"], 1), "unit": "GB/s",
-                                  "frac_of_copy": round(achieved / max(peak["copy_GBps"], 1e-9), 4)},
-                "kernel": kernel_name, "kernel_ms": round(kernel_ms, 5),
-                "bytes_per_ray": round(ab["B_ray"] / n_rays, 1),
-                "bytes_per_ray_image": round(ab["B_image"] / n_rays, 1),
-                "achieved_image": round(achieved_img, 1), "frac_image": round(achieved_img / HBM_PEAK_GBPS, 4),
+                                  "frac_of_copy": round(ach / max(peak["copy_GBps"], 1e-9), 4)},
+                "kernel": kernel_name, "kernel_ms": round(kernel_ms, 5), "kernel_sources": src_hash,
+                "bytes_per_ray": round((ab["B_image"] if args.image else ab["B_ray"]) / n_rays, 1),
+                "bytes_per_ray_contract": round(ab["B_ray"] / n_rays, 1),
                 "walk_achieved": round(ab["B_walk"] / (kernel_ms * 1e6), 1),
                 "walk_frac": round(ab["B_walk"] / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "walk_target": 0.40,

@@ -39,6 +39,13 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
 if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res:
     h = res["TCC_HIT_sum"]["avg_per_launch"]; m = res["TCC_MISS_sum"]["avg_per_launch"]
     res["l2_hit_rate"] = h / (h + m) if h + m else None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hagrid_amd import build as _build
+res["source_hash"] = _build.source_hash()              # the kernel sources these counters measured (bench.py refuses another hash)
+res["commit"] = os.environ.get("HAGRID_COMMIT", "unknown")
+res["source"] = (f"round {os.path.basename(out.rstrip('/'))}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum passes of "
+                 "`python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --inflight 0` (tools/gpu_round.sh), FETCH x2 per the gfx950 note of "
+                 "MI355X_MICROARCH.md (HBM section); NOT measured in the bench run itself")
 print("== traversal kernel PMC ==")
 print(json.dumps(res, indent=1))
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
