@@ -18,6 +18,11 @@
  *      (traverse.cu:93 overwrites id with the step count).
  *  D5  cbrtf is replaced by a deterministic double-precision Newton cbrt so that the CPU and the
  *      GPU agree on integer grid dimensions.
+ *
+ * orc_set_cuda_quirks(mask) switches D1 (bit 0) and D2 (bit 1) to what a literal CUDA run with CUB would do, as far as the
+ * sources and CUB's documented behaviour say -- "as-CUDA" structure mode, only to QUANTIFY what D1 / D2 change (cells, references,
+ * traversal steps; tests/test_oracle_golden.py, tools/dev_cuda_quirks.py); hits are the same either way.  The product implements
+ * the documented intent (mask 0).
  */
 #include "hagrid_oracle.h"
 
@@ -27,6 +32,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+static int g_cuda_quirks = 0;          /* bit 0: CUB's reversed rear partition (D1), bit 1: expand's stale double buffer (D2) */
+void orc_set_cuda_quirks(int mask) { g_cuda_quirks = mask; }
+int orc_get_cuda_quirks(void) { return g_cuda_quirks; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* small vector helpers: hagrid::min/max are `a < b ? a : b` / `a > b ? a : b` (common.h:23-25) */
@@ -448,6 +457,13 @@ int orc_build_grid(const OTri* tris, int num_tris, OGrid* grid, float top_densit
             if (c >= 0 && ENTRY_LOG_DIM(L->entries[c]) == 0) { nref[num_kept] = L->ref_ids[i]; ncel[num_kept] = c; num_kept++; }
         }
         int rear = num_kept;
+        if (g_cuda_quirks & 1) {
+            /* cub::DevicePartition::Flagged (parallel.cuh:59-71): "rejected items are written to the rear in REVERSE order" */
+            for (int i = num_refs - 1; i >= 0; i--) {
+                int c = L->cell_ids[i];
+                if (!(c >= 0 && ENTRY_LOG_DIM(L->entries[c]) == 0)) { nref[rear] = L->ref_ids[i]; ncel[rear] = c; rear++; }
+            }
+        } else
         for (int i = 0; i < num_refs; i++) {
             int c = L->cell_ids[i];
             if (!(c >= 0 && ENTRY_LOG_DIM(L->entries[c]) == 0)) { nref[rear] = L->ref_ids[i]; ncel[rear] = c; rear++; }
@@ -960,7 +976,12 @@ int orc_expand_grid_ex(OGrid* grid, const OTri* tris, int iters, int subset_only
                 g_walk_iters = 0; g_walk_max = 0;
             }
             for (int id = 0; id < n; id++) {                                      /* overlap_step expand.cu:145-182 */
-                if ((flags[id] & (1 << axis)) == 0) { new_cells[id] = cells[id]; continue; } /* D2 */
+                if ((flags[id] & (1 << axis)) == 0) {
+                    /* D2: copied through.  As-CUDA (expand.cu:154-155: `return` without a store): the slot keeps what the pass two passes
+                     * ago left there.  (The first three passes process every cell, so no slot is ever uninitialised.) */
+                    if (!(g_cuda_quirks & 2)) new_cells[id] = cells[id];
+                    continue;
+                }
                 OCell cell = cells[id];
                 int flag = 0;
                 int ov1 = find_overlap(axis, 0, &k, grid->entries, grid->ref_ids, cells, &cell, &flag);

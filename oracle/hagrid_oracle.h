@@ -121,6 +121,11 @@ void orc_brute_force(const OTri* tris, int num_tris, const ORay* rays, OHit* hit
 /* structural invariants of a finished grid; returns 0 if ok, else a negative code; msg gets text */
 int  orc_check_grid(const OGrid* grid, const OTri* tris, int num_tris, int check_coverage, char* msg, int msg_len);
 
+/* "as-CUDA" structure mode (test / analysis only): bit 0 = the rejected half of the partition in reverse order (CUB), bit 1 = expand
+ * leaves unprocessed cells stale.  0 (default) = the documented intent, which the product implements. */
+void orc_set_cuda_quirks(int mask);
+int orc_get_cuda_quirks(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         L.orc_traverse_grid_mt.argtypes = [vp, vp, vp, vp, i64, i32, vp]
         L.orc_brute_force.argtypes = [vp, i32, vp, vp, i64, i32]
         L.orc_check_grid.restype = i32; L.orc_check_grid.argtypes = [vp, vp, i32, i32, C.c_char_p, i32]
+        L.orc_set_cuda_quirks.restype = None; L.orc_set_cuda_quirks.argtypes = [i32]
+        L.orc_get_cuda_quirks.restype = i32; L.orc_get_cuda_quirks.argtypes = []
         _lib = L
     return _lib
 
@@ -287,3 +289,24 @@ def algorithmic_bytes(stats: dict, compressed: bool) -> dict:
     walk = 4 * stats["entry_words"] + s_cell * stats["cells"]
     total = 48 * stats["rays"] + walk + 52 * stats["refs"] + 4 * stats["sentinels"]
     return {"B_ray": total, "B_walk": walk}
+
+
+class cuda_quirks:
+    """`with cuda_quirks(mask):` -- the oracle's construction as a literal CUDA run with CUB would do it ("as-CUDA" structure mode):
+    bit 0 = the rejected half of the level partition in reverse order (cub::DevicePartition::Flagged, parallel.cuh:59-71 -> descending
+    reference lists on odd levels, which count_union / merge_refs / is_subset silently mis-handle), bit 1 = expand leaves unprocessed
+    cells stale (expand.cu:154-155,181).  Analysis only: the product and the default oracle implement the documented intent; hits are
+    the same either way."""
+    D1_REVERSED_PARTITION, D2_STALE_EXPAND = 1, 2
+
+    def __init__(self, mask: int):
+        self.mask = int(mask)
+
+    def __enter__(self):
+        self.old = lib().orc_get_cuda_quirks()
+        lib().orc_set_cuda_quirks(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_cuda_quirks(self.old)
+        return False

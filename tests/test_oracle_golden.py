@@ -250,3 +250,35 @@ def test_any_hit_and_uvs_walks(config1):
     assert ((anyh["id"] >= 0) == hit).all() and (anyh["t"][hit] >= nearest["t"][hit]).all() and (anyh["id"] != nearest["id"]).any()
     brute = O.brute_force(tris, rays, nthreads=8)
     assert ((brute["id"] >= 0) == (anyh["id"] >= 0)).all()
+
+
+def test_as_cuda_structure_mode_changes_the_grid_not_the_hits(config1):
+    """what a literal CUDA run with CUB would do differently (reversed rear partition -> unsorted lists that
+    count_union / is_subset mis-handle; stale expand buffer) gives a DIFFERENT grid -- more cells or fewer merges, less expansion --
+    that is still a valid grid with the same hits.  This pins the claim "never wrong hits, only a worse structure" and gives the
+    numbers DESIGN.md quotes; the product implements the documented intent (mask 0)."""
+    tris, rays, gid, gt = config1
+    base = O.Grid.full(tris)
+    _, sb = base.traverse(tris, rays, nthreads=8)
+    seen = {}
+    for mask in (1, 2, 3):
+        with O.cuda_quirks(mask):
+            G = O.Grid.full(tris)
+        assert O.lib().orc_get_cuda_quirks() == 0
+        h, st = G.traverse(tris, rays, nthreads=8)
+        assert (h["id"] == gid).all() and (bits(h["t"]) == bits(gt)).all(), mask          # the reference's brute force, bit for bit
+        seen[mask] = (G.num_cells, G.num_refs, st["cells"], st["refs"])
+    # D1: lists that are not ascending make count_union over-count -> fewer merges -> at least as many cells
+    assert seen[1][0] >= base.num_cells and seen[1] != (base.num_cells, base.num_refs, sb["cells"], sb["refs"])
+    # D2: lost expansion steps -> rays cross at least as many cells (the cell / reference counts do not change: expansion moves boxes only)
+    assert seen[2][0] == base.num_cells and seen[2][1] == base.num_refs and seen[2][2] >= sb["cells"]
+    # the D1 grid really holds lists that are not ascending (what merge.cu:57 / expand.cu:20 assume): the invariant checker says so;
+    # the D2 grid passes every invariant (boxes that grew less are still valid boxes)
+    with O.cuda_quirks(1):
+        G = O.Grid.full(tris)
+    rc, msg = G.check(tris, 1)
+    assert rc != 0 and "ascending" in msg, (rc, msg)
+    with O.cuda_quirks(2):
+        G = O.Grid.full(tris)
+    rc, msg = G.check(tris, 1)
+    assert rc == 0, msg
