@@ -198,7 +198,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
-            quad_pct = (!perm && blocks > slots && 4ll * blocks <= 9 * slots) ? 25 : 0;
+            // an image that is shared between contexts (hagrid_share_traversal) says several batches are in flight: then the drain of
+            // one launch is filled by the next and the extra wavefronts only cost issue slots (two in flight: 0.118 -> 0.144 ms)
+            const bool shared = ctx->image.alive && ctx->image.alive.use_count() > 1;
+            quad_pct = (!perm && !shared && blocks > slots && 4ll * blocks <= 9 * slots) ? 25 : 0;
         }
         if (quad_pct > 0 && ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
