@@ -68,7 +68,6 @@ struct hagrid_ctx {
     unsigned long long* lb_state = nullptr;   // status words of the look-back scans (wave_prims.h), never cleared: epochs
     size_t lb_words = 0;
     unsigned lb_epoch = 0;
-    unsigned lb_ticket_base = 0;              // value of the scans' ticket counter (first word of lb_state) once all queued scans are done
     int* row_scores = nullptr;           // row-length detection from origins: one score per candidate + a ticket counter
     int* bin_diff = nullptr;             // automatic ray binning: 64 partial counts of neighbouring rays in different bins
 

@@ -305,7 +305,7 @@ extern "C" int hagrid_bandwidth_probe(hagrid_ctx* ctx, size_t bytes, int iters, 
 }
 
 unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int words_per_tile, unsigned* epoch) {
-    const size_t need = size_t(tiles > 0 ? tiles : 1) * size_t(words_per_tile) + 16;     // + kLbTicketWords (wave_prims.h): the ticket counter in front
+    const size_t need = size_t(tiles > 0 ? tiles : 1) * size_t(words_per_tile);
     if (need > ctx->lb_words || ctx->lb_epoch >= (1u << 30) - 2u) {
         // grow (or restart the epochs): the words must start out as "never published"
         (void)hipStreamSynchronize(ctx->stream);
@@ -318,7 +318,6 @@ unsigned long long* hagrid_impl::lookback_state(hagrid_ctx* ctx, int tiles, int 
         }
         (void)hipMemsetAsync(ctx->lb_state, 0, ctx->lb_words * sizeof(unsigned long long), ctx->stream);
         ctx->lb_epoch = 0;
-        ctx->lb_ticket_base = 0;
     }
     *epoch = ++ctx->lb_epoch;
     return ctx->lb_state;

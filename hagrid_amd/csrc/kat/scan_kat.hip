@@ -32,7 +32,7 @@ extern "C" int hagrid_kat_scan(hagrid_ctx* ctx, const int32_t* values, int n, in
     if (carry_in) { zero[0] = carry_in[0]; if (words == 2) zero[1] = carry_in[1]; }
     HG_TRY(hagrid_mem_copy_h2d(ctx, scalars, zero, sizeof(zero)));
     const int saved = ctx->opt_lookback;
-    ctx->opt_lookback = lookback ? 1 : 0;
+    ctx->opt_lookback = lookback == 2 ? 2 : (lookback ? 1 : 0);      // 2: the helping path at the first miss
     bool ok;
     if (words == 1) ok = ctx_scan<int>(ctx, IntIn{d_in}, IntOut{d_out}, n, partials, carry_in ? scalars : (const int*)nullptr, scalars + 2);
     else ok = ctx_scan<Int2>(ctx, PairIn{d_in}, PairOut{d_out}, n, reinterpret_cast<Int2*>(partials),

@@ -190,17 +190,18 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
 // aggregates / inclusive prefixes (64 at a time, one per lane of wavefront 0), publishes its own inclusive prefix and scans
 // its items from registers.  A status word carries (epoch, flag, 32-bit value) and is written / read with one agent-scope
 // 64-bit atomic, so it is valid across the 8 L2s; the epoch makes last call's words invalid without clearing the array.
-// Forward progress depends neither on the dispatch order of workgroups nor on how many of them are resident (other contexts,
-// streams and processes share the device): tiles are handed out in increasing order by a ticket counter, one draw per tile by a
-// workgroup that is RUNNING, so the lowest unfinished tile always belongs to a running workgroup that has nothing left to wait
-// for.  The counter is never reset: a launch draws exactly tiles + gridDim.x tickets (every workgroup overshoots once), the host
-// passes the counter's value at launch (`ticket_base`) and adds that sum.
+// Workgroup b owns the tiles b, b + G, b + 2G, ... in increasing order, and the launch has no more workgroups than an EMPTY device keeps
+// resident of this kernel: then all of them run and the lowest unfinished tile always belongs to a running workgroup that has nothing
+// left to wait for.  The device need not be empty, though (other contexts, streams, processes), and the contract promises nothing about
+// dispatch order or residency -- so nobody waits for ever: a lane whose predecessor tile has not published anything after `help_after`
+// polls computes that tile's aggregate ITSELF from the items (any workgroup may: an aggregate is a pure function of the input) and goes
+// on.  In the worst case a workgroup sums its way back to tile 0 alone: slow, never stuck.  (Round 3 first handed tiles out by a
+// ticket counter instead: a same-address atomic per workgroup and tile, ~88 per us -- 3600-tile scans took 38 instead of 20 us.)
 constexpr int kLbVec = 4;                            // consecutive items per lane and row
 constexpr int kLbItems = 8;                          // items per thread of the look-back scan
 constexpr int kLbWindows = 4;                        // predecessors examined per look-back round: 64 lanes x kLbWindows
 constexpr int kLbTile = kBlock * kLbItems;
 constexpr unsigned kLbAggregate = 1u, kLbPrefix = 2u;
-constexpr int kLbTicketWords = 16;                   // 64-bit words in front of the status words: the ticket counter on its own line
 
 __device__ __forceinline__ unsigned long long lb_pack(unsigned epoch, unsigned flag, int value) {
     return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned)value;
@@ -262,22 +263,13 @@ template <typename V, typename Out> __device__ __forceinline__ void lb_store_row
 }
 
 template <typename V, typename In, typename Out>
-__global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, unsigned* ticket, unsigned ticket_base, const V* carry_in, V* total_out) {
+__global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, int tiles, unsigned long long* state, unsigned epoch, unsigned help_after, const V* carry_in, V* total_out) {
     __shared__ V lds[kWaves];
     __shared__ V tile_prefix;
-    __shared__ unsigned drawn;
     // A wavefront owns a contiguous run of the tile; a lane owns kLbVec CONSECUTIVE items per row (four 4-byte items = one 16-byte
     // access per array: the streaming rate of the part needs wide accesses), a row is 64 x kLbVec items.
     constexpr int kWaveItems = kLbItems * 64, kRows = kLbItems / kLbVec;
-    unsigned next = 0;                                                   // thread 0: the ticket drawn ahead, while the current tile is worked on
-    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
-    for (;;) {
-        if (threadIdx.x == 0) drawn = next;                              // (the last readers of `drawn` passed a barrier of the previous tile)
-        __syncthreads();
-        const unsigned t = drawn;
-        if (t >= unsigned(tiles)) break;
-        const int tile = int(t);
-        if (threadIdx.x == 0) next = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int base = tile * kLbTile + wave_id() * kWaveItems + lane_id() * kLbVec;
         // all loads of the tile first, then the scan of the wavefront's run entirely in registers (no workgroup barrier): after
         // this v[j] is the exclusive prefix of item j inside the run and `run` the run's total
@@ -320,11 +312,21 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
                         pv[w] = zero_of(V()); flag[w] = kLbPrefix;      // lanes before tile 0 end the search with a zero
                         ok[w] = p - w * 64 - lane_id() < 0;
                     }
-                    for (;;) {                                           // all outstanding looks of a trip are in flight together
+                    for (unsigned polls = 0;; polls++) {                 // all outstanding looks of a trip are in flight together
                         bool all = true;
 #pragma unroll
                         for (int w = 0; w < kLbWindows; w++) {
-                            if (!ok[w]) ok[w] = lb_try(state, p - w * 64 - lane_id(), epoch, pv[w], flag[w]);
+                            if (!ok[w]) {
+                                ok[w] = lb_try(state, p - w * 64 - lane_id(), epoch, pv[w], flag[w]);
+                                if (!ok[w] && polls >= help_after) {     // its owner may not be running at all: sum the tile here
+                                    const int t = p - w * 64 - lane_id();
+                                    const int first = t * kLbTile, last = min(n, first + kLbTile);
+                                    V sum = zero_of(V());
+                                    for (int i = first; i < last; i++) sum = sum + in(i);
+                                    if (t == 0 && carry_in) sum = sum + *carry_in;       // tile 0's inclusive prefix starts from the carry
+                                    pv[w] = sum; flag[w] = t == 0 ? kLbPrefix : kLbAggregate; ok[w] = true;
+                                }
+                            }
                             all = all && ok[w];
                         }
                         if (all) break;
@@ -369,12 +371,12 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
 
 inline int scan_num_tiles(int n) { return (n + kScanTile - 1) / kScanTile; }
 
-/// Single-pass scan.  `state` holds lb_words<V>() 64-bit words per tile and must never have seen `epoch` before; `*ticket` equals
-/// `*ticket_base` when the kernel starts (hagrid_impl::lookback_state hands all of them out); *ticket_base is advanced here.
+/// Single-pass scan.  `state` holds lb_words<V>() 64-bit words per tile and must never have seen `epoch` before
+/// (hagrid_impl::lookback_state hands out both).
 template <typename V, typename In, typename Out>
-inline void device_scan_lookback(hipStream_t stream, int num_cus, In in, Out out, int n, unsigned long long* state, unsigned epoch, unsigned* ticket, unsigned* ticket_base, const V* carry_in, V* total_out) {
-    // as many workgroups as an empty device keeps resident of this instantiation (less one per CU, at most 8, at least 1): more
-    // would only queue.  Correctness does not depend on the number (tickets).
+inline void device_scan_lookback(hipStream_t stream, int num_cus, In in, Out out, int n, unsigned long long* state, unsigned epoch, unsigned help_after, const V* carry_in, V* total_out) {
+    // workgroups that are resident together: what the runtime reports for this instantiation, less one per CU (the report can
+    // be one too high, MI355X_MICROARCH.md "Residency and cooperative launch"), at most 8, at least 1
     static const int per_cu = [] {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_lookback<V, In, Out>, kBlock, 0) != hipSuccess) { (void)hipGetLastError(); n = 2; }
@@ -382,8 +384,7 @@ inline void device_scan_lookback(hipStream_t stream, int num_cus, In in, Out out
     }();
     const int tiles = (n + kLbTile - 1) / kLbTile;
     const int blocks = std::max(1, std::min(tiles, std::max(num_cus, 1) * per_cu));
-    scan_lookback<V, In, Out><<<blocks, kBlock, 0, stream>>>(in, out, n, tiles, state, epoch, ticket, *ticket_base, carry_in, total_out);
-    *ticket_base += unsigned(tiles) + unsigned(blocks);
+    scan_lookback<V, In, Out><<<blocks, kBlock, 0, stream>>>(in, out, n, tiles, state, epoch, help_after, carry_in, total_out);
 }
 
 /// Launches the three scan kernels.  `partials` must hold scan_num_tiles(n) values of V.
@@ -404,7 +405,9 @@ inline bool ctx_scan(hagrid_ctx* ctx, In in, Out out, int n, V* partials, const 
     unsigned epoch = 0;
     unsigned long long* state = lookback_state(ctx, scan_num_tiles(n), lb_words<V>(), &epoch);
     if (!state) return false;
-    device_scan_lookback<V>(ctx->stream, ctx->num_cus, in, out, n, state + kLbTicketWords, epoch, reinterpret_cast<unsigned*>(state), &ctx->lb_ticket_base, carry_in, total_out);
+    // (a status poll is an L2 round trip, ~1 us: 4096 polls are milliseconds -- far beyond any wait of a healthy launch; opt_lookback == 2,
+    // a test setting, helps at the first miss so that the helping path is exercised)
+    device_scan_lookback<V>(ctx->stream, ctx->num_cus, in, out, n, state, epoch, ctx->opt_lookback == 2 ? 0u : 4096u, carry_in, total_out);
     HG_DBG(ctx);
     return true;
 }

@@ -30,7 +30,7 @@ def scan(mem, values, words, carry, lookback):
     return out, total
 
 
-@pytest.mark.parametrize("lookback", [1, 0])
+@pytest.mark.parametrize("lookback", [1, 0, 2])
 @pytest.mark.parametrize("words", [1, 2])
 def test_scan_sizes_and_carry(mem, words, lookback):
     rng = np.random.default_rng(7)
