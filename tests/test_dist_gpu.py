@@ -204,3 +204,58 @@ def test_bench_single_gpu_line_carries_the_pipelined_block():
     assert not r.timed_out, r.diagnosis
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["pipelined"] is None
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_damaged_grid_file_is_refused_before_it_becomes_a_grid(tmp_path, compress):
+    """a grid file is foreign data and the traversal kernels check nothing.  Every index a walk would follow is validated
+    when the blob is unpacked (header: top-level cells vs entries, level offsets; device pass: entry targets, cells' reference ranges,
+    reference ids, the last sentinel of a compressed grid): a damaged file gives an error with its reason, not a grid, and the pool
+    gets the memory back."""
+    from hagrid_amd import api, dist as hdist, lib
+    n_tris = 20_000
+    tris = scene.make_soup(n_tris)
+    mem = api.MemManager(keep=False)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, n_tris, compress=compress)
+    path = str(tmp_path / "g.blob")
+    hdist.save_grid(mem, grid, d_tris, n_tris, path)
+    good = bytearray(open(path, "rb").read())
+    h = lib.BlobHeader.from_buffer_copy(bytes(good[:256]))
+    mem2 = api.MemManager(keep=False)
+    base_usage = mem2.usage()
+
+    def refused(blob, why):
+        open(path, "wb").write(bytes(blob))
+        with pytest.raises(api.HagridError, match=why):
+            hdist.load_grid(mem2, path)
+        assert mem2.usage() == base_usage, why
+
+    def put32(blob, off, value):
+        blob[off:off + 4] = int(value & 0xffffffff).to_bytes(4, "little")
+
+    b = bytearray(good); put32(b, h.off_entries + 4 * 5, (h.num_cells + 7) << 2)                     # a leaf entry beyond the cells
+    refused(b, "voxel-map entry")
+    b = bytearray(good); put32(b, h.off_entries + 4 * 9, ((h.num_entries - 3) << 2) | 1)            # a node whose eight children run off the end
+    refused(b, "voxel-map entry")
+    if not compress:
+        b = bytearray(good); put32(b, h.off_cells + 32 * 11 + 28, h.num_refs + 1)                   # Cell.end beyond the references
+        refused(b, "reference range")
+    else:
+        b = bytearray(good); put32(b, h.off_cells + 16 * 11 + 12, h.num_refs)                       # SmallCell.begin beyond the references
+        refused(b, "reference range")
+        b = bytearray(good); put32(b, h.off_refs + 4 * (h.num_refs - 1), 3)                          # the last list loses its sentinel
+        refused(b, "names no triangle|no end")
+    b = bytearray(good); put32(b, h.off_refs + 4 * 17, n_tris)                                       # a reference to a triangle that is not there
+    refused(b, "names no triangle")
+    b = bytearray(good); put32(b, 8, h.dims[0] * 40)                                                 # header: more top-level cells than entries
+    refused(b, "top-level cells|level offsets")
+    b = bytearray(good); put32(b, 48 + 0, h.offsets[0] + 1)                                          # header: offsets[0] != number of top-level cells
+    refused(b, "level offsets")
+    b = bytearray(good); b[232:240] = (1 << 60).to_bytes(8, "little")                                # header: a size nobody has
+    refused(b, "inconsistent section table|no host memory")
+    # and the undamaged file still loads
+    open(path, "wb").write(bytes(good))
+    g2, t2, n2 = hdist.load_grid(mem2, path)
+    assert n2 == n_tris and g2.summary() == grid.summary()
+    mem2.close(); mem.close()
