@@ -78,8 +78,8 @@ struct hagrid_ctx {
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
-    int opt_super_log2 = 4;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside)
-    int opt_xcd_chunk_log2 = 4; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each
+    int opt_super_log2 = 3;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside); round-3 sweep: 3 (profiles/dev_r3_tile_params.txt)
+    int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger

@@ -81,7 +81,8 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
-    a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2; a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2;
+    a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
+    a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
     a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
@@ -243,7 +244,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
-        {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -1, 16},
+        {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},
     };

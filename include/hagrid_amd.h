@@ -262,8 +262,10 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
  * also from the origins alone -- bounce rays in the image order of their primary hits; a row length that was found is kept per ray buffer and count and
  * looked for again every 16th call ("not image-ordered" is not kept once the host has seen it), "traverse.row_cache" = 0: at every call -- it only steers the lane <-> ray assignment, hits never
- * depend on it), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
- * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each;
+ * depend on it), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside; default 3), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
+ * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each, -2 (default) = 3 for launches of up to about two rounds of the
+ * resident wavefronts, else 5; "traverse.quad_tail": per cent of the tiles, the last in dispatch order, that start with four lanes per ray
+ * (-1, default = a quarter of them for launches between one and two rounds whose image is not shared between contexts, else none);
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
  * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
  * ray.h:22 documents; t is the same either way);

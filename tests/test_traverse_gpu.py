@@ -310,7 +310,7 @@ def test_tile_packets_give_identical_hits(mem):
                     got = gpu_traverse(mem, grid, d_tris, rays)
                     assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (name, width, sl)
     finally:
-        mem.set_option("traverse.image_width", 0); mem.set_option("traverse.super_tile", 4)
+        mem.set_option("traverse.image_width", 0); mem.set_option("traverse.super_tile", 3)
     grid.free(); mem.free(d_tris)
 
 
