@@ -192,17 +192,19 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         int blocks = grid_blocks(num_rays, 64);
         const bool narrow = img_narrow;
         // Tail kernel: "traverse.quad_tail" per cent of the tiles, the last in dispatch order, start with four lanes per ray.  -1 (default):
-        // a quarter of the tiles when the launch is between one and two rounds of the resident wavefronts (1024^2 rays on 256 CUs) --
-        // there the last wavefronts to start are what the launch waits for (1024^2: 0.179 -> 0.175 ms; 6 / 12 / 37 / 50 %: 0.180 /
-        // 0.181 / 0.189 / 0.204 ms).  Larger launches are throughput-bound and lose (2048^2 at 12 %: +3 %, 4096^2: +10 %), binned
-        // batches too; an unordered 1M batch gains up to 20 % at 100 (profiles/dev_r3_quad_tail.txt).  Hits do not depend on it.
+        // by the size of the launch in rounds of the resident wavefronts (256 CUs x 32).  A launch of a few rounds is as long as its last
+        // wavefronts' chains, and wavefront slots are free while it drains: the fewer rounds, the larger the share that pays
+        // (profiles/dev_r3_quad_tail.txt, 14 image sizes x 8 shares on the 1M-triangle scene: up to 0.4 rounds all tiles (-11 ... -25 %),
+        // up to 0.65 half of them (-14 % at 640 x 480), up to 1.1 rounds 37 % (-7 ... -16 %), up to 3.2 rounds a quarter (-3 ... -6 %;
+        // 1024^2: 0.176 -> 0.171 ms), beyond that none (throughput-bound: +2 % at 1920 x 1080, +10 % at 4096^2).  Not for binned batches
+        // (they lose), not while the image is shared between contexts: several batches in flight fill each other's drain and the
+        // extra wavefronts only cost issue slots (two in flight: 0.117 -> 0.144 ms per batch).  Hits do not depend on it.
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
-            // an image that is shared between contexts (hagrid_share_traversal) says several batches are in flight: then the drain of
-            // one launch is filled by the next and the extra wavefronts only cost issue slots (two in flight: 0.118 -> 0.144 ms)
             const bool shared = ctx->image.alive && ctx->image.alive.use_count() > 1;
-            quad_pct = (!perm && !shared && blocks > slots && 4ll * blocks <= 9 * slots) ? 25 : 0;
+            const long long r100 = 100ll * blocks / std::max(slots, 1ll);           // rounds, in per cent
+            quad_pct = (perm || shared) ? 0 : (r100 <= 40 ? 100 : (r100 <= 65 ? 50 : (r100 <= 110 ? 37 : (r100 <= 320 ? 25 : 0))));
         }
         if (quad_pct > 0 && ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);

@@ -24,7 +24,9 @@ gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bb
         "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
         "incoherent 1M": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4)}
-rays = gens[batch](); n = rays.shape[0]
+import re
+m = re.match(r"primary (\d+)x(\d+)$", batch)
+rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, int(m.group(1)), int(m.group(2))) if m else gens[batch](); n = rays.shape[0]
 d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
 if "binned" in batch: mem.set_ray_binning(1)
 go = lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
