@@ -249,12 +249,13 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
- * kernel, 1 = plain reference-shaped kernel, 2 = latency-oriented, 3 = persistent vote-scheduled, 4 = traversal-image
- * kernel, an error without an image), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing),
+ * kernel: the traversal-image kernel when the grid has an image, else v2; 1 = plain reference-shaped kernel, 2 = latency-oriented v2 on the
+ * construction format, 4 = traversal-image kernel, an error without an image; 3, the persistent kernel of rounds 1-2, no longer exists: an error), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing),
  * "traverse.tail" (1, default = the table-free slim image is traversed by the kernel with the tail mode: a wavefront that holds at most 16
  * live rays spreads each over four lanes and tests a cell's inline list in one round; 0 = one ray per lane throughout),
  * "traverse.image_slim" (flat image of a grid of at most three levels: 1, default = 16-byte records where every cell fits them; 0 = 32-byte
- * records; 2 = the 26-bit id form even where 20 bits would do), "traverse.narrow" (1 = v2 uses 32-bit
+ * records; 2 = the 26-bit id form even where 20 bits would do), "traverse.lds_pad" (experiments: bytes of dynamic LDS per workgroup of the tail kernel, 0 by default -- limits the resident
+ * wavefronts, profiles/dev_r3_quad_tail.txt), "traverse.narrow" (1 = v2 uses 32-bit
  * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
  * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
