@@ -127,6 +127,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world:
+            # one node: RCCL's bootstrap sockets need no interface but the loopback (whatever else the box has need not route to itself);
+            # the data path between the GPUs is xGMI / shared memory either way.  A caller's own NCCL_SOCKET_IFNAME stands.
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:

@@ -16,12 +16,14 @@ class Result:
         return self.returncode is None
 
 
-def thread_report(pid):
+def _one_process(pid):
     lines = []
     try:
         tasks = sorted(os.listdir(f"/proc/{pid}/task"))
+        cmd = open(f"/proc/{pid}/cmdline").read().replace("\0", " ")[:200]
     except OSError as e:
-        return f"/proc/{pid}: {e}\n"
+        return [f"/proc/{pid}: {e}"]
+    lines.append(f" process {pid}: {cmd}")
     for t in tasks:
         try:
             wchan = open(f"/proc/{pid}/task/{t}/wchan").read()
@@ -29,19 +31,38 @@ def thread_report(pid):
             lines.append(f"  task {t}: wchan={wchan} {' '.join(st)}")
             try:
                 lines.append("    kstack: " + open(f"/proc/{pid}/task/{t}/stack").read().replace("\n", " | "))
-            except OSError as e:
-                lines.append(f"    kstack: {e}")
+            except OSError:
+                pass                                             # (not readable on the GPU box)
         except OSError as e:
             lines.append(f"  task {t}: {e}")
+    return lines
+
+
+def thread_report(pid):
+    """Every process of the session `pid` leads (the front-end re-executes itself once per rank): command line, and per thread the kernel
+    wait channel; user stacks of the leader through rocgdb where ptrace is allowed."""
+    lines = []
+    pids = [pid]
+    for d in os.listdir("/proc"):
+        if d.isdigit() and int(d) != pid:
+            try:
+                if os.getsid(int(d)) == pid:
+                    pids.append(int(d))
+            except OSError:
+                pass
+    for q in pids:
+        lines += _one_process(q)
     gdb = "/opt/rocm/bin/rocgdb"
     if os.path.exists(gdb):
-        try:
-            r = subprocess.run([gdb, "-p", str(pid), "-batch", "-ex", "set pagination off", "-ex", "thread apply all bt 30"],
-                               capture_output=True, text=True, timeout=120)
-            lines.append(r.stdout[-12000:])
-            lines.append(r.stderr[-2000:])
-        except Exception as e:                                   # diagnosis must never fail the caller
-            lines.append(f"  rocgdb: {e}")
+        for q in pids[:3]:
+            try:
+                r = subprocess.run([gdb, "-p", str(q), "-batch", "-ex", "set pagination off", "-ex", "thread apply all bt 30"],
+                                   capture_output=True, text=True, timeout=120)
+                if "Operation not permitted" in r.stderr:
+                    lines.append("  rocgdb: ptrace not permitted here"); break
+                lines.append(r.stdout[-8000:])
+            except Exception as e:                               # diagnosis must never fail the caller
+                lines.append(f"  rocgdb: {e}")
     return "\n".join(lines) + "\n"
 
 

@@ -240,7 +240,8 @@ def test_cli_save_grid_then_load_grid(cli_case):
 def test_cli_one_process_per_gpu_rccl_broadcast(cli_case):
     """One process per GPU, the grid broadcast from C++ with RCCL (here: one rank, all this box has)."""
     c = cli_case
-    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-k", "--gpus", "1", "-n", "2"], timeout=120)
+    # (RCCL's first initialisation on a fresh box loads its kernels and probes the topology: tens of seconds on a slow host)
+    r = _subproc.check([c.exe, c.obj, "-r", c.rays, "-k", "--gpus", "1", "-n", "2"], timeout=300)
     assert "1 rank(s), grid broadcast in " in r.stdout and f"{c.cells} cells, {c.refs} references)" in r.stdout
     assert f"{c.want} intersection(s)." in r.stdout and " Mrays/sec." in r.stdout
 

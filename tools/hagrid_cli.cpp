@@ -191,6 +191,9 @@ constexpr int kNcclSum = 0, kNcclMax = 2, kNcclInt32 = 2, kNcclFloat32 = 7;     
 
 // The launcher: creates the RCCL id, starts one copy of this program per GPU (rank and id travel in the environment) and waits.
 int launch_ranks(char** argv, int world) {
+    // All ranks are children of this process on this node: RCCL's bootstrap (the socket ncclGetUniqueId opens here, the ring the ranks form)
+    // needs no other interface than the loopback, and whatever else the box has need not route to itself.  A caller's own choice stands.
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
     Rccl r;
     if (!r.load()) { std::cerr << "--gpus needs RCCL (librccl.so)" << std::endl; return 1; }
     NcclId id;
