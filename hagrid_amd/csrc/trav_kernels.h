@@ -505,7 +505,8 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             const float tc = (float(c) * m_cs + m_gmin - m_org) * m_inv;
             texit = detail::fmin2(detail::fmin2(tc, quad_perm_f<9>(tc)), quad_perm_f<82>(tc));
             const float ev = (texit * m_dir + m_org - m_gmin) * m_ginv;
-            const int n = texit == tc ? c + (m_pos ? 0 : -1) : int(ev);
+            const int n_exit = c + (m_pos ? 0 : -1), n_other = int(ev);      // both, then one select: no divergent branch on the step's chain
+            const int n = texit == tc ? n_exit : n_other;
             m_v = med3_i32(n, m_v, m_pos ? 0x7fffffff : int(0x80000000));
             const int o = uint32_t(m_v) >= uint32_t(m_dims) ? 1 : 0;
             outside = (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0;
@@ -523,6 +524,8 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
             const uint32_t idx = quad_sum(((v >> (uint32_t(a.shift) - tab_d)) & ((1u << tab_d) - 1u)) << __umul24(uint32_t(ax), tab_d));
             return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
         };
+        const int my_word = (48 + (sub < NI ? sub : 0) * SLIM) >> 5;
+        const uint32_t my_shift = uint32_t(48 + (sub < NI ? sub : 0) * SLIM) & 31u;
         live = __ballot(alive);
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
@@ -530,7 +533,10 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
-                const int inl = by_index ? NONE : (sub == 0 ? i0 : (sub == 1 ? i1 : (sub == 2 ? i2 : i3)));
+                // this lane's id: field `sub` of the 80 id bits from bit 48 on -- two words chosen by the lane's constants, one funnel shift
+                const uint32_t id_lo = my_word == 1 ? ca.y : (my_word == 2 ? ca.z : ca.w), id_hi = my_word == 1 ? ca.z : (my_word == 2 ? ca.w : 0u);
+                const int mine_id = sub < NI ? int(__builtin_amdgcn_alignbit(id_hi, id_lo, my_shift) & uint32_t(NONE)) : NONE;
+                const int inl = by_index ? NONE : mine_id;
                 auto accept = [&](int ok, float t, float ad, int ref) {            // prims.h:284-292 with the tmax of this moment
                     if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
                 };
