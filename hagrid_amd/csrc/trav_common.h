@@ -38,6 +38,7 @@ struct TraverseArgs {
     const unsigned char* __restrict__ img_blocks;
     int num_rays;
     int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
+    int tail_dual;                // host side only: which instantiation of the tail kernel is launched
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
     int shift;

@@ -273,10 +273,12 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
 // UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
 // top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
-template <int SLIM, bool TIMES = false, bool UNIFORM = true>
+// DUAL: phase 1 tests the ids of an inline list two per round trip (see test_list)
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
+    __shared__ float4 tri_lds[DUAL ? 3 * 64 : 1];         // DUAL: a lane's second triangle of a round, written by the load itself (LDS-DMA)
     const int lane = threadIdx.x;
     struct Stamp {
         unsigned long long* p;
@@ -408,7 +410,35 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         int ref = int(field(rec, 48, SLIM));
         uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
                  q3 = NI > 3 ? field(rec, 48 + 3 * SLIM, SLIM) : uint32_t(NONE);
-        if (__ballot(by_index) == 0ull) {
+        if (DUAL && __ballot(by_index) == 0ull) {
+            // Two ids per round trip.  A list is tested front to back and every test waits for its triangle; with 64 registers a lane
+            // has room for one triangle, so the SECOND id of a round is requested straight into the lane's slots of `tri_lds`
+            // (global_load_lds: no registers) together with the first one's ordinary loads, and read from there when the first test is
+            // done.  Same tests, same order, same tmax at every test; a list of up to four ids costs two gather latencies instead of four.
+            typedef __attribute__((address_space(1))) const void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll 1
+            while (ref != NONE) {
+                const int second = int(q1);
+                if (second != NONE) {
+                    const float4* p = tri_ptr(second);
+                    // (the instruction's offset counts in the global AND in the LDS address: the LDS bases are 1024 - 16 and 2048 - 32 bytes)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds + 63), 16, 16, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds + 126), 16, 32, 0);
+                }
+                Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                if (second != NONE) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the requests landed: they were issued before the first triangle's loads)
+                    const float4 p0 = tri_lds[lane], p1 = tri_lds[64 + lane], p2 = tri_lds[128 + lane];
+                    (void)intersect_prim_ray(Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w), Ray(org, tmin, dir, h.t), second, h);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the slots are read before the next round's request may overwrite them)
+                }
+                hit_t = h.t; hit_id = h.id;
+                ref = int(q2); q1 = q3; q2 = uint32_t(NONE); q3 = uint32_t(NONE);
+            }
+        } else if (__ballot(by_index) == 0ull) {
 #pragma unroll 1
             while (ref != NONE) {
                 Hit h(hit_id, hit_t, 0.0f, 0.0f);
@@ -543,7 +573,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 if (__ballot(by_index) == 0ull) {
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
-                    if (inl != NONE) cd = tri_candidate(tri_for(inl), org, dir, tmin);
+                    if (inl != NONE) cd = tri_candidate(tri_vec(inl), org, dir, tmin);
                     const unsigned long long cand = __ballot(cd.ok);
                     if (cand != 0ull) {
                         // replay the acceptance in list order; every lane of the group computes the same.  A list position at which no

@@ -25,12 +25,17 @@ template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
     if (tail && MODE == 0 && slim && !uniform) {
-        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);      // (the table layout has no registers to spare for the second request)
         else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
     }
     else if (tail && MODE == 0 && uniform && slim) {
-        if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, a.lds_pad, st>>>(a);
-        else                 traverse_kernel_tail<26><<<blocks, 64, a.lds_pad, st>>>(a);
+        if (a.tail_dual) {
+            if (slim == 20) traverse_kernel_tail<20, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
     }
     else if (slim == 20 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
     else if (slim == 26 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
@@ -84,7 +89,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad;
+    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -199,6 +204,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // 1024^2: 0.176 -> 0.171 ms), beyond that none (throughput-bound: +2 % at 1920 x 1080, +10 % at 4096^2).  Not for binned batches
         // (they lose), not while the image is shared between contexts: several batches in flight fill each other's drain and the
         // extra wavefronts only cost issue slots (two in flight: 0.117 -> 0.144 ms per batch).  Hits do not depend on it.
+        // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
+        // LDS, trav_kernels.h test_list).  -1 (default): for rays in tile-packet order (1024^2: -2.6 %, 640 x 480: -4.4 %, 2048^2 and
+        // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly
+        // issued for one or two lanes).  Hits do not depend on it.
+        a.tail_dual = ctx->opt_tail_dual < 0 ? (perm ? 0 : 1) : ctx->opt_tail_dual;
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
@@ -246,6 +256,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
+        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},

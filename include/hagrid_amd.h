@@ -267,7 +267,9 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each, -2 (default) = 3 for launches of up to about two rounds of the
  * resident wavefronts, else 5; "traverse.quad_tail": per cent of the tiles, the last in dispatch order, that start with four lanes per ray
  * (-1, default = by the size of the launch: all tiles up to 0.4 rounds of the resident wavefronts, half up to 0.65, 37 % up to 1.1, a quarter up to 3.2 rounds,
- * none beyond, none for binned batches and none while the image is shared between contexts);
+ * none beyond, none for binned batches and none while the image is shared between contexts); "traverse.tail_dual": 1 = the one-ray-per-lane
+ * phase of the tail kernel tests two ids of an inline list per round trip, the second triangle loaded straight into LDS, 0 = one id per
+ * round trip, -1 (default) = 1 unless the batch is binned;
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
  * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
  * ray.h:22 documents; t is the same either way);
