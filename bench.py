@@ -260,6 +260,30 @@ def main():
     n_head = rays_head.shape[0]
     hits = mem.download(d_hits, api.HIT_DTYPE, n_head)
 
+    # ---- what the learned tile order is worth (outside the timed region) --------------------------------------------------------
+    # Launches over a ray buffer the context has seen before dispatch their 8x8 tiles longest first, by the costs the previous launches
+    # left (traverse.hip "tile order"); the W warm-up steps are where that is learned, the K timed steps are the steady state -- what the
+    # reference's own benchmark loop measures (main.cpp:398-447: the same rays, iteration after iteration).  The same K steps in the default
+    # order (= what the FIRST launch over a new buffer costs) are reported next to it.
+    tile_order = None
+    if not bin_rays:
+        try:
+            mem.set_option("traverse.tile_order", 0)
+            for _ in range(max(args.warmup, 1)):
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
+            ms0 = api.profile(lambda: [api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays) for _ in range(args.steps)], mem) / args.steps
+            hits0 = mem.download(d_hits, api.HIT_DTYPE, n_head)
+            tile_order = {"ms_per_step_default_order": round(ms0, 5), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
+                          (hits0["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()),
+                          "how": "`value` is the steady state of a renderer's loop: tiles dispatched longest first, by the costs the previous launches over the same ray "
+                                 "buffer left (learned in the warm-up steps, refreshed every 16th launch inside the timed region); ms_per_step_default_order = the "
+                                 "same K steps with traverse.tile_order = 0, i.e. what the first launch over a new buffer costs.  Hits do not depend on the order"}
+        except Exception as e:                                       # (an option the library does not know: older build)
+            log(f"[bench] tile order block skipped: {e}")
+        finally:
+            try: mem.set_option("traverse.tile_order", -1)
+            except Exception: pass
+
     # ---- independent batches in flight (extension; outside the timed region, never `value`) -------------------------------
     # One launch over 1M rays keeps the machine full for half of its time, the rest is the drain of its last wavefronts.  A caller
     # with independent batches puts each on a stream of its own: contexts 1.. traverse with context 0's traversal image.
@@ -376,6 +400,7 @@ def main():
                 "walk_target": 0.40,
                 "walk_achieved_image": round(ab["B_image_walk"] / (kernel_ms * 1e6), 1)},
             "pipelined": pipelined,
+            "tile_order": tile_order,
             "roofline_build": build_block,
             "memory": {"cells": cells_b, "entries": 4 * grid.num_entries, "refs": 4 * grid.num_refs, "tris": 48 * n_tris,
                        "traversal_image": image_b, "releasable_after_setup_traversal": cells_b + 4 * grid.num_entries, "rays": 32 * n_rays, "hits": 16 * n_rays, "pool_now": mem.usage(), "pool_peak": mem.max_usage(),

@@ -50,6 +50,7 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
     if (ctx->row_scores) (void)hipFree(ctx->row_scores);
+    if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
     if (ctx->lb_state) (void)hipFree(ctx->lb_state);
     delete ctx;
 }

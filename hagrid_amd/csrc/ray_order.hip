@@ -266,6 +266,43 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
     }
 }
 
+// ---- tile order: longest first ---------------------------------------------------------------------------------------------
+// order[0 .. n) = the tile indices sorted by descending cost (clamped to 255), equal costs in index order (so the Z curve survives inside
+// a class); cost[] is cleared for the next launches to fill.  One workgroup: a stable LSD radix sort of 8-bit keys in two 4-bit passes,
+// every thread owning a contiguous chunk of the input (n is a few ten thousand tiles; 16384 tiles: ~6 us, every 16th launch).
+constexpr int kOrderBlock = 512;
+__global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int* __restrict__ tmp, int n) {
+    __shared__ int cnt[16][kOrderBlock];
+    __shared__ int base[16];
+    const int t = threadIdx.x, chunk = (n + kOrderBlock - 1) / kOrderBlock, b0 = min(n, t * chunk), b1 = min(n, b0 + chunk);
+    const int lane = t & 63, wave = t >> 6;
+    for (int pass = 0; pass < 2; pass++) {
+        int* dst = pass ? order : tmp;
+        auto item = [&](int i) { return pass ? tmp[i] : i; };
+        auto digit = [&](int tile) { return ((255 - min(255, max(0, cost[tile]))) >> (4 * pass)) & 15; };
+        for (int d = 0; d < 16; d++) cnt[d][t] = 0;
+        for (int i = b0; i < b1; i++) cnt[digit(item(i))][t]++;
+        __syncthreads();
+        // exclusive prefix over the threads, digit by digit: wavefront w takes digits 2w and 2w + 1
+        for (int d = 2 * wave; d < 2 * wave + 2; d++) {
+            int carry = 0;
+            for (int r = 0; r < kOrderBlock / 64; r++) {
+                const int v = cnt[d][r * 64 + lane], incl = wave_inclusive_scan(v);
+                cnt[d][r * 64 + lane] = carry + incl - v;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) base[d] = carry;
+        }
+        __syncthreads();
+        if (t == 0) { int run = 0; for (int d = 0; d < 16; d++) { const int c = base[d]; base[d] = run; run += c; } }
+        __syncthreads();
+        for (int i = b0; i < b1; i++) { const int tile = item(i), d = digit(tile); dst[base[d] + cnt[d][t]++] = tile; }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i = b0; i < b1; i++) cost[i] = 0;
+}
+
 struct TableIn { const int* t; __device__ int operator()(int i) const { return t[i]; } };
 struct TableOut { int* t; __device__ void operator()(int i, int s) const { t[i] = s; } };
 
@@ -286,6 +323,21 @@ void hagrid_trav::launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_
     detect_ray_rows<<<1 + (kRowCandidates + 1 + 3) / 4, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, ctx->row_scores, 1.0f / (tau * tau), 1); HG_DBG(ctx);
 }
 
+
+// Tile order of the tail kernel (traverse.hip): the buffers of the context grown to `tiles` entries (cost, order, scratch; cost cleared)
+bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, int tiles) {
+    if (ctx->lpt_cap >= tiles && ctx->lpt_buf) return true;
+    if (ctx->lpt_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->lpt_buf); ctx->lpt_buf = nullptr; ctx->lpt_cap = 0; }
+    const int cap = std::max(tiles, 1 << 14);
+    if (hipMalloc((void**)&ctx->lpt_buf, size_t(cap) * 3 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->lpt_buf = nullptr; return false; }
+    (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(cap) * 3 * sizeof(int), ctx->stream);
+    ctx->lpt_cap = cap; ctx->lpt_valid = false;
+    return true;
+}
+void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, int tiles) {
+    int* cost = ctx->lpt_buf, *order = cost + ctx->lpt_cap, *scratch = order + ctx->lpt_cap;
+    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, scratch, tiles); HG_DBG(ctx);
+}
 
 int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
     a.perm = nullptr;

@@ -32,7 +32,8 @@ struct TraverseArgs {
     int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
     int super_log2;                          // tile packets: tiles per super-tile edge, log2
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
-    const int* __restrict__ tile_order;      // TIMES instantiations only (kat/kat.hip): packet b processes tile tile_order[b]
+    const int* __restrict__ tile_order;      // tail kernel (and the TIMES instantiations of kat/kat.hip): packet b processes tile tile_order[b]; nullptr: tile b
+    int* tile_cost;                          // tail kernel: a wavefront leaves the iterations it ran at its tile's index (atomicMax); nullptr: nothing
     unsigned long long* __restrict__ wave_times; // TIMES instantiations only: start / end of every wavefront, 100 MHz wall clock
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
@@ -267,6 +268,10 @@ void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mod
 // ray_order.hip: row length of an image-ordered batch -> row_len[0] on the device (0: none); nobody waits for it
 constexpr int kOriginMinRays = 1 << 22;
 void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays);
+// ray_order.hip: the tail kernel's tile order (longest tile first): buffers of the context for `tiles` tiles; order <- the costs the
+// launches since the last call left, costs cleared
+bool tile_order_buffers(hagrid_ctx* ctx, int tiles);
+void launch_tile_order(hagrid_ctx* ctx, int tiles);
 // ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the
 // automatic mode) from buffers of `tmp`, or leaves a.perm null for batches too small to bin
 int bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp);

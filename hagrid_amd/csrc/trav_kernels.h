@@ -278,6 +278,7 @@ template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
+    __shared__ int* cost_at;                              // where this wavefront leaves its cost (its tile's word of a.tile_cost), nullptr: nowhere
     __shared__ float4 tri_lds[DUAL ? 3 * 64 : 1];         // DUAL: a lane's second triangle of a round, written by the load itself (LDS-DMA)
     const int lane = threadIdx.x;
     struct Stamp {
@@ -302,7 +303,15 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         const int nb = min(int(gridDim.x), a.quad_first_block);
         b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, nb, a.xcd_chunk_log2) : xcd_split(blockIdx.x, nb);
     }
-    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, lane_in_tile) : b * 64 + lane_in_tile;
+    // Which tile: position b of the dispatch order, or -- when the previous launch over this ray buffer left its costs -- the tile that
+    // order names (longest first, traverse.hip "tile order").  The wavefront leaves its own cost (iterations = cells of its longest ray) behind.
+    int iters = 0;                                        // iterations this wavefront ran
+    int slot;
+    {
+        const int tile = (UNIFORM && w && a.tile_order) ? a.tile_order[b] : b;     // (the table layout has no register to spare for the bookkeeping)
+        slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
+        if (UNIFORM && lane == 0) cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr;      // (in LDS: the kernel has no register to spare for the whole traversal)
+    }
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
     bool pending = valid;                                  // this lane still owes its ray's hit to the hit buffer
@@ -423,9 +432,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 if (second != NONE) {
                     const float4* p = tri_ptr(second);
                     // (the instruction's offset counts in the global AND in the LDS address: the LDS bases are 1024 - 16 and 2048 - 32 bytes)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds + 63), 16, 16, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(tri_lds + 126), 16, 32, 0);
+                    // (and the address arithmetic is done on the LDS pointer: a generic pointer would be checked for null on its way to LDS)
+                    typedef __attribute__((address_space(3))) float4 lds_f4;
+                    lds_f4* const slots = (lds_f4*)tri_lds;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(slots), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(slots + 63), 16, 16, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p), (lptr_t)(slots + 126), 16, 32, 0);
                 }
                 Hit h(hit_id, hit_t, 0.0f, 0.0f);
                 (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
@@ -483,10 +495,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
+            if (UNIFORM) iters++;
         }
     }
     if (live == 0ull) {
         if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+        if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters);
         return;
     }
 
@@ -610,9 +624,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
+            if (UNIFORM) iters++;
         }
     }
     if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
+    if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters);
 }
 
 

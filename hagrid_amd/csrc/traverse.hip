@@ -85,7 +85,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.tris = static_cast<const float4*>(tris);
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
-    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr;
+    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
@@ -204,6 +204,39 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // 1024^2: 0.176 -> 0.171 ms), beyond that none (throughput-bound: +2 % at 1920 x 1080, +10 % at 4096^2).  Not for binned batches
         // (they lose), not while the image is shared between contexts: several batches in flight fill each other's drain and the
         // extra wavefronts only cost issue slots (two in flight: 0.117 -> 0.144 ms per batch).  Hits do not depend on it.
+        // Tile order ("traverse.tile_order", tail kernel, rays in tile-packet order).  A launch of a few rounds of resident wavefronts ends when
+        // the wavefronts that hold its longest rays end, and those start whenever the dispatch order reaches their tiles -- in the default
+        // order half of them in the second round.  Every wavefront therefore leaves the number of iterations it ran (= cells of its longest
+        // ray) at its tile's index, and the NEXT launches over the same ray buffer and count dispatch the tiles longest first (a stable sort of
+        // the costs, one small kernel behind the launch that learns and behind every 16th one after it; equal costs keep the Z order).  Like the
+        // row length this only steers which wavefront takes which rays: hits never depend on it, a buffer refilled with other rays runs on a
+        // stale order until the next refresh (slower at worst), a new buffer or count starts in the default order.
+        // Measured with the reference step counts as the key (tools/dev_wave_timeline.py): 1024^2 0.181 -> 0.152 ms, mean occupancy 0.61 -> 0.79.
+        const int tiles = blocks;
+        bool learn_order = false;
+        const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
+        {
+            const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow;     // (the table-free layout)
+            // by default for launches of up to twelve rounds (2048^2: -4.6 %, 2560^2: -0.7 %, 3072^2: +2.2 %, 4096^2: +5 % -- the tiles of a class of equal
+            // cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
+            // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch)
+            const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
+            const int want = ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
+            // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
+            // again -- every 16th call -- an order already in use stays in use)
+            const bool order_in_use = ctx->lpt_valid && ctx->lpt_rays == rays && ctx->lpt_n == num_rays;
+            const bool rows_known = a.row_len_hint > 0 || (a.row_len && (ctx->rowlen_known > 0 || (ctx->rowlen_known < 0 && order_in_use)));
+            if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, tiles)) {
+                if (ctx->lpt_rays != rays || ctx->lpt_n != num_rays || ctx->lpt_blocks != tiles) {
+                    ctx->lpt_rays = rays; ctx->lpt_n = num_rays; ctx->lpt_blocks = tiles; ctx->lpt_age = 0;
+                    if (ctx->lpt_valid) (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer left)
+                    ctx->lpt_valid = false;
+                }
+                a.tile_cost = ctx->lpt_buf;
+                if (ctx->lpt_valid) a.tile_order = ctx->lpt_buf + ctx->lpt_cap;
+                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= 16;
+            }
+        }
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
         // LDS, trav_kernels.h test_list).  -1 (default): for rays in tile-packet order (1024^2: -2.6 %, 640 x 480: -4.4 %, 2048^2 and
         // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly
@@ -215,6 +248,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool shared = ctx->image.alive && ctx->image.alive.use_count() > 1;
             const long long r100 = 100ll * blocks / std::max(slots, 1ll);           // rounds, in per cent
             quad_pct = (perm || shared) ? 0 : (r100 <= 40 ? 100 : (r100 <= 65 ? 50 : (r100 <= 110 ? 37 : (r100 <= 320 ? 25 : 0))));
+            // in a learned tile order the tiles with the longest rays come first: all tiles of a launch of up to one round start with four lanes
+            // per ray (256^2 ... 960 x 540: -8 ... -23 % against the shares above in the default order), none of a larger one
+            if (a.tile_order && !shared) quad_pct = r100 <= 100 ? 100 : 0;
         }
         if (quad_pct > 0 && ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
@@ -223,6 +259,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
+        if (learn_order) { launch_tile_order(ctx, tiles); ctx->lpt_valid = true; ctx->lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, false, a);
     } else {
@@ -256,7 +293,7 @@ extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
-        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},
+        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},          {"traverse.tile_order", &ctx->opt_tile_order, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},

@@ -680,6 +680,48 @@ def test_row_length_cache_never_changes_hits(mem):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
+def test_tile_order_never_changes_hits(mem):
+    """Launches over a ray buffer the context has seen before dispatch their tiles longest first, by the costs the previous launches left
+    ("traverse.tile_order"; the order is sorted behind the launch that learns and behind every 16th one after it).  It only steers which
+    wavefront takes which rays: one buffer traversed again and again, refilled in between with an image of another width, with unordered rays
+    and with the first image again -- stale orders, orders of another tiling, no order -- gives the oracle's hits at every call, with every share
+    of the tiles starting with four lanes per ray, forced on, by default and off."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(20000, seed=52)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+    n = 128 * 64
+    batches = [scene.make_rays_primary(lo, hi, 128, 64), scene.make_rays_primary(lo, hi, 64, 128),
+               scene.make_rays_incoherent(lo - 0.2, hi + 0.2, n, 31), scene.make_rays_primary(lo, hi, 256, 32)]
+    batches = [np.ascontiguousarray(b, np.float32) for b in batches]
+    want = [G.traverse(tris, b, nthreads=8)[0] for b in batches]
+    api.setup_traversal(grid)
+    assert mem.image_format(grid)["uniform"]                 # the layout whose kernel keeps the costs
+    d_rays = mem.upload(batches[0]); d_hits = mem.alloc(16 * n)
+    try:
+        for order, quad in ((1, -1), (-1, -1), (1, 30), (1, 100), (1, 0), (0, -1)):
+            mem.set_option("traverse.tile_order", order); mem.set_option("traverse.quad_tail", quad)
+            for call in range(72):
+                k = (call // 18) % 4 if call < 54 else (call * 7) % 4     # long runs over one filling (the order is learned, refreshed, reused), then a new filling per call
+                mem.copy_h2d(d_rays, batches[k])
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                assert (got["id"] == want[k]["id"]).all() and (bits(got["t"]) == bits(want[k]["t"])).all(), (order, quad, call, k)
+        # a shorter batch in the same buffer (another tile count: the order starts over), then the long one again
+        mem.set_option("traverse.tile_order", 1); mem.set_option("traverse.quad_tail", -1)
+        mem.copy_h2d(d_rays, batches[0])
+        for call in range(40):
+            m = n if (call // 10) % 2 == 0 else 128 * 40
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, m)
+            got = mem.download(d_hits, api.HIT_DTYPE, m)
+            assert (got["id"] == want[0]["id"][:m]).all() and (bits(got["t"]) == bits(want[0]["t"][:m])).all(), (call, m)
+    finally:
+        mem.set_option("traverse.tile_order", -1); mem.set_option("traverse.quad_tail", -1)
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
 # ---- any-hit and barycentrics (SURVEY 8(f) row 4) ------------------------------------------------------------------------
 
 def test_intersect_prim_ray_with_uvs_matches_reference_header(mem, golden_dir):

@@ -7,7 +7,10 @@ mem = api.MemManager(keep=True)
 tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, tris.shape[0]); api.setup_traversal(grid)
 sizes = [(256, 256), (384, 384), (512, 384), (512, 512), (640, 480), (800, 600), (960, 540), (1024, 768), (1280, 720), (1024, 1024), (1280, 1024), (1536, 1024), (1600, 1200), (1920, 1080)]
-pcts = [0, 12, 25, 37, 50, 62, 75, 100]
+pcts = [0, 12, 25, 37, 50, 75, 100]
+import os
+for kv in filter(None, os.environ.get('OPTS', '').split(',')):
+    k, v = kv.split('='); mem.set_option(k, int(v))
 for w, h in sizes:
     rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, w, h); n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
@@ -16,7 +19,7 @@ for w, h in sizes:
     for rep in range(2):
         for p in pcts:
             mem.set_option("traverse.quad_tail", p)
-            for _ in range(30): go()
+            for _ in range(40): go()
             mem.synchronize()
             ms = sorted(api.profile(lambda: [go() for _ in range(10)], mem) / 10 for _ in range(8))[3]
             row[p] = min(row.get(p, 9e9), ms)

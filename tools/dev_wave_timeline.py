@@ -47,3 +47,17 @@ assert (h1["id"] == h0["id"]).all() and (h1["t"].view(np.uint32) == h0["t"].view
 cls = np.minimum((dur0 / dur0.max() * 8).astype(np.int32), 7)
 dur2, h2 = run(np.argsort(-cls, kind="stable"), "8 duration classes, default order inside")
 print(json.dumps({"corr(duration default, duration LPT run) by tile": float(np.corrcoef(dur0[lpt], dur1)[0, 1])}))
+# LPT by the INTRINSIC work of a tile (reference step counts of its rays: cells + tests), not by a measured duration
+S = 8; tx_n = W // 8
+b = np.arange(nw); band = b // (tx_n * S); in_band = b - band * tx_n * S; col = in_band // (S * S); in_super = in_band - col * S * S
+def compact(v):
+    v = v & 0x55555555; v = (v | (v >> 1)) & 0x33333333; v = (v | (v >> 2)) & 0x0f0f0f0f; v = (v | (v >> 4)) & 0x00ff00ff; v = (v | (v >> 8)) & 0x0000ffff
+    return v
+tx = compact(in_super); ty = compact(in_super >> 1)
+px = ((col * S + tx) << 3)[:, None] + (np.arange(64) & 7)[None, :]; py = ((band * S + ty) << 3)[:, None] + (np.arange(64) >> 3)[None, :]
+tile_steps = steps[py * W + px]
+for label, key in (("longest ray of the tile first", tile_steps.max(axis=1)), ("most work (sum of steps) first", tile_steps.sum(axis=1)),
+                   ("16th longest ray first (what the one-ray-per-lane phase leaves)", np.sort(tile_steps, axis=1)[:, -16])):
+    d, h = run(np.argsort(-key, kind="stable"), label)
+    assert (h["id"] == h0["id"]).all()
+    print(json.dumps({"order": label, "corr(key, duration default order)": float(np.corrcoef(key, dur0)[0, 1])}))
