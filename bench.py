@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--build-iter", type=int, default=10)
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed burst of the same step before the warm-up steps, so that the timed region runs at settled clocks (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-order-compare", action="store_true", help="skip the extra K steps in the default tile order after the timed region (`tile_order` in the line); "
+                    "the counter passes of tools/gpu_round.sh use it so that their per-launch averages are the steady state's")
     ap.add_argument("--inflight", type=int, default=2, help="after the timed region (never part of `value`): the same K steps with this many independent calls in flight, "
                     "one context = one stream each over ONE traversal image (hagrid_share_traversal); reported as `pipelined`; 0 or 1: skip")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-cores baseline sample")
@@ -266,7 +268,7 @@ def main():
     # reference's own benchmark loop measures (main.cpp:398-447: the same rays, iteration after iteration).  The same K steps in the default
     # order (= what the FIRST launch over a new buffer costs) are reported next to it.
     tile_order = None
-    if not bin_rays:
+    if not bin_rays and not args.no_order_compare:
         try:
             mem.set_option("traverse.tile_order", 0)
             for _ in range(max(args.warmup, 1)):

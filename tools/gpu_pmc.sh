@@ -9,7 +9,7 @@ ROOT=$PWD
 i=0
 for set in "$@"; do
   i=$((i+1))
-  (cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$OUT/p$i -o pmc -- python $ROOT/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --build-iter 1 ${BENCH_ARGS} > /dev/null 2> $ROOT/$OUT/p$i.err)
+  (cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$OUT/p$i -o pmc -- python $ROOT/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --build-iter 1 --no-order-compare ${BENCH_ARGS} > /dev/null 2> $ROOT/$OUT/p$i.err)
   python - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/p$i/**/*counter_collection.csv", recursive=True)

@@ -14,7 +14,7 @@ fi
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err
 export TMPDIR=/tmp
 ROOT=$PWD
-BENCH="python $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --inflight 0"   # (the two-in-flight extra stretches its launches: kept out of the per-kernel averages)
+BENCH="python $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --inflight 0 --no-order-compare"   # (the two-in-flight extra stretches its launches: kept out of the per-kernel averages)
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o trace -- $BENCH > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err)
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -o pmc -- $BENCH > /dev/null 2> $ROOT/$OUT/pmc_fetch.err)
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_write -o pmc -- $BENCH > /dev/null 2> $ROOT/$OUT/pmc_write.err)
