@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     }
     // Which tile: position b of the dispatch order, or -- when the previous launch over this ray buffer left its costs -- the tile that
     // order names (longest first, traverse.hip "tile order").  The wavefront leaves its own cost (iterations = cells of its longest ray) behind.
-    int iters = 0;                                        // iterations this wavefront ran
+    int iters = 0;                                        // iterations this wavefront ran, those of phase 1 counted twice: its cost
     int slot;
     {
         const int tile = (UNIFORM && w && a.tile_order) ? a.tile_order[b] : b;     // (the table layout has no register to spare for the bookkeeping)
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
-            if (UNIFORM) iters++;
+            if (UNIFORM) iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
         }
     }
     if (live == 0ull) {

@@ -212,12 +212,14 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // row length this only steers which wavefront takes which rays: hits never depend on it, a buffer refilled with other rays runs on a
         // stale order until the next refresh (slower at worst), a new buffer or count starts in the default order.
         // Measured with the reference step counts as the key (tools/dev_wave_timeline.py): 1024^2 0.181 -> 0.152 ms, mean occupancy 0.61 -> 0.79.
+        // The kernel's own key counts an iteration with one ray per lane twice (its lists' rounds run one after the other): 1024^2 0.1455 ms with
+        // plain iterations, 0.1380 / 0.1389 with that phase counted twice / three times, 0.142 with 2.5 on a key of half the resolution.
         const int tiles = blocks;
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
         {
             const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow;     // (the table-free layout)
-            // by default for launches of up to twelve rounds (2048^2: -4.6 %, 2560^2: -0.7 %, 3072^2: +2.2 %, 4096^2: +5 % -- the tiles of a class of equal
+            // by default for launches of up to ten rounds (2048^2, eight rounds: -5 %; 2560^2: -0.7 %, 3072^2: +2.2 %, 4096^2: +4 % -- the tiles of a class of equal
             // cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
             // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch)
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
