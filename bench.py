@@ -278,7 +278,7 @@ def main():
             tile_order = {"ms_per_step_default_order": round(ms0, 5), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
                           (hits0["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()),
                           "how": "`value` is the steady state of a renderer's loop: tiles dispatched longest first, by the costs the previous launches over the same ray "
-                                 "buffer left (learned in the warm-up steps, refreshed every 16th launch inside the timed region); ms_per_step_default_order = the "
+                                 "buffer left (learned in the warm-up steps, refreshed every 32nd launch); ms_per_step_default_order = the "
                                  "same K steps with traverse.tile_order = 0, i.e. what the first launch over a new buffer costs.  Hits do not depend on the order"}
         except Exception as e:                                       # (an option the library does not know: older build)
             log(f"[bench] tile order block skipped: {e}")

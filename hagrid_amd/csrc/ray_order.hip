@@ -267,40 +267,57 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
 }
 
 // ---- tile order: longest first ---------------------------------------------------------------------------------------------
-// order[0 .. n) = the tile indices sorted by descending cost (clamped to 255), equal costs in index order (so the Z curve survives inside
-// a class); cost[] is cleared for the next launches to fill.  One workgroup: a stable LSD radix sort of 8-bit keys in two 4-bit passes,
-// every thread owning a contiguous chunk of the input (n is a few ten thousand tiles; 16384 tiles: ~6 us, every 16th launch).
-constexpr int kOrderBlock = 512;
-__global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int* __restrict__ tmp, int n) {
-    __shared__ int cnt[16][kOrderBlock];
-    __shared__ int base[16];
-    const int t = threadIdx.x, chunk = (n + kOrderBlock - 1) / kOrderBlock, b0 = min(n, t * chunk), b1 = min(n, b0 + chunk);
-    const int lane = t & 63, wave = t >> 6;
-    for (int pass = 0; pass < 2; pass++) {
-        int* dst = pass ? order : tmp;
-        auto item = [&](int i) { return pass ? tmp[i] : i; };
-        auto digit = [&](int tile) { return ((255 - min(255, max(0, cost[tile]))) >> (4 * pass)) & 15; };
-        for (int d = 0; d < 16; d++) cnt[d][t] = 0;
-        for (int i = b0; i < b1; i++) cnt[digit(item(i))][t]++;
-        __syncthreads();
-        // exclusive prefix over the threads, digit by digit: wavefront w takes digits 2w and 2w + 1
-        for (int d = 2 * wave; d < 2 * wave + 2; d++) {
-            int carry = 0;
-            for (int r = 0; r < kOrderBlock / 64; r++) {
-                const int v = cnt[d][r * 64 + lane], incl = wave_inclusive_scan(v);
-                cnt[d][r * 64 + lane] = carry + incl - v;
-                carry += __shfl(incl, 63, 64);
-            }
-            if (lane == 0) base[d] = carry;
-        }
-        __syncthreads();
-        if (t == 0) { int run = 0; for (int d = 0; d < 16; d++) { const int c = base[d]; base[d] = run; run += c; } }
-        __syncthreads();
-        for (int i = b0; i < b1; i++) { const int tile = item(i), d = digit(tile); dst[base[d] + cnt[d][t]++] = tile; }
-        __threadfence_block();
-        __syncthreads();
+// order[0 .. n) = the tile indices by descending cost (clamped to 4095); cost[] is cleared for the next launches to fill.  One workgroup, a
+// counting sort on the whole key: histogram in LDS (coalesced reads of the costs, LDS atomics), one scan over the 4096 bins, ranks from the
+// bins' counters.  Tiles of equal cost keep their order at the granularity of a sweep (1024 tiles); inside a sweep the LDS atomics decide --
+// the order only steers which wavefront takes which tile.  (A stable radix sort with a chunk of the input per thread took 70 us for
+// 16 384 tiles, every gather of a cost a dependent load: 3 % of the launches it was meant to speed up.)
+constexpr int kOrderBlock = 1024, kOrderBins = 4096;
+__global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int n) {
+    __shared__ int bins[kOrderBins];
+    __shared__ int wave_total[kOrderBlock / 64];
+    const int t = threadIdx.x;
+    for (int k = t; k < kOrderBins; k += kOrderBlock) bins[k] = 0;
+    __syncthreads();
+    auto bin_of = [&](int c) { return kOrderBins - 1 - min(kOrderBins - 1, max(0, c)); };        // descending cost = ascending bin
+    // (up to 32 768 tiles a thread keeps the bins of its tiles in registers: the second sweep over the costs would be sixteen dependent loads)
+    constexpr int kKeep = 32;
+    int mine[kKeep];
+    const bool keep = n <= kKeep * kOrderBlock;
+    if (keep) {
+#pragma unroll
+        for (int r = 0; r < kKeep; r++) { const int i = r * kOrderBlock + t; mine[r] = i < n ? bin_of(cost[i]) : -1; }
+#pragma unroll
+        for (int r = 0; r < kKeep; r++) if (mine[r] >= 0) atomicAdd(&bins[mine[r]], 1);
+    } else {
+        for (int i = t; i < n; i += kOrderBlock) atomicAdd(&bins[bin_of(cost[i])], 1);
     }
-    for (int i = b0; i < b1; i++) cost[i] = 0;
+    __syncthreads();
+    // exclusive scan over the bins: four consecutive bins per thread
+    int c[4], sum = 0;
+    for (int k = 0; k < 4; k++) { c[k] = bins[4 * t + k]; sum += c[k]; }
+    const int incl = wave_inclusive_scan(sum);
+    if ((t & 63) == 63) wave_total[t >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (t >> 6); w++) run += wave_total[w];
+    for (int k = 0; k < 4; k++) { bins[4 * t + k] = run; run += c[k]; }
+    __syncthreads();
+    if (keep) {
+#pragma unroll
+        for (int r = 0; r < kKeep; r++) {
+            if (r * kOrderBlock >= n) break;
+            const int i = r * kOrderBlock + t;
+            if (mine[r] >= 0) { order[atomicAdd(&bins[mine[r]], 1)] = i; cost[i] = 0; }
+            __syncthreads();                                   // (sweep after sweep: equal costs stay in tile order across sweeps)
+        }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += kOrderBlock) {
+            const int i = i0 + t;
+            if (i < n) { order[atomicAdd(&bins[bin_of(cost[i])], 1)] = i; cost[i] = 0; }
+            __syncthreads();
+        }
+    }
 }
 
 struct TableIn { const int* t; __device__ int operator()(int i) const { return t[i]; } };
@@ -324,19 +341,19 @@ void hagrid_trav::launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_
 }
 
 
-// Tile order of the tail kernel (traverse.hip): the buffers of the context grown to `tiles` entries (cost, order, scratch; cost cleared)
+// Tile order of the tail kernel (traverse.hip): the buffers of the context grown to `tiles` entries (cost, order; cost cleared)
 bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, int tiles) {
     if (ctx->lpt_cap >= tiles && ctx->lpt_buf) return true;
     if (ctx->lpt_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->lpt_buf); ctx->lpt_buf = nullptr; ctx->lpt_cap = 0; }
     const int cap = std::max(tiles, 1 << 14);
-    if (hipMalloc((void**)&ctx->lpt_buf, size_t(cap) * 3 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->lpt_buf = nullptr; return false; }
-    (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(cap) * 3 * sizeof(int), ctx->stream);
+    if (hipMalloc((void**)&ctx->lpt_buf, size_t(cap) * 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->lpt_buf = nullptr; return false; }
+    (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(cap) * 2 * sizeof(int), ctx->stream);
     ctx->lpt_cap = cap; ctx->lpt_valid = false;
     return true;
 }
 void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, int tiles) {
-    int* cost = ctx->lpt_buf, *order = cost + ctx->lpt_cap, *scratch = order + ctx->lpt_cap;
-    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, scratch, tiles); HG_DBG(ctx);
+    int* cost = ctx->lpt_buf, *order = cost + ctx->lpt_cap;
+    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles); HG_DBG(ctx);
 }
 
 int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {

@@ -208,7 +208,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // the wavefronts that hold its longest rays end, and those start whenever the dispatch order reaches their tiles -- in the default
         // order half of them in the second round.  Every wavefront therefore leaves the number of iterations it ran (= cells of its longest
         // ray) at its tile's index, and the NEXT launches over the same ray buffer and count dispatch the tiles longest first (a stable sort of
-        // the costs, one small kernel behind the launch that learns and behind every 16th one after it; equal costs keep the Z order).  Like the
+        // the costs, one small kernel behind the launch that learns and behind every 32nd one after it; equal costs keep the Z order).  Like the
         // row length this only steers which wavefront takes which rays: hits never depend on it, a buffer refilled with other rays runs on a
         // stale order until the next refresh (slower at worst), a new buffer or count starts in the default order.
         // Measured with the reference step counts as the key (tools/dev_wave_timeline.py): 1024^2 0.181 -> 0.152 ms, mean occupancy 0.61 -> 0.79.
@@ -236,7 +236,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 }
                 a.tile_cost = ctx->lpt_buf;
                 if (ctx->lpt_valid) a.tile_order = ctx->lpt_buf + ctx->lpt_cap;
-                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= 16;
+                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= 32;
             }
         }
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through

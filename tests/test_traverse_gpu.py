@@ -682,7 +682,7 @@ def test_row_length_cache_never_changes_hits(mem):
 
 def test_tile_order_never_changes_hits(mem):
     """Launches over a ray buffer the context has seen before dispatch their tiles longest first, by the costs the previous launches left
-    ("traverse.tile_order"; the order is sorted behind the launch that learns and behind every 16th one after it).  It only steers which
+    ("traverse.tile_order"; the order is sorted behind the launch that learns and behind every 32nd one after it).  It only steers which
     wavefront takes which rays: one buffer traversed again and again, refilled in between with an image of another width, with unordered rays
     and with the first image again -- stale orders, orders of another tiling, no order -- gives the oracle's hits at every call, with every share
     of the tiles starting with four lanes per ray, forced on, by default and off."""
@@ -703,8 +703,8 @@ def test_tile_order_never_changes_hits(mem):
     try:
         for order, quad in ((1, -1), (-1, -1), (1, 30), (1, 100), (1, 0), (0, -1)):
             mem.set_option("traverse.tile_order", order); mem.set_option("traverse.quad_tail", quad)
-            for call in range(72):
-                k = (call // 18) % 4 if call < 54 else (call * 7) % 4     # long runs over one filling (the order is learned, refreshed, reused), then a new filling per call
+            for call in range(126):
+                k = (call // 36) % 4 if call < 108 else (call * 7) % 4     # long runs over one filling (the order is learned, refreshed, reused), then a new filling per call
                 mem.copy_h2d(d_rays, batches[k])
                 api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
                 got = mem.download(d_hits, api.HIT_DTYPE, n)
