@@ -278,6 +278,7 @@ template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
+    __shared__ int cost_bonus;                            // iterations counted twice at the end (blocks without a one-ray-per-lane phase)
     __shared__ int* cost_at;                              // where this wavefront leaves its cost (its tile's word of a.tile_cost), nullptr: nowhere
     __shared__ float4 tri_lds[DUAL ? 3 * 64 : 1];         // DUAL: a lane's second triangle of a round, written by the load itself (LDS-DMA)
     const int lane = threadIdx.x;
@@ -310,7 +311,9 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     {
         const int tile = (UNIFORM && w && a.tile_order) ? a.tile_order[b] : b;     // (the table layout has no register to spare for the bookkeeping)
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
-        if (UNIFORM && lane == 0) cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr;      // (in LDS: the kernel has no register to spare for the whole traversal)
+        // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
+        // instead -- about what that phase lasts)
+        if (UNIFORM && lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
     }
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
@@ -500,7 +503,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     }
     if (live == 0ull) {
         if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-        if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters);
+        if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
         return;
     }
 
@@ -628,7 +631,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         }
     }
     if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-    if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters);
+    if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
 }
 
 

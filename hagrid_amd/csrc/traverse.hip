@@ -181,9 +181,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             int* row_len = ctx->dscratch + 236;
             const bool same = ctx->opt_row_cache && ctx->rowlen_rays == rays && ctx->rowlen_n == num_rays;
             if (same && ctx->rowlen_pending) {
-                if (hipEventQuery(ctx->rowlen_evt) == hipSuccess) { ctx->rowlen_known = ctx->mailbox[300]; ctx->rowlen_pending = false; }
+                if (hipEventQuery(ctx->rowlen_evt) == hipSuccess) { ctx->rowlen_known = ctx->mailbox[300]; ctx->rowlen_pending = false; ctx->rowlen_seen = ctx->rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
+            if (!same) ctx->rowlen_seen = 0;                              // (the last answer the host has seen for this buffer: outlives the next look)
             if (same && ctx->rowlen_known != 0 && ctx->rowlen_age < 15) ctx->rowlen_age++;
             else {
                 launch_detect(ctx, a, num_rays, row_len);
@@ -225,9 +226,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
             const int want = ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
-            // again -- every 16th call -- an order already in use stays in use)
-            const bool order_in_use = ctx->lpt_valid && ctx->lpt_rays == rays && ctx->lpt_n == num_rays;
-            const bool rows_known = a.row_len_hint > 0 || (a.row_len && (ctx->rowlen_known > 0 || (ctx->rowlen_known < 0 && order_in_use)));
+            // again -- every 16th call -- the last answer counts)
+            const bool rows_known = a.row_len_hint > 0 || (a.row_len && (ctx->rowlen_known > 0 || (ctx->rowlen_known < 0 && ctx->rowlen_seen > 0)));
             if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, tiles)) {
                 if (ctx->lpt_rays != rays || ctx->lpt_n != num_rays || ctx->lpt_blocks != tiles) {
                     ctx->lpt_rays = rays; ctx->lpt_n = num_rays; ctx->lpt_blocks = tiles; ctx->lpt_age = 0;
@@ -236,7 +236,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 }
                 a.tile_cost = ctx->lpt_buf;
                 if (ctx->lpt_valid) a.tile_order = ctx->lpt_buf + ctx->lpt_cap;
-                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= 32;
+                // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
+                // started with four lanes per ray and counted differently -- and behind every 32nd after that)
+                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= ctx->lpt_period;
             }
         }
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
@@ -261,7 +263,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (learn_order) { launch_tile_order(ctx, tiles); ctx->lpt_valid = true; ctx->lpt_age = 0; }
+        if (learn_order) { launch_tile_order(ctx, tiles); ctx->lpt_period = ctx->lpt_valid ? 32 : 1; ctx->lpt_valid = true; ctx->lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, false, a);
     } else {
