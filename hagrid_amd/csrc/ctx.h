@@ -91,7 +91,7 @@ struct hagrid_ctx {
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
-    int opt_tile_order_rounds = 1000;   // ... up to this many rounds of resident wavefronts, in per cent
+    int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
