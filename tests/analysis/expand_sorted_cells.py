@@ -26,7 +26,16 @@ def run(cells_a, entries_a, label):
     print(json.dumps({"cells": label, "expand ms (4 runs)": [round(t, 3) for t in times]}), flush=True)
 
 run(cells, entries, "construction order")
-for label, order in (("by largest face area, ascending", np.argsort(area, kind="stable")), ("by largest face area, descending", np.argsort(-area, kind="stable")),
+def morton(v):
+    v = v.astype(np.uint64); out = np.zeros(v.shape[0], np.uint64)
+    for b in range(10):
+        for a in range(3): out |= ((v[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return out
+top = (c[:, 0:3] >> G.shift)
+top_major = (top[:, 2].astype(np.int64) * G.dims[1] + top[:, 1]) * G.dims[0] + top[:, 0]
+for label, order in (("Morton order of the cells' lower corners", np.argsort(morton(c[:, 0:3]), kind="stable")),
+                     ("top-level cell major (x fastest), construction order inside", np.argsort(top_major, kind="stable")),
+                     ("by largest face area, ascending", np.argsort(area, kind="stable")), ("by largest face area, descending", np.argsort(-area, kind="stable")),
                      ("random", np.random.default_rng(1).permutation(cells.shape[0]))):
     new_id = np.empty(cells.shape[0], np.int64); new_id[order] = np.arange(cells.shape[0])
     e = entries.astype(np.uint32).copy()
