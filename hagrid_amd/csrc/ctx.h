@@ -61,7 +61,7 @@ struct hagrid_ctx {
     // profile()
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
-    // pinned mailbox for scalar read-backs (build passes) -- 256 ints, + words 256.. for values the host only polls (word 300: row length)
+    // pinned mailbox for scalar read-backs (build passes) -- 256 ints, + words 256.. for values the host only polls (words 300 .. 303: row lengths)
     int* mailbox = nullptr;
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
@@ -84,10 +84,19 @@ struct hagrid_ctx {
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
     int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
-    const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
-    hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
-    // tile order of the tail kernel (traverse.hip): cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
-    int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
+    // What the context remembers about a ray buffer it has traversed (traverse.hip): the row length found for it and the order of its tiles.  A few
+    // buffers are remembered at once (a renderer that alternates between two or three ray buffers keeps the hints of each); the least recently used
+    // slot is taken over by a new buffer.  Slot i owns the device word dscratch[236 + i] and the pinned word mailbox[300 + i].
+    struct RayHints {
+        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
+        hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
+        // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
+        int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
+        unsigned long long used = 0;                    // clock of the last call that used the slot
+    };
+    static constexpr int kRayHints = 4;
+    RayHints hints[kRayHints];
+    unsigned long long hint_clock = 0;
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch

@@ -39,18 +39,17 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->rowlen_pending = false;                                       // (its copy and event are behind the synchronisation above)
+    for (auto& h : ctx->hints) h.rowlen_pending = false;               // (their copies and events are behind the synchronisation above)
     if (!ctx->image.borrowed && ctx->image.alive) ctx->image.alive->store(false);      // borrowers of this context's image: refused from now on
     for (auto& s : ctx->slots)
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
-    if (ctx->rowlen_evt) (void)hipEventDestroy(ctx->rowlen_evt);
+    for (auto& h : ctx->hints) { if (h.rowlen_evt) (void)hipEventDestroy(h.rowlen_evt); if (h.lpt_buf) (void)hipFree(h.lpt_buf); }
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);
     if (ctx->row_scores) (void)hipFree(ctx->row_scores);
-    if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
     if (ctx->lb_state) (void)hipFree(ctx->lb_state);
     delete ctx;
 }

@@ -342,17 +342,17 @@ void hagrid_trav::launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_
 
 
 // Tile order of the tail kernel (traverse.hip): the buffers of the context grown to `tiles` entries (cost, order; cost cleared)
-bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, int tiles) {
-    if (ctx->lpt_cap >= tiles && ctx->lpt_buf) return true;
-    if (ctx->lpt_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->lpt_buf); ctx->lpt_buf = nullptr; ctx->lpt_cap = 0; }
+bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles) {
+    if (h.lpt_cap >= tiles && h.lpt_buf) return true;
+    if (h.lpt_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(h.lpt_buf); h.lpt_buf = nullptr; h.lpt_cap = 0; }
     const int cap = std::max(tiles, 1 << 14);
-    if (hipMalloc((void**)&ctx->lpt_buf, size_t(cap) * 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ctx->lpt_buf = nullptr; return false; }
-    (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(cap) * 2 * sizeof(int), ctx->stream);
-    ctx->lpt_cap = cap; ctx->lpt_valid = false;
+    if (hipMalloc((void**)&h.lpt_buf, size_t(cap) * 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); h.lpt_buf = nullptr; return false; }
+    (void)hipMemsetAsync(h.lpt_buf, 0, size_t(cap) * 2 * sizeof(int), ctx->stream);
+    h.lpt_cap = cap; h.lpt_valid = false;
     return true;
 }
-void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, int tiles) {
-    int* cost = ctx->lpt_buf, *order = cost + ctx->lpt_cap;
+void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles) {
+    int* cost = h.lpt_buf, *order = cost + h.lpt_cap;
     tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles); HG_DBG(ctx);
 }
 

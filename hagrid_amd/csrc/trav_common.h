@@ -270,8 +270,8 @@ constexpr int kOriginMinRays = 1 << 22;
 void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays);
 // ray_order.hip: the tail kernel's tile order (longest tile first): buffers of the context for `tiles` tiles; order <- the costs the
 // launches since the last call left, costs cleared
-bool tile_order_buffers(hagrid_ctx* ctx, int tiles);
-void launch_tile_order(hagrid_ctx* ctx, int tiles);
+bool tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
+void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
 // ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the
 // automatic mode) from buffers of `tmp`, or leaves a.perm null for batches too small to bin
 int bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp);

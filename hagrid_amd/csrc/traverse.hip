@@ -139,6 +139,19 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     bool publish_row_len = false;
     HG_TRY(bin_rays(ctx, a, num_rays, tmp));
     const int* perm = a.perm;
+    // the hints kept for this ray buffer (row length, tile order): its slot, or the least recently used one (which then forgets its buffer)
+    int hint_slot = 0;
+    {
+        int lru = 0;
+        bool found = false;
+        for (int i = 0; i < hagrid_ctx::kRayHints && !found; i++) {
+            if (ctx->hints[i].rowlen_rays == rays && ctx->hints[i].rowlen_n == num_rays) { hint_slot = i; found = true; }
+            if (ctx->hints[i].used < ctx->hints[lru].used) lru = i;
+        }
+        if (!found) hint_slot = lru;
+        ctx->hints[hint_slot].used = ++ctx->hint_clock;
+    }
+    hagrid_ctx::RayHints& H = ctx->hints[hint_slot];
     // Kernel choice.  With a traversal image (hagrid_setup_traversal built one for this very grid) its kernel is used for every
     // batch; without one the latency-oriented v2 walks the construction format (trav_plain.hip).
     // hagrid_set_option("traverse.variant", 1|2|4) forces the reference-shaped kernel, v2 or the image kernel (tests, experiments).
@@ -178,17 +191,17 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // polls) and never keeps "not image-ordered" once it has seen it, so a buffer that alternates between unordered rays and an
             // image looks every time.  A buffer refilled with rows of another length runs on the stale length for at most 15 calls --
             // slower, never wrong.
-            int* row_len = ctx->dscratch + 236;
-            const bool same = ctx->opt_row_cache && ctx->rowlen_rays == rays && ctx->rowlen_n == num_rays;
-            if (same && ctx->rowlen_pending) {
-                if (hipEventQuery(ctx->rowlen_evt) == hipSuccess) { ctx->rowlen_known = ctx->mailbox[300]; ctx->rowlen_pending = false; ctx->rowlen_seen = ctx->rowlen_known; }
+            int* row_len = ctx->dscratch + 236 + hint_slot;
+            const bool same = ctx->opt_row_cache && H.rowlen_rays == rays && H.rowlen_n == num_rays;
+            if (same && H.rowlen_pending) {
+                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { H.rowlen_known = ctx->mailbox[300 + hint_slot]; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
-            if (!same) ctx->rowlen_seen = 0;                              // (the last answer the host has seen for this buffer: outlives the next look)
-            if (same && ctx->rowlen_known != 0 && ctx->rowlen_age < 15) ctx->rowlen_age++;
+            if (!same) H.rowlen_seen = 0;                              // (the last answer the host has seen for this buffer: outlives the next look)
+            if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
             else {
                 launch_detect(ctx, a, num_rays, row_len);
-                ctx->rowlen_rays = rays; ctx->rowlen_n = num_rays; ctx->rowlen_age = 0; ctx->rowlen_known = -1;
+                H.rowlen_rays = rays; H.rowlen_n = num_rays; H.rowlen_age = 0; H.rowlen_known = -1;
                 publish_row_len = ctx->opt_row_cache != 0;
             }
             a.row_len = row_len;
@@ -227,18 +240,18 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const int want = ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
-            const bool rows_known = a.row_len_hint > 0 || (a.row_len && (ctx->rowlen_known > 0 || (ctx->rowlen_known < 0 && ctx->rowlen_seen > 0)));
-            if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, tiles)) {
-                if (ctx->lpt_rays != rays || ctx->lpt_n != num_rays || ctx->lpt_blocks != tiles) {
-                    ctx->lpt_rays = rays; ctx->lpt_n = num_rays; ctx->lpt_blocks = tiles; ctx->lpt_age = 0;
-                    if (ctx->lpt_valid) (void)hipMemsetAsync(ctx->lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer left)
-                    ctx->lpt_valid = false;
+            const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
+            if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, H, tiles)) {
+                if (H.lpt_rays != rays || H.lpt_n != num_rays || H.lpt_blocks != tiles) {
+                    H.lpt_rays = rays; H.lpt_n = num_rays; H.lpt_blocks = tiles; H.lpt_age = 0;
+                    if (H.lpt_valid) (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer left)
+                    H.lpt_valid = false;
                 }
-                a.tile_cost = ctx->lpt_buf;
-                if (ctx->lpt_valid) a.tile_order = ctx->lpt_buf + ctx->lpt_cap;
+                a.tile_cost = H.lpt_buf;
+                if (H.lpt_valid) a.tile_order = H.lpt_buf + H.lpt_cap;
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
-                learn_order = !ctx->lpt_valid || ++ctx->lpt_age >= ctx->lpt_period;
+                learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
             }
         }
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
@@ -263,7 +276,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (learn_order) { launch_tile_order(ctx, tiles); ctx->lpt_period = ctx->lpt_valid ? 32 : 1; ctx->lpt_valid = true; ctx->lpt_age = 0; }
+        if (learn_order) { launch_tile_order(ctx, H, tiles); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, false, a);
     } else {
@@ -278,10 +291,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     HG_DBG(ctx);                                   // the traversal kernel launched by one of the helpers above
     HG_HIP(ctx, hipGetLastError());
     if (publish_row_len) {                         // behind the traversal launch: nobody waits for it
-        if (!ctx->rowlen_evt) HG_HIP(ctx, hipEventCreateWithFlags(&ctx->rowlen_evt, hipEventDisableTiming));
-        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox + 300, ctx->dscratch + 236, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HG_HIP(ctx, hipEventRecord(ctx->rowlen_evt, ctx->stream));
-        ctx->rowlen_pending = true;
+        if (!H.rowlen_evt) HG_HIP(ctx, hipEventCreateWithFlags(&H.rowlen_evt, hipEventDisableTiming));
+        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox + 300 + hint_slot, ctx->dscratch + 236 + hint_slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HG_HIP(ctx, hipEventRecord(H.rowlen_evt, ctx->stream));
+        H.rowlen_pending = true;
     }
     return HAGRID_OK;
 }

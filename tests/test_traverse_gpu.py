@@ -717,6 +717,16 @@ def test_tile_order_never_changes_hits(mem):
             api.traverse_grid(grid, d_tris, d_rays, d_hits, m)
             got = mem.download(d_hits, api.HIT_DTYPE, m)
             assert (got["id"] == want[0]["id"][:m]).all() and (bits(got["t"]) == bits(want[0]["t"][:m])).all(), (call, m)
+        # several buffers in turn (the context keeps the hints of four): five buffers over four slots, two of them traded places half way
+        bufs = [mem.upload(batches[k % 4]) for k in range(5)]
+        for call in range(150):
+            j = call % 5 if call < 100 else (call * 3) % 5
+            if call == 75: mem.copy_h2d(bufs[1], batches[3]); mem.copy_h2d(bufs[3], batches[1])
+            k = (j % 4) if call < 75 or j not in (1, 3) else (3 if j == 1 else 1)
+            api.traverse_grid(grid, d_tris, bufs[j], d_hits, n)
+            got = mem.download(d_hits, api.HIT_DTYPE, n)
+            assert (got["id"] == want[k]["id"]).all() and (bits(got["t"]) == bits(want[k]["t"])).all(), ("buffers in turn", call, j, k)
+        for b in bufs: mem.free(b)
     finally:
         mem.set_option("traverse.tile_order", -1); mem.set_option("traverse.quad_tail", -1)
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
