@@ -88,6 +88,7 @@ struct hagrid_ctx {
     // buffers are remembered at once (a renderer that alternates between two or three ray buffers keeps the hints of each); the least recently used
     // slot is taken over by a new buffer.  Slot i owns the device word dscratch[236 + i] and the pinned word mailbox[300 + i].
     struct RayHints {
+        const void* key_rays = nullptr; int key_n = 0;       // the buffer the slot belongs to
         const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)

@@ -145,10 +145,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         int lru = 0;
         bool found = false;
         for (int i = 0; i < hagrid_ctx::kRayHints && !found; i++) {
-            if (ctx->hints[i].rowlen_rays == rays && ctx->hints[i].rowlen_n == num_rays) { hint_slot = i; found = true; }
+            if (ctx->hints[i].key_rays == rays && ctx->hints[i].key_n == num_rays) { hint_slot = i; found = true; }
             if (ctx->hints[i].used < ctx->hints[lru].used) lru = i;
         }
-        if (!found) hint_slot = lru;
+        if (!found) {
+            hint_slot = lru;
+            hagrid_ctx::RayHints& N = ctx->hints[lru];
+            N.key_rays = rays; N.key_n = num_rays;
+            N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
+            N.lpt_rays = nullptr; N.lpt_valid = false;
+        }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
     }
     hagrid_ctx::RayHints& H = ctx->hints[hint_slot];
@@ -244,7 +250,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, H, tiles)) {
                 if (H.lpt_rays != rays || H.lpt_n != num_rays || H.lpt_blocks != tiles) {
                     H.lpt_rays = rays; H.lpt_n = num_rays; H.lpt_blocks = tiles; H.lpt_age = 0;
-                    if (H.lpt_valid) (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer left)
+                    (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer may have left)
                     H.lpt_valid = false;
                 }
                 a.tile_cost = H.lpt_buf;

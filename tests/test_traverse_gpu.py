@@ -727,7 +727,14 @@ def test_tile_order_never_changes_hits(mem):
             got = mem.download(d_hits, api.HIT_DTYPE, n)
             assert (got["id"] == want[k]["id"]).all() and (bits(got["t"]) == bits(want[k]["t"])).all(), ("buffers in turn", call, j, k)
         for b in bufs: mem.free(b)
+        # the row length given by the caller instead of looked for ("traverse.image_width"): the order applies from the second call on
+        mem.set_option("traverse.image_width", 128); mem.copy_h2d(d_rays, batches[0])
+        for call in range(40):
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            got = mem.download(d_hits, api.HIT_DTYPE, n)
+            assert (got["id"] == want[0]["id"]).all() and (bits(got["t"]) == bits(want[0]["t"])).all(), ("given width", call)
     finally:
+        mem.set_option("traverse.image_width", 0)
         mem.set_option("traverse.tile_order", -1); mem.set_option("traverse.quad_tail", -1)
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
