@@ -373,7 +373,7 @@ def main():
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
                        "baseline_config": args.config, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
                        "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: f"flat blocks: one {record_bytes}-byte record per voxel, built by setup_traversal"}[args.image],
-                       "ray_packets": "8x8 pixel tiles, row length detected on the device (kept per ray buffer, looked for again every 16th call; buffer stays in image order)",
+                       "ray_packets": "8x8 pixel tiles, row length detected on the device (kept per ray buffer, looked for again every 16th call; buffer stays in image order); from the second launch over a buffer on the tiles are dispatched longest first, by the costs the previous launches left (`tile_order`)",
                        "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",
                        "grid": grid.summary(), "device": info},
             "build_ms": None if build_ms is None else round(build_ms, 3),                   # mean of --build-iter full constructions after two warm-up builds
