@@ -309,11 +309,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     int iters = 0;                                        // iterations this wavefront ran, those of phase 1 counted twice: its cost
     int slot;
     {
-        const int tile = (UNIFORM && w && a.tile_order) ? a.tile_order[b] : b;     // (the table layout has no register to spare for the bookkeeping)
+        const int tile = (w && a.tile_order) ? a.tile_order[b] : b;
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
         // instead -- about what that phase lasts)
-        if (UNIFORM && lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
+        if (lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
     }
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
@@ -498,12 +498,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
-            if (UNIFORM) iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
+            iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
         }
     }
     if (live == 0ull) {
         if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-        if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
+        if (lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
         return;
     }
 
@@ -627,11 +627,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
-            if (UNIFORM) iters++;
+            iters++;
         }
     }
     if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-    if (UNIFORM && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
+    if (lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
 }
 
 

@@ -238,7 +238,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
         {
-            const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow;     // (the table-free layout)
+            const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow;
             // by default for launches of up to 25 rounds (2048^2, eight rounds: -8 %; 2560^2: -4.9 %, 3072^2, 18 rounds: -1.3 %, 4096^2, 32 rounds: +-0 -- the tiles
             // of a class of equal cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
             // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch)

@@ -271,7 +271,7 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * phase of the tail kernel tests two ids of an inline list per round trip, the second triangle loaded straight into LDS, 0 = one id per
  * round trip, -1 (default) = 1 unless the batch is binned; "traverse.tile_order": 1 = launches over a ray buffer (pointer and count) the context has
  * traversed before dispatch their 8 x 8 tiles longest first, by the costs the previous launches left (every wavefront leaves the iterations it ran at its
- * tile; a stable sort behind the launch that learns and behind every 32nd one after it; the table-free image layout with rays in image order), 0 = always
+ * tile; a stable sort behind the launch that learns and behind every 32nd one after it; slim-record images, rays in image order), 0 = always
  * the default order, -1 (default) = 1 for launches of up to "traverse.tile_order_rounds" per cent (default 2500) of a round of resident wavefronts whose
  * image is not shared between contexts -- like the row length it only steers which wavefront takes which rays, hits never depend on it;
  * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel

@@ -680,7 +680,8 @@ def test_row_length_cache_never_changes_hits(mem):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
-def test_tile_order_never_changes_hits(mem):
+@pytest.mark.parametrize("params", [{}, dict(top_density=0.15, snd_density=3.0)], ids=["table_free", "table_layout"])
+def test_tile_order_never_changes_hits(mem, params):
     """Launches over a ray buffer the context has seen before dispatch their tiles longest first, by the costs the previous launches left
     ("traverse.tile_order"; the order is sorted behind the launch that learns and behind every 32nd one after it).  It only steers which
     wavefront takes which rays: one buffer traversed again and again, refilled in between with an image of another width, with unordered rays
@@ -689,7 +690,7 @@ def test_tile_order_never_changes_hits(mem):
     from oracle import oracle as O
     from hagrid_amd import api
     tris = scene.make_soup(20000, seed=52)
-    G = O.Grid.full(tris)
+    G = O.Grid.full(tris, **params)
     d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
     lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
     n = 128 * 64
@@ -698,7 +699,8 @@ def test_tile_order_never_changes_hits(mem):
     batches = [np.ascontiguousarray(b, np.float32) for b in batches]
     want = [G.traverse(tris, b, nthreads=8)[0] for b in batches]
     api.setup_traversal(grid)
-    assert mem.image_format(grid)["uniform"]                 # the layout whose kernel keeps the costs
+    info = mem.image_format(grid)
+    assert info["slim_id_bits"] == 20 and info["uniform"] == (not params), info          # both layouts of the tail kernel
     d_rays = mem.upload(batches[0]); d_hits = mem.alloc(16 * n)
     try:
         for order, quad in ((1, -1), (-1, -1), (1, 30), (1, 100), (1, 0), (0, -1)):

@@ -15,9 +15,11 @@ mem = api.MemManager(keep=True)
 for kv in filter(None, os.environ.get("OPTS", "").split(",")):
     k, v = kv.split("="); mem.set_option(k, int(v))
 td, sd = (0.15, 3.0) if "config3" in batch else (0.12, 2.4)
+td, sd = float(os.environ.get("TD", td)), float(os.environ.get("SD", sd))          # (other grids of the same scene: TD=0.15 SD=3.0 primary 1024^2 ...)
 tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
 api.setup_traversal(grid)
+print(json.dumps({"grid": grid.summary(), "image": mem.image_format(grid)}), flush=True)
 gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
         "primary 2048^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 2048, 2048),
         "primary 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
