@@ -274,7 +274,9 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
 // top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
 // DUAL: phase 1 tests the ids of an inline list two per round trip (see test_list)
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false>
+// COST: the wavefront counts its iterations and leaves them at its tile (the tile order of traverse.hip); the table layout pays for that bookkeeping with
+// a dozen spilled registers around its loops, so launches of it that keep no costs run the instantiation without
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
@@ -309,11 +311,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     int iters = 0;                                        // iterations this wavefront ran, those of phase 1 counted twice: its cost
     int slot;
     {
-        const int tile = (w && a.tile_order) ? a.tile_order[b] : b;
+        const int tile = (COST && w && a.tile_order) ? a.tile_order[b] : b;
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
         // instead -- about what that phase lasts)
-        if (lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
+        if (COST && lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
     }
     const bool valid = slot < a.num_rays;
     int id = valid ? (perm ? perm[slot] : slot) : 0;
@@ -498,12 +500,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
-            iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
+            if (COST) iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
         }
     }
     if (live == 0ull) {
         if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-        if (lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
+        if (COST && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
         return;
     }
 
@@ -627,11 +629,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 ca = na;
             }
             live = __ballot(alive);
-            iters++;
+            if (COST) iters++;
         }
     }
     if (pending) nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f);
-    if (lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
+    if (COST && lane == 0 && cost_at) atomicMax(cost_at, iters + min(iters, cost_bonus));
 }
 
 

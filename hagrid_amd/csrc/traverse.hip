@@ -25,8 +25,14 @@ template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
     if (tail && MODE == 0 && slim && !uniform) {
-        if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);      // (the table layout has no registers to spare for the second request)
-        else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+        // (the table layout has no registers to spare for the second request of "traverse.tail_dual", and keeps costs for the tile order only where asked to)
+        if (a.tile_cost) {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
     }
     else if (tail && MODE == 0 && uniform && slim) {
         if (a.tail_dual) {
