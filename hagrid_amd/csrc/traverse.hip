@@ -160,6 +160,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
             N.lpt_rays = nullptr; N.lpt_valid = false;
+            // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
+            // row length counts as seen (the kernel reads the one found for THIS buffer either way), its tile order is the first order (below).
+            const hagrid_ctx::RayHints* donor = nullptr;
+            for (const auto& d : ctx->hints)
+                if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
+            if (donor) N.rowlen_seen = donor->rowlen_seen;
         }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
     }
@@ -209,7 +215,6 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 if (hipEventQuery(H.rowlen_evt) == hipSuccess) { H.rowlen_known = ctx->mailbox[300 + hint_slot]; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
-            if (!same) H.rowlen_seen = 0;                              // (the last answer the host has seen for this buffer: outlives the next look)
             if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
             else {
                 launch_detect(ctx, a, num_rays, row_len);
@@ -258,6 +263,15 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     H.lpt_rays = rays; H.lpt_n = num_rays; H.lpt_blocks = tiles; H.lpt_age = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer may have left)
                     H.lpt_valid = false;
+                    // the order of the most recently used buffer of the same shape, if there is one
+                    const hagrid_ctx::RayHints* donor = nullptr;
+                    for (const auto& d : ctx->hints)
+                        if (&d != &H && d.lpt_valid && d.lpt_buf && d.lpt_n == num_rays && d.lpt_blocks == tiles && (!donor || d.used > donor->used)) donor = &d;
+                    if (donor && hipMemcpyAsync(H.lpt_buf + H.lpt_cap, donor->lpt_buf + donor->lpt_cap, size_t(tiles) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) {
+                        // (the stand-in's refresh count goes on: buffers that come and go -- a new allocation per frame -- still re-sort every 32nd launch,
+                        // from the costs of that one launch: every wavefront of a launch leaves its cost)
+                        H.lpt_valid = true; H.lpt_period = 32; H.lpt_age = donor->lpt_age;
+                    }
                 }
                 a.tile_cost = H.lpt_buf;
                 if (H.lpt_valid) a.tile_order = H.lpt_buf + H.lpt_cap;
