@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 otherwise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("--shard", default=None, metavar="R/W", help="one GPU, strong scaling only: trace the contiguous range rank R of W ranks would get (the per-GPU share of an 8-GPU run, "
+                    "e.g. --config 4 --shard 3/8 = 16M of the 128M rays); `value` is then this GPU's rate on that share, the line says so in config.shard")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, broadcast, all-reduce) even with one rank")
     args = ap.parse_args()
 
@@ -185,8 +187,15 @@ def main():
         total = args.total_rays or cfg.get("total", width * height)
     else:
         total = width * height
+    shard = None
+    if args.shard:
+        if world != 1 or scaling != "strong":
+            raise SystemExit("--shard R/W is the one-GPU view of a strong-scaling run: needs --gpus 1 and strong scaling")
+        shard = tuple(int(v) for v in args.shard.split("/"))
+        if not (len(shard) == 2 and 0 <= shard[0] < shard[1]):
+            raise SystemExit("--shard R/W: 0 <= R < W")
     if scaling == "strong":
-        first, end = scene.shard_range(total, rank, world)
+        first, end = scene.shard_range(total, *(shard or (rank, world)))
         n_rays = end - first
         sample, nsamples = 0, 1
     else:
@@ -341,15 +350,21 @@ def main():
         # measured.  A file measured on other sources is refused: traffic = null, traffic_source says "stale".
         from hagrid_amd import build as _build
         src_hash = _build.source_hash()
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and world == 1 and args.config == 2 and args.image == 2 and n_tris == 1_000_000 and (width, height) == (1024, 1024):
+        # config 2: profiles/traffic_latest.json (tools/gpu_round.sh); the other configurations: profiles/traffic_config<C>.json
+        # (tools/gpu_traffic_config.sh), which also names the ray count of the launch it measured -- a line over another count gets none
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.config == 2 else f"traffic_config{args.config}.json")
+        counters = None
+        std_shape = args.image == 2 and n_tris == cfg["tris"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
+        if os.path.exists(tpath) and world == 1 and std_shape:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("source_hash") == src_hash:
-                    traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate")
-                    traffic_source = f"profiles/traffic_latest.json (kernel sources {src_hash}, commit {tj.get('commit', '?')}): " + tj.get("source", "")
+                if tj.get("source_hash") != src_hash:
+                    traffic_source = f"stale: {os.path.relpath(tpath, ROOT)} measured kernel sources {tj.get('source_hash', 'unknown')}, this run has {src_hash}"
+                elif tj.get("rays", n_rays) != n_rays:
+                    traffic_source = f"other batch: {os.path.relpath(tpath, ROOT)} measured launches of {tj.get('rays')} rays, this run has {n_rays}"
                 else:
-                    traffic_source = f"stale: profiles/traffic_latest.json measured kernel sources {tj.get('source_hash', 'unknown')}, this run has {src_hash}"
+                    traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate"); counters = tj.get("counters")
+                    traffic_source = f"{os.path.relpath(tpath, ROOT)} (kernel sources {src_hash}, commit {tj.get('commit', '?')}): " + tj.get("source", "")
             except Exception as e:
                 traffic = None; traffic_source = f"unreadable: {e}"
         fmt = mem.image_format(grid) if args.image else {}
@@ -369,9 +384,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['baseline']} -- soup-{n_tris} triangles, "
                                    + (f"{ray_kind} rays, {total} in the batch" + (f" ({width}x{height})" if ray_kind != "incoherent" else ""))
-                                   + (f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
+                                   + (f", rays [{first}, {first + n_rays}) = the share of rank {shard[0]} of {shard[1]}, on ONE GPU" if shard else f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
-                       "baseline_config": args.config, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
+                       "baseline_config": args.config, "shard": args.shard, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
                        "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: f"flat blocks: one {record_bytes}-byte record per voxel, built by setup_traversal"}[args.image],
                        "ray_packets": "8x8 pixel tiles, row length detected on the device (kept per ray buffer, looked for again every 16th call; buffer stays in image order); from the second launch over a buffer on the tiles are dispatched longest first, by the costs the previous launches left (`tile_order`)",
                        "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",

@@ -25,7 +25,8 @@ int hagrid_kat_lookup_entry(hagrid_ctx* ctx, const uint32_t* entries, int num_en
                             const int32_t* voxels3, int n, uint32_t* out);
 /* The device-wide ordered exclusive scan the construction passes use in place of cub::DeviceScan::ExclusiveSum (parallel.cuh:31-42):
  * out[i] = carry + sum of values[0..i), total = carry + sum of all; words = 1 (int) or 2 (pairs of ints, interleaved); carry_in =
- * `words` ints or NULL; lookback != 0 runs the single-pass decoupled look-back form, 0 the three-kernel reduce-then-scan form. */
+ * `words` ints or NULL; lookback: 0 the three-kernel reduce-then-scan form, 1 the single-pass decoupled look-back form, 2 the same with the
+ * helping path taken at the first miss; + 4: the scan runs IN PLACE (output over the input, as several passes call it). */
 int hagrid_kat_scan(hagrid_ctx* ctx, const int32_t* values, int n, int words, const int32_t* carry_in, int lookback,
                     int32_t* out, int32_t* total);
 /* Tile packets (see "traverse.image_width"): the row length the device finds for a ray buffer in device memory (0 = not

@@ -23,7 +23,9 @@ extern "C" int hagrid_kat_scan(hagrid_ctx* ctx, const int32_t* values, int n, in
     PoolTemps tmp(ctx);
     const size_t bytes = size_t(n) * size_t(words) * sizeof(int);
     int* d_in = tmp.get<int>(size_t(n) * words + 2);
-    int* d_out = tmp.get<int>(size_t(n) * words + 2);
+    const bool in_place = (lookback & 4) != 0;             // the scan overwrites its input (merge.hip tile sums, ray_order.hip bin table, trav_image.hip sizes do)
+    lookback &= 3;
+    int* d_out = in_place ? d_in : tmp.get<int>(size_t(n) * words + 2);
     int* partials = tmp.get<int>(size_t(words) * (size_t(scan_num_tiles(n)) + 1));
     int* scalars = tmp.get<int>(8);                          // [0..1] carry in, [2..3] total out
     if (!d_in || !d_out || !partials || !scalars) return HAGRID_ENOMEM;

@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(kBlock) scan_apply(In in, Out out, int n, cons
 // resident of this kernel: then all of them run and the lowest unfinished tile always belongs to a running workgroup that has nothing
 // left to wait for.  The device need not be empty, though (other contexts, streams, processes), and the contract promises nothing about
 // dispatch order or residency -- so nobody waits for ever: a lane whose predecessor tile has not published anything after `help_after`
-// polls computes that tile's aggregate ITSELF from the items (any workgroup may: an aggregate is a pure function of the input) and goes
-// on.  In the worst case a workgroup sums its way back to tile 0 alone: slow, never stuck.  (Round 3 first handed tiles out by a
+// polls computes that tile's aggregate ITSELF from the items (any workgroup may: an aggregate is a pure function of the input; scans in
+// place: see the second look behind the sum) and goes on.  In the worst case a workgroup sums its way back to tile 0 alone: slow, never stuck.  (Round 3 first handed tiles out by a
 // ticket counter instead: a same-address atomic per workgroup and tile, ~88 per us -- 3600-tile scans took 38 instead of 20 us.)
 constexpr int kLbVec = 4;                            // consecutive items per lane and row
 constexpr int kLbItems = 8;                          // items per thread of the look-back scan
@@ -325,6 +325,13 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
                                     for (int i = first; i < last; i++) sum = sum + in(i);
                                     if (t == 0 && carry_in) sum = sum + *carry_in;       // tile 0's inclusive prefix starts from the carry
                                     pv[w] = sum; flag[w] = t == 0 ? kLbPrefix : kLbAggregate; ok[w] = true;
+                                    // Several callers scan IN PLACE (out(i) overwrites what in(i) reads).  An owner that was only late publishes and then
+                                    // stores its outputs, so the serial sum above may have read a mix of items and outputs.  Look once more, ordered behind
+                                    // the reads of the sum: a word published by now wins and the sum is dropped; a tile still unpublished has stored no output
+                                    // yet (outputs follow the owner's publish), so everything the sum read was input.
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                    V pub = zero_of(V()); unsigned pflag = 0u;
+                                    if (lb_try(state, t, epoch, pub, pflag)) { pv[w] = pub; flag[w] = pflag; }
                                 }
                             }
                             all = all && ok[w];

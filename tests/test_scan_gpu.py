@@ -30,7 +30,7 @@ def scan(mem, values, words, carry, lookback):
     return out, total
 
 
-@pytest.mark.parametrize("lookback", [1, 0, 2])
+@pytest.mark.parametrize("lookback", [1, 0, 2, 1 | 4, 2 | 4, 0 | 4])      # + 4: in place (a helper must not sum a tile its owner is overwriting)
 @pytest.mark.parametrize("words", [1, 2])
 def test_scan_sizes_and_carry(mem, words, lookback):
     rng = np.random.default_rng(7)
@@ -64,3 +64,17 @@ def test_scan_negative_values_and_wraparound(mem):
         out, total = scan(mem, v, 1, None, lookback)
         want = (np.concatenate([[0], np.cumsum(v.astype(np.int64))[:-1]]) & 0xffffffff).astype(np.uint32).view(np.int32)
         assert (out == want).all()
+
+
+def test_scan_in_place_forced_helping_repeated(mem):
+    """The helping path on scans that overwrite their input (merge.hip tile sums, ray_order.hip bin table, trav_image.hip sizes): every
+    lane helps at its first miss while the owners of those tiles are alive and storing outputs over the items -- a helper that summed a
+    half-overwritten tile would publish a wrong aggregate.  Many repetitions: the window is a race."""
+    rng = np.random.default_rng(23)
+    for it in range(60):
+        words = 1 + (it & 1)
+        n = int(rng.integers(200 * TILE, 900 * TILE))
+        v = rng.integers(1, 1000, size=(n, words), dtype=np.int32)
+        out, total = scan(mem, v.reshape(-1), words, None, 2 | 4)
+        incl = np.cumsum(v.astype(np.int64), axis=0)
+        assert (out.reshape(n, words)[1:] == incl[:-1]).all() and (out.reshape(n, words)[0] == 0).all() and (total == incl[-1]).all(), it
