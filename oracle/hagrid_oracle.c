@@ -24,11 +24,15 @@
  * traversal steps; tests/test_oracle_golden.py, tools/dev_cuda_quirks.py); hits are the same either way.  The product implements
  * the documented intent (mask 0).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE          /* pthread_setaffinity_np, cpu_set_t (the all-cores CPU baseline pins its threads) */
+#endif
 #include "hagrid_oracle.h"
 
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1158,39 +1162,61 @@ void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, i
     g_trace = NULL; g_trace_ids = NULL;
 }
 
+/* Threads take chunks of kChunk consecutive rays from one shared counter (dynamic scheduling: ray costs differ by two orders of
+ * magnitude and a static split leaves threads idle), count into a LOCAL statistics block (the per-thread blocks used to sit side
+ * by side in one array -- every cell of every ray was a write to a cache line shared with the neighbour thread) and may be pinned,
+ * one per entry of `cpus` (oracle.py: one hardware thread per physical core).  Test infrastructure: the CPU baseline of bench.py. */
+enum { kChunk = 4096 };
 typedef struct {
-    const OGrid* grid; const OTri* tris; const ORay* rays; OHit* hits; int64_t begin, end; OStats stats; int num_tris; int brute; unsigned mode;
+    const OGrid* grid; const OTri* tris; const ORay* rays; OHit* hits; int64_t n; int64_t* next; int cpu;
+    int num_tris; int brute; unsigned mode;
+    char pad0[64];
+    OStats stats;
+    char pad1[64];
 } Job;
 
 static void* job_main(void* p) {
     Job* j = (Job*)p;
-    if (j->brute) {
-        for (int64_t i = j->begin; i < j->end; i++) {
-            OHit hit = { -1, j->rays[i].tmax, 0, 0 };
-            for (int t = 0; t < j->num_tris; t++) {
-                ORay r2 = { j->rays[i].org, j->rays[i].tmin, j->rays[i].dir, hit.t };
-                orc_intersect_prim_ray(&j->tris[t], &r2, t, &hit);
-            }
-            j->hits[i] = hit;
-        }
-    } else {
-        TravConsts k; setup_consts(j->grid, &k);
-        g_mode = j->mode;
-        memset(&j->stats, 0, sizeof(j->stats));
-        for (int64_t i = j->begin; i < j->end; i++) traverse_one(&k, j->grid, j->tris, &j->rays[i], &j->hits[i], NULL, &j->stats);
-        g_mode = 0;
+    if (j->cpu >= 0) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(j->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      /* best effort: a refused mask leaves the thread where it is */
     }
+    OStats local; memset(&local, 0, sizeof(local));
+    TravConsts k;
+    if (!j->brute) { setup_consts(j->grid, &k); g_mode = j->mode; }
+    for (;;) {
+        const int64_t begin = __atomic_fetch_add(j->next, (int64_t)kChunk, __ATOMIC_RELAXED);
+        if (begin >= j->n) break;
+        const int64_t end = begin + kChunk < j->n ? begin + kChunk : j->n;
+        if (j->brute) {
+            for (int64_t i = begin; i < end; i++) {
+                OHit hit = { -1, j->rays[i].tmax, 0, 0 };
+                for (int t = 0; t < j->num_tris; t++) {
+                    ORay r2 = { j->rays[i].org, j->rays[i].tmin, j->rays[i].dir, hit.t };
+                    orc_intersect_prim_ray(&j->tris[t], &r2, t, &hit);
+                }
+                j->hits[i] = hit;
+            }
+        } else {
+            for (int64_t i = begin; i < end; i++) traverse_one(&k, j->grid, j->tris, &j->rays[i], &j->hits[i], NULL, &local);
+        }
+    }
+    g_mode = 0;
+    j->stats = local;
     return NULL;
 }
 
-static void run_jobs(Job* proto, int64_t n, int nthreads, OStats* stats) {
+static void run_jobs_on(Job* proto, int64_t n, int nthreads, const int* cpus, int num_cpus, OStats* stats) {
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
+    if (nthreads > 1024) nthreads = 1024;
     Job* jobs = (Job*)xmalloc(sizeof(Job) * (size_t)nthreads);
     pthread_t* th = (pthread_t*)xmalloc(sizeof(pthread_t) * (size_t)nthreads);
+    int64_t* next = (int64_t*)xmalloc(256);                    /* the chunk counter on a cache line of its own */
+    next[16] = 0;
     for (int t = 0; t < nthreads; t++) {
         jobs[t] = *proto;
-        jobs[t].begin = n * t / nthreads; jobs[t].end = n * (t + 1) / nthreads;
+        jobs[t].n = n; jobs[t].next = next + 16;
+        jobs[t].cpu = (cpus && num_cpus > 0) ? cpus[t % num_cpus] : -1;
         memset(&jobs[t].stats, 0, sizeof(OStats));
         if (nthreads == 1) job_main(&jobs[t]); else pthread_create(&th[t], NULL, job_main, &jobs[t]);
     }
@@ -1204,7 +1230,16 @@ static void run_jobs(Job* proto, int64_t n, int nthreads, OStats* stats) {
             stats->long_list_refs += jobs[t].stats.long_list_refs;
         }
     }
-    free(jobs); free(th);
+    free(jobs); free(th); free(next);
+}
+static void run_jobs(Job* proto, int64_t n, int nthreads, OStats* stats) { run_jobs_on(proto, n, nthreads, NULL, 0, stats); }
+
+/* as orc_traverse_grid_mt, thread t pinned to cpus[t % num_cpus] (NULL: not pinned) */
+void orc_traverse_grid_pinned(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits, int64_t n, int nthreads,
+                              const int* cpus, int num_cpus, OStats* stats) {
+    Job p; memset(&p, 0, sizeof(p));
+    p.grid = grid; p.tris = tris; p.rays = rays; p.hits = hits; p.brute = 0;
+    run_jobs_on(&p, n, nthreads, cpus, num_cpus, stats);
 }
 
 void orc_traverse_grid_mt(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits, int64_t n, int nthreads, OStats* stats) {

@@ -104,9 +104,12 @@ int  orc_compress_grid(OGrid* grid);   /* 1 on success, 0 if dims do not fit 16 
  * the reference's step counter (traverse.cu:80,93) */
 void orc_traverse_grid(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits,
                        int64_t num_rays, int* steps, OStats* stats);
-/* same, contiguous ray ranges over nthreads pthreads (CPU baseline) */
+/* same over nthreads pthreads that take chunks of 4096 consecutive rays from a shared counter (CPU baseline) */
 void orc_traverse_grid_mt(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits,
                           int64_t num_rays, int nthreads, OStats* stats);
+/* same, thread t pinned to hardware thread cpus[t % num_cpus] (oracle.py: one per physical core; NULL: not pinned) */
+void orc_traverse_grid_pinned(const OGrid* grid, const OTri* tris, const ORay* rays, OHit* hits,
+                              int64_t num_rays, int nthreads, const int* cpus, int num_cpus, OStats* stats);
 /* traversal variants: ORC_ANY_HIT = the walk stops at the first accepted intersection (shadow rays:
  * id/t of that intersection), ORC_UVS = hits carry the barycentrics of prims.h:285-288 */
 #define ORC_ANY_HIT 1u

@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         L.orc_compress_grid.restype = i32; L.orc_compress_grid.argtypes = [vp]
         L.orc_traverse_grid.argtypes = [vp, vp, vp, vp, i64, vp, vp]
         L.orc_traverse_grid_mt.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+        L.orc_traverse_grid_pinned.restype = None; L.orc_traverse_grid_pinned.argtypes = [vp, vp, vp, vp, i64, i32, vp, i32, vp]
         L.orc_brute_force.argtypes = [vp, i32, vp, vp, i64, i32]
         L.orc_check_grid.restype = i32; L.orc_check_grid.argtypes = [vp, vp, i32, i32, C.c_char_p, i32]
         L.orc_set_cuda_quirks.restype = None; L.orc_set_cuda_quirks.argtypes = [i32]
@@ -243,7 +244,13 @@ class Grid:
                 "num_entries": self.num_entries, "offsets": self.offsets, "compressed": bool(self.g.small_cells)}
 
     # -- queries ------------------------------------------------------------------------------
-    def traverse(self, tris, rays, nthreads: int = 1, want_steps: bool = False):
+    def traverse(self, tris, rays, nthreads: int = 1, want_steps: bool = False, cpus="allowed"):
+        """cpus: hardware threads the worker threads are pinned to, thread t to cpus[t % len] ("allowed": every hardware thread this process may
+        run on; physical_cpus(): one per physical core; None: not pinned -- on the boxes this runs on unpinned threads stay on the CPU that
+        created them and the traversal does not scale at all)"""
+        if isinstance(cpus, str):
+            import os
+            cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
         tris = np.ascontiguousarray(tris, dtype=np.float32); rays = np.ascontiguousarray(rays, dtype=np.float32)
         n = rays.shape[0]
         hits = np.zeros(n, dtype=HIT_DTYPE)
@@ -254,6 +261,9 @@ class Grid:
             return hits, st.as_dict(), steps
         if nthreads <= 1:
             lib().orc_traverse_grid(C.byref(self.g), _p(tris), _p(rays), _p(hits), n, None, C.byref(st))
+        elif cpus is not None and len(cpus):
+            c = np.ascontiguousarray(cpus, dtype=np.int32)
+            lib().orc_traverse_grid_pinned(C.byref(self.g), _p(tris), _p(rays), _p(hits), n, nthreads, _p(c), int(c.size), C.byref(st))
         else:
             lib().orc_traverse_grid_mt(C.byref(self.g), _p(tris), _p(rays), _p(hits), n, nthreads, C.byref(st))
         return hits, st.as_dict()
@@ -310,3 +320,20 @@ class cuda_quirks:
     def __exit__(self, *exc):
         lib().orc_set_cuda_quirks(self.old)
         return False
+
+
+def physical_cpus():
+    """One hardware thread per physical core among those this process may run on (the first sibling of every
+    /sys/devices/system/cpu/cpuN/topology/thread_siblings_list): the threads of the all-cores CPU baseline are pinned to these --
+    two traversal threads on one core share its load ports and caches and gain little (bench.py `cpu_baseline`)."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, out = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib); out.append(c)
+    return out

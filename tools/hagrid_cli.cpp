@@ -356,12 +356,6 @@ int main(int argc, char** argv) {
         mem.free(d_t); mem.free(d_n);
     }
     if (root) hagrid_cli::report_timings(std::cout, std::vector<double>(timings.begin(), timings.end()), all_rays, intr);
-    // Everything the caller asked for is on stdout.  What follows returns device memory and takes the runtime down; a runtime that
-    // does not come back from that (seen once in the round-2 driver run: the report printed, the process never exited) must not
-    // hold the caller: after kTeardownSeconds the process says so on stderr and ends with the status of its work.
-    std::cout.flush();
-    arm_teardown_watchdog();
-
     if (!opts.out_image.empty() && opts.ray_file.empty() && world == 1) {
         std::ofstream img(opts.out_image, std::ofstream::binary);
         img << "P5\n" << opts.width << " " << opts.height << "\n255\n";
@@ -382,6 +376,12 @@ int main(int argc, char** argv) {
         std::cout << "Steps per ray: max " << top << ", mean " << std::accumulate(host_steps.begin(), host_steps.end(), 0.0) / host_steps.size() << std::endl;
         mem.free(steps);
     }
+    // Everything the caller asked for is on stdout and in its files (the image outputs above are work, not teardown: they may take as
+    // long as they take).  What follows returns device memory and takes the runtime down; a runtime that does not come back from that
+    // (seen once in the round-2 driver run: the report printed, the process never exited) must not hold the caller: after
+    // kTeardownSeconds the process says so on stderr and ends with the status of its work.
+    std::cout.flush();
+    arm_teardown_watchdog();
     mem.free(rays); mem.free(hits); release(); mem.free(tris);
     if (comm) rccl.comm_destroy(comm);
     return 0;
