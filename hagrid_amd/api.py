@@ -82,9 +82,15 @@ class MemManager:
         2 = automatic: the device bins a batch only if it is neither image-ordered nor coherent (no host round trip)."""
         _check(self, self._L.hagrid_set_ray_binning(self._ctx, int(mode)), "set_ray_binning")
 
+    PRODUCT_OPTIONS = ("expand.subset_only", "traverse.id_is_steps", "traverse.image", "traverse.image_max_mb", "traverse.image_width", "traverse.tile_order")
+
     def set_option(self, key: str, value: int):
-        """Tuning knobs for experiments/tests (include/hagrid_amd.h: hagrid_set_option); results never depend on them."""
-        _check(self, self._L.hagrid_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+        """The product's options (include/hagrid_amd.h: hagrid_set_option); any other key is a code-path selector of the test library
+        (csrc/kat/hagrid_amd_kat.h: hagrid_kat_set_option -- tests and dev tools).  Hits never depend on either."""
+        if key in self.PRODUCT_OPTIONS:
+            _check(self, self._L.hagrid_set_option(self._ctx, key.encode(), int(value)), f"set_option({key})")
+        else:
+            _check(self, self._K.hagrid_kat_set_option(self._ctx, key.encode(), int(value)), f"kat_set_option({key})")
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(128); cus = C.c_int(); mem = C.c_int64()

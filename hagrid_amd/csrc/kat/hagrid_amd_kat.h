@@ -46,6 +46,25 @@ int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* grid, const vo
  * HAGRID_EINVAL when the context holds no image of this grid. */
 int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);
 
+/* Code-path selectors for the parity tests and the sweep tools (NOT options of the product; hits never depend on them; keys of the product's
+ * hagrid_set_option are passed through):
+ *   "traverse.variant"   0 = choose (the traversal-image kernel when the grid has an image, else v2), 1 = the reference-shaped kernel, 2 = v2 on the
+ *                        construction format, 4 = the traversal-image kernel (an error without an image); 3 no longer exists
+ *   "traverse.narrow"    1 (default) = 32-bit offsets / 24-bit multiplies when every gathered array is below 4 GB, 0 = 64-bit addressing
+ *   "traverse.image_uniform" / "traverse.image_slim"   flat image: table-free layout when it is not much bigger (1) / 16-byte records where every
+ *                        cell fits them (1), 32-byte records (0), the 26-bit id form even where 20 bits would do (2)
+ *   "traverse.tail"      1 (default) = slim-record images are traversed by the kernel with the tail mode, 0 = one ray per lane throughout
+ *   "traverse.quad_tail" per cent of the tiles, the last in dispatch order, that start with four lanes per ray; -1 (default) = by launch size
+ *   "traverse.tail_dual" 1 = phase 1 of the tail kernel tests two ids of an inline list per round trip; -1 (default) = 1 unless the batch is binned
+ *   "traverse.tile_order_rounds"  the tile order is used for launches of up to this many per cent of a round of resident wavefronts (2500)
+ *   "traverse.super_tile", "traverse.xcd_chunk"   tile packets: log2 of the tiles per super-tile edge (3); the XCDs take chunks of 2^k wavefronts in
+ *                        turn (k >= 0), one eighth of the range each (-1), by launch size (-2, default)
+ *   "traverse.row_cache" 1 (default) = a row length found for a ray buffer is kept for the next 15 calls, 0 = looked for at every call
+ *   "traverse.lds_pad"   bytes of dynamic LDS per workgroup of the tail kernel (limits the resident wavefronts: profiles/dev_r3_quad_tail.txt)
+ *   "merge.narrow_cells" 1 (default) = 16-byte working cell records between the merge passes when the virtual resolution is below 65536
+ *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss, 0 = three kernels */
+int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
+
 #ifdef __cplusplus
 }
 #endif

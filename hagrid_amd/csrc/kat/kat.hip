@@ -244,3 +244,25 @@ extern "C" int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* gri
     HG_HIP(ctx, hipGetLastError());
     return HAGRID_OK;
 }
+
+// Which of several equivalent code paths runs: forced by the parity tests (every path must give the oracle's hits / arrays) and swept by
+// tools/dev_option_sweep.py.  Not options of the product (include/hagrid_amd.h: hagrid_set_option); hits never depend on them.
+extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return HAGRID_EINVAL;
+    struct { const char* name; int* dst; int lo, hi; } table[] = {
+        {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
+        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
+        {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
+        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20},
+        {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
+        {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
+        {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 0, 2},
+    };
+    for (auto& t : table)
+        if (!strcmp(key, t.name)) {
+            if (value < t.lo || value > t.hi || (t.dst == &ctx->opt_variant && value == 3)) HG_FAIL(ctx, HAGRID_EINVAL, "kat_set_option: value out of range");
+            *t.dst = value;
+            return HAGRID_OK;
+        }
+    return hagrid_set_option(ctx, key, value);              // the product's own options
+}

@@ -327,23 +327,17 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
 
 extern "C" int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return HAGRID_EINVAL;
+    // The product's options: behaviour a caller may want.  Which of several equivalent code paths runs (kernel variants, record forms, dispatch
+    // geometry) is not an option of the product: the parity tests and the sweep tools force those through hagrid_kat_set_option of the test
+    // library (csrc/kat/kat.hip), which is not installed.
     struct { const char* name; int* dst; int lo, hi; } table[] = {
-        // behaviour a caller may want
         {"expand.subset_only", &ctx->opt_expand_subset_only, 0, 1}, {"traverse.id_is_steps", &ctx->opt_id_is_steps, 0, 1},
         {"traverse.image", &ctx->opt_image, 0, 2},                  {"traverse.image_max_mb", &ctx->opt_image_max_mb, 0, 1 << 20},
-        {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24},
-        // which of several equivalent code paths runs: the parity tests force each of them, tools/dev_option_sweep.py times them
-        {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
-        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
-        {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
-        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},          {"traverse.tile_order", &ctx->opt_tile_order, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20},
-        {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
-        {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
-        {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},
+        {"traverse.image_width", &ctx->opt_image_width, -1, 1 << 24}, {"traverse.tile_order", &ctx->opt_tile_order, -1, 1},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {
-            if (value < t.lo || value > t.hi || (t.dst == &ctx->opt_variant && value == 3)) HG_FAIL(ctx, HAGRID_EINVAL, "set_option: value out of range");
+            if (value < t.lo || value > t.hi) HG_FAIL(ctx, HAGRID_EINVAL, "set_option: value out of range");
             *t.dst = value;
             return HAGRID_OK;
         }

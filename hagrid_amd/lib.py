@@ -14,7 +14,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAGRID_AMD_LIB") or os.path.join(HERE, "libhagrid_amd.so")     # the override serves A/B runs of two builds
 MAX_LEVELS = 32
-ABI_VERSION = 2             # HAGRID_ABI_VERSION of include/hagrid_amd.h this loader was written against
+ABI_VERSION = 3             # HAGRID_ABI_VERSION of include/hagrid_amd.h this loader was written against
 
 OK, EINVAL, EHIP, ENOMEM, ERANGE, ENODEV = 0, -1, -2, -3, -4, -5
 
@@ -130,6 +130,7 @@ KAT_SIGNATURES = {
     "hagrid_kat_compute_grid_dims": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "hagrid_kat_lookup_entry": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "hagrid_kat_set_option": (_i32, [_vp, C.c_char_p, _i32]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "hagrid_kat_tile_slots": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),
@@ -188,6 +189,11 @@ def load_kat() -> C.CDLL:
     if _kat is not None:
         return _kat
     load()
+    if os.path.realpath(LIB_PATH) != os.path.realpath(os.path.join(HERE, "libhagrid_amd.so")):
+        # The test library links its SIBLING product library (rpath $ORIGIN): with HAGRID_AMD_LIB pointing elsewhere it would pull a second,
+        # different copy of the product into the process and hand it contexts created by the first.
+        raise HagridError(f"HAGRID_AMD_LIB={LIB_PATH} overrides the product library, but {KAT_LIB_PATH} is built against its sibling "
+                          f"{os.path.join(HERE, 'libhagrid_amd.so')}: the test hooks (known-answer tests, code-path selectors) cannot be used in an A/B run")
     if not os.path.exists(KAT_LIB_PATH):
         raise HagridError(f"{KAT_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     try:

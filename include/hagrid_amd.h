@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HAGRID_ABI_VERSION 2   /* 2: hagrid_traversal_stats grew by long_list_refs (64 bytes); hagrid_grid_broadcast checks the communicator */
+#define HAGRID_ABI_VERSION 3   /* 3: code-path selectors left hagrid_set_option (test library); 2: hagrid_traversal_stats grew by long_list_refs (64 bytes), hagrid_grid_broadcast checks the communicator */
 #define HAGRID_MAX_LEVELS 32
 
 enum {
@@ -248,40 +248,27 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
  * the call stays asynchronous. */
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
-/* Tuning knobs for experiments and tests; the defaults are the tuned values.  Keys: "traverse.variant" (0 = choose the
- * kernel: the traversal-image kernel when the grid has an image, else v2; 1 = plain reference-shaped kernel, 2 = latency-oriented v2 on the
- * construction format, 4 = traversal-image kernel, an error without an image; 3, the persistent kernel of rounds 1-2, no longer exists: an error), "traverse.image" (what hagrid_setup_traversal builds: 2 = flat traversal image, default; 1 = compact; 0 = nothing),
- * "traverse.tail" (1, default = the table-free slim image is traversed by the kernel with the tail mode: a wavefront that holds at most 16
- * live rays spreads each over four lanes and tests a cell's inline list in one round; 0 = one ray per lane throughout),
- * "traverse.image_slim" (flat image of a grid of at most three levels: 1, default = 16-byte records where every cell fits them; 0 = 32-byte
- * records; 2 = the 26-bit id form even where 20 bits would do), "traverse.lds_pad" (experiments: bytes of dynamic LDS per workgroup of the tail kernel, 0 by default -- limits the resident
- * wavefronts, profiles/dev_r3_quad_tail.txt), "traverse.narrow" (1 = v2 uses 32-bit
- * offsets and 24-bit multiplies when every array it gathers from is smaller than 4 GB, default; 0 = always 64-bit addressing),
- * "traverse.waves_per_cu", "traverse.chunk", "traverse.both_phases", "traverse.refill_at";
- * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it)
- * is traversed with one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is
- * looked for on the device at every call (constant (origin, direction) step along a row; for batches of 4M rays or more
- * also from the origins alone -- bounce rays in the image order of their primary hits; a row length that was found is kept per ray buffer and count and
- * looked for again every 16th call ("not image-ordered" is not kept once the host has seen it), "traverse.row_cache" = 0: at every call -- it only steers the lane <-> ray assignment, hits never
- * depend on it), > 0 = w given by the caller, -1 = off; "traverse.super_tile": log2 of the tiles per super-tile edge (Z order inside; default 3), "traverse.xcd_chunk": k >= 0 = the 8 XCDs
- * take chunks of 2^k wavefronts in turn, -1 = one eighth of the block range each, -2 (default) = 3 for launches of up to about two rounds of the
- * resident wavefronts, else 5; "traverse.quad_tail": per cent of the tiles, the last in dispatch order, that start with four lanes per ray
- * (-1, default = by the size of the launch: all tiles up to 0.4 rounds of the resident wavefronts, half up to 0.65, 37 % up to 1.1, a quarter up to 3.2 rounds,
- * none beyond, none for binned batches and none while the image is shared between contexts); "traverse.tail_dual": 1 = the one-ray-per-lane
- * phase of the tail kernel tests two ids of an inline list per round trip, the second triangle loaded straight into LDS, 0 = one id per
- * round trip, -1 (default) = 1 unless the batch is binned; "traverse.tile_order": 1 = launches over a ray buffer (pointer and count) the context has
- * traversed before dispatch their 8 x 8 tiles longest first, by the costs the previous launches left (every wavefront leaves the iterations it ran at its
- * tile; a stable sort behind the launch that learns and behind every 32nd one after it; slim-record images, rays in image order), 0 = always
- * the default order, -1 (default) = 1 for launches of up to "traverse.tile_order_rounds" per cent (default 2500) of a round of resident wavefronts whose
- * image is not shared between contexts -- like the row length it only steers which wavefront takes which rays, hits never depend on it;
- * "traverse.id_is_steps" (1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel
- * leaves there, traverse.cu:80,93, for its viewer's step / heat-map display, main.cpp:100-107; 0, default = the primitive id or -1 that
- * ray.h:22 documents; t is the same either way);
- * "merge.narrow_cells" (1, default = hagrid_merge_grid keeps 16-byte working cell records between its passes when the virtual
- * resolution is below 65536; 0 = the 32-byte record throughout; the result is the same);
- * "expand.subset_only" (1 = the reference's compiled setting, default; 0 = the precise expansion of
- * expand.cu:39-57,96-127 -- this one changes the grid, not the hits).  Returns HAGRID_EINVAL for an
- * unknown key or a value out of range.  Hits never depend on these settings ("traverse.id_is_steps" changes what Hit.id MEANS, not t). */
+/* Options: behaviour a caller may want to change; the defaults are the reference's behaviour at the tuned speed.  Keys:
+ * "traverse.image": what hagrid_setup_traversal builds -- 2 (default) = the flat traversal image (one record per voxel), 1 = the compact one,
+ *   0 = nothing (traversal walks the construction format);
+ * "traverse.image_max_mb": size limit of the flat image in MB (0, default = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built;
+ * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it) is traversed with
+ *   one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is looked for on the device (constant
+ *   (origin, direction) step along a row; for batches of 4M rays or more also from the origins alone -- bounce rays in the image order of
+ *   their primary hits), > 0 = w given by the caller, -1 = off.  It only steers the lane <-> ray assignment: hits never depend on it;
+ * "traverse.tile_order": -1 (default) / 1 = launches over a ray buffer the context has traversed before dispatch their 8 x 8 tiles longest
+ *   first, by the costs the previous launches left (the order is dropped on the device when the buffer holds other rays than the ones it was
+ *   learned on); 0 = every launch in the default order, no state kept between calls -- like the row length it only steers which wavefront
+ *   takes which rays, hits never depend on it;
+ * "traverse.id_is_steps": 1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel leaves
+ *   there (traverse.cu:80,93) for its viewer's heat-map display (main.cpp:100-107); 0 (default) = the primitive id or -1 that ray.h:22
+ *   documents; t is the same either way;
+ * "expand.subset_only": 1 (default) = the reference's compiled setting; 0 = the precise expansion of expand.cu:39-57,96-127 -- this one
+ *   changes the grid, not the hits.
+ * Returns HAGRID_EINVAL for an unknown key or a value out of range.  (Which of several equivalent kernels / record forms / dispatch
+ * geometries runs is not an option of the product: the parity tests force each of them through the test library, csrc/kat/hagrid_amd_kat.h.
+ * ABI version 3: the keys "traverse.variant|narrow|image_uniform|image_slim|tail|quad_tail|tail_dual|tile_order_rounds|super_tile|
+ * xcd_chunk|row_cache|lds_pad" and "merge.narrow_cells" of version 2 moved there; version 2 had moved the known-answer test hooks out of this library.) */
 int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 
 /* The traversal image this context holds for `grid`: format4 = { flat (a record per voxel), uniform (table-free), bits per packed

@@ -27,7 +27,7 @@ int run(const void* host_tris, int n, const void* host_rays, int nrays, void* ho
     if (rc == HAGRID_OK && hagrid_compress_grid(ctx, &grid) < 0) rc = HAGRID_EHIP;
     if (rc == HAGRID_OK) rc = hagrid_setup_traversal(ctx, &grid);
     if (rc == HAGRID_OK) rc = hagrid_set_ray_binning(ctx, 1);
-    if (rc == HAGRID_OK) rc = hagrid_set_option(ctx, "traverse.variant", 0);
+    if (rc == HAGRID_OK) rc = hagrid_set_option(ctx, "traverse.tile_order", 0);
     if (rc == HAGRID_OK) rc = hagrid_traverse_grid(ctx, &grid, tris, rays, hits, nrays);
     if (rc == HAGRID_OK) rc = hagrid_traverse_grid_stats(ctx, &grid, tris, rays, hits, nrays, NULL, &st);
     if (rc == HAGRID_OK) {      /* a second context traversing with the first one's traversal image: same hits, written last */

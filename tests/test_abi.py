@@ -28,7 +28,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/hagrid_amd.h but not exported"
     assert sorted(built.SIGNATURES) == names, "hagrid_amd/lib.py signature table out of sync with the header"
-    assert L.hagrid_abi_version() == built.ABI_VERSION == 2
+    assert L.hagrid_abi_version() == built.ABI_VERSION == 3
     # the product library carries no test hooks (they live in libhagrid_amd_kat.so)
     import subprocess
     exported = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout

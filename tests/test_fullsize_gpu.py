@@ -31,6 +31,17 @@ def traverse(mem, grid, d_tris, rays):
     return hits
 
 
+_ORACLE_GRIDS = {}
+
+
+def oracle_grid(tris, *params):
+    """the oracle's construction of the 1M-triangle grid (about 12 s of CPU), built once per parameter set"""
+    from oracle import oracle as O
+    if params not in _ORACLE_GRIDS:
+        _ORACLE_GRIDS[params] = O.Grid.full(tris, *params)
+    return _ORACLE_GRIDS[params]
+
+
 def same_hits(a, b):
     return bool((a["id"] == b["id"]).all() and (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all())
 
@@ -41,7 +52,7 @@ def test_config2_structure_and_hits_match_oracle(world):
     from oracle import oracle as O
     mem, tris, d_tris = world
     grid = api.build_all(mem, d_tris, tris.shape[0])
-    G = O.Grid.full(tris)
+    G = oracle_grid(tris)
     d = grid.download()
     assert grid.summary() == G.summary()
     assert (d["entries"] == G.entries).all() and (d["ref_ids"] == G.ref_ids).all()
@@ -57,6 +68,45 @@ def test_config2_structure_and_hits_match_oracle(world):
         h = O.brute_force(tris[hits["id"][i]:hits["id"][i] + 1], rays[i:i + 1])
         assert h["id"][0] == 0 and h["t"].view(np.uint32)[0] == hits["t"].view(np.uint32)[i]
     grid.free()
+
+
+def test_config2_loop_over_one_buffer_learned_tile_order_matches_oracle(world):
+    """configs[1] as the bench line measures it: ONE 1024 x 1024 ray buffer traversed 40 times (main.cpp:398-447, the reference's benchmark
+    loop).  Launch 1 runs in the default tile order, launches 2 and 3 in the orders sorted behind launches 1 and 2, launch 33 behind the
+    first periodic refresh, launch 40 in the steady state: the hits of each of them are the oracle's, bit for bit.  Then the buffer is
+    refilled with another image (flipped top to bottom) -- the launches over it start on the stale order or on the default one, whichever the
+    context decides: same requirement."""
+    from hagrid_amd import api
+    mem, tris, d_tris = world
+    grid = api.build_all(mem, d_tris, tris.shape[0])
+    G = oracle_grid(tris)
+    assert grid.summary() == G.summary()
+    w = h = 1024
+    rays = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, w, h)
+    n = rays.shape[0]
+    oh, _ = G.traverse(tris, rays, nthreads=8)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    fmt = mem.image_format(grid)
+    assert fmt.get("slim_id_bits"), fmt                              # the tail kernel with its tile order is what runs here
+    checked = []
+    for launch in range(1, 41):
+        mem.zero(d_hits, 16 * n)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        if launch in (1, 2, 3, 33, 40):
+            mem.synchronize()                                        # (the host sees the row length: the order is learned from the next launch on)
+            assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), oh), f"launch {launch}"
+            checked.append(launch)
+    assert checked == [1, 2, 3, 33, 40]
+    flipped = np.ascontiguousarray(rays.reshape(h, w, 8)[::-1].reshape(n, 8))
+    oh2 = np.ascontiguousarray(oh.reshape(h, w)[::-1].reshape(n))
+    mem.copy_h2d(d_rays, flipped)
+    for launch in range(1, 6):
+        mem.zero(d_hits, 16 * n)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        mem.synchronize()
+        assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), oh2), f"refilled buffer, launch {launch}"
+    mem.free(d_rays); mem.free(d_hits); grid.free()
 
 
 def test_config3_dense_grid_16M_primary_rays(world):
