@@ -284,11 +284,37 @@ def main():
                 api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
             ms0 = api.profile(lambda: [api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays) for _ in range(args.steps)], mem) / args.steps
             hits0 = mem.download(d_hits, api.HIT_DTYPE, n_head)
-            tile_order = {"ms_per_step_default_order": round(ms0, 5), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
+            tile_order = {"ms_per_step_default_order": round(ms0, 5),
+                          # the fractions of the roofline block on the default-order time (what a first launch over a new buffer reaches)
+                          "walk_frac_default_order": round(ab["B_walk"] / (ms0 * 1e6) / HBM_PEAK_GBPS, 4),
+                          "frac_default_order": round(ab["B_image"] / (ms0 * 1e6) / HBM_PEAK_GBPS, 4), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
                           (hits0["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()),
                           "how": "`value` is the steady state of a renderer's loop: tiles dispatched longest first, by the costs the previous launches over the same ray "
                                  "buffer left (learned in the warm-up steps, refreshed every 32nd launch); ms_per_step_default_order = the "
                                  "same K steps with traverse.tile_order = 0, i.e. what the first launch over a new buffer costs.  Hits do not depend on the order"}
+            # A frame loop with a MOVING camera (the reference's viewer, main.cpp:597-603: new rays into the same buffer every frame): per frame the
+            # view turns by 0.005 rad and the eye moves sideways by 0.005 scene diagonals -- one mouse pixel and one key event of that viewer --
+            # and a quarter of that; the host synchronises per frame.  The order is followed only while the buffer's rays are near the ones it was
+            # learned on (checked on the device); a buffer refilled with another image (flipped) every 8th frame shows what a stale order costs now.
+            if ray_kind == "primary" and n_rays == width * height and n_rays <= (1 << 22) and world == 1:
+                def frames_ms(speed, order, refill=0, frames=32):
+                    mem.set_option("traverse.tile_order", order)
+                    ms = []
+                    for f in range(frames):
+                        r = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist, yaw=0.005 * speed * f, strafe=0.005 * speed * f)
+                        if refill and (f // refill) % 2:
+                            r = np.ascontiguousarray(r.reshape(height, width, 8)[::-1].reshape(n_rays, 8))
+                        mem.copy_h2d(d_rays, r)
+                        ms.append(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays), mem))
+                    return round(float(np.mean(ms[8:])), 5)
+                tile_order["moving_camera"] = {
+                    "viewer_speed": {"ms_per_frame": frames_ms(1.0, -1), "ms_per_frame_default_order": frames_ms(1.0, 0)},
+                    "quarter_speed": {"ms_per_frame": frames_ms(0.25, -1), "ms_per_frame_default_order": frames_ms(0.25, 0)},
+                    "frozen": {"ms_per_frame": frames_ms(0.0, -1), "ms_per_frame_default_order": frames_ms(0.0, 0)},
+                    "refilled_every_8th_frame": {"ms_per_frame": frames_ms(0.0, -1, refill=8), "ms_per_frame_default_order": frames_ms(0.0, 0, refill=8)},
+                    "how": "mean traversal ms (HIP events) of frames 9-32 of a loop that writes each frame's rays into the one ray buffer and synchronises per frame; "
+                           "viewer speed = 0.005 rad turn + 0.005 scene diagonals sideways per frame (main.cpp:579-586: one mouse pixel, one key event)"}
+                mem.copy_h2d(d_rays, scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist))      # the batch of the line again
         except Exception as e:                                       # (an option the library does not know: older build)
             log(f"[bench] tile order block skipped: {e}")
         finally:

@@ -34,6 +34,9 @@ struct TraverseArgs {
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
     const int* __restrict__ tile_order;      // tail kernel (and the TIMES instantiations of kat/kat.hip): packet b processes tile tile_order[b]; nullptr: tile b
     int* tile_cost;                          // tail kernel: a wavefront leaves the iterations it ran at its tile's index (atomicMax); nullptr: nothing
+    const float4* __restrict__ order_samples; // tail kernel: four sample rays the tile order was learned on (org | tolerance^2, unit dir | cos^2 of the tolerance); nullptr: the order is used unseen
+    int* order_report;                       // pinned host word: receives order_epoch when the samples no longer fit the buffer
+    int order_epoch;
     unsigned long long* __restrict__ wave_times; // TIMES instantiations only: start / end of every wavefront, 100 MHz wall clock
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
@@ -270,8 +273,32 @@ constexpr int kOriginMinRays = 1 << 22;
 void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays);
 // ray_order.hip: the tail kernel's tile order (longest tile first): buffers of the context for `tiles` tiles; order <- the costs the
 // launches since the last call left, costs cleared
+constexpr int kMaxOrderTiles = 1 << 18;          // launches of more tiles keep the default order whatever the options say (the sort is one workgroup)
 bool tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
-void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
+void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a);
+inline float4* tile_order_samples(const hagrid_ctx::RayHints& h) { return reinterpret_cast<float4*>(h.lpt_buf + 2 * size_t(h.lpt_cap)); }
+
+// Does the tile order still describe the rays in the buffer?  Lanes 0 .. 3 compare one sample ray each (row (2j + 1) / 8 of the image, the column
+// the sort chose) with the ray the order was learned on: origin within the tolerance, direction within the tolerated angle.  Uniform over the
+// launch -- every wavefront looks at the same four rays -- so either all wavefronts follow the order or none does (a bijection either way).
+__device__ __forceinline__ size_t order_sample_index(int n, int w, int j) {
+    const int rows = n / w;
+    return size_t(((2 * j + 1) * rows) >> 3) * size_t(w) + size_t(w >= 16 ? (w >> 1) - 8 : 0);
+}
+__device__ __forceinline__ bool order_still_fits(const TraverseArgs& a, int w, int lane) {
+    bool bad = false;
+    if (lane < 4) {
+        const size_t i = order_sample_index(a.num_rays, w, lane);
+        const float4 r0 = a.rays[2 * i], r1 = a.rays[2 * i + 1];
+        const float4 s0 = a.order_samples[2 * lane], s1 = a.order_samples[2 * lane + 1];
+        const float dx = r0.x - s0.x, dy = r0.y - s0.y, dz = r0.z - s0.z;
+        const float dot = r1.x * s1.x + r1.y * s1.y + r1.z * s1.z, dd = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
+        bad = !(dx * dx + dy * dy + dz * dz <= s0.w) || !(dot > 0.0f) || !(dot * dot >= s1.w * dd);       // (NaN: bad)
+    }
+    const bool fits = __ballot(bad) == 0ull;
+    if (!fits && blockIdx.x == 0 && lane == 0 && a.order_report) *a.order_report = a.order_epoch;
+    return fits;
+}
 // ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the
 // automatic mode) from buffers of `tmp`, or leaves a.perm null for batches too small to bin
 int bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp);

@@ -311,7 +311,13 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     int iters = 0;                                        // iterations this wavefront ran, those of phase 1 counted twice: its cost
     int slot;
     {
-        const int tile = (COST && w && a.tile_order) ? a.tile_order[b] : b;
+        int tile = b;
+        if (COST && w && a.tile_order) {
+            const int in_order = a.tile_order[b];
+            // (an order learned on other rays than the buffer holds now -- refilled, another buffer at a recycled address, the camera moved far -- is
+            // not followed: a stale order is slower than none)
+            tile = (!a.order_samples || order_still_fits(a, w, lane)) ? in_order : b;
+        }
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
         // instead -- about what that phase lasts)

@@ -91,7 +91,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.tris = static_cast<const float4*>(tris);
     a.rays = static_cast<const float4*>(rays);
     a.hits = static_cast<float4*>(hits);
-    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr;
+    a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr; a.order_samples = nullptr; a.order_report = nullptr; a.order_epoch = 0;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
@@ -258,7 +258,20 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
-            if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= (1 << 20) && tile_order_buffers(ctx, H, tiles)) {
+            if (H.cooldown > 0) H.cooldown--;              // orders did not last on this buffer (a camera that moves fast): not learned for a while
+            else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
+                int* report = ctx->mailbox + 304 + hint_slot;
+                if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && *report == H.lpt_epoch) {
+                    // A launch since the last sort found other rays in the buffer than the order was learned on (and ran in the default order): learn
+                    // again, from costs of the new rays only.  Three such orders in a row that lasted fewer than eight launches each: give up for 64 launches.
+                    H.relearn_streak = ctx->hint_clock - H.relearn_clock < 8 ? H.relearn_streak + 1 : 0;
+                    H.relearn_clock = ctx->hint_clock;
+                    H.lpt_valid = false; H.lpt_age = 0;
+                    (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
+                    if (H.relearn_streak >= 3) { H.relearn_streak = 0; H.cooldown = 64; }
+                }
+                if (H.cooldown > 0) { /* this launch and the next 63: default order, no costs */ }
+                else {
                 if (H.lpt_rays != rays || H.lpt_n != num_rays || H.lpt_blocks != tiles) {
                     H.lpt_rays = rays; H.lpt_n = num_rays; H.lpt_blocks = tiles; H.lpt_age = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);   // (costs some launch over another buffer may have left)
@@ -267,17 +280,20 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     const hagrid_ctx::RayHints* donor = nullptr;
                     for (const auto& d : ctx->hints)
                         if (&d != &H && d.lpt_valid && d.lpt_buf && d.lpt_n == num_rays && d.lpt_blocks == tiles && (!donor || d.used > donor->used)) donor = &d;
-                    if (donor && hipMemcpyAsync(H.lpt_buf + H.lpt_cap, donor->lpt_buf + donor->lpt_cap, size_t(tiles) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) {
+                    if (donor && hipMemcpyAsync(H.lpt_buf + H.lpt_cap, donor->lpt_buf + donor->lpt_cap, size_t(tiles) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                        hipMemcpyAsync(tile_order_samples(H), tile_order_samples(*donor), 8 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) {
+                        // (with the donor's sample rays: the order is followed only if THIS buffer's rays are near them)
                         // (the stand-in's refresh count goes on: buffers that come and go -- a new allocation per frame -- still re-sort every 32nd launch,
                         // from the costs of that one launch: every wavefront of a launch leaves its cost)
                         H.lpt_valid = true; H.lpt_period = 32; H.lpt_age = donor->lpt_age;
                     }
                 }
                 a.tile_cost = H.lpt_buf;
-                if (H.lpt_valid) a.tile_order = H.lpt_buf + H.lpt_cap;
+                if (H.lpt_valid) { a.tile_order = H.lpt_buf + H.lpt_cap; a.order_samples = tile_order_samples(H); a.order_report = report; a.order_epoch = H.lpt_epoch; }
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
                 learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
+                }
             }
         }
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
@@ -302,7 +318,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (learn_order) { launch_tile_order(ctx, H, tiles); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
+        if (learn_order) { launch_tile_order(ctx, H, tiles, a); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, false, a);
     } else {

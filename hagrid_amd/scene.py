@@ -129,14 +129,20 @@ def make_rays_incoherent(bbox_min, bbox_max, num_rays: int, seed: int, first: in
     return rays
 
 
-def camera(bbox_min, bbox_max, eye_dist: float = 0.8, fov: float = 60.0, ratio: float = 1.0):
-    """gen_camera (main.cpp:42-50) looking down +z at the bbox centre from eye_dist * diagonal away."""
+def camera(bbox_min, bbox_max, eye_dist: float = 0.8, fov: float = 60.0, ratio: float = 1.0, yaw: float = 0.0, strafe: float = 0.0):
+    """gen_camera (main.cpp:42-50) looking down +z at the bbox centre from eye_dist * diagonal away.  yaw (radians) turns the view about the
+    up axis and strafe (scene diagonals) moves the eye sideways: what the reference's viewer does per mouse pixel (0.005 rad) and per key
+    event (0.005 x the scene size), main.cpp:579-586 -- a frame loop with a moving camera (tools/dev_moving_camera.py, bench.py)."""
     lo = np.asarray(bbox_min, dtype=np.float32); hi = np.asarray(bbox_max, dtype=np.float32)
     ext = hi - lo
     diag = np.float32(np.sqrt(np.float32(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2])))
     center = np.float32(0.5) * (hi + lo)
     eye = (center + np.float32([0.0, 0.0, -1.0]) * np.float32(eye_dist) * diag).astype(np.float32)
     up0 = np.float32([0.0, 1.0, 0.0])
+    if yaw or strafe:
+        eye = (eye + np.float32([1.0, 0.0, 0.0]) * np.float32(strafe) * diag).astype(np.float32)
+        fwd = np.float32([np.sin(yaw), 0.0, np.cos(yaw)])
+        center = (eye + fwd * np.float32(eye_dist) * diag).astype(np.float32)
 
     def norm(v):
         return (v * (np.float32(1.0) / np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))))).astype(np.float32)
@@ -152,11 +158,11 @@ def camera(bbox_min, bbox_max, eye_dist: float = 0.8, fov: float = 60.0, ratio: 
 
 
 def make_rays_primary(bbox_min, bbox_max, width: int, height: int, first: int = 0, count: int | None = None,
-                      eye_dist: float = 0.8, fov: float = 60.0, sample: int = 0, num_samples: int = 1) -> np.ndarray:
+                      eye_dist: float = 0.8, fov: float = 60.0, sample: int = 0, num_samples: int = 1, yaw: float = 0.0, strafe: float = 0.0) -> np.ndarray:
     """gen_rays (main.cpp:52-66): pixel (x, y) -> dir = cam.dir + right*kx + up*ky, tmax = clip = |extents|.
     sample / num_samples shifts the pixel by a sub-pixel offset in x (sample 0 of 1 = the reference's rays):
     the weak-scaling batches of a multi-GPU run are the N sub-pixel samples of the same camera."""
-    eye, cdir, right, up, diag = camera(bbox_min, bbox_max, eye_dist, fov, width / float(height))
+    eye, cdir, right, up, diag = camera(bbox_min, bbox_max, eye_dist, fov, width / float(height), yaw, strafe)
     if count is None:
         count = width * height - first
     pid = np.arange(first, first + count, dtype=np.int64)
