@@ -147,16 +147,18 @@ __global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __
 //   device_scan     : exclusive scan of the table in (bin, workgroup) order = first slot of every (bin, workgroup) run
 //   ray_bin_scatter : slot = run start + rank inside the run (LDS atomic), perm[slot] = ray index
 // The order inside a bin is irrelevant.  No global atomics; one extra 4-byte word per ray.
-constexpr int kBinBits = 3;
-constexpr int kBins = 1 << (3 * kBinBits);
+// BITS bits per axis: 3 (512 bins, the default: scenes whose image and triangles fit the Infinity Cache) or 4 (4096 bins: scenes far beyond
+// it, where a bin's share of the image should fit an XCD's L2 -- "traverse.bin_bits" of the test library, chosen per grid by bin_rays below)
 constexpr int kBinItems = 16;                       // rays per thread
 constexpr int kBinTile = kBlock * kBinItems;        // rays per workgroup
 
-__device__ __forceinline__ uint32_t spread3(uint32_t x) {   // 3 bits -> every third bit
-    return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4);
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {   // 4 bits -> every third bit
+    return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4) | ((x & 8u) << 6);
 }
 
+template <int BITS>
 __device__ __forceinline__ int ray_bin_key(const TraverseArgs& a, int id) {
+    constexpr int kBinBits = BITS;
     const float4 r0 = a.rays[2 * size_t(id)], r1 = a.rays[2 * size_t(id) + 1];
     const vec3 org(r0.x, r0.y, r0.z), dir(r1.x, r1.y, r1.z);
     const vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
@@ -175,8 +177,10 @@ __device__ __forceinline__ int ray_bin_key(const TraverseArgs& a, int id) {
 
 // auto mode: `skip_if` (the row length found by detect_ray_rows) > 0 means the batch is image-ordered and is left alone;
 // `diff` (64 words) receives the number of neighbouring rays (i, i + 1) whose keys differ -- the coherence estimate
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, unsigned short* __restrict__ keys, int* __restrict__ table,
                                                         const int* __restrict__ skip_if, int* __restrict__ diff) {
+    constexpr int kBins = 1 << (3 * BITS);
     __shared__ int hist[kBins];
     __shared__ unsigned short tile_keys[kBinTile];
     __shared__ int lds[kWaves];
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) ray_bin_count(const TraverseArgs a, un
     for (int j = 0; j < kBinItems; j++) {
         const int id = base + j * kBlock + threadIdx.x;
         if (id < a.num_rays) {
-            const int k = ray_bin_key(a, id);
+            const int k = ray_bin_key<BITS>(a, id);
             keys[id] = (unsigned short)k;
             if (diff) tile_keys[j * kBlock + threadIdx.x] = (unsigned short)k;
             atomicAdd(&hist[k], 1);
@@ -217,17 +221,18 @@ __global__ void __launch_bounds__(64) ray_bin_decide(const int* __restrict__ row
 // The rays of a tile are first put in bin order inside LDS (local histogram -> local scan -> local rank), then written out: lanes
 // that are neighbours in LDS write neighbouring words of `perm`, so a store instruction touches the runs of a few bins instead of 64
 // unrelated lines (the lane-by-lane form moved 512 MB in 2.3 ms for 128M rays: bound by write transactions, not by bytes).
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* __restrict__ keys, const int* __restrict__ table_scan,
                                                           int num_rays, int* __restrict__ perm, const int* __restrict__ only_if) {
-    static_assert(kBins == 2 * kBlock, "two bins per thread in the local scan");
-    __shared__ int count[kBins];               // rays of the tile per bin, then the cursor of the local ranks
+    constexpr int kBins = 1 << (3 * BITS), kPer = kBins / kBlock;       // bins per thread in the local scan
+    static_assert(kBins % kBlock == 0, "whole bins per thread in the local scan");
+    __shared__ int count[kBins];               // rays of the tile per bin (the cursor of the local ranks), then the first slot of the (bin, workgroup) run in perm
     __shared__ int lstart[kBins + 1];          // first LDS slot of every bin
-    __shared__ int gstart[kBins];              // first slot of the (bin, workgroup) run in perm
     __shared__ int sorted_id[kBinTile];
     __shared__ unsigned short sorted_key[kBinTile];
     __shared__ int wsum[kWaves];
     if (only_if && *only_if == 0) return;
-    for (int i = threadIdx.x; i < kBins; i += kBlock) { count[i] = 0; gstart[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x]; }
+    for (int i = threadIdx.x; i < kBins; i += kBlock) count[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * kBinTile;
     int key[kBinItems], rank[kBinItems];
@@ -239,18 +244,21 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
 #pragma unroll
     for (int j = 0; j < kBinItems; j++) rank[j] = key[j] >= 0 ? atomicAdd(&count[key[j]], 1) : 0;
     __syncthreads();
-    {   // exclusive scan of the 512 counts: two per thread, wavefront scan, wavefront sums through LDS
-        const int c0 = count[2 * threadIdx.x], c1 = count[2 * threadIdx.x + 1];
-        const int incl = wave_inclusive_scan(c0 + c1);
+    {   // exclusive scan of the counts: kPer consecutive bins per thread, wavefront scan, wavefront sums through LDS
+        int c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = count[kPer * threadIdx.x + q]; sum += c[q]; }
+        const int incl = wave_inclusive_scan(sum);
         if (lane_id() == 63) wsum[wave_id()] = incl;
         __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave_id(); w++) before += wsum[w];
-        const int ex = before + incl - (c0 + c1);
-        lstart[2 * threadIdx.x] = ex; lstart[2 * threadIdx.x + 1] = ex + c0;
-        if (threadIdx.x == kBlock - 1) lstart[kBins] = ex + c0 + c1;
+        int run = incl - sum;
+        for (int w = 0; w < wave_id(); w++) run += wsum[w];
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { lstart[kPer * threadIdx.x + q] = run; run += c[q]; }
+        if (threadIdx.x == kBlock - 1) lstart[kBins] = run;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < kBins; i += kBlock) count[i] = table_scan[size_t(i) * gridDim.x + blockIdx.x];      // (the ranks are drawn: the array is free)
 #pragma unroll
     for (int j = 0; j < kBinItems; j++)
         if (key[j] >= 0) {
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
     const int total = lstart[kBins];
     for (int i = threadIdx.x; i < total; i += kBlock) {
         const int k = sorted_key[i];
-        perm[gstart[k] + (i - lstart[k])] = sorted_id[i];
+        perm[count[k] + (i - lstart[k])] = sorted_id[i];
     }
 }
 
@@ -388,9 +396,10 @@ void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, in
     h.lpt_epoch++;
 }
 
-int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
-    a.perm = nullptr;
-    if (!ctx->ray_binning || num_rays <= kBinTile) return HAGRID_OK;
+namespace {
+template <int BITS>
+int bin_rays_bits(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
+    constexpr int kBins = 1 << (3 * BITS);
     const int tiles = grid_blocks(num_rays, kBinTile);
     const int table_n = kBins * tiles;
     int* perm = tmp.get<int>(size_t(num_rays));
@@ -408,18 +417,31 @@ int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTe
             HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));
         }
         launch_detect(ctx, a, ctx->opt_image_width >= 0 ? num_rays : 0, row_len);
-        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff); HG_DBG(ctx);
+        ray_bin_count<BITS><<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, row_len, ctx->bin_diff); HG_DBG(ctx);
         if (!ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
         ray_bin_decide<<<1, 64, 0, ctx->stream>>>(row_len, ctx->bin_diff, num_rays, flag); HG_DBG(ctx);
-        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag); HG_DBG(ctx);
+        ray_bin_scatter<BITS><<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, flag); HG_DBG(ctx);
         a.perm_flag = flag;
         if (ctx->opt_image_width == 0) a.row_len = row_len;
         else if (ctx->opt_image_width > 0) a.row_len_hint = ctx->opt_image_width;
     } else {
-        ray_bin_count<<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr); HG_DBG(ctx);
+        ray_bin_count<BITS><<<tiles, kBlock, 0, ctx->stream>>>(a, bin_keys, bin_table, nullptr, nullptr); HG_DBG(ctx);
         if (!ctx_scan<int>(ctx, TableIn{bin_table}, TableOut{bin_table}, table_n, bin_partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
-        ray_bin_scatter<<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr); HG_DBG(ctx);
+        ray_bin_scatter<BITS><<<tiles, kBlock, 0, ctx->stream>>>(bin_keys, bin_table, num_rays, perm, nullptr); HG_DBG(ctx);
     }
     a.perm = perm;
     return HAGRID_OK;
+}
+} // namespace
+
+int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
+    a.perm = nullptr;
+    if (!ctx->ray_binning || num_rays <= kBinTile) return HAGRID_OK;
+    // Bins per axis.  What a bin is for: the wavefronts an XCD has resident at a time come from one or two bins, and what they gather -- the
+    // bin's share of the traversal image and of the triangles, and a margin around it -- should stay in that XCD's 4 MB of L2.  512 bins do
+    // that for working sets up to a few hundred MB (which the Infinity Cache holds anyway); beyond, 4096 bins (BASELINE configuration 5:
+    // 1.35 GB of image and triangles).  "traverse.bin_bits" (test library) forces 3 or 4.
+    int bits = ctx->opt_bin_bits;
+    if (bits == 0) bits = a.bin_working_set > (size_t(512) << 20) ? 4 : 3;
+    return bits == 4 ? bin_rays_bits<4>(ctx, a, num_rays, tmp) : bin_rays_bits<3>(ctx, a, num_rays, tmp);
 }

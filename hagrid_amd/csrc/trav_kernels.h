@@ -270,6 +270,14 @@ template <int CTRL> __device__ __forceinline__ float quad_perm_f(float x) { retu
 
 constexpr int kTailRays = 16;        // live rays at which a wavefront compacts (64 lanes / 4 lanes per ray)
 
+// Sensitivity experiments (tools/dev_ab.sh: HAGRID_HIPCC_EXTRA=-DHG_EXTRA_NOPS=20 builds ab/libB.so): this many v_nop per triangle round of the
+// tail kernel -- what the launch pays for VALU issue slots.  Not defined in the product.
+#ifdef HG_EXTRA_NOPS
+#define HG_NOPS() asm volatile(".rept %0\n v_nop\n .endr" :: "n"(HG_EXTRA_NOPS))
+#else
+#define HG_NOPS() do { } while (0)
+#endif
+
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
 // UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
 // top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
@@ -468,6 +476,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
                 hit_t = h.t; hit_id = h.id;
                 ref = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE);
+                HG_NOPS();
             }
         } else {
             if (by_index) {
@@ -599,6 +608,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
                     if (inl != NONE) cd = tri_candidate(tri_vec(inl), org, dir, tmin);
+                    HG_NOPS();
                     const unsigned long long cand = __ballot(cd.ok);
                     if (cand != 0ull) {
                         // replay the acceptance in list order; every lane of the group computes the same.  A list position at which no

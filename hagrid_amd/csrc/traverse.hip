@@ -95,7 +95,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -143,6 +143,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // keep mode free() only marks the slot (work of one context is stream-ordered), otherwise free() synchronises the stream first
     PoolTemps tmp(ctx);
     bool publish_row_len = false;
+    {   // what the batch gathers from: the traversal image (or cells and entries), the references, the triangles
+        const bool img = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
+        a.bin_working_set = (img ? ctx->image.block_bytes : size_t(grid->num_cells) * (grid->small_cells ? 16 : 32) + size_t(grid->num_entries) * 4)
+                            + size_t(grid->num_refs) * 4 + size_t(std::max<int64_t>(ctx->counts.num_tris, 0)) * 48;
+    }
     HG_TRY(bin_rays(ctx, a, num_rays, tmp));
     const int* perm = a.perm;
     // the hints kept for this ray buffer (row length, tile order): its slot, or the least recently used one (which then forgets its buffer)
