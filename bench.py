@@ -35,6 +35,43 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# What else can bind a gather kernel, measured on this part (profiles/micro_r2l_vector_memory.txt: tools/micro/l1_gather.hip, every lane its own random
+# 16-byte record; tools/micro/valu_lanes.hip): requests per second the memory side serves by where the working set lives, and the SIMD cycles a
+# wavefront VALU instruction costs whatever its live lanes.
+L2_GATHER_GPS = 256.0       # G requests/s, working set 1 MB (L2-resident)
+MALL_GATHER_GPS = 80.0      # G requests/s, working set 16 MB ... 256 MB (Infinity Cache)
+HBM_GATHER_GPS = 55.0       # G requests/s, working set 1 GB (52 - 57 measured): the chip's rate of random 64-byte fetches from HBM
+VALU_CYCLES_PER_INST = 2.2
+SHADER_CLOCK_HZ = 2.4e9
+NUM_SIMDS = 1024
+
+
+def binding_resources(counters: dict, kernel_ms: float, working_set_bytes: int, traffic_bytes):
+    """Fractions of the resources a traversal launch can be bound by, from the counters of tools/gpu_traffic_config.sh (per launch) and the
+    kernel time of THIS run.  Every fraction is achieved / what the part delivers for that access pattern: <= 1 up to measurement noise."""
+    t = kernel_ms * 1e-3
+    out = {}
+    if traffic_bytes is not None:
+        out["hbm_bytes"] = {"achieved": round(traffic_bytes / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(traffic_bytes / t / 1e9 / HBM_PEAK_GBPS, 4),
+                            "what": "fabric-side bytes of the L2s (FETCH_SIZE raw + WRITE_SIZE; Infinity-Cache hits included) against the HBM peak"}
+    if "TCC_MISS_sum" in counters:
+        beyond = working_set_bytes > (256 << 20)
+        peak = HBM_GATHER_GPS if beyond else MALL_GATHER_GPS
+        out["fabric_fetch_rate"] = {"achieved": round(counters["TCC_MISS_sum"] / t / 1e9, 2), "peak": peak, "unit": "G requests/s", "frac": round(counters["TCC_MISS_sum"] / t / 1e9 / peak, 4),
+                                    "what": "L2 misses per second against the measured rate of random fetches " + ("from HBM (working set beyond the 256 MB Infinity Cache)" if beyond else "from the Infinity Cache (working set within its 256 MB)")}
+    if "TCP_TCC_READ_REQ_sum" in counters:
+        out["l2_request_rate"] = {"achieved": round(counters["TCP_TCC_READ_REQ_sum"] / t / 1e9, 2), "peak": L2_GATHER_GPS, "unit": "G requests/s",
+                                  "frac": round(counters["TCP_TCC_READ_REQ_sum"] / t / 1e9 / L2_GATHER_GPS, 4), "what": "vector-L1 misses per second against the measured rate of L2-resident random gathers"}
+    if "SQ_INSTS_VALU" in counters:
+        cyc = counters["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / NUM_SIMDS
+        out["valu_issue"] = {"achieved": round(counters["SQ_INSTS_VALU"] / t / 1e9, 2), "peak": round(NUM_SIMDS * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9, 1), "unit": "G wavefront-instructions/s",
+                             "frac": round(cyc / (SHADER_CLOCK_HZ * t), 4), "what": f"VALU wavefront-instructions x {VALU_CYCLES_PER_INST} SIMD-cycles (whatever the live lanes) against 1024 SIMDs x 2.4 GHz",
+                             "lanes_enabled": None if not counters.get("SQ_THREAD_CYCLES_VALU") else round(counters["SQ_THREAD_CYCLES_VALU"] / counters["SQ_INSTS_VALU"] / 64, 3)}
+    if counters.get("SQ_WAVE_CYCLES"):
+        out["wave_time"] = {"waiting_for_memory": round(counters.get("SQ_WAIT_ANY", 0) / counters["SQ_WAVE_CYCLES"], 3), "waiting_to_issue": round(counters.get("SQ_WAIT_INST_ANY", 0) / counters["SQ_WAVE_CYCLES"], 3),
+                            "issuing": round(counters.get("SQ_ACTIVE_INST_ANY", 0) / counters["SQ_WAVE_CYCLES"], 3), "what": "where the resident wavefronts spend their time (not a throughput fraction)"}
+    ranked = sorted(((v["frac"], k) for k, v in out.items() if "frac" in v), reverse=True)
+    return out, (ranked[0][1] if ranked else None), (ranked[0][0] if ranked else None)
 
 CONFIGS = {
     2: dict(baseline="1M-triangle synthetic scene, default densities, 1M primary rays on 1xMI355X", tris=1_000_000, rays="primary",
@@ -378,7 +415,9 @@ def main():
         src_hash = _build.source_hash()
         # config 2: profiles/traffic_latest.json (tools/gpu_round.sh); the other configurations: profiles/traffic_config<C>.json
         # (tools/gpu_traffic_config.sh), which also names the ray count of the launch it measured -- a line over another count gets none
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json" if args.config == 2 else f"traffic_config{args.config}.json")
+        tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
+        if args.config == 2 and not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")        # (round 3's file: four counters)
         counters = None
         std_shape = args.image == 2 and n_tris == cfg["tris"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
         if os.path.exists(tpath) and world == 1 and std_shape:
@@ -389,7 +428,10 @@ def main():
                 elif tj.get("rays", n_rays) != n_rays:
                     traffic_source = f"other batch: {os.path.relpath(tpath, ROOT)} measured launches of {tj.get('rays')} rays, this run has {n_rays}"
                 else:
-                    traffic = tj.get("hbm_bytes_per_launch"); l2_hit = tj.get("l2_hit_rate"); counters = tj.get("counters")
+                    # fabric-side bytes: by request size where that pass exists; else FETCH_SIZE raw (+ WRITE_SIZE) for the gather kernels -- their L2 misses
+                    # fetch 64-byte sectors (52.8 / 62.8 bytes per miss in profiles/r4a) -- and the x2-corrected figure only in round 3's file
+                    traffic = tj.get("hbm_bytes_per_launch_by_request_size") or (tj.get("hbm_bytes_per_launch_raw") if "counters" in tj else tj.get("hbm_bytes_per_launch"))
+                    l2_hit = tj.get("l2_hit_rate"); counters = tj.get("counters")
                     traffic_source = f"{os.path.relpath(tpath, ROOT)} (kernel sources {src_hash}, commit {tj.get('commit', '?')}): " + tj.get("source", "")
             except Exception as e:
                 traffic = None; traffic_source = f"unreadable: {e}"
@@ -422,14 +464,16 @@ def main():
             "grid_broadcast_ms": round(t_bcast, 3),
             "setup_traversal_ms": round(setup_ms, 3),
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
+            # `achieved` / `frac`: the contract's figure -- ALGORITHMIC bytes (what the kernel gathers) over the kernel time against the HBM peak.  It is
+            # not a bound for a kernel whose working set is cache-resident (it can exceed 1: bytes served by L1 / L2 never reach HBM), so `binding` names
+            # what does bind, from the counters of this configuration measured on these kernel sources (tools/gpu_traffic_config.sh): every fraction
+            # there is against what the part delivers for that access pattern.
             "roofline": {
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "bytes": "B_image: what the traversal-image kernel gathers (DESIGN.md 4.2)" if args.image else "B_ray: SURVEY.md 8(d) on the construction format",
                 "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / HBM_PEAK_GBPS, 4),     # SURVEY.md 8(d) formula, construction format
                 "traffic": traffic, "traffic_source": traffic_source,
-                # what binds according to the counters (profiles/): the working set is L2 / Infinity-Cache resident, the kernel is
-                # limited by instruction issue with partly idle wavefronts and by the line rate of the vector L1, NOT by HBM bandwidth
-                "binding_resource": "instruction issue and the CUs' vector-memory address/L1 path (~12 cycles per wavefront load + 1-10 per live lane and line, profiles/micro_r2l_vector_memory.txt) while the machine is full, the dependent chains of the last wavefronts in the drain (profiles/dev_r2_wave_timeline_tail.txt); working set cache-resident, HBM itself runs at `hbm_measured`",
+                "binding": None,
                 "hbm_measured": None if traffic is None else round(traffic / (kernel_ms * 1e6), 1),
                 "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "l2_hit_rate": l2_hit,
@@ -449,6 +493,14 @@ def main():
                        "traversal_image": image_b, "releasable_after_setup_traversal": cells_b + 4 * grid.num_entries, "rays": 32 * n_rays, "hits": 16 * n_rays, "pool_now": mem.usage(), "pool_peak": mem.max_usage(),
                        "unit": "bytes", "reference": "main.cpp:523-533"},
         }
+        working_set = image_b + 48 * n_tris + 4 * grid.num_refs if args.image else cells_b + 4 * grid.num_entries + 4 * grid.num_refs + 48 * n_tris
+        if counters:
+            res, top, top_frac = binding_resources(counters, kernel_ms, working_set, traffic)
+            out["roofline"]["binding"] = {"resource": top, "frac": top_frac, "resources": res, "working_set_bytes": working_set,
+                                          "how": "counters per launch from separate rocprofv3 --pmc passes on these kernel sources (traffic_source), divided by this run's kernel time"}
+            out["roofline"]["bound"] = top if top in ("hbm_bytes",) else f"{top} (not hbm bytes: see binding)"
+        else:
+            out["roofline"]["binding"] = {"resource": None, "why": traffic_source or "no counter file for this configuration and batch (tools/gpu_traffic_config.sh)"}
         # ---- CPU baseline + parity check: the oracle on the SAME grid, rank 0, N = 1 only ---------------------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O

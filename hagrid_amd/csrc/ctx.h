@@ -43,6 +43,7 @@ struct TravImageCache {
     // identity of the source grid
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;
+    int max_ref = -1;               // largest primitive id the grid refers to
 };
 
 } // namespace hagrid_impl
@@ -76,6 +77,8 @@ struct hagrid_ctx {
     int opt_bin_bits = 0;       // ray binning: Morton bits per axis of the bin key (3 = 512 bins, 4 = 4096 bins); 0: by the size of what the batch gathers from
     int opt_variant = 0;        // 0 = the image kernel when the grid has an image, else v2; 1 / 2 / 4 = force the reference-shaped kernel / v2 / the image kernel
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
+    int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once a pass merges less than a tenth of its cells
+    int opt_merge_inplace_iters = 0;   // tests: leave the in-place mode after this many iterations (0: only for lack of room), the next iteration compacts
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
@@ -104,6 +107,7 @@ struct hagrid_ctx {
     static constexpr int kRayHints = 4;
     RayHints hints[kRayHints];
     unsigned long long hint_clock = 0;
+    int opt_tri_pad = -1;       // tail kernel: triangles read from a copy padded to 64 bytes each (one L2 / HBM sector per triangle instead of 1.5), made at every call; -1: chosen per launch
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch

@@ -146,6 +146,25 @@ __device__ __forceinline__ void write_union(const int* __restrict__ a, int na, c
     }
 }
 
+// The surface-area test of merge.cu:113-133 for two aligned cells with their list ranges filled in: the size of the merged list if merging
+// does not raise the cost, else -1.
+__device__ __forceinline__ int merged_size_if_cheaper(const MergeK& k, int axis, const CellRec& c1, const CellRec& c2, const int* __restrict__ refs) {
+    const float unit_cost = 1.0f;
+    const vec3 e1 = vec3(c1.hi - c1.lo) * k.cell_size;
+    const vec3 e2 = vec3(c2.hi - c2.lo) * k.cell_size;
+    const float a1 = e1.x * (e1.y + e1.z) + e1.y * e1.z;
+    const float a2 = e2.x * (e2.y + e2.z) + e2.y * e2.z;
+    const float a = a1 + a2 - comp(e1, (axis + 1) % 3) * comp(e1, (axis + 2) % 3);
+    const int n1 = c1.end - c1.begin, n2 = c2.end - c2.begin;
+    const float cc1 = a1 * (n1 + unit_cost), cc2 = a2 * (n2 + unit_cost);
+    if (a * (max(n1, n2) + unit_cost) <= cc1 + cc2) {
+        const int n = union_size(refs + c1.begin, n1, refs + c2.begin, n2);
+        const float c = a * (n + unit_cost);
+        if (c <= cc1 + cc2) return n;
+    }
+    return -1;
+}
+
 // compute_merge_counts (merge.cu:91-142)
 template <bool NARROW>
 __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells,
@@ -155,7 +174,6 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
     using F = CellFmt<NARROW>;
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= (n_dev ? *n_dev : num_cells)) return;
-    const float unit_cost = 1.0f;
     CellRec c1 = F::load(cells, id);
     F::finish(cells, id, c1);
     const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
@@ -166,18 +184,8 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
         CellRec c2 = F::load(cells, next_id);
         if (aligned(axis, c1, c2)) {
             F::finish(cells, next_id, c2);
-            const vec3 e1 = vec3(c1.hi - c1.lo) * k.cell_size;
-            const vec3 e2 = vec3(c2.hi - c2.lo) * k.cell_size;
-            const float a1 = e1.x * (e1.y + e1.z) + e1.y * e1.z;
-            const float a2 = e2.x * (e2.y + e2.z) + e2.y * e2.z;
-            const float a = a1 + a2 - comp(e1, (axis + 1) % 3) * comp(e1, (axis + 2) % 3);
-            const int n1 = c1.end - c1.begin, n2 = c2.end - c2.begin;
-            const float cc1 = a1 * (n1 + unit_cost), cc2 = a2 * (n2 + unit_cost);
-            if (a * (max(n1, n2) + unit_cost) <= cc1 + cc2) {
-                const int n = union_size(refs + c1.begin, n1, refs + c2.begin, n2);
-                const float c = a * (n + unit_cost);
-                if (c <= cc1 + cc2) count = n;
-            }
+            const int n = merged_size_if_cheaper(k, axis, c1, c2, refs);
+            if (n >= 0) count = n;
         }
     }
     merge_counts[id] = count;
@@ -294,6 +302,204 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     for (int i = 0; i < n1; i++) new_refs[nb + i] = refs[cell.begin + i];
 }
 
+
+// ---- iterations in place ------------------------------------------------------------------------------------------------------
+// After the first iteration a pass merges a few per cent of the cells, later ones a few per mille (1M-triangle soup: 19, 17, 8, 3.3, 1.8, 0.6,
+// 0.3, 0.08, 0.02 %), yet a compacting pass streams every cell, every reference and every voxel-map word to merge them.  Once a pass merges
+// less than a tenth of its cells the remaining iterations therefore run IN PLACE on the 16-byte working records:
+//   * cells keep their slot; the cell that absorbs its neighbour takes the merged box and a list appended behind the live references
+//     (so a list needs an explicit end: list_end[]), the absorbed one becomes a TOMBSTONE that names its absorber (look-ups through the voxel
+//     map, which is not rewritten, follow tombstones);
+//   * a pass only looks at cells whose situation changed since the last pass of its axis: a cell is DIRTY for an axis when it or the cell behind
+//     its face in that direction was merged (the absorber marks itself for all axes and, per axis, the one cell that can be aligned with it from
+//     behind: the cell that holds the voxel in front of its lower corner).  A cell that is not dirty decided "no" before, on the same boxes and
+//     lists and under a mask that has only become stricter since (merge.cu:361: 1, 3, 7, 15; from the fifth iteration on the mask is 0 and every cell is
+//     looked at again once), so it would decide "no" again.
+//   * slots for the merged lists come from a scan over the absorbers of the pass (no atomics); ONE compaction at the very end restores the
+//     public arrays: cells in slot order (= the order repeated compactions give: the absorber keeps its place), lists in cell order, the voxel
+//     map rewritten once.
+// Round 3 built in-place iterations without the dirty marks (every pass still evaluated every cell: no gain, reverted); with them a late pass
+// costs a few sweeps over byte flags.
+constexpr uint32_t kTombLo = 0xffffu;             // lo.x of a tombstone (the working record is used below virtual resolutions of 65536: no cell has it)
+__device__ __forceinline__ bool ip_is_tomb(const uint4& v) { return (v.x & 0xffffu) == kTombLo; }
+__device__ __forceinline__ int ip_live(const void* cells, int id) {          // the live cell a slot stands for
+    for (;;) {
+        const uint4 v = reinterpret_cast<const uint4*>(cells)[id];
+        if (!ip_is_tomb(v)) return id;
+        id = int(v.w);
+    }
+}
+__device__ __forceinline__ CellRec ip_load(const void* cells, const int* list_end, int id) {
+    CellRec c = CellFmt<true>::load(cells, id);
+    c.end = list_end[id];
+    return c;
+}
+
+// entering the mode: explicit list ends, every cell dirty for every axis
+__global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= slots) return;
+    list_end[id] = int(reinterpret_cast<const uint4*>(cells)[size_t(id) + 1].w);
+    dirty[id] = 1; dirty[size_t(slots) + id] = 1; dirty[2 * size_t(slots) + id] = 1;
+}
+
+// compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis
+__global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
+                                                    const int* __restrict__ refs, int slots, unsigned char* __restrict__ dirty_axis,
+                                                    Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
+                                                    unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= slots || !dirty_axis[id]) return;
+    dirty_axis[id] = 0;
+    if (ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) return;
+    const CellRec c1 = ip_load(cells, list_end, id);
+    const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
+    if (!merge_allowed(k, empty_mask, comp(c1.lo, axis)) || comp(np, axis) >= comp(k.dims, axis)) return;
+    const int next_id = ip_live(cells, int(lookup_entry(entries, k.shift, k.top, np)));
+    const CellRec c2 = ip_load(cells, list_end, next_id);
+    if (!aligned(axis, c1, c2)) return;
+    const int n = merged_size_if_cheaper(k, axis, c1, c2, refs);
+    if (n < 0) return;
+    minfo[id] = Int2{ n, (c1.end - c1.begin) + (c2.end - c2.begin) - n };     // merged size, references that disappear
+    nexts[id] = next_id;
+    evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
+    has_prev[next_id] = (unsigned char)pass_tag;
+}
+
+// compute_cell_flags (merge.cu:145-170): chain heads name the absorbers of their chain (every second cell, while it has a successor)
+__global__ void __launch_bounds__(kBlock) ip_chains(int slots, const int* __restrict__ nexts, const unsigned char* __restrict__ evaluated,
+                                                    const unsigned char* __restrict__ has_prev, unsigned char* __restrict__ absorbs, int pass_tag, int* __restrict__ acc) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    int merges = 0;
+    if (id < slots && evaluated[id] == pass_tag && has_prev[id] != pass_tag) {
+        int cur = id, pos = 0;
+        for (;;) {
+            const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
+            if (nxt < 0) break;
+            if (!(pos & 1)) { absorbs[cur] = (unsigned char)pass_tag; merges++; }
+            cur = nxt; pos++;
+        }
+    }
+    merges = wave_sum(merges);
+    // (the number of merges of the pass: 64 words take the sums of the wavefronts -- one word would take ~88 atomics per us)
+    if (lane_id() == 0 && merges) atomicAdd(acc + ((blockIdx.x * kWaves + wave_id()) & 63), merges);
+}
+
+__global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __restrict__ absorbs, int pass_tag, const Int2* __restrict__ minfo, int slots,
+                                                       Int2* __restrict__ sums, int num_tiles) {
+    const int tile = blockIdx.x * kWaves + wave_id();
+    if (tile >= num_tiles) return;
+    Int2 s{0, 0};
+    for (int c = 0; c < 4; c++) {
+        const int i = tile * kMergeTile + c * 64 + lane_id();
+        if (i < slots && absorbs[i] == pass_tag) s = s + minfo[i];
+    }
+    s = Int2{wave_sum(s.a), wave_sum(s.b)};
+    if (lane_id() == 0) sums[tile] = s;
+}
+
+// merge (merge.cu:189-278), in place
+__global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, int* refs, const unsigned char* __restrict__ absorbs, int pass_tag,
+                                                   const Int2* __restrict__ minfo, const int* __restrict__ nexts, const Int2* __restrict__ tile_prefix,
+                                                   int slots, const int* __restrict__ cursor) {
+    __shared__ int lds[kWaves];
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const bool mine = id < slots && absorbs[id] == pass_tag;
+    const int m = mine ? minfo[id].a : 0;
+    const int incl = wave_inclusive_scan(m);
+    if (lane_id() == 63) lds[wave_id()] = incl;
+    __syncthreads();
+    if (!mine) return;
+    int at = *cursor + tile_prefix[blockIdx.x].a + incl - m;
+    for (int w = 0; w < wave_id(); w++) at += lds[w];
+    const int other = nexts[id];
+    const CellRec c = ip_load(cells, list_end, id), n = ip_load(cells, list_end, other);
+    write_union(refs + c.begin, c.end - c.begin, refs + n.begin, n.end - n.begin, refs + at, m);
+    CellFmt<true>::store(cells, id, min(n.lo, c.lo), at, max(n.hi, c.hi), 0);
+    list_end[id] = at + m;
+    reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
+}
+
+// who has to look again: the absorber for every axis and, per axis, the cell behind its lower corner; thread 0 closes the books of the pass
+__global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const unsigned char* __restrict__ absorbs,
+                                                  int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
+                                                  int* __restrict__ acc, int* __restrict__ books /* cursor, live cells, live refs */, int* __restrict__ snap) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id == 0) {
+        int merges = 0;
+        for (int i = 0; i < 64; i++) { merges += acc[i]; acc[i] = 0; }
+        books[0] += pass_total->a; books[1] -= merges; books[2] -= pass_total->b;
+        snap[0] = books[1]; snap[1] = books[2];
+    }
+    if (id >= slots || absorbs[id] != pass_tag) return;
+    const CellRec c = CellFmt<true>::load(cells, id);
+    for (int axis = 0; axis < 3; axis++) {
+        dirty[size_t(axis) * slots + id] = 1;
+        ivec3 p = c.lo;
+        if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
+        if (comp(p, axis) < 0) continue;
+        dirty[size_t(axis) * slots + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
+    }
+}
+
+__global__ void ip_set_books(int* __restrict__ books, int cursor, int cells, int refs, int* __restrict__ acc) {
+    if (threadIdx.x == 0) { books[0] = cursor; books[1] = cells; books[2] = refs; }
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+}
+
+// ---- leaving the mode: one compaction ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) ip_live_sums(const void* __restrict__ cells, const int* __restrict__ list_end, int slots, Int2* __restrict__ sums, int num_tiles) {
+    const int tile = blockIdx.x * kWaves + wave_id();
+    if (tile >= num_tiles) return;
+    Int2 s{0, 0};
+    for (int c = 0; c < 4; c++) {
+        const int i = tile * kMergeTile + c * 64 + lane_id();
+        if (i < slots) {
+            const uint4 v = reinterpret_cast<const uint4*>(cells)[i];
+            if (!ip_is_tomb(v)) s = s + Int2{1, list_end[i] - int(v.w)};
+        }
+    }
+    s = Int2{wave_sum(s.a), wave_sum(s.b)};
+    if (lane_id() == 0) sums[tile] = s;
+}
+// live cells -> the public 32-byte records in slot order, their lists in cell order; new_ids[slot] = the cell's new index (-1 - absorber for a tombstone)
+__global__ void __launch_bounds__(kBlock) ip_compact(const void* __restrict__ cells, const int* __restrict__ list_end, const int* __restrict__ refs, int slots,
+                                                     const Int2* __restrict__ tile_prefix, Cell* __restrict__ out_cells, int* __restrict__ out_refs, int* __restrict__ new_ids) {
+    __shared__ Int2 lds[kWaves];
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    uint4 v = make_uint4(kTombLo, 0u, 0u, 0u);
+    if (id < slots) v = reinterpret_cast<const uint4*>(cells)[id];
+    const bool live = id < slots && !ip_is_tomb(v);
+    const int end = live ? list_end[id] : 0;
+    const Int2 item = live ? Int2{1, end - int(v.w)} : Int2{0, 0};
+    const Int2 incl = wave_inclusive_scan(item);
+    if (lane_id() == 63) lds[wave_id()] = incl;
+    __syncthreads();
+    if (id >= slots) return;
+    if (!live) { new_ids[id] = -1 - int(v.w); return; }
+    Int2 at = tile_prefix[blockIdx.x];
+    for (int w = 0; w < wave_id(); w++) at = at + lds[w];
+    const int new_id = at.a + incl.a - 1, nb = at.b + incl.b - item.b;
+    const CellRec c = CellFmt<true>::load(cells, id);
+    CellFmt<false>::store(out_cells, new_id, c.lo, nb, c.hi, nb + item.b);
+    for (int i = 0; i < item.b; i++) out_refs[nb + i] = refs[c.begin + i];
+    new_ids[id] = new_id;
+}
+__global__ void __launch_bounds__(kBlock) ip_resolve_tombs(int* __restrict__ new_ids, int slots) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= slots) return;
+    int v = new_ids[id];
+    if (v >= 0) return;
+    // (live cells' words are final and never written here; a tombstone's word names its absorber until this thread -- and only it -- replaces it)
+    int cur = -1 - v;
+    for (;;) {
+        const int w = __hip_atomic_load(new_ids + cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w >= 0) { v = w; break; }
+        cur = -1 - w;
+    }
+    new_ids[id] = v;
+}
+
 // working records -> the public 32-byte cells
 __global__ void __launch_bounds__(kBlock) widen_cells_kernel(const void* __restrict__ narrow, Cell* __restrict__ cells, const Int2* __restrict__ totals) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
@@ -370,12 +576,104 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int prev_num_cells = 0, iter = 0, pass_tag = 0;
     bool in_narrow = false;                                                // the caller's cells are 32-byte records
     (void)hipMemsetAsync(prevs, 0, nc0, st);                               // tag 0 = never had a predecessor
+    hagrid_build_counts& bc = ctx->counts;                                 // sizes that entered the passes (diagnostics)
+    auto record = [&](int c, int r) {
+        if (bc.merge_passes < HAGRID_MAX_MERGE_PASSES) { bc.merge_cells[bc.merge_passes] = c; bc.merge_refs[bc.merge_passes] = r; bc.merge_passes++; }
+    };
+
+    // ---- iterations in place (see the kernels above): state of the mode ----
+    bool in_place = false;
+    int ip_slots = 0, ip_iters = 0, prev_mask = 0;
+    long long ip_cap = 0, ip_cursor = 0;
+    int* ip_refs = nullptr; int* list_end = nullptr; unsigned char* dirty = nullptr; unsigned char* evaluated = nullptr; Int2* minfo = nullptr;
+    int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references
+    int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
+    Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
+    int* acc = ctx->dscratch + 64;                                        // 64 partial merge counts
+    auto ip_release = [&]() {
+        hagrid_mem_free(ctx, list_end); hagrid_mem_free(ctx, dirty); hagrid_mem_free(ctx, evaluated); hagrid_mem_free(ctx, minfo);
+        list_end = nullptr; dirty = nullptr; evaluated = nullptr; minfo = nullptr;
+    };
+    // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).  The merged lists
+    // are appended behind the live references; a pass appends at most the references of the cells it merges, so an iteration of three
+    // passes needs room for three times the live references at most: the buffer holds four times the references there are now.
+    auto ip_enter = [&]() -> bool {
+        ip_slots = num_cells;
+        ip_cap = 4ll * std::max(num_refs, 1);
+        if (ip_cap > 0x7fffffffll) return false;
+        ip_refs = pool_alloc<int>(ctx, size_t(ip_cap));
+        list_end = pool_alloc<int>(ctx, size_t(ip_slots) + 1);
+        dirty = pool_alloc<unsigned char>(ctx, 3 * size_t(ip_slots) + 4);
+        evaluated = pool_alloc<unsigned char>(ctx, size_t(ip_slots) + 4);
+        minfo = pool_alloc<Int2>(ctx, size_t(ip_slots) + 1);
+        if (!ip_refs || !list_end || !dirty || !evaluated || !minfo) { hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr; ip_release(); return false; }
+        (void)hipMemcpyAsync(ip_refs, refs, size_t(num_refs) * sizeof(int), hipMemcpyDeviceToDevice, st);
+        (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
+        (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);         // (the mode's `absorbs` tags)
+        ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty); HG_DBG(ctx);
+        ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs, acc); HG_DBG(ctx);
+        ip_cursor = num_refs;
+        in_place = true;
+        return true;
+    };
+    // Leaves the mode: the live cells become public 32-byte records in `cells_other`, their lists go to the reference buffer that is not in
+    // use, the voxel map is rewritten once.  Afterwards the grid is in the state a compacting pass with 32-byte output leaves it in.
+    auto ip_leave = [&]() -> int {
+        const int tiles = grid_blocks(ip_slots, kMergeTile);
+        ip_live_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cells, list_end, ip_slots, tile_sums, tiles); HG_DBG(ctx);
+        if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) return HAGRID_ENOMEM;
+        ip_compact<<<tiles, kBlock, 0, st>>>(cells, list_end, ip_refs, ip_slots, tile_sums, static_cast<Cell*>(cells_other), refs_b, nexts); HG_DBG(ctx);
+        ip_resolve_tombs<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(nexts, ip_slots); HG_DBG(ctx);
+        remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
+        std::swap(cells, cells_other);
+        std::swap(refs, refs_b);
+        int h[2];
+        HG_TRY(read_back(ctx, ip_total, h, sizeof(h)));                    // (also: the kernels above are done, their buffers can go)
+        if (h[0] != num_cells) return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, "merge_grid: the books of the in-place iterations do not add up");
+        num_refs = h[1];
+        hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr;
+        ip_release();
+        in_place = false; in_narrow = false;
+        return HAGRID_OK;
+    };
+
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
         const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
+        // no room for another iteration in place (or a test asks for it): back to the public arrays, this iteration compacts
+        if (in_place && (ip_cursor + 3ll * num_refs > ip_cap || (ctx->opt_merge_inplace_iters > 0 && ip_iters >= ctx->opt_merge_inplace_iters))) {
+            rc = ip_leave(); ip_iters = 0;
+            if (rc != HAGRID_OK) break;
+        }
+        if (in_place) {
+            // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
+            if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * size_t(ip_slots), st);
+            const int blocks = grid_blocks(ip_slots, kBlock), tiles = grid_blocks(ip_slots, kMergeTile);
+            const Entry* ent = reinterpret_cast<const Entry*>(entries);
+            for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {
+                if (++pass_tag == 256) {                                   // tags are bytes
+                    pass_tag = 1;
+                    (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
+                }
+                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, ip_refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
+                ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag, acc); HG_DBG(ctx);
+                ip_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tiles); HG_DBG(ctx);
+                if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
+                ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, ip_refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books); HG_DBG(ctx);
+                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, acc, books, snap + 2 * axis); HG_DBG(ctx);
+            }
+            if (rc != HAGRID_OK) break;
+            int h[10];                                                     // books (3), a spare word, the three snapshots
+            rc = read_back(ctx, books, h, sizeof(h));
+            if (rc != HAGRID_OK) break;
+            record(num_cells, num_refs); record(h[4], h[5]); record(h[6], h[7]);
+            ip_cursor = h[0]; num_cells = h[8]; num_refs = h[9];
+            ip_iters++;
+        } else {
         // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
         // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
         // read the real one.  One host round trip per iteration instead of three.
+        int last_pass_in = 0, last_pass_out = 0;
         for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
             const int blocks = grid_blocks(num_cells, kBlock);
             Int2* tot = total + axis;
@@ -402,20 +700,24 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
                 int h[6];
                 rc = read_back(ctx, total, h, sizeof(int) * 6);
                 if (rc != HAGRID_OK) break;
-                hagrid_build_counts& bc = ctx->counts;                     // sizes that entered the passes (diagnostics)
-                auto record = [&](int c, int r) {
-                    if (bc.merge_passes < HAGRID_MAX_MERGE_PASSES) { bc.merge_cells[bc.merge_passes] = c; bc.merge_refs[bc.merge_passes] = r; bc.merge_passes++; }
-                };
                 record(num_cells, num_refs); record(h[0], h[1]); record(h[2], h[3]);
+                last_pass_in = h[2]; last_pass_out = h[4];
                 num_cells = h[4]; num_refs = h[5];
             }
         }
+        if (rc != HAGRID_OK) break;
+        // the next iterations in place: once a pass merges less than a tenth of its cells (working records only: below 65536 per axis)
+        if (in_narrow && ctx->opt_merge_inplace && 10ll * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) (void)ip_enter();
+        }
+        prev_mask = mask;
         iter++;
     } while (rc == HAGRID_OK && num_cells < alpha * prev_num_cells);
-    if (rc == HAGRID_OK && in_narrow) {                                    // back to the public record
+    if (rc == HAGRID_OK && in_place) rc = ip_leave();
+    else if (rc == HAGRID_OK && in_narrow) {                               // back to the public record
         widen_cells_kernel<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(cells, static_cast<Cell*>(cells_other), total + 2); HG_DBG(ctx);
         std::swap(cells, cells_other);
     }
+    if (rc != HAGRID_OK && in_place) { (void)hipStreamSynchronize(st); hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr; ip_release(); }
 
     if (rc == HAGRID_OK) {
         hipError_t e = hipGetLastError();

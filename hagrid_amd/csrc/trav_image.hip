@@ -550,6 +550,16 @@ void hagrid_impl::trav_image_source_touched(hagrid_ctx* ctx, const void* ptr, si
         trav_image_drop(ctx);
 }
 
+namespace {
+// the largest primitive id the grid refers to (sentinels of a compressed grid are negative): traverse_grid sizes its padded triangle copy by it
+__global__ void __launch_bounds__(kBlock) max_ref_kernel(const int* __restrict__ refs, int n, int* __restrict__ out) {
+    int m = -1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) m = max(m, refs[i]);
+    m = wave_max(m);
+    if (lane_id() == 0 && m >= 0) atomicMax(out, m);
+}
+} // namespace
+
 int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     trav_image_drop(ctx);
     if (!ctx->opt_image || !g->entries || (!g->cells && !g->small_cells) || !g->ref_ids || g->num_cells <= 0) return HAGRID_OK;
@@ -595,6 +605,12 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
     img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
     if (img.valid) img.alive = std::make_shared<std::atomic<bool>>(true);
+    if (img.valid && g->num_refs > 0) {
+        int* word = ctx->dscratch + 240;
+        HG_HIP(ctx, hipMemsetAsync(word, 0xff, sizeof(int), ctx->stream));
+        max_ref_kernel<<<std::min(grid_blocks(g->num_refs, kBlock), 2048), kBlock, 0, ctx->stream>>>(static_cast<const int*>(g->ref_ids), g->num_refs, word); HG_DBG(ctx);
+        HG_TRY(read_back(ctx, word, &img.max_ref, sizeof(int)));
+    }
     ctx->image = img;
     return HAGRID_OK;
 }

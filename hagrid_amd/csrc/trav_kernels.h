@@ -284,7 +284,9 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // DUAL: phase 1 tests the ids of an inline list two per round trip (see test_list)
 // COST: the wavefront counts its iterations and leaves them at its tile (the tile order of traverse.hip); the table layout pays for that bookkeeping with
 // a dozen spilled registers around its loops, so launches of it that keep no costs run the instantiation without
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM>
+// TRI64: the triangles are read from a copy padded to 64 bytes each (traverse.hip, "traverse.tri_pad"): a triangle is then ONE 64-byte sector of L2 / HBM
+// (the caller's 48-byte records straddle two sectors every second time) -- a third fewer requests to L2 per triangle test
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     __shared__ int lanes_of[64];
@@ -379,8 +381,11 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     };
     auto tri_ptr = [&](int ref) -> const float4* {
         uint32_t r3, o;
-        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+        if (TRI64) asm("v_lshlrev_b32 %0, 6, %1" : "=v"(o) : "v"(ref));
+        else {
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
+        }
         return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
     };
     auto tri_vec = [&](int ref) -> Tri {
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     };
     auto tri_for = [&](int ref) -> Tri {                   // every live lane the same triangle: through the scalar cache
         const int f = __builtin_amdgcn_readfirstlane(ref);
-        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar(a.tris, f);
+        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar<TRI64 ? 64 : 48>(a.tris, f);
         return tri_vec(ref);
     };
     auto field = [&](const uint4& rec, int pos, int n) -> uint32_t {

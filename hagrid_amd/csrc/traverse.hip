@@ -20,6 +20,14 @@ using namespace hagrid_trav;
 
 namespace {
 
+// The caller's triangles, 48 bytes each, copied to 64-byte slots (the fourth 16 bytes of a slot are never read): one thread per 16-byte piece.
+__global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ tris, int num_pieces, float4* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_pieces) return;
+    const int t = int(uint32_t(i) / 3u);
+    out[i + t] = tris[i];                            // piece p of triangle t: 4 t + p = i + t
+}
+
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
@@ -32,6 +40,15 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
         } else {
             if (slim == 20) traverse_kernel_tail<20, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
+    }
+    else if (tail && MODE == 0 && uniform && slim && a.tri64) {
+        if (a.tail_dual) {
+            if (slim == 20) traverse_kernel_tail<20, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
     else if (tail && MODE == 0 && uniform && slim) {
@@ -95,7 +112,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -320,6 +337,22 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
+        }
+        // "traverse.tri_pad": the tail kernel (table-free slim image) reads the triangles from a copy padded to 64 bytes each, made by THIS call (the
+        // caller's array may change between calls, so nothing is kept): a 48-byte triangle straddles two 64-byte sectors every second time, and the
+        // incoherent / beyond-cache batches are bound by the number of requests the vector L1s have in flight (profiles/r4a), not by bytes.  The copy
+        // streams 112 bytes per triangle; -1 (default): when the batch has at least four rays per triangle the grid refers to (the copy then costs
+        // under 3 % of the launch).
+        if (ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
+            const long long n_tris = (long long)ctx->image.max_ref + 1;
+            const bool want = ctx->opt_tri_pad < 0 ? (long long)num_rays >= 4 * n_tris : ctx->opt_tri_pad != 0;
+            if (want) {
+                float4* padded = tmp.get<float4>(size_t(n_tris) * 4);
+                if (padded) {
+                    pad_triangles<<<grid_blocks(3 * n_tris, 256), 256, 0, ctx->stream>>>(a.tris, int(3 * n_tris), padded); HG_DBG(ctx);
+                    a.tris = padded; a.tri64 = 1;
+                }
+            }
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");

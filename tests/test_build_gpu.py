@@ -84,6 +84,33 @@ def test_merge_with_wide_working_cells(mem):
     mem.free(d_tris)
 
 
+@pytest.mark.parametrize("n,seed,td,sd,alpha", [(30000, 91, 0.12, 2.4, 0.995), (60000, 5, 0.12, 2.4, 0.9999), (20000, 6, 0.5, 8.0, 0.9999), (4000, 7, 0.3, 1.0, 0.99999),
+                                                (200000, 8, 0.12, 2.4, 0.999)])
+def test_merge_iterations_in_place_and_compacting_agree_with_the_oracle(mem, n, seed, td, sd, alpha):
+    """merge_grid runs its late iterations in place (dirty cells only, tombstones, one compaction at the end; merge.hip).  The arrays must be
+    the oracle's whatever the mode: in place (default), compacting throughout (merge.inplace = 0), and leaving the mode after every in-place
+    iteration so that compacting and in-place iterations alternate (merge.inplace_iters = 1).  alpha close to 1 runs many iterations:
+    beyond the fourth the mask of merge.cu:361 drops to 0 and every cell has to look again."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(n, seed=seed)
+    d_tris = mem.upload(tris)
+    G = O.Grid.build(tris, td, sd).merge(alpha)
+    try:
+        for inplace, iters in ((1, 0), (0, 0), (1, 1), (1, 2)):
+            mem.set_option("merge.inplace", inplace); mem.set_option("merge.inplace_iters", iters)
+            grid = api.Grid()
+            api.build_grid(mem, d_tris, n, grid, td, sd)
+            api.merge_grid(mem, grid, alpha)
+            assert_same_grid(grid.download(), G, ("merge", inplace, iters))
+            bc = mem.build_counts()
+            assert bc["merged_cells"] == G.num_cells and bc["merged_refs"] == G.num_refs
+            grid.free()
+    finally:
+        mem.set_option("merge.inplace", 1); mem.set_option("merge.inplace_iters", 0)
+    mem.free(d_tris)
+
+
 @pytest.mark.parametrize("n,td,sd", [(1, 0.12, 2.4), (2, 0.12, 2.4), (37, 0.12, 2.4), (3000, 0.15, 3.0), (50000, 0.12, 2.4), (20000, 0.5, 8.0)])
 def test_build_sizes_and_densities(mem, n, td, sd):
     tris = scene.make_soup(n, seed=1234 + n)

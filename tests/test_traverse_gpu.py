@@ -634,20 +634,23 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             # (tail mode, per cent of the tiles that START with four lanes per ray -- "traverse.quad_tail", 16 rays per wavefront)
             # ... and "traverse.tail_dual": two ids of an inline list per round trip in phase 1, the second triangle through LDS (forced on
             # for binned batches as well, where the default switches it off)
-            for tail, quad, dual in ((1, -1, -1), (1, 0, 1), (1, 0, 0), (1, 30, 1), (1, 100, 0), (0, 0, -1)):
+            # ... and "traverse.tri_pad": the triangles read from a copy padded to 64 bytes each, made by the call (forced on here: the default
+            # takes it for batches of at least four rays per triangle)
+            for tail, quad, dual, pad in ((1, -1, -1, -1), (1, 0, 1, 0), (1, 0, 0, 1), (1, 30, 1, 1), (1, 100, 0, 1), (0, 0, -1, 1)):
                 mem.set_option("traverse.tail", tail); mem.set_option("traverse.quad_tail", quad); mem.set_option("traverse.tail_dual", dual)
+                mem.set_option("traverse.tri_pad", pad)
                 for binning in (0, 1):
                     mem.set_ray_binning(binning)
                     for first, n in ((0, rays.shape[0]), (0, 64 * 48), (0, 64), (5, 1), (7, 15), (0, 16), (3, 17), (64 * 48, 4099)):
                         got = gpu_traverse(mem, grid, d_tris, rays[first:first + n])
                         w = want[first:first + n]
-                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, quad, dual, binning, first, n)
+                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, quad, dual, pad, binning, first, n)
             if name == "long_lists":
                 assert (want["id"] >= 0).any()
             grid.free(); mem.free(d_tris)
     finally:
         mem.set_option("traverse.tail", 1); mem.set_option("traverse.quad_tail", -1); mem.set_option("traverse.tail_dual", -1)
-        mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0)
+        mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0); mem.set_option("traverse.tri_pad", -1)
 
 
 def test_row_length_cache_never_changes_hits(mem):

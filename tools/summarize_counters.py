@@ -58,6 +58,11 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     f = c["FETCH_SIZE"] * 1024; w = c["WRITE_SIZE"] * 1024
     res["hbm_bytes_per_launch_raw"] = f + w
     res["hbm_bytes_per_launch"] = 2 * f + w                 # gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section)
+if "TCC_EA0_RDREQ_sum" in c and "WRITE_SIZE" in c:
+    # the read requests of the L2s to the fabric by size: what FETCH_SIZE approximates (it tallies a 128-byte request as 64 bytes on gfx950)
+    n32 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0); n128 = c.get("TCC_EA0_RDREQ_128B_sum", 0.0); n64 = c["TCC_EA0_RDREQ_sum"] - n32 - n128
+    res["fabric_read_requests"] = {"32B": n32, "64B": n64, "128B": n128}
+    res["hbm_bytes_per_launch_by_request_size"] = 32 * n32 + 64 * n64 + 128 * n128 + c["WRITE_SIZE"] * 1024
 if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
     res["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 from hagrid_amd import build as _build
