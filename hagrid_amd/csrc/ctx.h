@@ -79,6 +79,7 @@ struct hagrid_ctx {
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once a pass merges less than a tenth of its cells
     int opt_merge_inplace_iters = 0;   // tests: leave the in-place mode after this many iterations (0: only for lack of room), the next iteration compacts
+    int opt_merge_inplace_room = 0;    // tests: the in-place mode may use the reference buffer up to this index only (0: all of it) -- the overflow path
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller

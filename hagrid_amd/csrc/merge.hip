@@ -399,11 +399,20 @@ __global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __re
 }
 
 // merge (merge.cu:189-278), in place
+// The merged lists are appended behind the live references in the SAME buffer (its tail is free once the first iterations have shrunk the lists).
+// A pass whose lists do not fit is not applied at all, nor is any later pass of the iteration (books[3] = 1 + its axis, sticky): the host compacts and
+// runs those passes the compacting way.
 __global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, int* refs, const unsigned char* __restrict__ absorbs, int pass_tag,
                                                    const Int2* __restrict__ minfo, const int* __restrict__ nexts, const Int2* __restrict__ tile_prefix,
-                                                   int slots, const int* __restrict__ cursor) {
+                                                   int slots, int* __restrict__ books, const Int2* __restrict__ pass_total, int capacity, int axis) {
     __shared__ int lds[kWaves];
     const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int* cursor = books;
+    const int overflow = __hip_atomic_load(books + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (overflow > 0 || (long long)*cursor + pass_total->a > (long long)capacity) {       // (the same answer in every thread: books[0] and the total do not change in this kernel)
+        if (id == 0 && overflow <= 0) __hip_atomic_store(books + 3, -(1 + axis), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // negative: "this pass"; ip_mark makes it sticky
+        return;
+    }
     const bool mine = id < slots && absorbs[id] == pass_tag;
     const int m = mine ? minfo[id].a : 0;
     const int incl = wave_inclusive_scan(m);
@@ -425,13 +434,15 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
                                                   int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
                                                   int* __restrict__ acc, int* __restrict__ books /* cursor, live cells, live refs */, int* __restrict__ snap) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int overflow = books[3];                    // (written by the previous kernel at the latest; this kernel's thread 0 only changes its sign)
     if (id == 0) {
         int merges = 0;
         for (int i = 0; i < 64; i++) { merges += acc[i]; acc[i] = 0; }
-        books[0] += pass_total->a; books[1] -= merges; books[2] -= pass_total->b;
+        if (overflow == 0) { books[0] += pass_total->a; books[1] -= merges; books[2] -= pass_total->b; }
+        else if (overflow < 0) books[3] = -overflow;
         snap[0] = books[1]; snap[1] = books[2];
     }
-    if (id >= slots || absorbs[id] != pass_tag) return;
+    if (overflow != 0 || id >= slots || absorbs[id] != pass_tag) return;
     const CellRec c = CellFmt<true>::load(cells, id);
     for (int axis = 0; axis < 3; axis++) {
         dirty[size_t(axis) * slots + id] = 1;
@@ -443,7 +454,7 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
 }
 
 __global__ void ip_set_books(int* __restrict__ books, int cursor, int cells, int refs, int* __restrict__ acc) {
-    if (threadIdx.x == 0) { books[0] = cursor; books[1] = cells; books[2] = refs; }
+    if (threadIdx.x == 0) { books[0] = cursor; books[1] = cells; books[2] = refs; books[3] = 0; }
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
 }
 
@@ -582,69 +593,95 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     };
 
     // ---- iterations in place (see the kernels above): state of the mode ----
+    // No buffer of its own: the explicit list ends live in `merge_counts`, the per-slot scratch of the mode (merged size / disappearing references,
+    // dirty bytes per axis, "evaluated" tags) in the cell buffer that is not in use, and the merged lists go behind the live references of `refs`.
     bool in_place = false;
     int ip_slots = 0, ip_iters = 0, prev_mask = 0;
-    long long ip_cap = 0, ip_cursor = 0;
-    int* ip_refs = nullptr; int* list_end = nullptr; unsigned char* dirty = nullptr; unsigned char* evaluated = nullptr; Int2* minfo = nullptr;
-    int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references
+    int* list_end = merge_counts;
+    Int2* minfo = nullptr; unsigned char* dirty = nullptr; unsigned char* evaluated = nullptr;
+    int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references, overflow (1 + axis of the first pass that did not fit)
     int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
     Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
     int* acc = ctx->dscratch + 64;                                        // 64 partial merge counts
-    auto ip_release = [&]() {
-        hagrid_mem_free(ctx, list_end); hagrid_mem_free(ctx, dirty); hagrid_mem_free(ctx, evaluated); hagrid_mem_free(ctx, minfo);
-        list_end = nullptr; dirty = nullptr; evaluated = nullptr; minfo = nullptr;
-    };
-    // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).  The merged lists
-    // are appended behind the live references; a pass appends at most the references of the cells it merges, so an iteration of three
-    // passes needs room for three times the live references at most: the buffer holds four times the references there are now.
-    auto ip_enter = [&]() -> bool {
+    const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
+    // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).
+    auto ip_enter = [&]() {
         ip_slots = num_cells;
-        ip_cap = 4ll * std::max(num_refs, 1);
-        if (ip_cap > 0x7fffffffll) return false;
-        ip_refs = pool_alloc<int>(ctx, size_t(ip_cap));
-        list_end = pool_alloc<int>(ctx, size_t(ip_slots) + 1);
-        dirty = pool_alloc<unsigned char>(ctx, 3 * size_t(ip_slots) + 4);
-        evaluated = pool_alloc<unsigned char>(ctx, size_t(ip_slots) + 4);
-        minfo = pool_alloc<Int2>(ctx, size_t(ip_slots) + 1);
-        if (!ip_refs || !list_end || !dirty || !evaluated || !minfo) { hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr; ip_release(); return false; }
-        (void)hipMemcpyAsync(ip_refs, refs, size_t(num_refs) * sizeof(int), hipMemcpyDeviceToDevice, st);
+        char* scratch = static_cast<char*>(cells_other);                   // 32 bytes per cell of the un-merged grid: 12 per slot are used
+        minfo = reinterpret_cast<Int2*>(scratch);
+        dirty = reinterpret_cast<unsigned char*>(scratch + ((size_t(ip_slots) * 8 + 255) & ~size_t(255)));
+        evaluated = dirty + ((3 * size_t(ip_slots) + 255) & ~size_t(255));
         (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
         (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);         // (the mode's `absorbs` tags)
         ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty); HG_DBG(ctx);
         ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs, acc); HG_DBG(ctx);
-        ip_cursor = num_refs;
         in_place = true;
-        return true;
     };
-    // Leaves the mode: the live cells become public 32-byte records in `cells_other`, their lists go to the reference buffer that is not in
-    // use, the voxel map is rewritten once.  Afterwards the grid is in the state a compacting pass with 32-byte output leaves it in.
+    // Leaves the mode: the live cells become public 32-byte records in `cells_other` (the scratch above is dead by then), their lists go to the
+    // reference buffer that is not in use, the voxel map is rewritten once.  Afterwards the grid is in the state a compacting pass with 32-byte
+    // output leaves it in.
     auto ip_leave = [&]() -> int {
         const int tiles = grid_blocks(ip_slots, kMergeTile);
         ip_live_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cells, list_end, ip_slots, tile_sums, tiles); HG_DBG(ctx);
         if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) return HAGRID_ENOMEM;
-        ip_compact<<<tiles, kBlock, 0, st>>>(cells, list_end, ip_refs, ip_slots, tile_sums, static_cast<Cell*>(cells_other), refs_b, nexts); HG_DBG(ctx);
+        ip_compact<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, ip_slots, tile_sums, static_cast<Cell*>(cells_other), refs_b, nexts); HG_DBG(ctx);
         ip_resolve_tombs<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(nexts, ip_slots); HG_DBG(ctx);
         remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
         std::swap(cells, cells_other);
         std::swap(refs, refs_b);
         int h[2];
-        HG_TRY(read_back(ctx, ip_total, h, sizeof(h)));                    // (also: the kernels above are done, their buffers can go)
+        HG_TRY(read_back(ctx, ip_total, h, sizeof(h)));
         if (h[0] != num_cells) return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, "merge_grid: the books of the in-place iterations do not add up");
         num_refs = h[1];
-        hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr;
-        ip_release();
-        in_place = false; in_narrow = false;
+        in_place = false; in_narrow = false; ip_iters = 0;
+        return HAGRID_OK;
+    };
+    // The compacting passes of one iteration from `first_axis` on (merge_iteration<axis>, merge.cu:292-329).  They run back to back: the cell count
+    // of the second and third pass is only known to the device (the previous pass's scan total); their kernels are launched for the count the first
+    // of them starts from and read the real one.  One host round trip per iteration instead of three.
+    int last_pass_in = 0, last_pass_out = 0;
+    auto compacting_passes = [&](int first_axis, int mask) -> int {
+        for (int axis = first_axis; axis < 3; axis++) {
+            const int blocks = grid_blocks(num_cells, kBlock);
+            Int2* tot = total + axis;
+            const int* n_dev = axis > first_axis ? &total[axis - 1].a : nullptr;
+            const Entry* ent = reinterpret_cast<const Entry*>(entries);
+            if (++pass_tag == 256) { pass_tag = 1; (void)hipMemsetAsync(prevs, 0, nc0, st); }      // tags are bytes
+            if (in_narrow) merge_counts_kernel<true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
+            else           merge_counts_kernel<false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
+            HG_DBG(ctx);
+            cell_flags_kernel<<<grid_blocks((num_cells + 3) / 4, kBlock), kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
+            const int tiles = grid_blocks(num_cells, kMergeTile);
+            merge_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, merge_counts, num_cells, n_dev, tile_sums, tiles); HG_DBG(ctx);
+            if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, tot)) return HAGRID_ENOMEM;
+            // (new_cell_ids = nexts: dead after the flags)
+            if (in_narrow)   merge_kernel<true, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else if (narrow) merge_kernel<false, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            else             merge_kernel<false, false><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            HG_DBG(ctx);
+            in_narrow = narrow;
+            remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
+            std::swap(cells, cells_other);
+            std::swap(refs, refs_b);
+        }
+        int h[6];
+        HG_TRY(read_back(ctx, total, h, sizeof(int) * 6));
+        for (int axis = first_axis; axis < 3; axis++) {
+            record(num_cells, num_refs);
+            if (axis == 2) { last_pass_in = num_cells; last_pass_out = h[4]; }
+            num_cells = h[2 * axis]; num_refs = h[2 * axis + 1];
+        }
         return HAGRID_OK;
     };
 
     do {                                                                   // merge.cu:357-367
         prev_num_cells = num_cells;
         const int mask = iter > 3 ? 0 : (1 << (iter + 1)) - 1;
-        // no room for another iteration in place (or a test asks for it): back to the public arrays, this iteration compacts
-        if (in_place && (ip_cursor + 3ll * num_refs > ip_cap || (ctx->opt_merge_inplace_iters > 0 && ip_iters >= ctx->opt_merge_inplace_iters))) {
-            rc = ip_leave(); ip_iters = 0;
+        if (in_place && ctx->opt_merge_inplace_iters > 0 && ip_iters >= ctx->opt_merge_inplace_iters) {      // (tests: alternate the modes)
+            rc = ip_leave();
             if (rc != HAGRID_OK) break;
         }
+        int first_compacting_axis = 0;
         if (in_place) {
             // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
             if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * size_t(ip_slots), st);
@@ -655,59 +692,32 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
                     pass_tag = 1;
                     (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
                 }
-                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, ip_refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
+                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
                 ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag, acc); HG_DBG(ctx);
                 ip_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tiles); HG_DBG(ctx);
                 if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
-                ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, ip_refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books); HG_DBG(ctx);
+                ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books, ip_total,
+                                                    ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity, axis); HG_DBG(ctx);
                 ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, acc, books, snap + 2 * axis); HG_DBG(ctx);
             }
             if (rc != HAGRID_OK) break;
-            int h[10];                                                     // books (3), a spare word, the three snapshots
+            int h[10];                                                     // books (4), the three snapshots
             rc = read_back(ctx, books, h, sizeof(h));
             if (rc != HAGRID_OK) break;
-            record(num_cells, num_refs); record(h[4], h[5]); record(h[6], h[7]);
-            ip_cursor = h[0]; num_cells = h[8]; num_refs = h[9];
+            const int applied = h[3] > 0 ? h[3] - 1 : 3;                   // the passes before the first one whose lists did not fit
+            for (int axis = 0; axis < applied; axis++) { record(num_cells, num_refs); num_cells = h[4 + 2 * axis]; num_refs = h[5 + 2 * axis]; }
             ip_iters++;
-        } else {
-        // The three axis passes of an iteration run back to back: the cell count of the second and third pass is only known
-        // to the device (the previous pass's scan total); their kernels are launched for the iteration's starting count and
-        // read the real one.  One host round trip per iteration instead of three.
-        int last_pass_in = 0, last_pass_out = 0;
-        for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {          // merge_iteration<axis>, merge.cu:292-329
-            const int blocks = grid_blocks(num_cells, kBlock);
-            Int2* tot = total + axis;
-            const int* n_dev = axis ? &total[axis - 1].a : nullptr;
-            const Entry* ent = reinterpret_cast<const Entry*>(entries);
-            if (++pass_tag == 256) { pass_tag = 1; (void)hipMemsetAsync(prevs, 0, nc0, st); }      // tags are bytes
-            if (in_narrow) merge_counts_kernel<true><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
-            else           merge_counts_kernel<false><<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, refs, merge_counts, nexts, prevs, pass_tag, mask, num_cells, n_dev);
-            HG_DBG(ctx);
-            cell_flags_kernel<<<grid_blocks((num_cells + 3) / 4, kBlock), kBlock, 0, st>>>(nexts, prevs, pass_tag, cell_flags, num_cells, n_dev); HG_DBG(ctx);
-            const int tiles = grid_blocks(num_cells, kMergeTile);
-            merge_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, merge_counts, num_cells, n_dev, tile_sums, tiles); HG_DBG(ctx);
-            if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, tot)) { rc = HAGRID_ENOMEM; break; }
-            // (new_cell_ids = nexts: dead after the flags)
-            if (in_narrow)   merge_kernel<true, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else if (narrow) merge_kernel<false, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else             merge_kernel<false, false><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            HG_DBG(ctx);
-            in_narrow = narrow;
-            remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
-            std::swap(cells, cells_other);
-            std::swap(refs, refs_b);
-            if (axis == 2) {
-                int h[6];
-                rc = read_back(ctx, total, h, sizeof(int) * 6);
+            if (applied < 3) {                                             // no room: back to the public arrays; the rest of the iteration compacts
+                rc = ip_leave();
                 if (rc != HAGRID_OK) break;
-                record(num_cells, num_refs); record(h[0], h[1]); record(h[2], h[3]);
-                last_pass_in = h[2]; last_pass_out = h[4];
-                num_cells = h[4]; num_refs = h[5];
+                first_compacting_axis = applied;
             }
         }
-        if (rc != HAGRID_OK) break;
-        // the next iterations in place: once a pass merges less than a tenth of its cells (working records only: below 65536 per axis)
-        if (in_narrow && ctx->opt_merge_inplace && 10ll * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) (void)ip_enter();
+        if (!in_place) {
+            if (first_compacting_axis < 3) rc = compacting_passes(first_compacting_axis, mask);
+            if (rc != HAGRID_OK) break;
+            // the next iterations in place: once a pass merges less than a tenth of its cells (working records only: below 65536 per axis)
+            if (in_narrow && ctx->opt_merge_inplace && 10ll * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) ip_enter();
         }
         prev_mask = mask;
         iter++;
@@ -717,7 +727,6 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         widen_cells_kernel<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(cells, static_cast<Cell*>(cells_other), total + 2); HG_DBG(ctx);
         std::swap(cells, cells_other);
     }
-    if (rc != HAGRID_OK && in_place) { (void)hipStreamSynchronize(st); hagrid_mem_free(ctx, ip_refs); ip_refs = nullptr; ip_release(); }
 
     if (rc == HAGRID_OK) {
         hipError_t e = hipGetLastError();
