@@ -79,10 +79,12 @@ struct hagrid_ctx {
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once a pass merges less than a tenth of its cells
     int opt_merge_inplace_iters = 0;   // tests: leave the in-place mode after this many iterations (0: only for lack of room), the next iteration compacts
+    int opt_merge_inplace_div = 0;     // the mode is entered once a pass merges less than 1 / this of its cells (0: 50); tests enter earlier
     int opt_merge_inplace_room = 0;    // tests: the in-place mode may use the reference buffer up to this index only (0: all of it) -- the overflow path
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
+    int opt_band_rows = 0;      // tile packets: rows of super-tiles per band; 0 = as many as make the in-flight tiles a square block of the image
     int opt_super_log2 = 3;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside); round-3 sweep: 3 (profiles/dev_r3_tile_params.txt)
     int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it

@@ -195,11 +195,11 @@ extern "C" int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev,
 }
 
 extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots) {
-    if (!ctx || num_rays <= 0 || !slots || super_log2 < 0 || super_log2 > 8) return HAGRID_EINVAL;
+    if (!ctx || num_rays <= 0 || !slots || super_log2 < 0 || (super_log2 & 0xff) > 8) return HAGRID_EINVAL;          // (bits 8..: rows of super-tiles per band)
     const int blocks = grid_blocks(num_rays, 64);
     TraverseArgs a;
     memset(&a, 0, sizeof(a));
-    a.num_rays = num_rays; a.row_len_hint = row_len; a.super_log2 = super_log2; a.xcd_chunk_log2 = xcd_chunk_log2;
+    a.num_rays = num_rays; a.row_len_hint = row_len; a.super_log2 = super_log2 & 0xff; a.band_rows = super_log2 >> 8; a.xcd_chunk_log2 = xcd_chunk_log2;
     Staged o(ctx, nullptr, size_t(blocks) * 64 * 4);
     if (!o.d) return HAGRID_ENOMEM;
     kat_tile_slots<<<blocks, 64, 0, ctx->stream>>>(a, (int*)o.d); HG_DBG(ctx);
@@ -257,8 +257,8 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 0, 2},
-        {"traverse.order_drift", &ctx->opt_order_drift, 0, 1 << 16}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.tri_pad", &ctx->opt_tri_pad, -1, 1},
-        {"merge.inplace", &ctx->opt_merge_inplace, 0, 1},           {"merge.inplace_iters", &ctx->opt_merge_inplace_iters, 0, 1 << 20}, {"merge.inplace_room", &ctx->opt_merge_inplace_room, 0, 0x7fffffff},
+        {"traverse.order_drift", &ctx->opt_order_drift, 0, 1 << 16}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.tri_pad", &ctx->opt_tri_pad, -1, 1},
+        {"merge.inplace", &ctx->opt_merge_inplace, 0, 1},           {"merge.inplace_iters", &ctx->opt_merge_inplace_iters, 0, 1 << 20}, {"merge.inplace_room", &ctx->opt_merge_inplace_room, 0, 0x7fffffff}, {"merge.inplace_div", &ctx->opt_merge_inplace_div, 0, 1 << 20},
     };
     for (auto& t : table)
         if (!strcmp(key, t.name)) {

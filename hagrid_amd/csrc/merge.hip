@@ -368,34 +368,33 @@ __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const En
 
 // compute_cell_flags (merge.cu:145-170): chain heads name the absorbers of their chain (every second cell, while it has a successor)
 __global__ void __launch_bounds__(kBlock) ip_chains(int slots, const int* __restrict__ nexts, const unsigned char* __restrict__ evaluated,
-                                                    const unsigned char* __restrict__ has_prev, unsigned char* __restrict__ absorbs, int pass_tag, int* __restrict__ acc) {
+                                                    const unsigned char* __restrict__ has_prev, unsigned char* __restrict__ absorbs, int pass_tag) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
-    int merges = 0;
-    if (id < slots && evaluated[id] == pass_tag && has_prev[id] != pass_tag) {
-        int cur = id, pos = 0;
-        for (;;) {
-            const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
-            if (nxt < 0) break;
-            if (!(pos & 1)) { absorbs[cur] = (unsigned char)pass_tag; merges++; }
-            cur = nxt; pos++;
-        }
+    if (id >= slots || evaluated[id] != pass_tag || has_prev[id] == pass_tag) return;
+    int cur = id, pos = 0;
+    for (;;) {
+        const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
+        if (nxt < 0) break;
+        if (!(pos & 1)) absorbs[cur] = (unsigned char)pass_tag;
+        cur = nxt; pos++;
     }
-    merges = wave_sum(merges);
-    // (the number of merges of the pass: 64 words take the sums of the wavefronts -- one word would take ~88 atomics per us)
-    if (lane_id() == 0 && merges) atomicAdd(acc + ((blockIdx.x * kWaves + wave_id()) & 63), merges);
 }
 
+// per tile: {slots its merged lists need, merges} for the scan (its total closes the books of the pass), and on the side the references that disappear
+// (first tile sums of a pass on a same-line set of words by atomics cost 115 us per pass: the L2 serialises them; this costs nothing)
 __global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __restrict__ absorbs, int pass_tag, const Int2* __restrict__ minfo, int slots,
-                                                       Int2* __restrict__ sums, int num_tiles) {
+                                                       Int2* __restrict__ sums, int* __restrict__ removed, int num_tiles) {
     const int tile = blockIdx.x * kWaves + wave_id();
     if (tile >= num_tiles) return;
     Int2 s{0, 0};
+    int gone = 0;
     for (int c = 0; c < 4; c++) {
         const int i = tile * kMergeTile + c * 64 + lane_id();
-        if (i < slots && absorbs[i] == pass_tag) s = s + minfo[i];
+        if (i < slots && absorbs[i] == pass_tag) { const Int2 m = minfo[i]; s = s + Int2{m.a, 1}; gone += m.b; }
     }
     s = Int2{wave_sum(s.a), wave_sum(s.b)};
-    if (lane_id() == 0) sums[tile] = s;
+    gone = wave_sum(gone);
+    if (lane_id() == 0) { sums[tile] = s; removed[tile] = gone; }
 }
 
 // merge (merge.cu:189-278), in place
@@ -432,15 +431,20 @@ __global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, i
 // who has to look again: the absorber for every axis and, per axis, the cell behind its lower corner; thread 0 closes the books of the pass
 __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const unsigned char* __restrict__ absorbs,
                                                   int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
-                                                  int* __restrict__ acc, int* __restrict__ books /* cursor, live cells, live refs */, int* __restrict__ snap) {
+                                                  const int* __restrict__ removed, int num_tiles, int* __restrict__ books /* cursor, live cells, live refs, overflow */,
+                                                  int* __restrict__ snap) {
+    __shared__ int lds[kWaves];
     const int id = blockIdx.x * kBlock + threadIdx.x;
     const int overflow = books[3];                    // (written by the previous kernel at the latest; this kernel's thread 0 only changes its sign)
-    if (id == 0) {
-        int merges = 0;
-        for (int i = 0; i < 64; i++) { merges += acc[i]; acc[i] = 0; }
-        if (overflow == 0) { books[0] += pass_total->a; books[1] -= merges; books[2] -= pass_total->b; }
-        else if (overflow < 0) books[3] = -overflow;
-        snap[0] = books[1]; snap[1] = books[2];
+    if (blockIdx.x == 0) {                            // the books of the pass: cursor, live cells, live references
+        int gone = 0;
+        for (int i = threadIdx.x; i < num_tiles; i += kBlock) gone += removed[i];
+        gone = block_sum(gone, lds);
+        if (threadIdx.x == 0) {
+            if (overflow == 0) { books[0] += pass_total->a; books[1] -= pass_total->b; books[2] -= gone; }
+            else if (overflow < 0) books[3] = -overflow;
+            snap[0] = books[1]; snap[1] = books[2];
+        }
     }
     if (overflow != 0 || id >= slots || absorbs[id] != pass_tag) return;
     const CellRec c = CellFmt<true>::load(cells, id);
@@ -453,9 +457,8 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
     }
 }
 
-__global__ void ip_set_books(int* __restrict__ books, int cursor, int cells, int refs, int* __restrict__ acc) {
+__global__ void ip_set_books(int* __restrict__ books, int cursor, int cells, int refs) {
     if (threadIdx.x == 0) { books[0] = cursor; books[1] = cells; books[2] = refs; books[3] = 0; }
-    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
 }
 
 // ---- leaving the mode: one compaction ---------------------------------------------------------------------------------------------
@@ -602,7 +605,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references, overflow (1 + axis of the first pass that did not fit)
     int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
     Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
-    int* acc = ctx->dscratch + 64;                                        // 64 partial merge counts
+    int* tile_removed = nullptr;                                          // references that disappear, per tile of the pass
     const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
     // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).
     auto ip_enter = [&]() {
@@ -611,10 +614,11 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         minfo = reinterpret_cast<Int2*>(scratch);
         dirty = reinterpret_cast<unsigned char*>(scratch + ((size_t(ip_slots) * 8 + 255) & ~size_t(255)));
         evaluated = dirty + ((3 * size_t(ip_slots) + 255) & ~size_t(255));
+        tile_removed = reinterpret_cast<int*>(evaluated + ((size_t(ip_slots) + 255) & ~size_t(255)));
         (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
         (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);         // (the mode's `absorbs` tags)
         ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty); HG_DBG(ctx);
-        ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs, acc); HG_DBG(ctx);
+        ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs); HG_DBG(ctx);
         in_place = true;
     };
     // Leaves the mode: the live cells become public 32-byte records in `cells_other` (the scratch above is dead by then), their lists go to the
@@ -693,12 +697,12 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
                     (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
                 }
                 ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
-                ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag, acc); HG_DBG(ctx);
-                ip_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tiles); HG_DBG(ctx);
+                ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag); HG_DBG(ctx);
+                ip_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tile_removed, tiles); HG_DBG(ctx);
                 if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
                 ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books, ip_total,
                                                     ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity, axis); HG_DBG(ctx);
-                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, acc, books, snap + 2 * axis); HG_DBG(ctx);
+                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, tile_removed, tiles, books, snap + 2 * axis); HG_DBG(ctx);
             }
             if (rc != HAGRID_OK) break;
             int h[10];                                                     // books (4), the three snapshots
@@ -716,8 +720,11 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         if (!in_place) {
             if (first_compacting_axis < 3) rc = compacting_passes(first_compacting_axis, mask);
             if (rc != HAGRID_OK) break;
-            // the next iterations in place: once a pass merges less than a tenth of its cells (working records only: below 65536 per axis)
-            if (in_narrow && ctx->opt_merge_inplace && 10ll * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) ip_enter();
+            // The next iterations in place: once a pass merges less than one cell in fifty (working records only: below 65536 per axis).  While a pass
+            // merges more -- the 1M-triangle soup: 3.3 / 1.8 / 0.6 % in its second iteration -- most cells are dirty and its marks and appended lists cost
+            // what the compaction costs (measured: 175 against 160 us per pass); at a few per mille a pass in place costs a handful of sweeps over flags.
+            const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 50;
+            if (in_narrow && ctx->opt_merge_inplace && (long long)div * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) ip_enter();
         }
         prev_mask = mask;
         iter++;

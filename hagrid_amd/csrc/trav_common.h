@@ -31,6 +31,7 @@ struct TraverseArgs {
     const int* __restrict__ row_len;         // optional, device: row length found by detect_ray_rows (0 = none)
     int row_len_hint;                        // > 0: row length given by the caller ("traverse.image_width")
     int super_log2;                          // tile packets: tiles per super-tile edge, log2
+    int band_rows;                           // tile packets: rows of super-tiles per band (tile_packet_slot)
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
     const int* __restrict__ tile_order;      // tail kernel (and the TIMES instantiations of kat/kat.hip): packet b processes tile tile_order[b]; nullptr: tile b
     int* tile_cost;                          // tail kernel: a wavefront leaves the iterations it ran at its tile's index (atomicMax); nullptr: nothing
@@ -130,20 +131,28 @@ __device__ __forceinline__ int tile_packet_row_len(const TraverseArgs& a) {     
     return (w < 8 || (w & 7) || a.num_rays / w < 8) ? 0 : w;
 }
 
+// Order of the tiles: BANDS of `band_rows` rows of super-tiles; inside a band the super-tile columns from left to right, inside a column its
+// super-tiles from top to bottom, inside a super-tile the Z curve.  With one row per band (rounds 1-3) the tiles the machine holds at a time -- 8192
+// wavefronts -- are a stripe across the whole image, 64 pixels high at 8192 pixels per row: primary rays of a stripe stay inside its thin frustum,
+// but rays that start there in arbitrary directions (bounce rays in the image order of their primary hits) leave it at once and share nothing.
+// Bands about as high as the in-flight set is wide make that set a compact block of the image.
 __device__ __forceinline__ int tile_packet_slot(const TraverseArgs& a, int w, int b, int lane) {
     const int identity = b * 64 + lane;
     if (!w) return identity;
     const int tiles_x = w >> 3, tiles_y = (a.num_rays / w) >> 3;
     if (b >= tiles_x * tiles_y) return identity;             // ragged rows at the bottom, rays past the last full row
     const int S = 1 << a.super_log2;
-    const int band = b / (tiles_x * S), in_band = b - band * tiles_x * S;
-    const int hb = min(S, tiles_y - band * S);               // tile rows in this band of super-tiles
-    const int col = in_band / (S * hb), in_super = in_band - col * S * hb;
-    const int wc = min(S, tiles_x - col * S);                // tile columns in this super-tile
+    const int band_h = S * max(a.band_rows, 1);              // tile rows per band
+    const int band = b / (tiles_x * band_h), in_band = b - band * tiles_x * band_h;
+    const int hb = min(band_h, tiles_y - band * band_h);     // tile rows in this band
+    const int col = in_band / (S * hb), in_col = in_band - col * S * hb;
+    const int wc = min(S, tiles_x - col * S);                // tile columns in this column of super-tiles
+    const int st = in_col / (wc * S), in_super = in_col - st * wc * S;       // (the super-tiles above this one in the column are S rows high)
+    const int hs = min(S, hb - st * S);                      // tile rows in this super-tile
     int tx, ty;
-    if (wc == S && hb == S) { tx = int(compact1by1(uint32_t(in_super))); ty = int(compact1by1(uint32_t(in_super) >> 1)); }
+    if (wc == S && hs == S) { tx = int(compact1by1(uint32_t(in_super))); ty = int(compact1by1(uint32_t(in_super) >> 1)); }
     else                    { ty = in_super / wc; tx = in_super - ty * wc; }
-    const int px = ((col * S + tx) << 3) + (lane & 7), py = ((band * S + ty) << 3) + (lane >> 3);
+    const int px = ((col * S + tx) << 3) + (lane & 7), py = ((band * band_h + st * S + ty) << 3) + (lane >> 3);
     return py * w + px;
 }
 

@@ -110,6 +110,12 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr; a.order_samples = nullptr; a.order_report = nullptr; a.order_epoch = 0;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
+    // bands as high as the set of tiles the machine holds at a time is wide: sqrt(resident wavefronts) tiles, in super-tiles ("traverse.band_rows" > 0 forces it)
+    {
+        int side = 1;
+        while ((long long)(side + 1) * (side + 1) <= (long long)std::max(ctx->num_cus, 1) * 32) side++;
+        a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : std::max(1, (side + (1 << a.super_log2) / 2) >> a.super_log2);
+    }
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
     a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0;

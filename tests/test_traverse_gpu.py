@@ -235,7 +235,7 @@ def test_tile_packets_assign_every_ray_to_exactly_one_lane(mem, n, w):
     """The lane <-> ray assignment of the tile packets is a bijection for every batch size / row length / super-tile
     size / XCD order (values >= n are idle lanes), and where it applies a wavefront really holds an 8 x 8 pixel tile."""
     tiled = w >= 8 and w % 8 == 0 and (n // w) >= 8
-    for sl in (0, 2, 5):
+    for sl in (0, 2, 5, 3 | (11 << 8), 2 | (3 << 8), 3 | (1000 << 8)):            # (bits 8..: rows of super-tiles per band, 0 = one)
         for chunked in (-1, 0, 3, 10):
             slots = _tile_slots(mem, n, w, sl, chunked)
             live = slots[slots < n]
