@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
                                                        const Int2* __restrict__ tile_prefix, const int* __restrict__ merge_counts,
                                                        int* new_cell_ids /* holds nexts on entry */,
                                                        void* __restrict__ new_cells, int* __restrict__ new_refs, int num_cells, const int* __restrict__ n_dev,
-                                                       const Int2* __restrict__ totals) {
+                                                       const Int2* __restrict__ totals,
+                                                       const unsigned char* __restrict__ stamp_in, unsigned char* __restrict__ stamp_out, int stamp) {
     using FI = CellFmt<IN_NARROW>;
     using FO = CellFmt<OUT_NARROW>;
     __shared__ Int2 lds[kWaves];
@@ -286,6 +287,8 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     // cell of a merging pair is overwritten by another thread, and that cell is residue (flag 0) -- it never gets here
     const int next_id = new_cell_ids[id];
     new_cell_ids[id] = new_id;
+    // the pass that gave the cell its present box and list (0: the construction): what the in-place iterations start from (ip_begin)
+    if (stamp_out) stamp_out[new_id] = (unsigned char)(mc >= 0 ? stamp : (stamp_in ? stamp_in[id] : 0));
     const int n1 = cell.end - cell.begin;
     if (mc >= 0) {
         CellRec nc = FI::load(cells, next_id);
@@ -335,22 +338,56 @@ __device__ __forceinline__ CellRec ip_load(const void* cells, const int* list_en
     return c;
 }
 
-// entering the mode: explicit list ends, every cell dirty for every axis
-__global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty) {
+// The sweeps of a pass read a flag byte per slot and mostly find nothing to do: four slots per thread, one 4-byte load of the flags.
+constexpr int kIpPer = 4;
+constexpr int kIpTile = kBlock * kIpPer;            // slots per workgroup of the sweeps, and per tile of the slot scan
+__device__ __forceinline__ uint32_t ip_flags4(const unsigned char* __restrict__ f, int id4, int slots) {
+    if (id4 + 4 <= slots) return *reinterpret_cast<const uint32_t*>(f + id4);
+    uint32_t v = 0;
+    for (int c = 0; c < 4; c++) if (id4 + c < slots) v |= uint32_t(f[id4 + c]) << (8 * c);
+    return v;
+}
+__device__ __forceinline__ uint32_t ip_match4(uint32_t flags, int tag) {      // bit 8c set where byte c equals tag
+    uint32_t m = 0;
+    for (int c = 0; c < 4; c++) if (int((flags >> (8 * c)) & 0xffu) == tag) m |= 1u << (8 * c);
+    return m;
+}
+
+// Entering the mode: explicit list ends; a cell is dirty for an axis when it was made by a merge after the last evaluation of that axis
+// (stamps: the pass that gave a cell its box and list; since[a]: the pass of the last evaluation of axis a) -- and so is the cell behind
+// its lower corner (ip_mark_entry).  Without stamps every cell is dirty.
+__global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty,
+                                                   const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= slots) return;
     list_end[id] = int(reinterpret_cast<const uint4*>(cells)[size_t(id) + 1].w);
-    dirty[id] = 1; dirty[size_t(slots) + id] = 1; dirty[2 * size_t(slots) + id] = 1;
+    const int st = stamps ? stamps[id] : 255;
+    dirty[id] = st >= since_x; dirty[size_t(slots) + id] = st >= since_y; dirty[2 * size_t(slots) + id] = st >= since_z;
+}
+__global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, int slots,
+                                                        unsigned char* __restrict__ dirty, const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z) {
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    if (id4 >= slots) return;
+    const uint32_t f = ip_flags4(stamps, id4, slots);
+    const int since_min = min(since_x, min(since_y, since_z));
+    for (int c = 0; c < 4; c++) {
+        const int st = int((f >> (8 * c)) & 0xffu), id = id4 + c;
+        if (id >= slots || st < since_min) continue;
+        const CellRec cell = CellFmt<true>::load(cells, id);
+        for (int axis = 0; axis < 3; axis++) {
+            if (st < (axis == 0 ? since_x : (axis == 1 ? since_y : since_z))) continue;
+            ivec3 p = cell.lo;
+            if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
+            if (comp(p, axis) < 0) continue;
+            dirty[size_t(axis) * slots + int(lookup_entry(entries, k.shift, k.top, p))] = 1;
+        }
+    }
 }
 
 // compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis
-__global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
-                                                    const int* __restrict__ refs, int slots, unsigned char* __restrict__ dirty_axis,
-                                                    Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
-                                                    unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= slots || !dirty_axis[id]) return;
-    dirty_axis[id] = 0;
+__device__ __forceinline__ void ip_count_one(int id, int axis, const MergeK& k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
+                                             const int* __restrict__ refs, Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
+                                             unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
     if (ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) return;
     const CellRec c1 = ip_load(cells, list_end, id);
     const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
@@ -365,39 +402,56 @@ __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const En
     evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
     has_prev[next_id] = (unsigned char)pass_tag;
 }
+__global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
+                                                    const int* __restrict__ refs, int slots, unsigned char* __restrict__ dirty_axis,
+                                                    Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
+                                                    unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    if (id4 >= slots) return;
+    const uint32_t f = ip_flags4(dirty_axis, id4, slots);
+    if (!f) return;
+    for (int c = 0; c < 4; c++) {
+        if (!((f >> (8 * c)) & 0xffu)) continue;
+        dirty_axis[id4 + c] = 0;
+        ip_count_one(id4 + c, axis, k, entries, cells, list_end, refs, minfo, nexts, evaluated, has_prev, pass_tag, empty_mask);
+    }
+}
 
 // compute_cell_flags (merge.cu:145-170): chain heads name the absorbers of their chain (every second cell, while it has a successor)
 __global__ void __launch_bounds__(kBlock) ip_chains(int slots, const int* __restrict__ nexts, const unsigned char* __restrict__ evaluated,
                                                     const unsigned char* __restrict__ has_prev, unsigned char* __restrict__ absorbs, int pass_tag) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= slots || evaluated[id] != pass_tag || has_prev[id] == pass_tag) return;
-    int cur = id, pos = 0;
-    for (;;) {
-        const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
-        if (nxt < 0) break;
-        if (!(pos & 1)) absorbs[cur] = (unsigned char)pass_tag;
-        cur = nxt; pos++;
-    }
-}
-
-// per tile: {slots its merged lists need, merges} for the scan (its total closes the books of the pass), and on the side the references that disappear
-// (first tile sums of a pass on a same-line set of words by atomics cost 115 us per pass: the L2 serialises them; this costs nothing)
-__global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __restrict__ absorbs, int pass_tag, const Int2* __restrict__ minfo, int slots,
-                                                       Int2* __restrict__ sums, int* __restrict__ removed, int num_tiles) {
-    const int tile = blockIdx.x * kWaves + wave_id();
-    if (tile >= num_tiles) return;
-    Int2 s{0, 0};
-    int gone = 0;
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    if (id4 >= slots) return;
+    const uint32_t heads = ip_match4(ip_flags4(evaluated, id4, slots), pass_tag) & ~ip_match4(ip_flags4(has_prev, id4, slots), pass_tag);
+    if (!heads) return;
     for (int c = 0; c < 4; c++) {
-        const int i = tile * kMergeTile + c * 64 + lane_id();
-        if (i < slots && absorbs[i] == pass_tag) { const Int2 m = minfo[i]; s = s + Int2{m.a, 1}; gone += m.b; }
+        if (!(heads & (1u << (8 * c)))) continue;
+        int cur = id4 + c, pos = 0;
+        for (;;) {
+            const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
+            if (nxt < 0) break;
+            if (!(pos & 1)) absorbs[cur] = (unsigned char)pass_tag;
+            cur = nxt; pos++;
+        }
     }
-    s = Int2{wave_sum(s.a), wave_sum(s.b)};
-    gone = wave_sum(gone);
-    if (lane_id() == 0) { sums[tile] = s; removed[tile] = gone; }
 }
 
-// merge (merge.cu:189-278), in place
+// per tile of kIpTile slots: {slots its merged lists need, merges} for the scan (its total closes the books of the pass), and on the side the
+// references that disappear (sums of a pass kept by atomics on a handful of words of one cache line cost 115 us per pass: the L2 serialises them)
+__global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __restrict__ absorbs, int pass_tag, const Int2* __restrict__ minfo, int slots,
+                                                       Int2* __restrict__ sums, int* __restrict__ removed) {
+    __shared__ int lds[kWaves];
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    int need = 0, merges = 0, gone = 0;
+    if (id4 < slots) {
+        const uint32_t m = ip_match4(ip_flags4(absorbs, id4, slots), pass_tag);
+        for (int c = 0; c < 4; c++) if (m & (1u << (8 * c))) { const Int2 v = minfo[id4 + c]; need += v.a; merges++; gone += v.b; }
+    }
+    need = block_sum(need, lds); merges = block_sum(merges, lds); gone = block_sum(gone, lds);
+    if (threadIdx.x == 0) { sums[blockIdx.x] = Int2{need, merges}; removed[blockIdx.x] = gone; }
+}
+
+// merge (merge.cu:189-278), in place.
 // The merged lists are appended behind the live references in the SAME buffer (its tail is free once the first iterations have shrunk the lists).
 // A pass whose lists do not fit is not applied at all, nor is any later pass of the iteration (books[3] = 1 + its axis, sticky): the host compacts and
 // runs those passes the compacting way.
@@ -405,36 +459,41 @@ __global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, i
                                                    const Int2* __restrict__ minfo, const int* __restrict__ nexts, const Int2* __restrict__ tile_prefix,
                                                    int slots, int* __restrict__ books, const Int2* __restrict__ pass_total, int capacity, int axis) {
     __shared__ int lds[kWaves];
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
     const int* cursor = books;
     const int overflow = __hip_atomic_load(books + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (overflow > 0 || (long long)*cursor + pass_total->a > (long long)capacity) {       // (the same answer in every thread: books[0] and the total do not change in this kernel)
-        if (id == 0 && overflow <= 0) __hip_atomic_store(books + 3, -(1 + axis), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // negative: "this pass"; ip_mark makes it sticky
+        if (id4 == 0 && overflow <= 0) __hip_atomic_store(books + 3, -(1 + axis), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // negative: "this pass"; ip_mark makes it sticky
         return;
     }
-    const bool mine = id < slots && absorbs[id] == pass_tag;
-    const int m = mine ? minfo[id].a : 0;
-    const int incl = wave_inclusive_scan(m);
+    const uint32_t mine = id4 < slots ? ip_match4(ip_flags4(absorbs, id4, slots), pass_tag) : 0u;
+    int m[4], total = 0;
+    for (int c = 0; c < 4; c++) { m[c] = (mine & (1u << (8 * c))) ? minfo[id4 + c].a : 0; total += m[c]; }
+    const int incl = wave_inclusive_scan(total);
     if (lane_id() == 63) lds[wave_id()] = incl;
     __syncthreads();
     if (!mine) return;
-    int at = *cursor + tile_prefix[blockIdx.x].a + incl - m;
+    int at = *cursor + tile_prefix[blockIdx.x].a + incl - total;
     for (int w = 0; w < wave_id(); w++) at += lds[w];
-    const int other = nexts[id];
-    const CellRec c = ip_load(cells, list_end, id), n = ip_load(cells, list_end, other);
-    write_union(refs + c.begin, c.end - c.begin, refs + n.begin, n.end - n.begin, refs + at, m);
-    CellFmt<true>::store(cells, id, min(n.lo, c.lo), at, max(n.hi, c.hi), 0);
-    list_end[id] = at + m;
-    reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
+    for (int c = 0; c < 4; c++) {
+        if (!(mine & (1u << (8 * c)))) continue;
+        const int id = id4 + c, other = nexts[id];
+        const CellRec a = ip_load(cells, list_end, id), n = ip_load(cells, list_end, other);
+        write_union(refs + a.begin, a.end - a.begin, refs + n.begin, n.end - n.begin, refs + at, m[c]);
+        CellFmt<true>::store(cells, id, min(n.lo, a.lo), at, max(n.hi, a.hi), 0);
+        list_end[id] = at + m[c];
+        reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
+        at += m[c];
+    }
 }
 
-// who has to look again: the absorber for every axis and, per axis, the cell behind its lower corner; thread 0 closes the books of the pass
+// who has to look again: the absorber for every axis and, per axis, the cell behind its lower corner; block 0 closes the books of the pass
 __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const unsigned char* __restrict__ absorbs,
                                                   int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
                                                   const int* __restrict__ removed, int num_tiles, int* __restrict__ books /* cursor, live cells, live refs, overflow */,
                                                   int* __restrict__ snap) {
     __shared__ int lds[kWaves];
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
     const int overflow = books[3];                    // (written by the previous kernel at the latest; this kernel's thread 0 only changes its sign)
     if (blockIdx.x == 0) {                            // the books of the pass: cursor, live cells, live references
         int gone = 0;
@@ -446,14 +505,20 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
             snap[0] = books[1]; snap[1] = books[2];
         }
     }
-    if (overflow != 0 || id >= slots || absorbs[id] != pass_tag) return;
-    const CellRec c = CellFmt<true>::load(cells, id);
-    for (int axis = 0; axis < 3; axis++) {
-        dirty[size_t(axis) * slots + id] = 1;
-        ivec3 p = c.lo;
-        if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
-        if (comp(p, axis) < 0) continue;
-        dirty[size_t(axis) * slots + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
+    if (overflow != 0 || id4 >= slots) return;
+    const uint32_t mine = ip_match4(ip_flags4(absorbs, id4, slots), pass_tag);
+    if (!mine) return;
+    for (int c = 0; c < 4; c++) {
+        if (!(mine & (1u << (8 * c)))) continue;
+        const int id = id4 + c;
+        const CellRec cell = CellFmt<true>::load(cells, id);
+        for (int axis = 0; axis < 3; axis++) {
+            dirty[size_t(axis) * slots + id] = 1;
+            ivec3 p = cell.lo;
+            if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
+            if (comp(p, axis) < 0) continue;
+            dirty[size_t(axis) * slots + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
+        }
     }
 }
 
@@ -564,15 +629,20 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* nexts = pool_alloc<int>(ctx, nc0 + 1);
     unsigned char* prevs = pool_alloc<unsigned char>(ctx, nc0 + 4);
     unsigned char* cell_flags = pool_alloc<unsigned char>(ctx, nc0 + 4);
+    // per cell: the pass that made it (0: the construction); two buffers that swap with the cells.  One allocation: the halves are 256-byte aligned
+    const size_t stamp_stride = (nc0 + 4 + 255) & ~size_t(255);
+    unsigned char* stamps = pool_alloc<unsigned char>(ctx, 2 * stamp_stride);
+    unsigned char* stamps_other = stamps ? stamps + stamp_stride : nullptr;
+    unsigned char* const stamps_base = stamps;
     const int max_tiles = grid_blocks(grid->num_cells, kMergeTile);
     Int2* tile_sums = pool_alloc<Int2>(ctx, size_t(max_tiles) + 1);
     Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(max_tiles)) + 1);
     Int2* total = reinterpret_cast<Int2*>(ctx->dscratch);
     auto release = [&]() {
         hagrid_mem_free(ctx, merge_counts); hagrid_mem_free(ctx, nexts); hagrid_mem_free(ctx, prevs); hagrid_mem_free(ctx, cell_flags);
-        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials);
+        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, stamps_base);
     };
-    if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !tile_sums || !partials) {
+    if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !tile_sums || !partials || !stamps) {
         release(); hagrid_mem_free(ctx, cells_b); hagrid_mem_free(ctx, refs_b);
         return HAGRID_ENOMEM;
     }
@@ -598,6 +668,9 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     // ---- iterations in place (see the kernels above): state of the mode ----
     // No buffer of its own: the explicit list ends live in `merge_counts`, the per-slot scratch of the mode (merged size / disappearing references,
     // dirty bytes per axis, "evaluated" tags) in the cell buffer that is not in use, and the merged lists go behind the live references of `refs`.
+    int global_pass = 0;                                                   // passes run so far (the stamp of the cells the next one makes is global_pass + 1)
+    bool have_stamps = false;                                              // `stamps` describes `cells`
+    int since[3] = {0, 0, 0};                                              // the pass of the last evaluation of every axis
     bool in_place = false;
     int ip_slots = 0, ip_iters = 0, prev_mask = 0;
     int* list_end = merge_counts;
@@ -617,7 +690,10 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         tile_removed = reinterpret_cast<int*>(evaluated + ((size_t(ip_slots) + 255) & ~size_t(255)));
         (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
         (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);         // (the mode's `absorbs` tags)
-        ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty); HG_DBG(ctx);
+        // dirty cells: the ones made after the last evaluation of the axis (their stamps say so) and the cells behind their lower corners
+        const unsigned char* stp = have_stamps ? stamps : nullptr;
+        ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2]); HG_DBG(ctx);
+        if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2]); HG_DBG(ctx);
         ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs); HG_DBG(ctx);
         in_place = true;
     };
@@ -638,6 +714,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         if (h[0] != num_cells) return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, "merge_grid: the books of the in-place iterations do not add up");
         num_refs = h[1];
         in_place = false; in_narrow = false; ip_iters = 0;
+        have_stamps = false;                                               // (the compaction does not carry them: a later entry starts with every cell dirty)
         return HAGRID_OK;
     };
     // The compacting passes of one iteration from `first_axis` on (merge_iteration<axis>, merge.cu:292-329).  They run back to back: the cell count
@@ -659,10 +736,17 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             merge_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, merge_counts, num_cells, n_dev, tile_sums, tiles); HG_DBG(ctx);
             if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, tot)) return HAGRID_ENOMEM;
             // (new_cell_ids = nexts: dead after the flags)
-            if (in_narrow)   merge_kernel<true, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else if (narrow) merge_kernel<false, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
-            else             merge_kernel<false, false><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot);
+            // (stamps are bytes: a merge of more than 250 passes goes on without them -- and without the in-place mode)
+            global_pass++;
+            const bool stamping = global_pass < 250 && (have_stamps || global_pass == 1);
+            const unsigned char* st_in = stamping && have_stamps ? stamps : nullptr;
+            unsigned char* st_out = stamping ? stamps_other : nullptr;
+            if (in_narrow)   merge_kernel<true, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot, st_in, st_out, global_pass);
+            else if (narrow) merge_kernel<false, true><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot, st_in, st_out, global_pass);
+            else             merge_kernel<false, false><<<tiles, kBlock, 0, st>>>(axis, k, ent, cells, refs, cell_flags, tile_sums, merge_counts, nexts, cells_other, refs_b, num_cells, n_dev, tot, st_in, st_out, global_pass);
             HG_DBG(ctx);
+            have_stamps = stamping; since[axis] = global_pass;
+            std::swap(stamps, stamps_other);
             in_narrow = narrow;
             remap_entries_kernel<<<grid_blocks((num_entries + 3) / 4, kBlock), kBlock, 0, st>>>(entries, nexts, num_entries); HG_DBG(ctx);
             std::swap(cells, cells_other);
@@ -689,16 +773,17 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         if (in_place) {
             // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
             if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * size_t(ip_slots), st);
-            const int blocks = grid_blocks(ip_slots, kBlock), tiles = grid_blocks(ip_slots, kMergeTile);
+            const int blocks = grid_blocks(ip_slots, kIpTile), tiles = blocks;
             const Entry* ent = reinterpret_cast<const Entry*>(entries);
             for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {
+                global_pass++;
                 if (++pass_tag == 256) {                                   // tags are bytes
                     pass_tag = 1;
                     (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
                 }
                 ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
                 ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag); HG_DBG(ctx);
-                ip_tile_sums<<<grid_blocks(tiles, kWaves), kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tile_removed, tiles); HG_DBG(ctx);
+                ip_tile_sums<<<tiles, kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tile_removed); HG_DBG(ctx);
                 if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
                 ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books, ip_total,
                                                     ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity, axis); HG_DBG(ctx);
@@ -720,11 +805,12 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         if (!in_place) {
             if (first_compacting_axis < 3) rc = compacting_passes(first_compacting_axis, mask);
             if (rc != HAGRID_OK) break;
-            // The next iterations in place: once a pass merges less than one cell in fifty (working records only: below 65536 per axis).  While a pass
-            // merges more -- the 1M-triangle soup: 3.3 / 1.8 / 0.6 % in its second iteration -- most cells are dirty and its marks and appended lists cost
-            // what the compaction costs (measured: 175 against 160 us per pass); at a few per mille a pass in place costs a handful of sweeps over flags.
-            const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 50;
-            if (in_narrow && ctx->opt_merge_inplace && (long long)div * (last_pass_in - last_pass_out) < last_pass_in && num_cells < alpha * prev_num_cells) ip_enter();
+            // The next iterations in place: once an iteration merges less than an eighth of its cells (working records only: below 65536 per axis).
+            // The first in-place iteration looks at the cells the last compacting one made and their neighbours (stamps): about two cells per merge
+            // and axis, so below an eighth most cells are skipped.  1M-triangle soup: the first iteration merges 39 % of the cells, the second 5.7 %, the
+            // third 0.4 %; a compacting pass costs ~160 us whatever it merges, a pass in place over a few per cent of dirty cells a handful of sweeps over flags.
+            const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 8;
+            if (in_narrow && ctx->opt_merge_inplace && (long long)div * (prev_num_cells - num_cells) < prev_num_cells && num_cells < alpha * prev_num_cells) ip_enter();
         }
         prev_mask = mask;
         iter++;

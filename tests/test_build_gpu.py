@@ -99,8 +99,10 @@ def test_merge_iterations_in_place_and_compacting_agree_with_the_oracle(mem, n, 
     try:
         # room: the in-place mode appends its merged lists behind the live references of the same buffer; a pass whose lists do not fit is not
         # applied and the rest of its iteration compacts -- forced here by capping the buffer (1: the very first pass; final size + a little: a later one)
-        # div: the mode is entered once a pass merges less than 1 / div of its cells (default 50); 3 enters behind the first iteration, where most cells merge
-        for inplace, iters, room, div in ((1, 0, 0, 0), (0, 0, 0, 0), (1, 0, 0, 3), (1, 1, 0, 3), (1, 2, 0, 10), (1, 0, 1, 3), (1, 0, G.num_refs + 64, 3), (1, 0, G.num_refs + G.num_refs // 16, 3)):
+        # div: the mode is entered once an iteration merges less than 1 / div of its cells (default 8); 1 enters behind the first iteration, where the
+        # stamps of the compacting passes make most cells dirty, 2 / 4 somewhere in between
+        for inplace, iters, room, div in ((1, 0, 0, 0), (0, 0, 0, 0), (1, 0, 0, 1), (1, 0, 0, 2), (1, 1, 0, 1), (1, 2, 0, 4), (1, 0, 1, 1), (1, 0, G.num_refs + 64, 1),
+                                          (1, 0, G.num_refs + G.num_refs // 16, 1)):
             mem.set_option("merge.inplace", inplace); mem.set_option("merge.inplace_iters", iters); mem.set_option("merge.inplace_room", room)
             mem.set_option("merge.inplace_div", div)
             grid = api.Grid()
