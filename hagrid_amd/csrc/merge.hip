@@ -829,11 +829,11 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         if (!in_place) {
             if (first_compacting_axis < 3) rc = compacting_passes(first_compacting_axis, mask);
             if (rc != HAGRID_OK) break;
-            // The next iterations in place: once an iteration merges less than an eighth of its cells (working records only: below 65536 per axis).
-            // The first in-place iteration looks at the cells the last compacting one made and their neighbours (stamps): about two cells per merge
-            // and axis, so below an eighth most cells are skipped.  1M-triangle soup: the first iteration merges 39 % of the cells, the second 5.7 %, the
-            // third 0.4 %; a compacting pass costs ~160 us whatever it merges, a pass in place over a few per cent of dirty cells a handful of sweeps over flags.
-            const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 8;
+            // The next iterations in place: once an iteration merges less than half of its cells (working records only: below 65536 per axis).  The
+            // first in-place iteration looks at the cells the last compacting one made and at the cells behind them (stamps): about two cells per merge
+            // and axis.  1M-triangle soup: the first iteration merges 39 % of the cells, the second 5.7 %, the third 0.4 %; a compacting pass costs ~160 us
+            // whatever it merges, a pass in place 75 - 130 us in the second iteration and ~45 us in the third (profiles/NOTES.md "Round 4").
+            const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 2;
             if (in_narrow && ctx->opt_merge_inplace && (long long)div * (prev_num_cells - num_cells) < prev_num_cells && num_cells < alpha * prev_num_cells) ip_enter();
         }
         prev_mask = mask;

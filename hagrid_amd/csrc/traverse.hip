@@ -114,7 +114,9 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     {
         int side = 1;
         while ((long long)(side + 1) * (side + 1) <= (long long)std::max(ctx->num_cus, 1) * 32) side++;
-        a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : std::max(1, (side + (1 << a.super_log2) / 2) >> a.super_log2);
+        // (measured, profiles/NOTES.md "Round 4": a square in-flight block -- 11 rows -- costs the primary batches 1 - 2 %; about a third of it, 4 rows at
+        // 8192 slots, is neutral for them and the best for the bounce rays of configuration 5: +3.7 %)
+        a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : std::max(1, (side / 3 + (1 << a.super_log2) / 2) >> a.super_log2);
     }
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
@@ -345,13 +347,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
         }
         // "traverse.tri_pad": the tail kernel (table-free slim image) reads the triangles from a copy padded to 64 bytes each, made by THIS call (the
-        // caller's array may change between calls, so nothing is kept): a 48-byte triangle straddles two 64-byte sectors every second time, and the
-        // incoherent / beyond-cache batches are bound by the number of requests the vector L1s have in flight (profiles/r4a), not by bytes.  The copy
-        // streams 112 bytes per triangle; -1 (default): when the batch has at least four rays per triangle the grid refers to (the copy then costs
-        // under 3 % of the launch).
+        // caller's array may change between calls, so nothing is kept): a 48-byte triangle straddles two 64-byte sectors every second time, which costs
+        // a binned incoherent batch a quarter more requests from the vector L1s to L2 than it needs (profiles/r4a).  Measured (NOTES "Round 4"): +2.4 % on
+        // the 16M-ray share of configuration 4, nothing on image-ordered batches, -13 % where the copy (112 bytes per triangle) is not small against the
+        // launch.  -1 (default): for binned batches of at least four rays per triangle the grid refers to.
         if (ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
             const long long n_tris = (long long)ctx->image.max_ref + 1;
-            const bool want = ctx->opt_tri_pad < 0 ? (long long)num_rays >= 4 * n_tris : ctx->opt_tri_pad != 0;
+            const bool want = ctx->opt_tri_pad < 0 ? (perm != nullptr && (long long)num_rays >= 4 * n_tris) : ctx->opt_tri_pad != 0;
             if (want) {
                 float4* padded = tmp.get<float4>(size_t(n_tris) * 4);
                 if (padded) {
