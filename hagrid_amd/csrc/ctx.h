@@ -110,6 +110,7 @@ struct hagrid_ctx {
     static constexpr int kRayHints = 4;
     RayHints hints[kRayHints];
     unsigned long long hint_clock = 0;
+    int opt_mailbox = -1;       // tail kernel: per ray a mailbox of the last four triangles it was tested against (LDS); -1: chosen per launch
     int opt_tri_pad = -1;       // tail kernel: triangles read from a copy padded to 64 bytes each (one L2 / HBM sector per triangle instead of 1.5), made at every call; -1: chosen per launch
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel

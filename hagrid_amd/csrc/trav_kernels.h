@@ -286,14 +286,24 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // a dozen spilled registers around its loops, so launches of it that keep no costs run the instantiation without
 // TRI64: the triangles are read from a copy padded to 64 bytes each (traverse.hip, "traverse.tri_pad"): a triangle is then ONE 64-byte sector of L2 / HBM
 // (the caller's 48-byte records straddle two sectors every second time) -- a third fewer requests to L2 per triangle test
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false>
-__global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs a) {
+// MAILBOX: every ray remembers the last four triangles it was tested against (a FIFO of ids per lane in LDS: the kernel has no registers for it) and skips
+// a test it has made before.  A triangle is referenced by the several cells it overlaps and a ray that passes it crosses several of them: on the oracle's
+// traces a quarter of the tests of a ray repeat one of its last four (15 % one of its last two), primary and incoherent batches alike.  A repeated test
+// is a no-op by construction -- rejected before the tmax comparison: rejected again (the ray has not changed); rejected by it: tmax has only fallen since;
+// accepted: it either writes the same id and t again or is rejected -- so the hits stay bit-identical.  What it saves is the three lane accesses of the
+// triangle in the vector L1 and its L2 / HBM sector: the resources the incoherent and the beyond-cache batches are bound by (profiles/r4a).  It costs an LDS
+// round trip in front of every triangle round.
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false>
+__global__ void __launch_bounds__(64, MAILBOX ? 7 : 8) traverse_kernel_tail(const TraverseArgs a) {
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
+    static_assert(!(MAILBOX && DUAL), "the mailbox is built into the one-id-per-round loops");
     __shared__ int lanes_of[64];
+    __shared__ int4 mailbox[MAILBOX ? 64 : 1];            // MAILBOX: the last four ids tested for the ray in this lane (phase 2: for the ray of the group, in its first lane's slot)
     __shared__ int cost_bonus;                            // iterations counted twice at the end (blocks without a one-ray-per-lane phase)
     __shared__ int* cost_at;                              // where this wavefront leaves its cost (its tile's word of a.tile_cost), nullptr: nowhere
     __shared__ float4 tri_lds[DUAL ? 3 * 64 : 1];         // DUAL: a lane's second triangle of a round, written by the load itself (LDS-DMA)
     const int lane = threadIdx.x;
+    if (MAILBOX) mailbox[lane] = make_int4(-1, -1, -1, -1);          // (ids are >= 0; a wavefront is its own workgroup: LDS operations of a wavefront execute in order)
     struct Stamp {
         unsigned long long* p;
         __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
@@ -477,9 +487,17 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
         } else if (__ballot(by_index) == 0ull) {
 #pragma unroll 1
             while (ref != NONE) {
-                Hit h(hit_id, hit_t, 0.0f, 0.0f);
-                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
-                hit_t = h.t; hit_id = h.id;
+                bool fresh = true;
+                if (MAILBOX) {
+                    const int4 m = mailbox[lane];
+                    fresh = !(ref == m.x || ref == m.y || ref == m.z || ref == m.w);
+                    if (fresh) mailbox[lane] = make_int4(m.y, m.z, m.w, ref);
+                }
+                if (fresh) {
+                    Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                    (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                    hit_t = h.t; hit_id = h.id;
+                }
                 ref = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE);
                 HG_NOPS();
             }
@@ -495,9 +513,17 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 int next;
                 if (by_index) { next = q1 < q2 ? ref_at(q1) : NONE; q1++; }
                 else { next = int(q1); q1 = q2; q2 = q3; q3 = uint32_t(NONE); }
-                Hit h(hit_id, hit_t, 0.0f, 0.0f);
-                (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
-                hit_t = h.t; hit_id = h.id;
+                bool fresh = true;
+                if (MAILBOX) {
+                    const int4 m = mailbox[lane];
+                    fresh = !(ref == m.x || ref == m.y || ref == m.z || ref == m.w);
+                    if (fresh) mailbox[lane] = make_int4(m.y, m.z, m.w, ref);
+                }
+                if (fresh) {
+                    Hit h(hit_id, hit_t, 0.0f, 0.0f);
+                    (void)intersect_prim_ray(tri_for(ref), Ray(org, tmin, dir, hit_t), ref, h);
+                    hit_t = h.t; hit_id = h.id;
+                }
                 ref = next;
             }
         }
@@ -545,6 +571,12 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
     vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
     ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
     if (!UNIFORM) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
+    if (MAILBOX) {                                         // the mailbox moves with its ray: the group's first lane's slot holds it from here on
+        const int4 m = mailbox[lanes_of[alive ? group : 0]];
+        __syncthreads();                                   // (every slot is read before any is overwritten)
+        if (alive && sub == 0) mailbox[lane] = m;
+        __syncthreads();
+    }
     }
 
     // ---- phase 2: four lanes per ray ------------------------------------------------------------------------------------------
@@ -612,7 +644,14 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_tail(const TraverseArgs
                 if (__ballot(by_index) == 0ull) {
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
-                    if (inl != NONE) cd = tri_candidate(tri_vec(inl), org, dir, tmin);
+                    int mine_now = inl;
+                    if (MAILBOX && inl != NONE) {
+                        // the group's mailbox as the one-ray-per-lane phase left it (its first lane's slot): a lane whose id is in it skips its test.
+                        // (Entering the ids tested here as well costs the phase a dozen registers it does not have: 20 spilled.)
+                        const int4 m = mailbox[lane & ~3];
+                        if (inl == m.x || inl == m.y || inl == m.z || inl == m.w) mine_now = NONE;
+                    }
+                    if (mine_now != NONE) cd = tri_candidate(tri_vec(mine_now), org, dir, tmin);
                     HG_NOPS();
                     const unsigned long long cand = __ballot(cd.ok);
                     if (cand != 0ull) {

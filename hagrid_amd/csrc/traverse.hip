@@ -42,6 +42,15 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
             else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
+    else if (tail && MODE == 0 && uniform && slim && a.mailbox) {          // (one id per round trip: the mailbox sits in front of every round)
+        if (a.tri64) {
+            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
+    }
     else if (tail && MODE == 0 && uniform && slim && a.tri64) {
         if (a.tail_dual) {
             if (slim == 20) traverse_kernel_tail<20, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -120,7 +129,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     }
     a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -331,6 +340,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly
         // issued for one or two lanes).  Hits do not depend on it.
         a.tail_dual = ctx->opt_tail_dual < 0 ? (perm ? 0 : 1) : ctx->opt_tail_dual;
+        // "traverse.mailbox": every ray skips a triangle it was tested against among its last four tests (trav_kernels.h, MAILBOX); 1 switches the
+        // second id per round trip off.  -1 (default): TODO measured policy
+        a.mailbox = ctx->opt_mailbox < 0 ? 0 : ctx->opt_mailbox;
+        if (a.mailbox) a.tail_dual = 0;
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
