@@ -42,6 +42,9 @@ L2_GATHER_GPS = 256.0       # G requests/s, working set 1 MB (L2-resident)
 MALL_GATHER_GPS = 80.0      # G requests/s, working set 16 MB ... 256 MB (Infinity Cache)
 HBM_GATHER_GPS = 55.0       # G requests/s, working set 1 GB (52 - 57 measured): the chip's rate of random 64-byte fetches from HBM
 VALU_CYCLES_PER_INST = 2.2
+TA_CYCLES_PER_LANE_ACCESS = 1.25    # CU-cycles per live lane of a 16-byte gather that hits the vector L1 (80 per 64-lane instruction)
+TA_EXTRA_CYCLES_PER_L1_MISS = 1.17  # ... and on top when it goes to L2 (155 per instruction)
+NUM_CUS = 256
 SHADER_CLOCK_HZ = 2.4e9
 NUM_SIMDS = 1024
 
@@ -62,6 +65,12 @@ def binding_resources(counters: dict, kernel_ms: float, working_set_bytes: int, 
     if "TCP_TCC_READ_REQ_sum" in counters:
         out["l2_request_rate"] = {"achieved": round(counters["TCP_TCC_READ_REQ_sum"] / t / 1e9, 2), "peak": L2_GATHER_GPS, "unit": "G requests/s",
                                   "frac": round(counters["TCP_TCC_READ_REQ_sum"] / t / 1e9 / L2_GATHER_GPS, 4), "what": "vector-L1 misses per second against the measured rate of L2-resident random gathers"}
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in counters and "TCP_TCC_READ_REQ_sum" in counters:
+        cyc = counters["TCP_TOTAL_CACHE_ACCESSES_sum"] * TA_CYCLES_PER_LANE_ACCESS + counters["TCP_TCC_READ_REQ_sum"] * TA_EXTRA_CYCLES_PER_L1_MISS
+        out["vector_memory_path"] = {"achieved": round(counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / t / 1e9, 2), "unit": "G lane accesses/s",
+                                     "peak": round(NUM_CUS * SHADER_CLOCK_HZ / TA_CYCLES_PER_LANE_ACCESS / 1e9, 1), "frac": round(cyc / (NUM_CUS * SHADER_CLOCK_HZ * t), 4),
+                                     "what": f"lane accesses of the vector L1s x {TA_CYCLES_PER_LANE_ACCESS} CU-cycles + their misses x {TA_EXTRA_CYCLES_PER_L1_MISS} more (16-byte gathers, every lane its own line: "
+                                             "tools/micro/ta_lanes.hip, 80 / 155 cycles per 64-lane instruction from L1 / L2) against 256 CUs x 2.4 GHz: the address / tag path of the CUs"}
     if "SQ_INSTS_VALU" in counters:
         cyc = counters["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / NUM_SIMDS
         out["valu_issue"] = {"achieved": round(counters["SQ_INSTS_VALU"] / t / 1e9, 2), "peak": round(NUM_SIMDS * SHADER_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9, 1), "unit": "G wavefront-instructions/s",
@@ -509,6 +518,19 @@ def main():
             # all host cores: worker threads take 4096-ray chunks from a shared counter and are pinned (oracle/hagrid_oracle.c run_jobs_on) -- once to
             # one hardware thread per physical core, once to every hardware thread; the better of the two is `value`
             phys = O.physical_cpus(); allhw = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+            # the container may hold less CPU time than the cores it sees (cgroup quota): more threads than that only take turns
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            except Exception:
+                try:
+                    q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    quota = q / per if q > 0 else None
+                except Exception:
+                    pass
+            if quota and quota < len(phys):
+                phys = phys[:max(1, int(quota + 0.999))]; allhw = allhw[:max(1, int(2 * quota + 0.999))]
             cores = len(phys)
             probe = min(65536, n_head)
             t0 = time.perf_counter(); oh, _ = G.traverse(tris_host, rays_head[:probe], nthreads=cores, cpus=phys); t_probe = time.perf_counter() - t0
@@ -537,7 +559,8 @@ def main():
                                    "physical_cores": {"value": round(rate_phys, 4), "threads": len(phys), "scaling_vs_one_thread": round(rate_phys / rate_one, 1),
                                                       "efficiency": round(rate_phys / rate_one / len(phys), 3)},
                                    "all_hardware_threads": None if rate_all is None else {"value": round(rate_all, 4), "threads": len(allhw), "scaling_vs_one_thread": round(rate_all / rate_one, 1)},
-                                   "single_thread": {"value": round(rate_one, 4), "unit": "Mrays/s", "cores": 1, "sample": f"first {one_n} rays of the batch"}}
+                                   "single_thread": {"value": round(rate_one, 4), "unit": "Mrays/s", "cores": 1, "sample": f"first {one_n} rays of the batch"},
+                                   "host": {"hardware_threads": os.cpu_count(), "physical_cores_visible": len(O.physical_cpus()), "cgroup_cpu_quota_cores": quota}}
             if n_tris <= 1_000_000:      # CPU construction of the same grid, one core (the oracle's passes are scalar)
                 t0 = time.perf_counter()
                 Gc = O.Grid.full(tris_host, top_density, snd_density, args.alpha, expansion, compress)

@@ -116,6 +116,7 @@ struct hagrid_ctx {
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
     int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
+    int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
     int opt_order_drift = 16;           // ... while the sample rays have drifted by at most this many eighths of a tile from where the order was learned
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch

@@ -119,15 +119,11 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr; a.order_samples = nullptr; a.order_report = nullptr; a.order_epoch = 0;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
-    // bands as high as the set of tiles the machine holds at a time is wide: sqrt(resident wavefronts) tiles, in super-tiles ("traverse.band_rows" > 0 forces it)
-    {
-        int side = 1;
-        while ((long long)(side + 1) * (side + 1) <= (long long)std::max(ctx->num_cus, 1) * 32) side++;
-        // (measured, profiles/NOTES.md "Round 4": a square in-flight block -- 11 rows -- costs the primary batches 1 - 2 %; about a third of it, 4 rows at
-        // 8192 slots, is neutral for them and the best for the bounce rays of configuration 5: +3.7 %)
-        a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : std::max(1, (side / 3 + (1 << a.super_log2) / 2) >> a.super_log2);
-    }
-    a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
+    // Bands of four rows of super-tiles for launches of at least eight rounds of the resident wavefronts, one row below ("traverse.band_rows" > 0
+    // forces it).  Measured (profiles/NOTES.md "Round 4"): the bounce rays of configuration 5 (16 rounds at its per-GPU share) +3.7 % with four rows,
+    // +1.9 % with eleven (a square in-flight block), -2 % with 22; primary batches of 8 and 32 rounds +-0 with four, -1 ... -2 % with eleven; a 1024^2
+    // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
+    a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr;
     a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
@@ -328,7 +324,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     }
                 }
                 a.tile_cost = H.lpt_buf;
-                if (H.lpt_valid) { a.tile_order = H.lpt_buf + H.lpt_cap; a.order_samples = tile_order_samples(H); a.order_report = report; a.order_epoch = H.lpt_epoch; }
+                if (H.lpt_valid) { a.tile_order = H.lpt_buf + H.lpt_cap; a.order_samples = ctx->opt_order_gate ? tile_order_samples(H) : nullptr; a.order_report = report; a.order_epoch = H.lpt_epoch; }
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
                 learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
