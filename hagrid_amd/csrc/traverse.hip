@@ -119,6 +119,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr; a.order_samples = nullptr; a.order_report = nullptr; a.order_epoch = 0;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
+    a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
     // Bands of four rows of super-tiles for launches of at least eight rounds of the resident wavefronts, one row below ("traverse.band_rows" > 0
     // forces it).  Measured (profiles/NOTES.md "Round 4"): the bounce rays of configuration 5 (16 rounds at its per-GPU share) +3.7 % with four rows,
     // +1.9 % with eleven (a square in-flight block), -2 % with 22; primary batches of 8 and 32 rounds +-0 with four, -1 ... -2 % with eleven; a 1024^2
