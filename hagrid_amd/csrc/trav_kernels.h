@@ -645,11 +645,18 @@ __global__ void __launch_bounds__(64, MAILBOX ? 7 : 8) traverse_kernel_tail(cons
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
                     int mine_now = inl;
-                    if (MAILBOX && inl != NONE) {
-                        // the group's mailbox as the one-ray-per-lane phase left it (its first lane's slot): a lane whose id is in it skips its test.
-                        // (Entering the ids tested here as well costs the phase a dozen registers it does not have: 20 spilled.)
+                    if (MAILBOX) {
+                        // the group's mailbox (its first lane's slot): a lane whose id is in it skips its test; the ids of this cell then replace the
+                        // oldest entries -- the first lane of the group stores them (one dword per id: no registers for the old entries)
                         const int4 m = mailbox[lane & ~3];
-                        if (inl == m.x || inl == m.y || inl == m.z || inl == m.w) mine_now = NONE;
+                        if (inl != NONE && (inl == m.x || inl == m.y || inl == m.z || inl == m.w)) mine_now = NONE;
+                        if (sub == 0 && i0 != NONE) {
+                            int* mb = reinterpret_cast<int*>(&mailbox[lane]);
+                            if (i3 != NONE)      { mb[0] = i0; mb[1] = i1; mb[2] = i2; mb[3] = i3; }
+                            else if (i2 != NONE) { mb[0] = m.w; mb[1] = i0; mb[2] = i1; mb[3] = i2; }
+                            else if (i1 != NONE) { mb[0] = m.z; mb[1] = m.w; mb[2] = i0; mb[3] = i1; }
+                            else                 { mb[0] = m.y; mb[1] = m.z; mb[2] = m.w; mb[3] = i0; }
+                        }
                     }
                     if (mine_now != NONE) cd = tri_candidate(tri_vec(mine_now), org, dir, tmin);
                     HG_NOPS();

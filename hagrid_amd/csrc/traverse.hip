@@ -337,9 +337,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly
         // issued for one or two lanes).  Hits do not depend on it.
         a.tail_dual = ctx->opt_tail_dual < 0 ? (perm ? 0 : 1) : ctx->opt_tail_dual;
-        // "traverse.mailbox": every ray skips a triangle it was tested against among its last four tests (trav_kernels.h, MAILBOX); 1 switches the
-        // second id per round trip off.  -1 (default): TODO measured policy
-        a.mailbox = ctx->opt_mailbox < 0 ? 0 : ctx->opt_mailbox;
+        // "traverse.mailbox": every ray skips a triangle it was tested against among its last four tests (trav_kernels.h, MAILBOX; seven instead of eight
+        // wavefronts per SIMD, one id per round trip).  What it saves are triangle fetches; what it costs is an LDS round trip in front of every
+        // triangle round and a resident wavefront.  Measured (profiles/NOTES.md "Round 4"): +4 % where the launch is bound by fetches from HBM (8M triangles:
+        // image and triangles five times the Infinity Cache), -1 % on the cache-resident incoherent batch, -13 % on the 1024^2 launch.  -1 (default):
+        // for launches of at least eight rounds of wavefronts over a working set beyond 512 MB.
+        a.mailbox = ctx->opt_mailbox < 0 ? (a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32) : ctx->opt_mailbox;
         if (a.mailbox) a.tail_dual = 0;
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
