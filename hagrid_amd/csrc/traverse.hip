@@ -339,10 +339,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         a.tail_dual = ctx->opt_tail_dual < 0 ? (perm ? 0 : 1) : ctx->opt_tail_dual;
         // "traverse.mailbox": every ray skips a triangle it was tested against among its last four tests (trav_kernels.h, MAILBOX; seven instead of eight
         // wavefronts per SIMD, one id per round trip).  What it saves are triangle fetches; what it costs is an LDS round trip in front of every
-        // triangle round and a resident wavefront.  Measured (profiles/NOTES.md "Round 4"): +4 % where the launch is bound by fetches from HBM (8M triangles:
-        // image and triangles five times the Infinity Cache), -1 % on the cache-resident incoherent batch, -13 % on the 1024^2 launch.  -1 (default):
-        // for launches of at least eight rounds of wavefronts over a working set beyond 512 MB.
-        a.mailbox = ctx->opt_mailbox < 0 ? (a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32) : ctx->opt_mailbox;
+        // triangle round and a resident wavefront.  Measured (profiles/NOTES.md "Round 4"), 8M triangles (image and triangles five times the Infinity
+        // Cache): +3.6 % on the 8.4M-ray share of configuration 5, where nearly every fetch is a first touch, -5 % on its whole 64M-ray batch, whose rays
+        // reuse each other's lines; -1 % on the cache-resident incoherent batch, -13 % on the 1024^2 launch.  -1 (default): for launches of at least
+        // eight rounds of wavefronts whose rays are fewer than the 64-byte sectors of a working set beyond 512 MB.
+        a.mailbox = ctx->opt_mailbox < 0 ? (a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 &&
+                                            size_t(num_rays) * 64 < a.bin_working_set)
+                                         : ctx->opt_mailbox;
         if (a.mailbox) a.tail_dual = 0;
         int quad_pct = ctx->opt_quad_tail;
         if (quad_pct < 0) {
