@@ -31,6 +31,7 @@ extern "C" int hagrid_ctx_create(hagrid_ctx** out, int device, int keep) {
         hagrid_ctx_destroy(ctx);
         return HAGRID_EHIP;
     }
+    memset(ctx->mailbox, 0, 320 * sizeof(int));      // (the host polls words of it that the device may never have written: row lengths, tile-order epochs)
     *out = ctx;
     return HAGRID_OK;
 }

@@ -172,15 +172,18 @@ def test_ray_binning_gives_identical_hits(mem):
             mem.set_ray_binning(0)
             plain = gpu_traverse(mem, grid, d_tris, rays)
             mem.set_ray_binning(1)
-            binned = gpu_traverse(mem, grid, d_tris, rays)
-            assert (plain["id"] == binned["id"]).all() and (bits(plain["t"]) == bits(binned["t"])).all()
+            for bin_bits in (0, 3, 4):                       # 512 bins, or 4096 (chosen for working sets beyond 512 MB; forced here)
+                mem.set_option("traverse.bin_bits", bin_bits)
+                binned = gpu_traverse(mem, grid, d_tris, rays)
+                assert (plain["id"] == binned["id"]).all() and (bits(plain["t"]) == bits(binned["t"])).all(), bin_bits
+            mem.set_option("traverse.bin_bits", 0)
         oh, _ = G.traverse(tris, batches[0], nthreads=8)
         assert (binned["id"] == plain["id"]).all()
         mem.set_ray_binning(1)
         b0 = gpu_traverse(mem, grid, d_tris, batches[0])
         assert (b0["id"] == oh["id"]).all() and (bits(b0["t"]) == bits(oh["t"])).all()
     finally:
-        mem.set_ray_binning(0)
+        mem.set_ray_binning(0); mem.set_option("traverse.bin_bits", 0)
     with pytest.raises(api.HagridError):
         mem.set_ray_binning(7)
     grid.free(); mem.free(d_tris)
