@@ -374,9 +374,12 @@ __device__ __forceinline__ int ip_compact_tile(uint32_t mask4 /* bit 8c: slot id
 // (stamps: the pass that gave a cell its box and list; since[a]: the pass of the last evaluation of axis a) -- and so is the cell behind
 // its lower corner (ip_mark_entry).  Without stamps every cell is dirty.
 __global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty,
-                                                   const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z) {
+                                                   const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z,
+                                                   unsigned char* __restrict__ evaluated, unsigned char* __restrict__ absorbs, int* __restrict__ books, int num_refs) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id == 0) { books[0] = num_refs; books[1] = slots; books[2] = num_refs; books[3] = 0; }      // cursor, live cells, live references, overflow
     if (id >= slots) return;
+    evaluated[id] = 0; absorbs[id] = 0;                                       // the tags of the mode's passes
     list_end[id] = int(reinterpret_cast<const uint4*>(cells)[size_t(id) + 1].w);
     const int st = stamps ? stamps[id] : 255;
     dirty[id] = st >= since_x; dirty[size_t(slots) + id] = st >= since_y; dirty[2 * size_t(slots) + id] = st >= since_z;
@@ -546,10 +549,6 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
     }
 }
 
-__global__ void ip_set_books(int* __restrict__ books, int cursor, int cells, int refs) {
-    if (threadIdx.x == 0) { books[0] = cursor; books[1] = cells; books[2] = refs; books[3] = 0; }
-}
-
 // ---- leaving the mode: one compaction ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) ip_live_sums(const void* __restrict__ cells, const int* __restrict__ list_end, int slots, Int2* __restrict__ sums, int num_tiles) {
     const int tile = blockIdx.x * kWaves + wave_id();
@@ -712,13 +711,11 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         dirty = reinterpret_cast<unsigned char*>(scratch + ((size_t(ip_slots) * 8 + 255) & ~size_t(255)));
         evaluated = dirty + ((3 * size_t(ip_slots) + 255) & ~size_t(255));
         tile_removed = reinterpret_cast<int*>(evaluated + ((size_t(ip_slots) + 255) & ~size_t(255)));
-        (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
-        (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);         // (the mode's `absorbs` tags)
         // dirty cells: the ones made after the last evaluation of the axis (their stamps say so) and the cells behind their lower corners
         const unsigned char* stp = have_stamps ? stamps : nullptr;
-        ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2]); HG_DBG(ctx);
+        ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2],
+                                                                   evaluated, cell_flags /* the mode's `absorbs` tags */, books, num_refs); HG_DBG(ctx);
         if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2]); HG_DBG(ctx);
-        ip_set_books<<<1, 64, 0, st>>>(books, num_refs, num_cells, num_refs); HG_DBG(ctx);
         in_place = true;
     };
     // Leaves the mode: the live cells become public 32-byte records in `cells_other` (the scratch above is dead by then), their lists go to the
