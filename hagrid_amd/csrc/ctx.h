@@ -100,9 +100,9 @@ struct hagrid_ctx {
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
         int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
-        // The order is only as good as the rays it was learned on: the sort leaves four sample rays of the buffer (+ how far they may drift) behind the
-        // order (lpt_buf + 2 * lpt_cap: 8 float4), every launch compares them with the buffer's rays ON THE DEVICE and falls back to the default order when
-        // the buffer holds other rays (refilled, recycled address, camera moved far); it then reports the order's epoch in the pinned word mailbox[304 + i],
+        // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
+        // (lpt_buf + 2 * lpt_cap: 2 float4), every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and falls back to the default order
+        // when the buffer holds other rays (refilled, recycled address, a camera that moved); it then reports the order's epoch in the pinned word mailbox[304 + i],
         // which the host polls: the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
         int lpt_epoch = 0, relearn_streak = 0, cooldown = 0; unsigned long long relearn_clock = 0;
         unsigned long long used = 0;                    // clock of the last call that used the slot
@@ -117,7 +117,6 @@ struct hagrid_ctx {
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
     int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
     int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
-    int opt_order_drift = 16;           // ... while the sample rays have drifted by at most this many eighths of a tile from where the order was learned
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids

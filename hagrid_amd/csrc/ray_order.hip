@@ -281,38 +281,13 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
 // the order only steers which wavefront takes which tile.  (A stable radix sort with a chunk of the input per thread took 70 us for
 // 16 384 tiles, every gather of a cost a dependent load: 3 % of the launches it was meant to speed up.)
 constexpr int kOrderBlock = 1024, kOrderBins = 4096;
-// The sort also leaves behind WHAT the order was learned on: four sample rays of the buffer (the ones order_still_fits of trav_common.h looks at)
-// with the drift every launch tolerates before it drops the order -- `drift8` eighths of a tile: the angle (for a camera that turns) or the distance
-// (for one that moves: the shift of a point one scene diagonal away) between rays eight pixels apart, whichever applies.
-__device__ __forceinline__ void leave_order_samples(const TraverseArgs& a, int w, int drift8, float diag, float4* __restrict__ samples, int j) {
-    const int n = a.num_rays;
-    const size_t i = order_sample_index(n, w, j), nb = i + 8 < size_t(n) ? i + 8 : (i >= 8 ? i - 8 : i);
-    const float4 r0 = a.rays[2 * i], r1 = a.rays[2 * i + 1], q0 = a.rays[2 * nb], q1 = a.rays[2 * nb + 1];
-    const float rl = rsqrtf(r1.x * r1.x + r1.y * r1.y + r1.z * r1.z), ql = rsqrtf(q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
-    const float ux = r1.x * rl, uy = r1.y * rl, uz = r1.z * rl;
-    const float c = ux * q1.x * ql + uy * q1.y * ql + uz * q1.z * ql;
-    const float k = float(drift8) * 0.125f;
-    float sin_tile = sqrtf(fmaxf(0.0f, 1.0f - c * c));                        // rays a tile apart: sine of the angle between them
-    if (!(sin_tile >= 0.0f)) sin_tile = 0.0f;                                 // (NaN: a degenerate direction -- tolerate nothing)
-    const float s = fminf(k * sin_tile, 0.7f);                                // tolerated angle (sine), at most ~45 degrees
-    const float cos2_min = fmaxf(0.0f, (1.0f - s * s) * (1.0f - 1e-6f));      // cos^2; the last factor lets the learned ray itself pass
-    const float ox = q0.x - r0.x, oy = q0.y - r0.y, oz = q0.z - r0.z;
-    const float tile_dist = fmaxf(sqrtf(ox * ox + oy * oy + oz * oz), sin_tile * diag);
-    const float tol = k * tile_dist + 1e-6f * diag;
-    samples[2 * j] = make_float4(r0.x, r0.y, r0.z, tol * tol);
-    samples[2 * j + 1] = make_float4(ux, uy, uz, cos2_min);
-}
-
+// The sort also leaves behind WHAT the order was learned on: a copy of the sample ray order_still_fits (trav_common.h) compares the buffer with.
 __global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int n,
-                                                                 const TraverseArgs a, int drift8, float diag, float4* __restrict__ samples) {
+                                                                 const float4* __restrict__ rays, int num_rays, float4* __restrict__ samples) {
     __shared__ int bins[kOrderBins];
     __shared__ int wave_total[kOrderBlock / 64];
     const int t = threadIdx.x;
-    if (t < 4 && samples) {
-        const int w = tile_packet_row_len(a);
-        if (w) leave_order_samples(a, w, drift8, diag, samples, t);
-        else { samples[2 * t] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); samples[2 * t + 1] = make_float4(0.0f, 0.0f, 0.0f, 2.0f); }    // (no rows: nothing fits)
-    }
+    if (t < 2 && samples) samples[t] = rays[2 * order_sample_index(num_rays) + t];
     for (int k = t; k < kOrderBins; k += kOrderBlock) bins[k] = 0;
     __syncthreads();
     auto bin_of = [&](int c) { return kOrderBins - 1 - min(kOrderBins - 1, max(0, c)); };        // descending cost = ascending bin
@@ -391,8 +366,7 @@ bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, i
 }
 void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a) {
     int* cost = h.lpt_buf, *order = cost + h.lpt_cap;
-    const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
-    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles, a, ctx->opt_order_drift, length(ext), tile_order_samples(h)); HG_DBG(ctx);
+    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles, a.rays, a.num_rays, tile_order_samples(h)); HG_DBG(ctx);
     h.lpt_epoch++;
 }
 

@@ -35,7 +35,7 @@ struct TraverseArgs {
     int xcd_chunk_log2;                      // tile packets: blocks per XCD chunk, log2 (< 0: one eighth of the range per XCD)
     const int* __restrict__ tile_order;      // tail kernel (and the TIMES instantiations of kat/kat.hip): packet b processes tile tile_order[b]; nullptr: tile b
     int* tile_cost;                          // tail kernel: a wavefront leaves the iterations it ran at its tile's index (atomicMax); nullptr: nothing
-    const float4* __restrict__ order_samples; // tail kernel: four sample rays the tile order was learned on (org | tolerance^2, unit dir | cos^2 of the tolerance); nullptr: the order is used unseen
+    const float4* __restrict__ order_samples; // tail kernel: copy of the sample ray the tile order was learned on (2 float4); nullptr: the order is used unseen
     int* order_report;                       // pinned host word: receives order_epoch when the samples no longer fit the buffer
     int order_epoch;
     unsigned long long* __restrict__ wave_times; // TIMES instantiations only: start / end of every wavefront, 100 MHz wall clock
@@ -143,7 +143,17 @@ __device__ __forceinline__ int tile_packet_slot(const TraverseArgs& a, int w, in
     const int tiles_x = w >> 3, tiles_y = (a.num_rays / w) >> 3;
     if (b >= tiles_x * tiles_y) return identity;             // ragged rows at the bottom, rays past the last full row
     const int S = 1 << a.super_log2;
-    const int band_h = S * max(a.band_rows, 1);              // tile rows per band
+    if (a.band_rows <= 1) {                                  // one row of super-tiles per band (launches of a few rounds): one division fewer on every wavefront's way to its rays
+        const int band = b / (tiles_x * S), in_band = b - band * tiles_x * S;
+        const int hb = min(S, tiles_y - band * S);
+        const int col = in_band / (S * hb), in_super = in_band - col * S * hb;
+        const int wc = min(S, tiles_x - col * S);
+        int tx, ty;
+        if (wc == S && hb == S) { tx = int(compact1by1(uint32_t(in_super))); ty = int(compact1by1(uint32_t(in_super) >> 1)); }
+        else                    { ty = in_super / wc; tx = in_super - ty * wc; }
+        return (((band * S + ty) << 3) + (lane >> 3)) * w + ((col * S + tx) << 3) + (lane & 7);
+    }
+    const int band_h = S * a.band_rows;                      // tile rows per band
     const int band = b / (tiles_x * band_h), in_band = b - band * tiles_x * band_h;
     const int hb = min(band_h, tiles_y - band * band_h);     // tile rows in this band
     const int col = in_band / (S * hb), in_col = in_band - col * S * hb;
@@ -291,27 +301,24 @@ bool tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
 void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a);
 inline float4* tile_order_samples(const hagrid_ctx::RayHints& h) { return reinterpret_cast<float4*>(h.lpt_buf + 2 * size_t(h.lpt_cap)); }
 
-// Does the tile order still describe the rays in the buffer?  Lanes 0 .. 3 compare one sample ray each (row (2j + 1) / 8 of the image, the column
-// the sort chose) with the ray the order was learned on: origin within the tolerance, direction within the tolerated angle.  Uniform over the
-// launch -- every wavefront looks at the same four rays -- so either all wavefronts follow the order or none does (a bijection either way).
-__device__ __forceinline__ size_t order_sample_index(int n, int w, int j) {
-    const int rows = n / w;
-    return size_t(((2 * j + 1) * rows) >> 3) * size_t(w) + size_t(w >= 16 ? (w >> 1) - 8 : 0);
-}
-__device__ __forceinline__ bool order_still_fits(const TraverseArgs& a, int w, int lane) {
-    bool bad = false;
-    if (lane < 4) {
-        const size_t i = order_sample_index(a.num_rays, w, lane);
-        const float4 r0 = a.rays[2 * i], r1 = a.rays[2 * i + 1];
-        const float4 s0 = a.order_samples[2 * lane], s1 = a.order_samples[2 * lane + 1];
-        const float dx = r0.x - s0.x, dy = r0.y - s0.y, dz = r0.z - s0.z;
-        const float dot = r1.x * s1.x + r1.y * s1.y + r1.z * s1.z, dd = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
-        bad = !(dx * dx + dy * dy + dz * dz <= s0.w) || !(dot > 0.0f) || !(dot * dot >= s1.w * dd);       // (NaN: bad)
+// Does the tile order still describe the rays in the buffer?  One sample ray (three eighths into the buffer) is compared BIT FOR BIT with the copy the sort
+// left behind the order: lanes 0 .. 7 load one dword of each, one compare, one ballot -- a dozen instructions before the wavefront picks its tile.  (A first
+// form with four samples, float arithmetic and a drift tolerance cost the 1024^2 launch 2 % -- compiled in, whether used or not: same-box A/B against round
+// 3's library -- and a tolerance buys nothing: a tile's cost is that of its longest ray, which half a pixel of camera motion carries into the next tile.  A form
+// on the scalar unit needs 16 - 32 scalar registers at the start of a kernel that has none to spare: five spilled values.)  Uniform over the launch: either
+// all wavefronts follow the order or none does (a bijection either way).
+__device__ __forceinline__ size_t order_sample_index(int n) { return size_t(uint32_t(n) >> 3) * 3u; }
+__device__ __forceinline__ bool order_still_fits(const TraverseArgs& a, int lane) {
+    uint32_t now = 0, then = 0;
+    if (lane < 8) {
+        now = reinterpret_cast<const uint32_t*>(a.rays + 2 * order_sample_index(a.num_rays))[lane];
+        then = reinterpret_cast<const uint32_t*>(a.order_samples)[lane];
     }
-    const bool fits = __ballot(bad) == 0ull;
+    const bool fits = __ballot(now != then) == 0ull;
     if (!fits && blockIdx.x == 0 && lane == 0 && a.order_report) *a.order_report = a.order_epoch;
     return fits;
 }
+
 // ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the
 // automatic mode) from buffers of `tmp`, or leaves a.perm null for batches too small to bin
 int bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp);

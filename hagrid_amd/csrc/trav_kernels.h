@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(64, MAILBOX ? 7 : 8) traverse_kernel_tail(cons
             const int in_order = a.tile_order[b];
             // (an order learned on other rays than the buffer holds now -- refilled, another buffer at a recycled address, the camera moved far -- is
             // not followed: a stale order is slower than none)
-            tile = (!a.order_samples || order_still_fits(a, w, lane)) ? in_order : b;
+            tile = (!a.order_samples || order_still_fits(a, lane)) ? in_order : b;
         }
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
