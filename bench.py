@@ -345,6 +345,12 @@ def main():
             if ray_kind == "primary" and n_rays == width * height and n_rays <= (1 << 22) and world == 1:
                 def frames_ms(speed, order, refill=0, frames=32):
                     mem.set_option("traverse.tile_order", order)
+                    # (a loop starts from a settled context: the frozen frame traversed often enough for an order to be learned and for the pause the
+                    # context takes from learning -- 64 launches, after orders that did not last in the loop before -- to be over)
+                    mem.copy_h2d(d_rays, scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist))
+                    for _ in range(100):
+                        api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
+                    mem.synchronize()
                     ms = []
                     for f in range(frames):
                         r = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist, yaw=0.005 * speed * f, strafe=0.005 * speed * f)
