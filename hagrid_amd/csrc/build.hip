@@ -283,9 +283,13 @@ __global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ 
                                                         int* __restrict__ totals) {
     __shared__ int lds[kWaves];
     int children = 0, kept = 0;
-    // grid-stride: the two totals cost one atomic pair per workgroup (a same-word atomic per 256 references
-    // would run into the ~88 atomics/us ceiling of a single L2 word)
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < num_refs; i += gridDim.x * kBlock) {
+    // several rounds per workgroup: the two totals cost one atomic pair per workgroup (a same-word atomic per 256 references
+    // would run into the ~88 atomics/us ceiling of a single L2 word).  A workgroup takes a contiguous stretch of the references and the stretches
+    // go to the XCDs eighth by eighth (wave_prims.h xcd_block): the references of a cell and of its neighbours -- the same triangles -- meet in one L2.
+    const int per = ((num_refs + int(gridDim.x) - 1) / int(gridDim.x) + kBlock - 1) / kBlock * kBlock;
+    const long long first = (long long)xcd_block(blockIdx.x, gridDim.x) * per;
+    const int last = int(first + per < num_refs ? first + per : num_refs);
+    for (int i = int(first < num_refs ? first : num_refs) + threadIdx.x; i < last; i += kBlock) {
         const int c = cell_ids[i];
         int m = 0, r = kNoRank;
         if (c >= 0) {

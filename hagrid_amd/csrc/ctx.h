@@ -82,6 +82,7 @@ struct hagrid_ctx {
     int opt_merge_inplace_div = 0;     // the mode is entered once a pass merges less than 1 / this of its cells (0: 50); tests enter earlier
     int opt_merge_inplace_room = 0;    // tests: the in-place mode may use the reference buffer up to this index only (0: all of it) -- the overflow path
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
+    int opt_expand_voxel_map = 1;     // expand_grid: the voxel map resolved into one word per voxel for the passes' look-ups (expand.hip); 0: the chain through the levels
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_band_rows = 0;      // tile packets: rows of super-tiles per band; 0 = as many as make the in-flight tiles a square block of the image
@@ -101,10 +102,10 @@ struct hagrid_ctx {
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
         int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
         // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
-        // (lpt_buf + 2 * lpt_cap: 2 float4), every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and falls back to the default order
-        // when the buffer holds other rays (refilled, recycled address, a camera that moved); it then reports the order's epoch in the pinned word mailbox[304 + i],
-        // which the host polls: the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
-        int lpt_epoch = 0, relearn_streak = 0, cooldown = 0; unsigned long long relearn_clock = 0;
+        // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
+        // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[304 + i],
+        // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
+        int lpt_epoch = 0, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
         unsigned long long used = 0;                    // clock of the last call that used the slot
     };
     static constexpr int kRayHints = 4;

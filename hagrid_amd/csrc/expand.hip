@@ -17,7 +17,7 @@ using namespace hagrid_impl;
 
 namespace {
 
-struct ExpandK { ivec3 dims; ivec3 top; int shift; vec3 gmin, cell_size, grid_inv; };   // expand.cu:5-9
+struct ExpandK { ivec3 dims; ivec3 top; int shift; vec3 gmin, cell_size, grid_inv; const int* voxel_cells; };   // expand.cu:5-9 (+ the flat map below)
 constexpr int kChanged = 1 << 3;     // cell_flags (one byte per cell): the cell's box changed in the previous pass (bits 0-2: expand.cu:145-182)
 struct CellRec { ivec3 lo; int begin; ivec3 hi; int end; };
 
@@ -69,6 +69,25 @@ __device__ __forceinline__ Tri load_tri(const float4* __restrict__ tris, int i) 
     return Tri(vec3(a.x, a.y, a.z), a.w, vec3(b.x, b.y, b.z), b.w, vec3(c.x, c.y, c.z), c.w);
 }
 
+// The expansion looks up the cell of a voxel for every neighbour of every face walk -- nine passes over the cells, a dozen look-ups per cell and
+// pass -- and the grid does not change its cells' numbers while it expands: the voxel map is resolved ONCE into one word per voxel (the cell that
+// holds it), top-level cell by top-level cell with x fastest inside (a face walk stays inside a few lines).  A look-up is then one load instead of
+// the chain through the voxel map's levels (two dependent loads after flatten_grid).  Grids whose virtual resolution exceeds 2^28 voxels keep the chain.
+__global__ void __launch_bounds__(kBlock) fill_voxel_cells(ExpandK k, const Entry* __restrict__ entries, int* __restrict__ voxel_cells, int voxels) {
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= voxels) return;
+    const int s = k.shift, m = (1 << s) - 1, top = v >> (3 * s), local = v & ((1 << (3 * s)) - 1);
+    const int tx = top % k.top.x, ty = (top / k.top.x) % k.top.y, tz = top / (k.top.x * k.top.y);
+    const ivec3 at((tx << s) + (local & m), (ty << s) + ((local >> s) & m), (tz << s) + (local >> (2 * s)));
+    voxel_cells[v] = int(lookup_entry(entries, s, k.top, at));
+}
+__device__ __forceinline__ int cell_of_voxel(const ExpandK& k, const Entry* __restrict__ entries, const ivec3& at) {
+    if (!k.voxel_cells) return int(lookup_entry(entries, k.shift, k.top, at));
+    const int s = k.shift, m = (1 << s) - 1;
+    const int top = (at.x >> s) + k.top.x * ((at.y >> s) + k.top.y * (at.z >> s));
+    return k.voxel_cells[(top << (3 * s)) + (at.x & m) + (((at.y & m) + ((at.z & m) << s)) << s)];
+}
+
 // Precise mode (expand.cu:39-57): a triangle the neighbour references and the cell does not limits the growth to the voxel layer
 // where its bounding box begins -- if the box overlaps the cell's cross-section at all.  `room` is the number of layers the face
 // may still move (a magnitude, whatever the direction).
@@ -104,7 +123,7 @@ __device__ __forceinline__ int face_growth(const ExpandK& k, const Entry* __rest
     int u = lo1, v = lo2, row_step = comp(k.dims, A2);
     for (;;) {
         const ivec3 at = AXIS == 0 ? ivec3(layer, u, v) : (AXIS == 1 ? ivec3(v, layer, u) : ivec3(u, v, layer));
-        const CellRec nb = load_cell(cells, int(lookup_entry(entries, k.shift, k.top, at)));
+        const CellRec nb = load_cell(cells, cell_of_voxel(k, entries, at));
         reach = min(reach, UP ? comp(nb.hi, AXIS) - face : face - comp(nb.lo, AXIS));
         room = min(room, reach);
         const int theirs = nb.end - nb.begin;
@@ -170,7 +189,7 @@ template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) overlap_step(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                        unsigned char* __restrict__ cell_flags, int num_cells) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int id = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;          // (the face walk reads the neighbours' cells and lists: one L2 per stretch of cells)
     if (id >= num_cells) return;
     const int flags = cell_flags[id];
     if ((flags & (1 << axis)) == 0) {      // copy through
@@ -240,9 +259,12 @@ template <int axis, bool SUBSET_ONLY>
 __global__ void __launch_bounds__(kBlock) expand_listed(ExpandK k, const Entry* __restrict__ entries, const int* __restrict__ refs,
                                                         const float4* __restrict__ tris, const Cell* __restrict__ cells, Cell* __restrict__ new_cells,
                                                         unsigned char* __restrict__ cell_flags, const int* __restrict__ list, const int* __restrict__ count) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    // (the grid is sized for all cells; the workgroups that hold listed cells -- the first ones -- take them XCD by XCD, like overlap_step)
+    const int n = *count, active = (2 * n + kBlock - 1) / kBlock;
+    if (int(blockIdx.x) >= active) return;
+    const int t = xcd_block(blockIdx.x, active) * kBlock + threadIdx.x;
     const int i = t >> 1;                                          // two lanes per listed cell, one per direction
-    if (i >= *count) return;
+    if (i >= n) return;
     const int id = list[i];
     grow_cell<axis, SUBSET_ONLY, true>(k, entries, refs, tris, cells, new_cells, cell_flags, id, cell_flags[id], (t & 1) != 0);
 }
@@ -284,6 +306,10 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
     int* list = iters > 1 ? pool_alloc<int>(ctx, size_t(n)) : nullptr;      // (without it the later iterations fall back to the all-cells pass)
+    const long long voxels = (long long)k.dims.x * k.dims.y * k.dims.z;
+    int* voxel_cells = (ctx->opt_expand_voxel_map && voxels <= (1ll << 28)) ? pool_alloc<int>(ctx, size_t(voxels)) : nullptr;   // (without it: the chain through the voxel map)
+    k.voxel_cells = voxel_cells;
+    if (voxel_cells) { ExpandK kf = k; kf.voxel_cells = nullptr; fill_voxel_cells<<<grid_blocks(voxels, kBlock), kBlock, 0, st>>>(kf, entries, voxel_cells, int(voxels)); HG_DBG(ctx); }
     int* counts = ctx->dscratch + 160;             // one list length per listed pass
     const int max_listed = 48;
     if (list) (void)hipMemsetAsync(counts, 0, max_listed * sizeof(int), st);
@@ -317,6 +343,7 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     hagrid_mem_free(ctx, flags);
     hagrid_mem_free(ctx, other);
     hagrid_mem_free(ctx, list);
+    hagrid_mem_free(ctx, voxel_cells);
     grid->cells = cells;
     if (e != hipSuccess) HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e));
     return HAGRID_OK;

@@ -172,8 +172,11 @@ __global__ void __launch_bounds__(kBlock) merge_counts_kernel(int axis, MergeK k
                                                               int* __restrict__ nexts, unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask, int num_cells,
                                                               const int* __restrict__ n_dev) {
     using F = CellFmt<NARROW>;
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= (n_dev ? *n_dev : num_cells)) return;
+    // (the workgroups that hold cells take them XCD by XCD -- wave_prims.h xcd_block: the neighbour's cell and list are then in the same L2)
+    const int n = n_dev ? *n_dev : num_cells, active = (n + kBlock - 1) / kBlock;
+    if (int(blockIdx.x) >= active) return;
+    const int id = xcd_block(blockIdx.x, active) * kBlock + threadIdx.x;
+    if (id >= n) return;
     CellRec c1 = F::load(cells, id);
     F::finish(cells, id, c1);
     const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
@@ -266,9 +269,12 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     using FI = CellFmt<IN_NARROW>;
     using FO = CellFmt<OUT_NARROW>;
     __shared__ Int2 lds[kWaves];
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const int n = n_dev ? min(num_cells, *n_dev) : num_cells, active = (n + kBlock - 1) / kBlock;
+    if (int(blockIdx.x) >= active && blockIdx.x != 0) return;                       // (uniform over the workgroup; workgroup 0 also runs for n == 0: the end marker)
+    const int tile = int(blockIdx.x) < active ? xcd_block(blockIdx.x, active) : 0;   // XCD by XCD, like merge_counts_kernel
+    const int id = tile * kBlock + threadIdx.x;
     if (id == 0) FO::store_end(new_cells, totals->a, totals->b);
-    const bool inside = id < (n_dev ? min(num_cells, *n_dev) : num_cells);
+    const bool inside = id < n;
     const int flag = inside ? cell_flags[id] : 0;
     const int mc = inside ? merge_counts[id] : 0;
     // {new cell id, first slot of the list} = exclusive scan of the kept cells' items: inside the tile here, the tile's offset
@@ -278,7 +284,7 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
     if (lane_id() == 63) lds[wave_id()] = incl;
     __syncthreads();
     if (!flag) return;
-    Int2 at = tile_prefix[blockIdx.x];
+    Int2 at = tile_prefix[tile];
     for (int w = 0; w < wave_id(); w++) at = at + lds[w];
     const int new_id = at.a + incl.a - item.a, nb = at.b + incl.b - item.b;
     CellRec cell = FI::load(cells, id);
@@ -433,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const En
                                                     unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
     __shared__ int list[kIpTile];
     __shared__ int count;
-    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    const int id4 = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * kIpPer;
     uint32_t mask = 0;
     if (id4 < slots) {
         const uint32_t f = ip_flags4(dirty_axis, id4, slots);

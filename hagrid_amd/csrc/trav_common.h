@@ -302,21 +302,20 @@ void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, cons
 inline float4* tile_order_samples(const hagrid_ctx::RayHints& h) { return reinterpret_cast<float4*>(h.lpt_buf + 2 * size_t(h.lpt_cap)); }
 
 // Does the tile order still describe the rays in the buffer?  One sample ray (three eighths into the buffer) is compared BIT FOR BIT with the copy the sort
-// left behind the order: lanes 0 .. 7 load one dword of each, one compare, one ballot -- a dozen instructions before the wavefront picks its tile.  (A first
-// form with four samples, float arithmetic and a drift tolerance cost the 1024^2 launch 2 % -- compiled in, whether used or not: same-box A/B against round
-// 3's library -- and a tolerance buys nothing: a tile's cost is that of its longest ray, which half a pixel of camera motion carries into the next tile.  A form
-// on the scalar unit needs 16 - 32 scalar registers at the start of a kernel that has none to spare: five spilled values.)  Uniform over the launch: either
-// all wavefronts follow the order or none does (a bijection either way).
+// left behind the order: lanes 0 .. 7 of the launch's FIRST wavefront load one dword of each, one compare, one ballot; when they differ the pinned word
+// `order_report` receives the order's epoch and the host learns the order again before its next launch (traverse.hip).  The launch that finds the
+// difference still follows the order it was given -- a bijection over the tiles whatever the rays are; a stale one costs that single launch up to a
+// tenth against the default order.  (Checked by EVERY wavefront in front of its choice of tile -- so that a stale order is not even followed once -- the
+// same dozen instructions cost the 1024^2 launch 1.6 %, a form with four samples and a drift tolerance 2 %: same-box A/B against round 3's library.  A
+// tolerance buys nothing: a tile's cost is that of its longest ray, which half a pixel of camera motion carries into the next tile.)
 __device__ __forceinline__ size_t order_sample_index(int n) { return size_t(uint32_t(n) >> 3) * 3u; }
-__device__ __forceinline__ bool order_still_fits(const TraverseArgs& a, int lane) {
+__device__ __forceinline__ void order_check(const TraverseArgs& a, int lane) {
     uint32_t now = 0, then = 0;
     if (lane < 8) {
         now = reinterpret_cast<const uint32_t*>(a.rays + 2 * order_sample_index(a.num_rays))[lane];
         then = reinterpret_cast<const uint32_t*>(a.order_samples)[lane];
     }
-    const bool fits = __ballot(now != then) == 0ull;
-    if (!fits && blockIdx.x == 0 && lane == 0 && a.order_report) *a.order_report = a.order_epoch;
-    return fits;
+    if (__ballot(now != then) != 0ull && lane == 0 && a.order_report) *a.order_report = a.order_epoch;
 }
 
 // ray_order.hip: ray binning as the context has it switched (hagrid_set_ray_binning); fills a.perm (+ a.perm_flag, a.row_len in the

@@ -333,10 +333,10 @@ __global__ void __launch_bounds__(64, MAILBOX ? 7 : 8) traverse_kernel_tail(cons
     {
         int tile = b;
         if (COST && w && a.tile_order) {
-            const int in_order = a.tile_order[b];
-            // (an order learned on other rays than the buffer holds now -- refilled, another buffer at a recycled address, the camera moved far -- is
-            // not followed: a stale order is slower than none)
-            tile = (!a.order_samples || order_still_fits(a, lane)) ? in_order : b;
+            tile = a.tile_order[b];
+            // (an order learned on other rays than the buffer holds now -- refilled, another buffer at a recycled address, the camera moved -- is
+            // reported by the first wavefront of the launch and not used again: a stale order is slower than none)
+            if (a.order_samples && blockIdx.x == 0) order_check(a, lane);
         }
         slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled

@@ -195,7 +195,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
             // row length counts as seen (the kernel reads the one found for THIS buffer either way), its tile order is the first order (below).
             const hagrid_ctx::RayHints* donor = nullptr;
@@ -298,15 +298,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
                 int* report = ctx->mailbox + 304 + hint_slot;
                 if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && *report == H.lpt_epoch) {
-                    // A launch since the last sort found other rays in the buffer than the order was learned on (and ran in the default order): learn
-                    // again, from costs of the new rays only.  Three such orders in a row that lasted fewer than eight launches each: give up for 64 launches.
+                    // A launch since the last sort found other rays in the buffer than the order was learned on (its first wavefront reported it): learn
+                    // again, from costs of the new rays only.  Three such orders in a row that lasted fewer than eight launches each: give up for 64 launches -- for twice as
+                    // many every time that happens again before an order has lasted through a refresh (a camera that keeps moving: up to 1024).
                     H.relearn_streak = ctx->hint_clock - H.relearn_clock < 8 ? H.relearn_streak + 1 : 0;
                     H.relearn_clock = ctx->hint_clock;
                     H.lpt_valid = false; H.lpt_age = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
-                    if (H.relearn_streak >= 3) { H.relearn_streak = 0; H.cooldown = 64; }
+                    if (H.relearn_streak >= 3) { H.relearn_streak = 0; H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
-                if (H.cooldown > 0) { /* this launch and the next 63: default order, no costs */ }
+                if (H.cooldown > 0) { /* this launch and the next ones: default order, no costs */ }
                 else {
                 if (H.lpt_rays != rays || H.lpt_n != num_rays || H.lpt_blocks != tiles) {
                     H.lpt_rays = rays; H.lpt_n = num_rays; H.lpt_blocks = tiles; H.lpt_age = 0;
@@ -329,6 +330,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
                 learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
+                if (H.lpt_valid && learn_order && H.lpt_period >= 32) H.cooldown_len = 64;       // an order that lasted through a refresh period
                 }
             }
         }

@@ -30,6 +30,24 @@ constexpr int kScanTile = kBlock * kScanItems;       // items per workgroup
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// The hardware deals consecutive workgroups to the eight XCDs in turn, and every XCD has its own L2.  A kernel that gathers from the neighbourhood of
+// its cell (the cells next to it, the references and triangles it shares with them) and takes its cells in the order of blockIdx.x has every such line
+// fetched into several L2s.  xcd_block gives workgroup b of nb a position such that the XCDs take CHUNKS of 2^kXcdChunkLog2 consecutive positions in
+// turn (a bijection on [0, nb)): neighbours meet in one L2, and the eight XCDs still advance through the array side by side (an eighth of the array
+// per XCD leaves them unevenly loaded: the all-cells passes of the expansion ran 2 - 12 % slower).  Only for kernels whose workgroups are
+// independent of each other's order (no look-back).
+#ifndef HG_XCD_CHUNK_LOG2
+#define HG_XCD_CHUNK_LOG2 6
+#endif
+constexpr int kXcdChunkLog2 = HG_XCD_CHUNK_LOG2;
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    if (kXcdChunkLog2 < 0) return b;
+    const int full = (nb >> (kXcdChunkLog2 + 3)) << (kXcdChunkLog2 + 3);       // positions in complete groups of 8 chunks; the rest keeps its order
+    if (b >= full) return b;
+    const int xcd = b & 7, j = b >> 3;
+    return ((((j >> kXcdChunkLog2) << 3) + xcd) << kXcdChunkLog2) + (j & ((1 << kXcdChunkLog2) - 1));
+}
+
 // ---- value types for scans: int and a pair of ints ---------------------------------------------------
 struct Int2 { int a, b; };   // trivial: lives in __shared__ arrays
 __host__ __device__ inline Int2 operator+(Int2 x, Int2 y) { return Int2{x.a + y.a, x.b + y.b}; }

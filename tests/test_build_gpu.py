@@ -275,6 +275,33 @@ def test_precise_expansion_matches_oracle(mem):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
+@pytest.mark.parametrize("flatten", [True, False])
+@pytest.mark.parametrize("subset_only", [1, 0])
+def test_expansion_with_and_without_the_resolved_voxel_map(mem, flatten, subset_only):
+    """expand_grid resolves the voxel map into one word per voxel for its look-ups (expand.hip, `expand.voxel_map`): with it and with the chain through
+    the map's levels -- on a flattened map and on the construction's own (deeper chains) -- the expansion is the oracle's."""
+    from hagrid_amd import api
+    from oracle import oracle as O
+    tris = scene.make_soup(30000, seed=5 + subset_only)
+    d_tris = mem.upload(tris)
+    G = O.Grid.build(tris, 0.12, 3.5).merge(0.995)
+    if flatten: G = G.flatten()
+    G = G.expand(tris, 3, subset_only=bool(subset_only))
+    try:
+        mem.set_option("expand.subset_only", subset_only)
+        for vm in (1, 0):
+            mem.set_option("expand.voxel_map", vm)
+            grid = api.Grid()
+            api.build_grid(mem, d_tris, tris.shape[0], grid, 0.12, 3.5); api.merge_grid(mem, grid, 0.995)
+            if flatten: api.flatten_grid(mem, grid)
+            api.expand_grid(mem, grid, d_tris, 3)
+            assert_same_grid(grid.download(), G, f"expand, voxel_map {vm}")
+            grid.free()
+    finally:
+        mem.set_option("expand.subset_only", 1); mem.set_option("expand.voxel_map", 1)
+    mem.free(d_tris)
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_random_scenes_and_parameters(mem, seed):
     """Randomised scenes (sizes 1..4000, clustered / stretched / degenerate variants) with random densities, merge

@@ -1,11 +1,11 @@
 #!/bin/bash
-# One-off experiment (round 4): the headline launch with this round's library and with round 3's (ab/libR3.so: commit aef0877, ABI number patched), same box, alternating.
+# One-off experiment (round 4): the headline launch with this library, with the one before the last change (ab/libHEADgate.so) and with round 3's (ab/libR3.so: commit aef0877, ABI number patched), same box, alternating.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-exp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" || exit 1
 B="python bench.py --gpus 1 --steps 20 --warmup 3 --build-iter 3 --no-cpu-baseline --inflight 0"
 for rep in 1 2; do
-  for v in HEAD R3 NEITHER; do
+  for v in HEAD HEADgate R3; do
     if [ $v = HEAD ]; then unset HAGRID_AMD_LIB; else export HAGRID_AMD_LIB=$PWD/ab/lib$v.so; fi
     timeout 600 $B > $OUT/${v}_$rep.json 2> $OUT/${v}_$rep.err
     python - $OUT/${v}_$rep.json "$v rep $rep" <<'PY'
