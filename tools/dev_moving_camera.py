@@ -2,19 +2,19 @@
 frame).  Per frame the camera turns by `speed` x 0.005 rad and moves sideways by `speed` x 0.005 scene diagonals (speed 1 = one mouse pixel
 and one key event of the reference's viewer per frame); the frame's rays are written into ONE device buffer and traversed; only the
 traversal is timed (HIP events), the host synchronises once per frame as a viewer does.  Reported per speed: mean ms per frame with the tile
-order at its defaults, with the order only followed for the very rays it was learned on (traverse.order_drift = 0), and in the default order
-(traverse.tile_order = 0); then a FROZEN camera and a buffer REFILLED with another image every 8th frame.
+order at its defaults and in the default order (traverse.tile_order = 0), frames 9 .. N and the first eight; with --long L also the mean over L frames at the
+viewer's speed (the give-up period of orders that do not last doubles: what a camera that keeps moving pays in the long run); then a buffer REFILLED
+with another image every 8th frame.
 
-usage: python tools/dev_moving_camera.py [--width 1024] [--frames 48] [--speeds 0,0.1,0.25,0.5,1,2] [--drifts 16,0]"""
+usage: python tools/dev_moving_camera.py [--width 1024] [--frames 48] [--speeds 0,0.1,0.25,0.5,1,2] [--long 400]"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hagrid_amd import api, scene
 
 arg = lambda name, default: (sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default)
-W = int(arg("--width", "1024")); frames = int(arg("--frames", "48"))
+W = int(arg("--width", "1024")); frames = int(arg("--frames", "48")); long_frames = int(arg("--long", "0"))
 speeds = [float(v) for v in arg("--speeds", "0,0.1,0.25,0.5,1,2").split(",")]
-drifts = [0]          # (round 4 ended with a bit-exact check: no drift tolerance left to sweep)
 mem = api.MemManager(keep=True)
 tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, tris.shape[0]); api.setup_traversal(grid)
@@ -51,6 +51,17 @@ for speed in speeds:
         settle()
         ms = loop(speed)
         row[label] = {"mean_ms": round(float(np.mean(ms[8:])), 4), "first8": round(float(np.mean(ms[:8])), 4)}
+    print(json.dumps(row), flush=True)
+if long_frames:
+    row = {"viewer speed, frames": long_frames}
+    for label, opts in [("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})]:
+        for k, v in opts.items(): mem.set_option(k, v)
+        settle()
+        frames, keep = long_frames, frames
+        ms = loop(1.0)
+        frames = keep
+        row[label] = {"mean_ms": round(float(np.mean(ms)), 4), "frames 1-16": round(float(np.mean(ms[:16])), 4), "frames 17-80": round(float(np.mean(ms[16:80])), 4),
+                      "after 80": round(float(np.mean(ms[80:])), 4) if len(ms) > 80 else None}
     print(json.dumps(row), flush=True)
 for label, opts in (("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})):
     for k, v in opts.items(): mem.set_option(k, v)
