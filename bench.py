@@ -511,9 +511,18 @@ def main():
         working_set = image_b + 48 * n_tris + 4 * grid.num_refs if args.image else cells_b + 4 * grid.num_entries + 4 * grid.num_refs + 48 * n_tris
         if counters:
             res, top, top_frac = binding_resources(counters, kernel_ms, working_set, traffic)
-            out["roofline"]["binding"] = {"resource": top, "frac": top_frac, "resources": res, "working_set_bytes": working_set,
-                                          "how": "counters per launch from separate rocprofv3 --pmc passes on these kernel sources (traffic_source), divided by this run's kernel time"}
-            out["roofline"]["bound"] = top if top in ("hbm_bytes",) else f"{top} (not hbm bytes: see binding)"
+            # `resource` names the MOST USED throughput resource.  It is the limiter only when it is close to 1: a launch whose wavefronts spend most of
+            # their time waiting for dependent gathers while no throughput resource is saturated is bound by the latency of its chains at the occupancy it
+            # has (Little's law).  Checked by intervention on the per-GPU share of configuration 5 (profiles/NOTES.md "Round 4", gpurun_out/r4w2, r4w3): triangles
+            # padded to 64 bytes took 15 % of the fabric fetches away (85.9M -> 72.5M per launch) and 1.2 % of the kernel time.
+            waiting = (res.get("wave_time") or {}).get("waiting_for_memory", 0.0)
+            limiter = "memory_latency" if (waiting >= 0.6 and top_frac is not None and top_frac < 0.95) else top
+            out["roofline"]["binding"] = {"resource": top, "frac": top_frac, "limiter": limiter, "resources": res, "working_set_bytes": working_set,
+                                          "how": "counters per launch from separate rocprofv3 --pmc passes on these kernel sources (traffic_source), divided by this run's kernel time; "
+                                                 "`resource` = the most used throughput resource; `limiter` = memory_latency when the wavefronts wait for memory >= 60 % of their time and no "
+                                                 "throughput fraction reaches 0.95 (dependent gathers at the occupancy the kernel has: fewer fetches do not make such a launch faster)"}
+            out["roofline"]["bound"] = top if top in ("hbm_bytes",) else (f"{top} (not hbm bytes: see binding)" if limiter == top else
+                                                                         f"memory latency of dependent gathers (wavefronts wait {waiting:.2f} of their time; most used resource: {top} {top_frac:.2f}; see binding)")
         else:
             out["roofline"]["binding"] = {"resource": None, "why": traffic_source or "no counter file for this configuration and batch (tools/gpu_traffic_config.sh)"}
         # ---- CPU baseline + parity check: the oracle on the SAME grid, rank 0, N = 1 only ---------------------------------
