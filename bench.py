@@ -423,16 +423,12 @@ def main():
         achieved_img = ab["B_image"] / (kernel_ms * 1e6)           # GB/s of the bytes the image kernel gathers for the same walk
         peak = mem.bandwidth_probe(1 << 30, 5)                     # measured in this process: float4 copy / triad over 1 GiB arrays
         traffic = None; traffic_source = None; l2_hit = None
-        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command
-        # (tools/gpu_round.sh) and committed as profiles/traffic_latest.json together with the hash of the kernel sources it
-        # measured.  A file measured on other sources is refused: traffic = null, traffic_source says "stale".
+        # HBM bytes per launch and the other counters of `binding`: collected in separate rocprofv3 --pmc passes of this very command
+        # (tools/gpu_traffic_config.sh) and committed as profiles/traffic_config<C>.json together with the hash of the kernel sources and the
+        # ray count of the launches it measured.  A file measured on other sources or another batch is refused: traffic = null, traffic_source says why.
         from hagrid_amd import build as _build
         src_hash = _build.source_hash()
-        # config 2: profiles/traffic_latest.json (tools/gpu_round.sh); the other configurations: profiles/traffic_config<C>.json
-        # (tools/gpu_traffic_config.sh), which also names the ray count of the launch it measured -- a line over another count gets none
         tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
-        if args.config == 2 and not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")        # (round 3's file: four counters)
         counters = None
         std_shape = args.image == 2 and n_tris == cfg["tris"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
         if os.path.exists(tpath) and world == 1 and std_shape:
