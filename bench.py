@@ -82,6 +82,15 @@ def binding_resources(counters: dict, kernel_ms: float, working_set_bytes: int, 
     ranked = sorted(((v["frac"], k) for k, v in out.items() if "frac" in v), reverse=True)
     return out, (ranked[0][1] if ranked else None), (ranked[0][0] if ranked else None)
 
+
+def binding_limiter(resources: dict, top, top_frac):
+    """`top` names the MOST USED throughput resource.  It is the limiter only when it is close to 1: a launch whose wavefronts spend most of their
+    time waiting for dependent gathers while no throughput resource is saturated is bound by the latency of its chains at the occupancy it has
+    (Little's law).  Checked by intervention on the per-GPU share of configuration 5 (profiles/NOTES.md "Round 4", gpurun_out/r4w2, r4w3): triangles
+    padded to 64 bytes took 15 % of the fabric fetches away (85.9M -> 72.5M per launch) and 1.2 % of the kernel time.  Returns (limiter, waiting)."""
+    waiting = (resources.get("wave_time") or {}).get("waiting_for_memory", 0.0)
+    return ("memory_latency" if (waiting >= 0.6 and top_frac is not None and top_frac < 0.95) else top), waiting
+
 CONFIGS = {
     2: dict(baseline="1M-triangle synthetic scene, default densities, 1M primary rays on 1xMI355X", tris=1_000_000, rays="primary",
             width=1024, height=1024, scaling="weak", params={}),
@@ -507,12 +516,7 @@ def main():
         working_set = image_b + 48 * n_tris + 4 * grid.num_refs if args.image else cells_b + 4 * grid.num_entries + 4 * grid.num_refs + 48 * n_tris
         if counters:
             res, top, top_frac = binding_resources(counters, kernel_ms, working_set, traffic)
-            # `resource` names the MOST USED throughput resource.  It is the limiter only when it is close to 1: a launch whose wavefronts spend most of
-            # their time waiting for dependent gathers while no throughput resource is saturated is bound by the latency of its chains at the occupancy it
-            # has (Little's law).  Checked by intervention on the per-GPU share of configuration 5 (profiles/NOTES.md "Round 4", gpurun_out/r4w2, r4w3): triangles
-            # padded to 64 bytes took 15 % of the fabric fetches away (85.9M -> 72.5M per launch) and 1.2 % of the kernel time.
-            waiting = (res.get("wave_time") or {}).get("waiting_for_memory", 0.0)
-            limiter = "memory_latency" if (waiting >= 0.6 and top_frac is not None and top_frac < 0.95) else top
+            limiter, waiting = binding_limiter(res, top, top_frac)
             out["roofline"]["binding"] = {"resource": top, "frac": top_frac, "limiter": limiter, "resources": res, "working_set_bytes": working_set,
                                           "how": "counters per launch from separate rocprofv3 --pmc passes on these kernel sources (traffic_source), divided by this run's kernel time; "
                                                  "`resource` = the most used throughput resource; `limiter` = memory_latency when the wavefronts wait for memory >= 60 % of their time and no "
