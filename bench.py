@@ -355,9 +355,10 @@ def main():
                 def frames_ms(speed, order, refill=0, frames=32):
                     mem.set_option("traverse.tile_order", order)
                     # (a loop starts from a settled context: the frozen frame traversed often enough for an order to be learned and for the pause the
-                    # context takes from learning -- 64 launches, after orders that did not last in the loop before -- to be over)
+                    # context takes from learning -- 64 launches and twice as many the next time, after orders that did not last in the loop before -- to be over:
+                    # 64 + a first order + the 32 launches after which an order that lasted resets that period fit into 200)
                     mem.copy_h2d(d_rays, scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist))
-                    for _ in range(100):
+                    for _ in range(200):
                         api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
                     mem.synchronize()
                     ms = []
