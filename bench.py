@@ -148,6 +148,7 @@ def main():
                     "one context = one stream each over ONE traversal image (hagrid_share_traversal); reported as `pipelined`; 0 or 1: skip")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-cores baseline sample")
     ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off, 1 compact, 2 flat (default)")
+    ap.add_argument("--hits-hash", action="store_true", help="experiments: `hits_sha256` of this rank's whole hit buffer after the timed steps in the line")
     ap.add_argument("--opts", default="", help="experiments: comma-separated key=value pairs for hagrid_set_option, e.g. traverse.image_slim=0")
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 otherwise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
@@ -325,6 +326,10 @@ def main():
 
     n_head = rays_head.shape[0]
     hits = mem.download(d_hits, api.HIT_DTYPE, n_head)
+    hits_sha = None
+    if args.hits_hash:      # (experiments: two libraries or two code paths over the same rays must leave the same bytes)
+        import hashlib
+        hits_sha = hashlib.sha256(mem.download(d_hits, api.HIT_DTYPE, n_rays).tobytes()).hexdigest()[:16]
 
     # ---- what the learned tile order is worth (outside the timed region) --------------------------------------------------------
     # Launches over a ray buffer the context has seen before dispatch their 8x8 tiles longest first, by the costs the previous launches
@@ -484,6 +489,7 @@ def main():
             "build_ms_min": None if build_ms is None else round(build_ms_min, 3),
             "grid_broadcast_ms": round(t_bcast, 3),
             "setup_traversal_ms": round(setup_ms, 3),
+            "hits_sha256": hits_sha,
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
             # `achieved` / `frac`: the contract's figure -- ALGORITHMIC bytes (what the kernel gathers) over the kernel time against the HBM peak.  It is
             # not a bound for a kernel whose working set is cache-resident (it can exceed 1: bytes served by L1 / L2 never reach HBM), so `binding` names
