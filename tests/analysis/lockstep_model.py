@@ -68,7 +68,41 @@ def stats(groups):     # groups: [waves, 64] ray indices
             "iterations per wavefront (p1 + p2)": round(float((p1 + p2).mean()), 2)}
 
 
+def refill_sim(K, refill_min=16, tail=16):
+    """The prototype of tools/proto/refill.patch on the traces: a wavefront owns K consecutive tiles; while the pool is not empty and at least `refill_min`
+    lanes are idle they take its next rays, which JOIN one iteration later; with the pool empty and at most `tail` rays alive the rest runs with four lanes
+    per ray.  Returns lock-step iterations per ray-tile (so that K = 1 is the kernel as it is) and the lane efficiency of phase 1."""
+    tiles = order.reshape(-1, 64)
+    nt = tiles.shape[0] // K * K
+    c = cells[tiles[:nt]].reshape(-1, K * 64)
+    it1 = it2 = 0; busy = 0
+    for wave in c:
+        left = wave[:64].copy(); nxt = 64; joining = None
+        while True:
+            alive = left > 0
+            na = int(alive.sum())
+            if nxt < wave.size and 64 - na >= refill_min:
+                idle = np.flatnonzero(~alive)
+                take = idle[: min(idle.size, wave.size - nxt)]
+                joining = (take, wave[nxt: nxt + take.size].copy()); nxt += take.size
+            if na <= tail and nxt >= wave.size and joining is None:
+                break
+            left[alive] -= 1; busy += na; it1 += 1
+            if joining is not None:
+                left[joining[0]] = joining[1]; joining = None
+        it2 += int(left.max()) if left.size else 0
+    return {"tiles per wavefront": K, "phase-1 iterations per tile": round(it1 / nt, 2), "phase-2 iterations per tile": round(it2 / nt, 2),
+            "iterations per tile": round((it1 + it2) / nt, 2), "phase-1 lane efficiency": round(busy / (64 * max(it1, 1)), 3)}
+
+
 out = {"config": config, "triangles": N, "rays": int(n), "as the kernel groups them": stats(order.reshape(-1, 64))}
+if os.environ.get("REFILL", "1") != "0":
+    sample = int(os.environ.get("SIM_TILES", 4096))       # (a python loop per wavefront: a sample of the tiles is enough)
+    keep_order = order
+    order = order[: min(order.size, sample * 64)]
+    out["refill prototype, simulated on the traces"] = [refill_sim(K) for K in (1, 2, 3, 4, 8)]
+    out["refill prototype, 32 idle lanes before a refill"] = [refill_sim(K, refill_min=32) for K in (2, 8)]
+    order = keep_order
 if W and super_tiles is not None:
     st = super_tiles.reshape(-1, 512)
     regrouped = np.take_along_axis(st, np.argsort(cells[st], axis=1, kind="stable"), axis=1).reshape(-1, 64)
