@@ -62,7 +62,11 @@ def stats(groups):     # groups: [waves, 64] ray indices
     p1 = c[:, 64 - 16 - 1]                      # iterations with more than 16 rays alive
     p2 = c[:, -1] - p1
     own = c.sum(axis=1)
-    return {"wavefronts": int(groups.shape[0]), "cells/ray": round(float(own.sum() / groups.size), 2), "tests/ray": round(float(tests[groups].sum() / groups.size), 2),
+    key = 2 * p1 + p2                            # what the kernel leaves at its tile for the learned order (iterations, those of phase 1 twice)
+    q = np.percentile(key, [5, 25, 50, 75, 95, 99, 100])
+    spread = {"tile cost percentiles 5/25/50/75/95/99/max": [round(float(v), 1) for v in q], "p95 / median": round(float(q[4] / max(q[2], 1e-9)), 2),
+              "tiles that cost nothing": round(float((key == 0).mean()), 3), "coefficient of variation": round(float(key.std() / max(key.mean(), 1e-9)), 3)}
+    return {"tile costs": spread, "wavefronts": int(groups.shape[0]), "cells/ray": round(float(own.sum() / groups.size), 2), "tests/ray": round(float(tests[groups].sum() / groups.size), 2),
             "phase-1 iterations": round(float(p1.mean()), 2), "phase-2 iterations": round(float(p2.mean()), 2), "longest ray of a wavefront": round(float(c[:, -1].mean()), 2),
             "lock-step efficiency": round(float(own.sum() / (64 * p1.sum() + 16 * p2.sum())), 3),
             "iterations per wavefront (p1 + p2)": round(float((p1 + p2).mean()), 2)}
