@@ -46,6 +46,7 @@ struct TraverseArgs {
     int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
     int tail_dual;                // host side only: which instantiation of the tail kernel is launched
     int mailbox;                  // host side only: the instantiation with a mailbox of the last four triangles per ray
+    int refill;                   // tail kernel (REFILL instantiations): tiles per wavefront whose lanes take new rays as they finish (0: off)
     int tri64;                    // host side only: `tris` is the copy padded to 64 bytes per triangle (instantiations with TRI64)
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)

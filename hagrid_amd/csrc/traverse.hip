@@ -11,7 +11,6 @@
 // format); how rays meet lanes: trav_common.h (tile packets), ray_order.hip (row-length detection, ray binning).  DESIGN.md 4.2.
 #include "trav_kernels.h"
 
-#include <cstdlib>
 #include <cstring>
 
 using namespace hagrid;
@@ -32,6 +31,16 @@ __global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ 
 template <unsigned MODE>
 bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
+    if (tail && MODE == 0 && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL)
+        if (a.mailbox) {
+            if (a.tri64) { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a); }
+            else         { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a); }
+        } else {
+            if (a.tri64) { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a); }
+            else         { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a); }
+        }
+        return true;
+    }
     if (tail && MODE == 0 && slim && !uniform) {
         // (the table layout has no registers to spare for the second request of "traverse.tail_dual", and keeps costs for the tile order only where asked to)
         if (a.tile_cost) {
@@ -126,7 +135,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -281,6 +290,19 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // Measured with the reference step counts as the key (tools/dev_wave_timeline.py): 1024^2 0.181 -> 0.152 ms, mean occupancy 0.61 -> 0.79.
         // The kernel's own key counts an iteration with one ray per lane twice (its lists' rounds run one after the other): 1024^2 0.1455 ms with
         // plain iterations, 0.1380 / 0.1389 with that phase counted twice / three times, 0.142 with 2.5 on a key of half the resolution.
+        // "traverse.refill": a wavefront of the tail kernel owns a POOL of this many tiles, and lanes whose rays are done take the pool's next rays (trav_kernels.h
+        // REFILL).  Measured on the prototype of round 4 (tools/proto/README.md): two tiles per wavefront +6.5 % on the 8.4M-ray share of configuration 5 (bounce rays in
+        // image order over 1.6 GB of image and triangles: 70 % of a wavefront's lock-step iterations have at most 16 of 64 rays alive), larger pools worse (K = 3 / 4 / 8:
+        // -1 / -11 / -27 % against two), -1.5 % on the binned incoherent share of configuration 4 (bound by the vector-memory path), +-0 on 16M primary rays, -3 % on
+        // configuration 5's whole 64M-ray batch (seven instead of eight wavefronts per SIMD).  -1 (default): two tiles where the mailbox rule applies to a batch in image
+        // order -- a launch of at least eight rounds whose rays are fewer than the 64-byte sectors of a working set beyond 512 MB.  A refilled launch follows no learned
+        // tile order (its rule misfires on such launches anyway: -5.3 % on that share) and starts no tile with four lanes per ray.  Hits do not depend on it.
+        int refill_k = 0;
+        {
+            const bool can = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow;
+            const bool first_touch = a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 && size_t(num_rays) * 64 < a.bin_working_set;
+            refill_k = !can ? 0 : (ctx->opt_refill < 0 ? ((!perm && first_touch) ? 2 : 0) : ctx->opt_refill);
+        }
         const int tiles = blocks;
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
@@ -290,7 +312,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // of a class of equal cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
             // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch)
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
-            const int want = ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
+            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
@@ -379,6 +401,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     a.tris = padded; a.tri64 = 1;
                 }
             }
+        }
+        if (refill_k > 1) {      // ("traverse.refill" above)
+            a.refill = refill_k; a.tail_dual = 0; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);
         }
         if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
