@@ -77,9 +77,9 @@ struct hagrid_ctx {
     int opt_bin_bits = 0;       // ray binning: Morton bits per axis of the bin key (3 = 512 bins, 4 = 4096 bins); 0: by the size of what the batch gathers from
     int opt_variant = 0;        // 0 = the image kernel when the grid has an image, else v2; 1 / 2 / 4 = force the reference-shaped kernel / v2 / the image kernel
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
-    int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once a pass merges less than a tenth of its cells
+    int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once an iteration has merged less than half of its cells (merge.inplace_div)
     int opt_merge_inplace_iters = 0;   // tests: leave the in-place mode after this many iterations (0: only for lack of room), the next iteration compacts
-    int opt_merge_inplace_div = 0;     // the mode is entered once a pass merges less than 1 / this of its cells (0: 50); tests enter earlier
+    int opt_merge_inplace_div = 0;     // the mode is entered once an iteration merges less than 1 / this of its cells (0: the default, 2); tests enter earlier or later
     int opt_merge_inplace_room = 0;    // tests: the in-place mode may use the reference buffer up to this index only (0: all of it) -- the overflow path
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
     int opt_refill = -1;        // tail kernel: tiles per wavefront whose lanes take new rays as they finish; -1 = two where the mailbox rule applies to an image-ordered batch, 0 / 1 = off
@@ -106,7 +106,7 @@ struct hagrid_ctx {
         // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[304 + i],
         // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
-        int lpt_epoch = 0, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
+        int lpt_epoch = 1 /* never 0: the pinned report word starts as 0 and is reset to -1 */, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
         unsigned long long used = 0;                    // clock of the last call that used the slot
     };
     static constexpr int kRayHints = 4;
@@ -169,6 +169,16 @@ void debug_sync(hagrid_ctx* ctx, const char* file, int line);
 template <typename T>
 inline T* pool_alloc(hagrid_ctx* ctx, size_t n) {
     return static_cast<T*>(hagrid_mem_alloc(ctx, (n ? n : 1) * sizeof(T)));
+}
+
+// An OPTIONAL buffer (a pass runs without it, only slower): a failed allocation leaves neither the runtime's sticky out-of-memory error nor a message in the
+// context behind -- the pass's final hipGetLastError() would otherwise turn its success into HAGRID_EHIP.
+template <typename T>
+inline T* pool_try_alloc(hagrid_ctx* ctx, size_t n) {
+    const std::string saved = ctx->err;
+    T* p = pool_alloc<T>(ctx, n);
+    if (!p) { (void)hipGetLastError(); ctx->err = saved; }
+    return p;
 }
 
 // Pool buffers that are released on every exit path of a pass.

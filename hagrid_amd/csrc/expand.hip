@@ -305,9 +305,9 @@ extern "C" int hagrid_expand_grid(hagrid_ctx* ctx, hagrid_grid* grid, const void
     const Entry* entries = static_cast<const Entry*>(grid->entries);
     const int* refs = static_cast<const int*>(grid->ref_ids);
     const int blocks = grid_blocks(n, kBlock);
-    int* list = iters > 1 ? pool_alloc<int>(ctx, size_t(n)) : nullptr;      // (without it the later iterations fall back to the all-cells pass)
+    int* list = iters > 1 ? pool_try_alloc<int>(ctx, size_t(n)) : nullptr;      // (without it the later iterations fall back to the all-cells pass)
     const long long voxels = (long long)k.dims.x * k.dims.y * k.dims.z;
-    int* voxel_cells = (ctx->opt_expand_voxel_map && voxels <= (1ll << 28)) ? pool_alloc<int>(ctx, size_t(voxels)) : nullptr;   // (without it: the chain through the voxel map)
+    int* voxel_cells = (ctx->opt_expand_voxel_map && voxels <= (1ll << 28)) ? pool_try_alloc<int>(ctx, size_t(voxels)) : nullptr;   // (without it: the chain through the voxel map)
     k.voxel_cells = voxel_cells;
     if (voxel_cells) { ExpandK kf = k; kf.voxel_cells = nullptr; fill_voxel_cells<<<grid_blocks(voxels, kBlock), kBlock, 0, st>>>(kf, entries, voxel_cells, int(voxels)); HG_DBG(ctx); }
     int* counts = ctx->dscratch + 160;             // one list length per listed pass

@@ -314,8 +314,8 @@ __global__ void __launch_bounds__(kBlock) merge_kernel(int axis, MergeK k, const
 
 // ---- iterations in place ------------------------------------------------------------------------------------------------------
 // After the first iteration a pass merges a few per cent of the cells, later ones a few per mille (1M-triangle soup: 19, 17, 8, 3.3, 1.8, 0.6,
-// 0.3, 0.08, 0.02 %), yet a compacting pass streams every cell, every reference and every voxel-map word to merge them.  Once a pass merges
-// less than a tenth of its cells the remaining iterations therefore run IN PLACE on the 16-byte working records:
+// 0.3, 0.08, 0.02 %), yet a compacting pass streams every cell, every reference and every voxel-map word to merge them.  Once an iteration has
+// merged less than half of its cells ("merge.inplace_div", default 2) the remaining iterations therefore run IN PLACE on the 16-byte working records:
 //   * cells keep their slot; the cell that absorbs its neighbour takes the merged box and a list appended behind the live references
 //     (so a list needs an explicit end: list_end[]), the absorbed one becomes a TOMBSTONE that names its absorber (look-ups through the voxel
 //     map, which is not rewritten, follow tombstones);
@@ -381,17 +381,17 @@ __device__ __forceinline__ int ip_compact_tile(uint32_t mask4 /* bit 8c: slot id
 // its lower corner (ip_mark_entry).  Without stamps every cell is dirty.
 __global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty,
                                                    const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z,
-                                                   unsigned char* __restrict__ evaluated, unsigned char* __restrict__ absorbs, int* __restrict__ books, int num_refs) {
+                                                   unsigned char* __restrict__ evaluated, unsigned char* __restrict__ absorbs, int* __restrict__ books, int num_refs, size_t dstride) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id == 0) { books[0] = num_refs; books[1] = slots; books[2] = num_refs; books[3] = 0; }      // cursor, live cells, live references, overflow
     if (id >= slots) return;
     evaluated[id] = 0; absorbs[id] = 0;                                       // the tags of the mode's passes
     list_end[id] = int(reinterpret_cast<const uint4*>(cells)[size_t(id) + 1].w);
     const int st = stamps ? stamps[id] : 255;
-    dirty[id] = st >= since_x; dirty[size_t(slots) + id] = st >= since_y; dirty[2 * size_t(slots) + id] = st >= since_z;
+    dirty[id] = st >= since_x; dirty[dstride + id] = st >= since_y; dirty[2 * dstride + id] = st >= since_z;
 }
 __global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, int slots,
-                                                        unsigned char* __restrict__ dirty, const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z) {
+                                                        unsigned char* __restrict__ dirty, const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z, size_t dstride) {
     __shared__ int list[kIpTile];
     __shared__ int count;
     const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* _
             ivec3 p = cell.lo;
             if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
             if (comp(p, axis) < 0) continue;
-            dirty[size_t(axis) * slots + int(lookup_entry(entries, k.shift, k.top, p))] = 1;
+            dirty[size_t(axis) * dstride + int(lookup_entry(entries, k.shift, k.top, p))] = 1;
         }
     }
 }
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, i
 __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const unsigned char* __restrict__ absorbs,
                                                   int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
                                                   const int* __restrict__ removed, int num_tiles, int* __restrict__ books /* cursor, live cells, live refs, overflow */,
-                                                  int* __restrict__ snap) {
+                                                  int* __restrict__ snap, size_t dstride) {
     __shared__ int lds[kWaves];
     const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
     const int overflow = books[3];                    // (written by the previous kernel at the latest; this kernel's thread 0 only changes its sign)
@@ -546,11 +546,11 @@ __global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restr
         const int id = list[i];
         const CellRec cell = CellFmt<true>::load(cells, id);
         for (int axis = 0; axis < 3; axis++) {
-            dirty[size_t(axis) * slots + id] = 1;
+            dirty[size_t(axis) * dstride + id] = 1;
             ivec3 p = cell.lo;
             if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
             if (comp(p, axis) < 0) continue;
-            dirty[size_t(axis) * slots + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
+            dirty[size_t(axis) * dstride + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
         }
     }
 }
@@ -710,19 +710,26 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* tile_removed = nullptr;                                          // references that disappear, per tile of the pass
     const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
     // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).
-    auto ip_enter = [&]() {
-        ip_slots = num_cells;
+    size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the sweeps load four flags at a time)
+    // (returns false -- and the merge goes on compacting -- when the scratch of the mode does not fit the idle cell buffer: grids of a few dozen cells)
+    auto ip_enter = [&]() -> bool {
+        const auto r256 = [](size_t n) { return (n + 255) & ~size_t(255); };
+        const size_t slots = size_t(num_cells), dstride = r256(slots);
+        const size_t off_dirty = r256(slots * 8), off_eval = off_dirty + 3 * dstride, off_removed = off_eval + r256(slots);
+        if (off_removed + r256(size_t(grid_blocks(num_cells, kIpTile)) * sizeof(int)) > nc0 * sizeof(Cell)) return false;
+        ip_slots = num_cells; ip_dstride = dstride;
         char* scratch = static_cast<char*>(cells_other);                   // 32 bytes per cell of the un-merged grid: 12 per slot are used
         minfo = reinterpret_cast<Int2*>(scratch);
-        dirty = reinterpret_cast<unsigned char*>(scratch + ((size_t(ip_slots) * 8 + 255) & ~size_t(255)));
-        evaluated = dirty + ((3 * size_t(ip_slots) + 255) & ~size_t(255));
-        tile_removed = reinterpret_cast<int*>(evaluated + ((size_t(ip_slots) + 255) & ~size_t(255)));
+        dirty = reinterpret_cast<unsigned char*>(scratch + off_dirty);
+        evaluated = reinterpret_cast<unsigned char*>(scratch + off_eval);
+        tile_removed = reinterpret_cast<int*>(scratch + off_removed);
         // dirty cells: the ones made after the last evaluation of the axis (their stamps say so) and the cells behind their lower corners
         const unsigned char* stp = have_stamps ? stamps : nullptr;
         ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2],
-                                                                   evaluated, cell_flags /* the mode's `absorbs` tags */, books, num_refs); HG_DBG(ctx);
-        if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2]); HG_DBG(ctx);
+                                                                   evaluated, cell_flags /* the mode's `absorbs` tags */, books, num_refs, ip_dstride); HG_DBG(ctx);
+        if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2], ip_dstride); HG_DBG(ctx);
         in_place = true;
+        return true;
     };
     // Leaves the mode: the live cells become public 32-byte records in `cells_other` (the scratch above is dead by then), their lists go to the
     // reference buffer that is not in use, the voxel map is rewritten once.  Afterwards the grid is in the state a compacting pass with 32-byte
@@ -799,7 +806,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         int first_compacting_axis = 0;
         if (in_place) {
             // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
-            if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * size_t(ip_slots), st);
+            if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * ip_dstride, st);
             const int blocks = grid_blocks(ip_slots, kIpTile), tiles = blocks;
             const Entry* ent = reinterpret_cast<const Entry*>(entries);
             for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {
@@ -808,13 +815,13 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
                     pass_tag = 1;
                     (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
                 }
-                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_slots, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
+                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_dstride, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
                 ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag); HG_DBG(ctx);
                 ip_tile_sums<<<tiles, kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tile_removed); HG_DBG(ctx);
                 if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
                 ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books, ip_total,
                                                     ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity, axis); HG_DBG(ctx);
-                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, tile_removed, tiles, books, snap + 2 * axis); HG_DBG(ctx);
+                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, tile_removed, tiles, books, snap + 2 * axis, ip_dstride); HG_DBG(ctx);
             }
             if (rc != HAGRID_OK) break;
             int h[10];                                                     // books (4), the three snapshots
@@ -837,7 +844,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             // and axis.  1M-triangle soup: the first iteration merges 39 % of the cells, the second 5.7 %, the third 0.4 %; a compacting pass costs ~160 us
             // whatever it merges, a pass in place 75 - 130 us in the second iteration and ~45 us in the third (profiles/NOTES.md "Round 4").
             const int div = ctx->opt_merge_inplace_div > 0 ? ctx->opt_merge_inplace_div : 2;
-            if (in_narrow && ctx->opt_merge_inplace && (long long)div * (prev_num_cells - num_cells) < prev_num_cells && num_cells < alpha * prev_num_cells) ip_enter();
+            if (in_narrow && ctx->opt_merge_inplace && (long long)div * (prev_num_cells - num_cells) < prev_num_cells && num_cells < alpha * prev_num_cells) (void)ip_enter();
         }
         prev_mask = mask;
         iter++;

@@ -205,6 +205,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
             N.lpt_rays = nullptr; N.lpt_valid = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
+            // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
+            N.lpt_epoch++; __atomic_store_n(ctx->mailbox + 304 + lru, -1, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
             // row length counts as seen (the kernel reads the one found for THIS buffer either way), its tile order is the first order (below).
             const hagrid_ctx::RayHints* donor = nullptr;
@@ -319,7 +321,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             if (H.cooldown > 0) H.cooldown--;              // orders did not last on this buffer (a camera that moves fast): not learned for a while
             else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
                 int* report = ctx->mailbox + 304 + hint_slot;
-                if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && *report == H.lpt_epoch) {
+                if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && __atomic_load_n(report, __ATOMIC_ACQUIRE) == H.lpt_epoch) {
                     // A launch since the last sort found other rays in the buffer than the order was learned on (its first wavefront reported it): learn
                     // again, from costs of the new rays only.  Three such orders in a row that lasted fewer than eight launches each: give up for 64 launches -- for twice as
                     // many every time that happens again before an order has lasted through a refresh (a camera that keeps moving: up to 1024).
@@ -345,6 +347,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                         // (the stand-in's refresh count goes on: buffers that come and go -- a new allocation per frame -- still re-sort every 32nd launch,
                         // from the costs of that one launch: every wavefront of a launch leaves its cost)
                         H.lpt_valid = true; H.lpt_period = 32; H.lpt_age = donor->lpt_age;
+                        H.lpt_epoch++;                 // an order of its own epoch: no report written so far can name it
                     }
                 }
                 a.tile_cost = H.lpt_buf;

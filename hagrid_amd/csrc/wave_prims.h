@@ -381,6 +381,11 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
             }
         }
         __syncthreads();
+        // In-place callers (out(i) overwrites what in(i) reads): a helper that sums this tile from its items (above) relies on "status still unpublished => no output
+        // stored yet".  The publish is a relaxed agent-scope store by lane 0 and the outputs below are plain stores of every thread: the release fence orders the
+        // publish (it happens before this point through the barrier) in front of them at agent scope; the helper's acquire fence sits between its item loads and
+        // its second look at the status word.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         // what is left after the wait: one add and the output per item
         V offset = tile_prefix;
         for (int w = 0; w < wave_id(); w++) offset = offset + lds[w];
