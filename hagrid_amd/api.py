@@ -141,11 +141,12 @@ class MemManager:
         return {"copy_GBps": float(c.value), "triad_GBps": float(t.value)}
 
     def image_format(self, grid: "Grid") -> dict:
-        """Layout of the traversal image held for `grid`: flat / uniform / slim id bits / bytes per record ({} without an image)."""
+        """Layout of the traversal image held for `grid`: flat / uniform (table-free) / general (a slim record per voxel-map entry) / slim id bits /
+        bytes per record ({} without an image)."""
         f = (C.c_int32 * 4)()
         if self._L.hagrid_traversal_image_info(self._ctx, C.byref(grid.pod), f, None) != 0:
             return {}
-        return {"flat": bool(f[0]), "uniform": bool(f[1]), "slim_id_bits": int(f[2]), "record_bytes": int(f[3])}
+        return {"flat": bool(f[0]), "uniform": bool(f[1]), "general": f[0] == 2, "slim_id_bits": int(f[2]), "record_bytes": int(f[3])}
 
     def image_record_bytes(self, grid: "Grid") -> int:
         """16 when the traversal image of `grid` holds slim records, else 32."""

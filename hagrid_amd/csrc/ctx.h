@@ -27,12 +27,14 @@ namespace hagrid_impl {
 
 // Traversal image (trav_image.hip): one per context, derived from the grid of the last hagrid_setup_traversal call.
 struct TravImageCache {
-    void* table = nullptr;          // uint2 per top-level cell
+    void* table = nullptr;          // uint2 per top-level cell; general layout: the wide records (16 bytes each)
+    size_t table_bytes = 0;
     void* blocks = nullptr;         // 128-byte aligned blocks: local voxel map + 32-byte cell records
     size_t block_bytes = 0;
     bool valid = false;
     bool flat = false;              // records indexed by the voxel (no slot bytes)
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
+    bool general = false;           // flat, one slim record per voxel-map entry at the entry's index (links to child blocks, wide records): any depth
     int slim = 0;                   // uniform layout with 16-byte records: bits per inline reference id (20: four ids, 26: three), 0 = 32-byte records
     bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
@@ -98,7 +100,7 @@ struct hagrid_ctx {
     // slot is taken over by a new buffer.  Slot i owns the device word dscratch[236 + i] and the pinned word mailbox[300 + i].
     struct RayHints {
         const void* key_rays = nullptr; int key_n = 0;       // the buffer the slot belongs to
-        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
+        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
         int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
@@ -118,6 +120,7 @@ struct hagrid_ctx {
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
     int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
+    int opt_tile_order_rounds_incoherent = 1000;   // ... and up to this many for rays in image order without coherent directions (rows found from the origins alone)
     int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch

@@ -62,10 +62,26 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
-    const uint2 tab = a.img_table[(vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift))];
+    const int top = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
+    const uint2 tab = (slim && !slim_uniform) ? make_uint2(0u, 0u) : a.img_table[top];
     if (slim) {     // a slim record, brought into the form of the 32-byte record
-        const int d = int(tab.y & 3u), sh = a.shift - d, m = (1 << d) - 1;             // (uniform layout: d == shift)
-        const uint4 r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(tab.x) + size_t(((vx >> sh) & m) + ((((vy >> sh) & m) + (((vz >> sh) & m) << d)) << d))];
+        uint4 r;
+        int region = a.shift;                   // general layout: log2 of the region the record's bound bytes count from
+        uint32_t links = 0;
+        if (slim_uniform) {
+            const int d = int(tab.y & 3u), sh = a.shift - d, m = (1 << d) - 1;             // (uniform layout: d == shift)
+            r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(tab.x) + size_t(((vx >> sh) & m) + ((((vy >> sh) & m) + (((vz >> sh) & m) << d)) << d))];
+        } else {
+            // general layout: from the top-level record down through the links, as lookup_entry walks the voxel map (grid.h:103-116)
+            const uint32_t none_ = (1u << slim) - 1u; const int last_ = 48 + (80 / slim - 1) * slim;
+            r = reinterpret_cast<const uint4*>(a.img_blocks)[top];
+            while (((r.w >> (last_ - 96)) & none_) == none_ - 2u) {
+                const int k = int((r.z >> 16) & 3u), m = (1 << k) - 1;
+                region -= k; links++;
+                const uint32_t first = (r.y >> 16) | (r.z << 16);
+                r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(first) + size_t(((vx >> region) & m) + ((((vy >> region) & m) + (((vz >> region) & m) << k)) << k))];
+            }
+        }
         const uint32_t w[5] = {r.x, r.y, r.z, r.w, 0u};
         auto field = [&](int pos, int nb) -> uint32_t {
             const int wi = pos >> 5, o = pos & 31;
@@ -80,17 +96,24 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
             o[1] = uint32_t(vy - int(field(16, 8))) | uint32_t(vy + int(field(24, 8))) << 16;
             o[2] = uint32_t(vz - int(field(32, 8))) | uint32_t(vz + int(field(40, 8))) << 16;
         } else {
-            const int om = ~((1 << a.shift) - 1);
-            o[0] = uint32_t((vx & om) + int(field(0, 8)) - 128) | uint32_t((vx & om) + int(field(8, 8)) - 128) << 16;
-            o[1] = uint32_t((vy & om) + int(field(16, 8)) - 128) | uint32_t((vy & om) + int(field(24, 8)) - 128) << 16;
-            o[2] = uint32_t((vz & om) + int(field(32, 8)) - 128) | uint32_t((vz & om) + int(field(40, 8)) - 128) << 16;
+            const int om = int(~0u << region);
+            o[0] = uint32_t((vx & om) - int(field(0, 8))) | uint32_t((vx & om) + int(field(8, 8))) << 16;
+            o[1] = uint32_t((vy & om) - int(field(16, 8))) | uint32_t((vy & om) + int(field(24, 8))) << 16;
+            o[2] = uint32_t((vz & om) - int(field(32, 8))) | uint32_t((vz & om) + int(field(40, 8))) << 16;
         }
-        if (field(48 + (ni - 1) * slim, slim) == none - 1u) {
+        const uint32_t marker = field(48 + (ni - 1) * slim, slim);
+        const bool wide = !slim_uniform && marker == none - 3u;
+        if (marker == none - 1u || wide) {
             const uint32_t cnt = field(80, 20);
+            uint32_t first = field(48, 32);
+            if (wide) {       // the cell's bounds and first reference index come from its wide record
+                const uint4 wr = reinterpret_cast<const uint4*>(a.img_table)[first];
+                o[0] = wr.x; o[1] = wr.y; o[2] = wr.z; first = wr.w;
+            }
             // lists of at most four ids are inline in the 32-byte record: read them through the index
-            o[3] = cnt | (cnt > 4 ? 0x80000000u : 0u);
-            if (cnt > 4) { o[4] = field(48, 32); o[5] = o[6] = o[7] = 0u; }
-            else for (uint32_t j = 0; j < 4; j++) o[4 + j] = j < cnt ? uint32_t(a.refs[field(48, 32) + j]) : ~0u;
+            o[3] = cnt | (cnt > 4 ? 0x80000000u : 0u) | (links ? 0x40000000u : 0u);
+            if (cnt > 4) { o[4] = first; o[5] = o[6] = o[7] = 0u; }
+            else for (uint32_t j = 0; j < 4; j++) o[4 + j] = j < cnt ? uint32_t(a.refs[first + j]) : ~0u;
         } else {
             uint32_t cnt = 0;
             for (int j = 0; j < 4; j++) {
@@ -98,7 +121,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
                 o[4 + j] = id == none ? ~0u : id;
                 if (id != none) cnt++;
             }
-            o[3] = cnt;
+            o[3] = cnt | (links ? 0x40000000u : 0u);        // bit 30: came through a link
         }
         return;
     }
@@ -191,7 +214,9 @@ extern "C" int hagrid_kat_detect_ray_rows(hagrid_ctx* ctx, const void* rays_dev,
     a.max_x = bbox_diag; a.min_x = 0.0f;                 // only the diagonal matters
     launch_detect(ctx, a, num_rays, d, 65536);            // the test hook runs the origin criterion from 64k rays on
     HG_HIP(ctx, hipGetLastError());
-    return read_back(ctx, d, row_len, sizeof(int));
+    HG_TRY(read_back(ctx, d, row_len, sizeof(int)));
+    *row_len &= kRowLenMask;                               // (bit 30: found from the origins alone)
+    return HAGRID_OK;
 }
 
 extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_log2, int xcd_chunk_log2, int32_t* slots) {
@@ -210,7 +235,7 @@ extern "C" int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len,
 extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes) {
     if (!ctx || !grid || n < 0) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
-    if (image_bytes) *image_bytes = (int64_t)ctx->image.block_bytes + 8ll * grid->dims[0] * grid->dims[1] * grid->dims[2];
+    if (image_bytes) *image_bytes = (int64_t)ctx->image.block_bytes + (int64_t)ctx->image.table_bytes;
     if (n == 0) return HAGRID_OK;
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a));
@@ -253,7 +278,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
-        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20},
+        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 0, 2},

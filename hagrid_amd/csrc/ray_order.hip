@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __
         const int horizontal = __hip_atomic_load(scores + kRowCandidates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int w1 = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long bar = mean - full * 8 / 100;
-        if (w1 == 0 && m != ~0ull && (long long)(m >> 32) < bar && horizontal < bar && horizontal > 0) out[0] = int(unsigned(m));
+        if (w1 == 0 && m != ~0ull && (long long)(m >> 32) < bar && horizontal < bar && horizontal > 0) out[0] = int(unsigned(m)) | kRowsFromOrigins;       // (rays in image order WITHOUT coherent directions: traverse.hip's tile-order rule)
         scores[kRowCandidates + 1] = 0;                              // ready for the next batch
     }
 }
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) ray_bin_decide(const int* __restrict__ row
     int d = diff[threadIdx.x];
     diff[threadIdx.x] = 0;                       // ready for the next batch
     d = wave_sum(d);
-    if (threadIdx.x == 0) flag[0] = (*row_len == 0 && 2ll * d > num_rays) ? 1 : 0;
+    if (threadIdx.x == 0) flag[0] = ((*row_len & kRowLenMask) == 0 && 2ll * d > num_rays) ? 1 : 0;
 }
 
 // The rays of a tile are first put in bin order inside LDS (local histogram -> local scan -> local rank), then written out: lanes

@@ -128,8 +128,11 @@ __device__ __forceinline__ int xcd_chunked(int b, int nb, int chunk_log2) {
     return ((((j >> chunk_log2) << 3) + xcd) << chunk_log2) + (j & ((1 << chunk_log2) - 1));
 }
 
+// the row-length word of detect_ray_rows: bit 30 = found by the second criterion (neighbouring ORIGINS: bounce rays in the image order of their primary hits --
+// an image without coherent directions), the length in the bits below
+constexpr int kRowsFromOrigins = 1 << 30, kRowLenMask = kRowsFromOrigins - 1;
 __device__ __forceinline__ int tile_packet_row_len(const TraverseArgs& a) {      // 0: buffer order
-    const int w = a.row_len_hint > 0 ? a.row_len_hint : (a.row_len ? __builtin_amdgcn_readfirstlane(*a.row_len) : 0);
+    const int w = a.row_len_hint > 0 ? a.row_len_hint : (a.row_len ? (__builtin_amdgcn_readfirstlane(*a.row_len) & kRowLenMask) : 0);
     return (w < 8 || (w & 7) || a.num_rays / w < 8) ? 0 : w;
 }
 
@@ -283,6 +286,47 @@ __device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int v
     if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
 }
 
+
+// ---- the general layout of slim records (trav_image.hip): one record per voxel-map entry, at the entry's index -------------------------------------
+// The walk to the record of a voxel is the reference's lookup_entry (grid.h:103-116) over 16-byte records: the top-level record of the voxel's top-level cell,
+// then -- while the record is a LINK -- the child the voxel selects in the block the link names.  A ray keeps the innermost block its last look-up ended in
+// (`blk`: its first record, `bks`: k | s << 2 with (2^k)^3 records of 2^s finest-level voxels each); while the next voxel lies inside that block's region the
+// look-up is one gather.  Per record form: LAST id field = NONE - 1 by index, NONE - 2 link, NONE - 3 wide (bounds in a.img_table as 16-byte wide records).
+template <int SLIM>
+struct GenWalk {
+    static constexpr int NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
+    static constexpr uint32_t NONE = (1u << SLIM) - 1u;
+    uint32_t blk, bks;
+    __device__ __forceinline__ static uint32_t last_field(const uint4& r) {
+        constexpr int o = LAST - 96;                       // LAST >= 100 for both id widths: the field lies in the record's fourth word
+        return (r.w >> o) & NONE;
+    }
+    __device__ __forceinline__ static bool is_link(const uint4& r) { return last_field(r) == NONE - 2u; }
+    __device__ __forceinline__ static bool is_wide(const uint4& r) { return last_field(r) == NONE - 3u; }
+    __device__ __forceinline__ static uint32_t word48(const uint4& r) { return (r.y >> 16) | (r.z << 16); }          // bits 48..79
+    __device__ __forceinline__ static uint32_t count80(const uint4& r) { return (r.z >> 16) | ((r.w & 0xfu) << 16); }  // bits 80..99
+    __device__ __forceinline__ int region_shift() const { return int(bks >> 2); }
+    __device__ __forceinline__ static uint4 rec_at(const TraverseArgs& a, uint32_t index) { return *reinterpret_cast<const uint4*>(a.img_blocks + (index << 4)); }
+    __device__ __forceinline__ static uint32_t child(int x, int y, int z, uint32_t k, uint32_t s) {
+        const uint32_t m = (1u << k) - 1u;
+        return ((uint32_t(x) >> s) & m) + (((((uint32_t(y) >> s) & m)) + (((uint32_t(z) >> s) & m) << k)) << k);
+    }
+    // the record of voxel (x, y, z) -- possibly a link: descend() before use; (px, py, pz): the voxel of the previous look-up
+    __device__ __forceinline__ uint4 lookup(const TraverseArgs& a, int x, int y, int z, int px, int py, int pz) {
+        const uint32_t k = bks & 3u, s = bks >> 2;
+        if (blk != ~0u && (uint32_t((x ^ px) | (y ^ py) | (z ^ pz)) >> (s + k)) == 0u) return rec_at(a, blk + child(x, y, z, k, s));
+        blk = ~0u; bks = uint32_t(a.shift) << 2;
+        return rec_at(a, uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
+    }
+    __device__ __forceinline__ void descend(const TraverseArgs& a, uint4& rec, int x, int y, int z) {
+        while (is_link(rec)) {
+            const uint32_t k = (rec.z >> 16) & 3u, s = (bks >> 2) - k;
+            blk = word48(rec); bks = k | s << 2;
+            rec = rec_at(a, blk + child(x, y, z, k, s));
+        }
+    }
+    __device__ __forceinline__ static uint4 wide_at(const TraverseArgs& a, const uint4& rec) { return reinterpret_cast<const uint4*>(a.img_table)[word48(rec)]; }
+};
 
 // ---- host entry points of the translation units ------------------------------------------------------------------------------
 // traverse.hip: the argument block of a grid (setup_traversal's constants, traverse.cu:97-109); tris / rays / hits may be null when num_rays == 0

@@ -58,7 +58,7 @@ struct ImgK {
     const uint4* __restrict__ small_cells; // compressed grid: one uint4 per cell (grid.h:36-45), lists end with a negative id
     const int* __restrict__ refs;
     int top_x, top_y, num_top;
-    int shift, num_entries;
+    int shift, num_entries, num_cells;
     long long source_bytes;                // entries + cells of the construction format
     // nested blocks (flat form, grids deeper than three levels): the entries at which a block stops resolving become roots
     int* claim;                            // per entry: -1, or the index of its root
@@ -325,24 +325,21 @@ __device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long l
     } else hi = (hi & ~(m << (pos - 64))) | (x << (pos - 64));
 }
 
-// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
-// not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
-// TABLE: the block of top-level cell T has depth metas[T] & 3 and starts at record offsets[T]; its bound bytes count from the origin
-// of the top-level cell, biased by 128.
-template <int D, int IDB, bool TABLE>
-__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
-                                                      const uint32_t* __restrict__ metas, const int* __restrict__ offsets) {
+// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels (the uniform layout: block T holds (2^D)^3 records and
+// starts at T * (2^D)^3).  status: bit 0 = a bound does not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more
+// than IDB bits.
+template <int D, int IDB>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status) {
     constexpr int NI = 80 / IDB;
     constexpr uint32_t NONE = (1u << IDB) - 1u;
     const int T = blockIdx.x, lane = threadIdx.x;
     const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
     const uint32_t topw = k.entries[T];
-    const int d = TABLE ? int(metas[T] & 3u) : D, sd = D - d, V = 1 << (3 * d);
-    const size_t first = TABLE ? size_t(offsets[T]) : size_t(T) << (3 * D);
-    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(d) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
+    constexpr int V = 1 << (3 * D);
+    const size_t first = size_t(T) << (3 * D);
+    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(D) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
     for (int f = lane; f < V; f += 64) {
-        // block voxel f at depth d -> its lowest finest-level voxel inside the top-level cell
-        const int rx = (f & ((1 << d) - 1)) << sd, ry = ((f >> d) & ((1 << d) - 1)) << sd, rz = (f >> (2 * d)) << sd;
+        const int rx = f & ((1 << D) - 1), ry = (f >> D) & ((1 << D) - 1), rz = f >> (2 * D);
         uint32_t w = topw;
         int depth = 0;
         while (w & 3u) {
@@ -365,11 +362,11 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
             lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
             begin = a.w; n = b.w - a.w;
         }
-        const int v[3] = {(tx << D) + (TABLE ? 0 : rx), (ty << D) + (TABLE ? 0 : ry), (tz << D) + (TABLE ? 0 : rz)};
+        const int v[3] = {(tx << D) + rx, (ty << D) + ry, (tz << D) + rz};
         unsigned long long rl = ~0ull << 48, rh = ~0ull;               // every id field "unused"
         int bad = 0;
         for (int ax = 0; ax < 3; ax++) {
-            const int dl = TABLE ? lo[ax] - v[ax] + 128 : v[ax] - lo[ax], dh = TABLE ? hi[ax] - v[ax] + 128 : hi[ax] - v[ax];
+            const int dl = v[ax] - lo[ax], dh = hi[ax] - v[ax];
             if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
             rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
         }
@@ -391,22 +388,10 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
     }
 }
 
-struct SlimSizeIn { const uint32_t* m; __device__ int operator()(int i) const { return 1 << (3 * int(m[i] & 3u)); } };
-struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
-
-// uniform: every block has (2^D)^3 records, block T starts at T * (2^D)^3; otherwise `metas` holds the depth of every block and the
-// offsets come from a scan over the block sizes.  Returns 1 when some cell does not fit a slim record.
+// The uniform layout with slim records.  Returns 1 when some cell does not fit a slim record.
 template <int D>
-int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
-    long long records = (long long)k.num_top << (3 * D);
-    if (!uniform) {
-        int* total = ctx->dscratch + 227;
-        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
-        int h = 0;
-        const int rc = read_back(ctx, total, &h, sizeof(h));
-        if (rc != HAGRID_OK) return rc;
-        records = h;
-    }
+int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table) {
+    const long long records = (long long)k.num_top << (3 * D);
     if (records <= 0 || records >= (1ll << 28)) return 1;               // record offsets of the narrow kernels: 32-bit byte offsets
     const size_t bytes = size_t(records) * 16u;
     uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
@@ -415,18 +400,13 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
     for (int idb : {20, 26}) {
         if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
         (void)hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream);
-        if (uniform) {
-            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
-            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
-        } else {
-            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
-            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
-        }
+        if (idb == 20) image_slim_fill<D, 20><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
+        else           image_slim_fill<D, 26><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
         HG_DBG(ctx);
         int h[2] = {0, 0};
         const int rc = read_back(ctx, status, h, sizeof(h));
         if (rc != HAGRID_OK) { hagrid_mem_free(ctx, recs); return rc; }
-        if (h[0]) break;                            // some cell does not fit a slim record: 32-byte records
+        if (h[0]) break;                            // some cell does not fit a slim record: the general layout has wide records for those
         if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
         if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
         img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
@@ -434,6 +414,208 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
     }
     hagrid_mem_free(ctx, recs);
     return 1;
+}
+
+// ---- general layout: one slim record per voxel-map ENTRY ---------------------------------------------------------------------------
+// Grids whose top-level cells differ in depth, and grids deeper than three levels (non-uniform scenes; the reference advertises N-level maps, README.md:12).
+// The image is the voxel map itself with every 4-byte entry widened to a 16-byte slim record at the SAME index: a leaf entry becomes its cell (bounds, ids
+// inline or by index: the slim record of the uniform layout), an inner entry a LINK to its block of (2^k)^3 children (which is where the map has it), so
+// the walk from the top level to a cell is the reference's lookup_entry (grid.h:103-116) with the cell at its end for free, and the kernel keeps the
+// innermost block it is in: while a ray stays inside that block's region a cell step is ONE 16-byte gather at any depth.
+//   bound bytes    offsets from the ORIGIN OF THE ENTRY'S REGION (origin - lo, hi - origin; the region is 2^s finest-level voxels wide, s = shift - depth)
+//   last id field  all ones - 1: list by index (as in the uniform layout) | - 2: link, bits 48..79 first child record, bits 80..81 k
+//                  | - 3: WIDE, the cell's bounds do not fit a byte (the large cells of empty space): bits 48..79 index of a wide record, bits 80..99 list length;
+//                  wide record (16 bytes, its own array): lo | hi << 16 per axis in absolute finest-level voxels, first reference index
+// Built top down, one launch per level of the map: the top-level entries by one thread each, then one wavefront per inner entry writes the records of its
+// children (it knows their origins) and lists the inner ones for the next launch.  Wide records are per CELL (a large cell is named by many entries).
+struct GenItem { int entry; uint32_t oxy, ozs; int pad; };           // inner entry, origin of its region (x | y << 16, z | s << 16)
+
+template <int IDB>
+__device__ __forceinline__ bool general_record(const ImgK& k, uint32_t word, int ox, int oy, int oz, uint4* __restrict__ rec, int* __restrict__ claim, int* __restrict__ status) {
+    constexpr int NI = 80 / IDB;
+    constexpr uint32_t NONE = (1u << IDB) - 1u;
+    unsigned long long rl = ~0ull << 48, rh = ~0ull;               // no bounds, every id field "unused"
+    if (word & 3u) {
+        rl &= ~(0xffffffffull << 48);
+        put_bits(rl, rh, 48, 32, word >> 2);
+        put_bits(rl, rh, 80, 2, word & 3u);
+        put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 2u);
+        *rec = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
+        return true;
+    }
+    const int c = int(word >> 2);
+    int lo[3], hi[3], begin, n;
+    if (k.small_cells) {
+        const uint4 sc = k.small_cells[c];
+        lo[0] = int(sc.x & 0xffffu); lo[1] = int(sc.x >> 16); lo[2] = int(sc.y & 0xffffu);
+        hi[0] = int(sc.y >> 16); hi[1] = int(sc.z & 0xffffu); hi[2] = int(sc.z >> 16);
+        begin = int(sc.w); n = 0;
+        if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
+        else begin = 0;
+    } else {
+        const int4 a = k.cells[2 * size_t(c)], b = k.cells[2 * size_t(c) + 1];
+        lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+        begin = a.w; n = b.w - a.w;
+    }
+    const int o[3] = {ox, oy, oz};
+    bool fits = true;
+    int bad = 0;
+    for (int ax = 0; ax < 3; ax++) {
+        const int dl = o[ax] - lo[ax], dh = hi[ax] - o[ax];
+        if (dl < 0 || dl > 255 || dh < 0 || dh > 255) fits = false;
+        rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
+    }
+    if (n >= (1 << 20)) bad |= 2;
+    if (!fits) {
+        // the cell's wide record: the first entry that names the cell draws its index; the record holds the CELL until image_general_patch
+        // replaces it by that index (the winner's store may not be visible to the other entries of the cell during this launch)
+        if (atomicCAS(claim + c, -1, -2) == -1) claim[c] = atomicAdd(status + 2, 1);
+        put_bits(rl, rh, 48, 32, uint32_t(c));
+        put_bits(rl, rh, 80, 20, uint32_t(n));
+        put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 3u);
+    } else {
+        bool wide_ids = false;               // an id that the field cannot tell from its markers: the whole image needs the wider field
+        for (int i = 0; i < n && i < NI; i++) wide_ids = wide_ids || uint32_t(k.refs[begin + i]) >= NONE - 3u;
+        if (n <= NI && wide_ids) atomicAdd(status + 1, 1);
+        if (n <= NI && !wide_ids) {
+            for (int i = 0; i < n; i++) put_bits(rl, rh, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
+        } else {
+            put_bits(rl, rh, 48, 32, uint32_t(begin));
+            put_bits(rl, rh, 80, 20, uint32_t(n));
+            put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
+        }
+    }
+    if (bad) atomicOr(status, bad);
+    *rec = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
+    return false;
+}
+
+// the top level: one thread per entry
+template <int IDB>
+__global__ void __launch_bounds__(kBlock) image_general_top(const ImgK k, uint4* __restrict__ recs, GenItem* __restrict__ items, int* __restrict__ num_items,
+                                                            int* __restrict__ claim, int* __restrict__ status) {
+    const int T = blockIdx.x * kBlock + threadIdx.x;
+    bool inner = false;
+    int ox = 0, oy = 0, oz = 0;
+    if (T < k.num_top) {
+        ox = (T % k.top_x) << k.shift; oy = ((T / k.top_x) % k.top_y) << k.shift; oz = (T / (k.top_x * k.top_y)) << k.shift;
+        const uint32_t w = k.entries[T];
+        inner = general_record<IDB>(k, w, ox, oy, oz, recs + T, claim, status);
+        if (inner && k.shift < int(w & 3u)) { atomicOr(status, 4); inner = false; }
+    }
+    const int at = wave_append(inner ? 1 : 0, num_items);
+    if (inner) items[at] = GenItem{T, uint32_t(ox) | uint32_t(oy) << 16, uint32_t(oz) | uint32_t(k.shift) << 16, 0};
+}
+// one level down: one wavefront per inner entry of the level above
+template <int IDB>
+__global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, uint4* __restrict__ recs, const GenItem* __restrict__ in, const int* __restrict__ num_in,
+                                                              GenItem* __restrict__ items, int* __restrict__ num_items, int* __restrict__ claim, int* __restrict__ status) {
+    const int i = blockIdx.x * kWaves + wave_id();
+    if (i >= *num_in) return;
+    const GenItem it = in[i];
+    const uint32_t word = k.entries[it.entry];
+    const int kk = int(word & 3u), first = int(word >> 2), s = int(it.ozs >> 16) - kk, m = (1 << kk) - 1;
+    const int ox = int(it.oxy & 0xffffu), oy = int(it.oxy >> 16), oz = int(it.ozs & 0xffffu);
+    for (int base = 0; base < (1 << (3 * kk)); base += 64) {               // (1, 8 or 64 children per round of the wavefront; 512 in eight rounds)
+        const int c = base + lane_id();
+        bool inner = false;
+        int cx = 0, cy = 0, cz = 0;
+        if (c < (1 << (3 * kk))) {
+            cx = ox + ((c & m) << s); cy = oy + (((c >> kk) & m) << s); cz = oz + ((c >> (2 * kk)) << s);
+            const uint32_t w = k.entries[first + c];
+            inner = general_record<IDB>(k, w, cx, cy, cz, recs + first + c, claim, status);
+            if (inner && s < int(w & 3u)) { atomicOr(status, 4); inner = false; }       // a map deeper than its shift says: not a grid
+        }
+        const int at = wave_append(inner ? 1 : 0, num_items);
+        if (inner) items[at] = GenItem{first + c, uint32_t(cx) | uint32_t(cy) << 16, uint32_t(cz) | uint32_t(s) << 16, 0};
+    }
+}
+// records that name a wide cell get the index of its wide record; the wide records themselves
+template <int IDB>
+__global__ void __launch_bounds__(kBlock) image_general_patch(uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim) {
+    constexpr int NI = 80 / IDB, LAST = 48 + (NI - 1) * IDB;
+    constexpr uint32_t NONE = (1u << IDB) - 1u;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_entries) return;
+    uint4 r = recs[i];
+    unsigned long long rl = r.x | (unsigned long long)r.y << 32, rh = r.z | (unsigned long long)r.w << 32;
+    const uint32_t last = uint32_t(rh >> (LAST - 64)) & NONE;
+    if (last != NONE - 3u) return;
+    const uint32_t c = uint32_t(rl >> 48) | uint32_t(rh & 0xffffu) << 16;
+    put_bits(rl, rh, 48, 32, uint32_t(claim[c]));
+    recs[i] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
+}
+__global__ void __launch_bounds__(kBlock) image_general_wide(const ImgK k, int num_cells, const int* __restrict__ claim, uint4* __restrict__ wide) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= num_cells || claim[c] < 0) return;
+    uint4 w;
+    if (k.small_cells) {
+        const uint4 sc = k.small_cells[c];               // min.x min.y | min.z max.x | max.y max.z  ->  lo | hi << 16 per axis
+        w.x = (sc.x & 0xffffu) | (sc.y & 0xffff0000u); w.y = (sc.x >> 16) | (sc.z << 16); w.z = (sc.y & 0xffffu) | (sc.z & 0xffff0000u);
+        w.w = int(sc.w) < 0 ? 0u : sc.w;
+    } else {
+        const int4 lo = k.cells[2 * size_t(c)], hi = k.cells[2 * size_t(c) + 1];
+        w.x = uint32_t(lo.x) | uint32_t(hi.x) << 16; w.y = uint32_t(lo.y) | uint32_t(hi.y) << 16; w.z = uint32_t(lo.z) | uint32_t(hi.z) << 16;
+        w.w = uint32_t(lo.w);
+    }
+    wide[claim[c]] = w;
+}
+
+// Returns 1 when the grid does not fit the general layout (ids beyond 26 bits, a list of 2^20 ids, 2^28 records): 32-byte records then.
+int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
+    const int num_cells = k.num_cells;
+    hipStream_t st = ctx->stream;
+    if (k.num_entries <= 0 || k.num_entries >= (1 << 28) || k.shift > 15) return 1;
+    if (ctx->opt_image_max_mb > 0 && size_t(k.num_entries) * 16u > (size_t(ctx->opt_image_max_mb) << 20)) return 1;      // ("traverse.image_max_mb")
+    const size_t cap = size_t(std::max(k.num_top, k.num_entries / 8)) + 1;
+    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(k.num_entries) * 16u));
+    GenItem* items[2] = {pool_alloc<GenItem>(ctx, cap), pool_alloc<GenItem>(ctx, cap)};
+    int* claim = pool_alloc<int>(ctx, size_t(num_cells));
+    auto release = [&]() { hagrid_mem_free(ctx, items[0]); hagrid_mem_free(ctx, items[1]); hagrid_mem_free(ctx, claim); };
+    if (!recs || !items[0] || !items[1] || !claim) { release(); hagrid_mem_free(ctx, recs); return HAGRID_ENOMEM; }
+    int* status = ctx->dscratch + 160;           // [0] does not fit | [1] lists with an id beyond the field | [2] wide records
+    int* counts = ctx->dscratch + 164;           // inner entries listed per level
+    int rc = 1;
+    for (int idb : {20, 26}) {
+        if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
+        (void)hipMemsetAsync(status, 0, 24 * sizeof(int), st);
+        (void)hipMemsetAsync(claim, 0xFF, size_t(num_cells) * sizeof(int), st);
+        if (idb == 20) image_general_top<20><<<grid_blocks(k.num_top, kBlock), kBlock, 0, st>>>(k, recs, items[0], counts, claim, status);
+        else           image_general_top<26><<<grid_blocks(k.num_top, kBlock), kBlock, 0, st>>>(k, recs, items[0], counts, claim, status);
+        HG_DBG(ctx);
+        int level = 0, n = 0;
+        rc = read_back(ctx, counts, &n, sizeof(int));
+        while (rc == HAGRID_OK && n > 0 && level < 16) {
+            GenItem* in = items[level & 1]; GenItem* out = items[(level + 1) & 1];
+            if (idb == 20) image_general_level<20><<<grid_blocks(n, kWaves), kBlock, 0, st>>>(k, recs, in, counts + level, out, counts + level + 1, claim, status);
+            else           image_general_level<26><<<grid_blocks(n, kWaves), kBlock, 0, st>>>(k, recs, in, counts + level, out, counts + level + 1, claim, status);
+            HG_DBG(ctx);
+            level++;
+            rc = read_back(ctx, counts + level, &n, sizeof(int));
+            if (size_t(n) > cap) { rc = 1; break; }                       // (cannot happen for a voxel map whose blocks are disjoint)
+        }
+        if (rc != HAGRID_OK) break;
+        int h[3] = {0, 0, 0};
+        rc = read_back(ctx, status, h, sizeof(h));
+        if (rc != HAGRID_OK) break;
+        if (h[0] || n > 0) { rc = 1; break; }       // a list of 2^20 ids, a map deeper than 16 levels
+        if (h[1]) { rc = 1; if (idb == 20) continue; break; }       // ids of more than 20 bits: three ids of 26 bits per record; of more than 26: 32-byte records
+        uint4* wide = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(std::max(h[2], 1)) * 16u));
+        if (!wide) { rc = HAGRID_ENOMEM; break; }
+        if (h[2] > 0) {
+            if (idb == 20) image_general_patch<20><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim);
+            else           image_general_patch<26><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim);
+            HG_DBG(ctx);
+            image_general_wide<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(k, num_cells, claim, wide); HG_DBG(ctx);
+        }
+        img.blocks = recs; img.block_bytes = size_t(k.num_entries) * 16u; img.table = wide; img.table_bytes = size_t(std::max(h[2], 1)) * 16u;
+        img.slim = idb; img.general = true; img.uniform = false;
+        rc = HAGRID_OK;
+        break;
+    }
+    release();
+    if (rc != HAGRID_OK) hagrid_mem_free(ctx, recs);
+    return rc;
 }
 
 struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
@@ -487,14 +669,16 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
-    if (FLAT && ctx->opt_image_slim && D == k.shift && D >= 1) {
-        // (three levels at most: every block resolves its cells, there are no links)  `sizes` is free again: the 32-byte fill below
-        // re-derives its offsets only in the non-uniform case, where the scan result is restored first
-        int* offs = nullptr;
-        if (!uniform) { offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1); if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; } }
-        const int rs = build_slim<D>(ctx, k, img, table, uniform, metas, offs, partials);
-        hagrid_mem_free(ctx, offs);
-        if (rs == HAGRID_OK) { release(); img.uniform = uniform; img.table = table; return HAGRID_OK; }
+    if (FLAT && ctx->opt_image_slim) {
+        // slim records: the uniform layout when every top-level cell has the full depth (three levels at most: no links), else -- or when some cell of it
+        // reaches further than a byte can say -- the general layout (a record per voxel-map entry)
+        int rs = 1;
+        if (uniform) rs = build_slim<D>(ctx, k, img, table);
+        if (rs == HAGRID_OK) { release(); img.uniform = true; img.table = table; img.table_bytes = size_t(k.num_top) * 8u; return HAGRID_OK; }
+        if (rs == 1) {
+            rs = build_general(ctx, k, img);
+            if (rs == HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return HAGRID_OK; }
+        }
         if (rs != 1) { release(); hagrid_mem_free(ctx, table); return rs; }
     }
     if ((long long)units + units1 >= (1ll << 31)) { release(); hagrid_mem_free(ctx, table); return 1; }
@@ -508,7 +692,7 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     hipError_t e = hipGetLastError();
     release();
     if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }
-    img.table = table; img.blocks = blocks; img.block_bytes = (size_t(units) + size_t(units1)) * 128u;
+    img.table = table; img.table_bytes = size_t(k.num_top) * 8u; img.blocks = blocks; img.block_bytes = (size_t(units) + size_t(units1)) * 128u;
     return HAGRID_OK;
 }
 
@@ -566,7 +750,6 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     // deep links (below six levels, or below three in the compact form) resolve through 32-byte cells only: a compressed grid
     // gets an image when blocks + nested blocks cover it
     const bool compressed_deep = g->small_cells && g->shift > 3;
-    if (compressed_deep && (g->shift > 6 || ctx->opt_image != 2)) return HAGRID_OK;
     if (g->shift < 0 || g->shift > 15) return HAGRID_OK;
     for (int i = 0; i < 3; i++)
         if (g->dims[i] <= 0 || (long long)g->dims[i] << g->shift > 65535) return HAGRID_OK;
@@ -580,12 +763,21 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     k.refs = static_cast<const int*>(g->ref_ids);
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
     k.source_bytes = 4ll * g->num_entries + (g->small_cells ? 16ll : 32ll) * g->num_cells;
-    k.num_entries = g->num_entries;
+    k.num_entries = g->num_entries; k.num_cells = g->num_cells;
     k.claim = nullptr; k.roots = nullptr; k.num_roots = nullptr; k.nested_off = nullptr; k.nested_d = nullptr; k.nested_base = 0;
     TravImageCache img;
     int rc = HAGRID_OK;
     bool flat = ctx->opt_image == 2;
-    for (;;) {
+    // grids deeper than three levels: the general layout of slim records, without the sizing passes of the block layouts
+    bool general = false;
+    if (flat && ctx->opt_image_slim && g->shift > 3) {
+        rc = build_general(ctx, k, img);
+        if (rc < 0) return rc;
+        general = rc == HAGRID_OK;
+        rc = HAGRID_OK;
+    }
+    if (compressed_deep && !general && (g->shift > 6 || ctx->opt_image != 2)) return HAGRID_OK;
+    while (!general) {
         switch (g->shift < 3 ? g->shift : 3) {
             case 0: rc = flat ? build_image<0, true>(ctx, k, img) : build_image<0, false>(ctx, k, img); break;
             case 1: rc = flat ? build_image<1, true>(ctx, k, img) : build_image<1, false>(ctx, k, img); break;
@@ -599,7 +791,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.flat = flat;
     if (rc != HAGRID_OK) return rc;
     img.valid = img.table != nullptr;
-    img.standalone = flat && g->shift <= 6;            // blocks + nested blocks resolve six levels; only deeper grids keep `deep` links
+    img.standalone = img.general || (flat && g->shift <= 6);            // the general layout never links back; blocks + nested blocks resolve six levels, only deeper grids keep `deep` links
     img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
     img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
@@ -646,7 +838,7 @@ extern "C" int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* g
     if (!ctx || !grid) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
     const TravImageCache& img = ctx->image;
-    if (format4) { format4[0] = img.flat ? 1 : 0; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
-    if (image_bytes) *image_bytes = (int64_t)img.block_bytes + 8ll * grid->dims[0] * grid->dims[1] * grid->dims[2];
+    if (format4) { format4[0] = img.general ? 2 : (img.flat ? 1 : 0); format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
+    if (image_bytes) *image_bytes = (int64_t)img.block_bytes + (int64_t)img.table_bytes;
     return HAGRID_OK;
 }

@@ -55,6 +55,11 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
         };
         auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
+        constexpr bool GENERAL = SLIM != 0 && !UNIFORM;                         // one slim record per voxel-map entry (trav_common.h GenWalk)
+        GenWalk<SLIM ? SLIM : 20> gw;
+        gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+        int pvx = vx, pvy = vy, pvz = vz;                                       // general layout: the voxel of the previous look-up
+        uint32_t wide_begin = 0u;
         uint32_t nest = ~0u;                                                    // innermost nested block the ray is inside (FLAT + NARROW, table layout)
         int nest_x = 0, nest_y = 0, nest_z = 0;                                 // ... and the voxel that led there
         // record of a voxel: FLAT + NARROW is one address computation off the scalar base
@@ -66,10 +71,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
                 ra = p[0];
                 if (!SLIM) rb = p[1];
-            } else if (FLAT && NARROW && SLIM) {          // table layout, no links: block offset in records, depth of the block
-                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
-                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                ra = *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
+            } else if (FLAT && NARROW && SLIM) {          // general layout: from the block of the last look-up, or from the top level (a link is resolved behind the tests)
+                ra = gw.lookup(a, x, y, z, pvx, pvy, pvz);
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
@@ -110,10 +113,11 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         const int sgx = px ? 1 : -1, sgy = py ? 1 : -1, sgz = pz ? 1 : -1;
         const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
         const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
-        int top_idx = UNIFORM ? 0 : top_index(vx, vy, vz);
-        uint2 tab = UNIFORM ? make_uint2(0u, 0u) : table_at(top_idx);
+        int top_idx = (UNIFORM || GENERAL) ? 0 : top_index(vx, vy, vz);
+        uint2 tab = (UNIFORM || GENERAL) ? make_uint2(0u, 0u) : table_at(top_idx);
         uint4 ca, cb = make_uint4(0u, 0u, 0u, 0u);
         record(tab, vx, vy, vz, ca, cb);
+        if (GENERAL) gw.descend(a, ca, vx, vy, vz);
 
         for (;;) {
             if (!UNIFORM && !SLIM && ca.w >= 0xfffffffeu) {                 // (the table-free layout and slim records need shift <= 3: every block resolves its cell fully)
@@ -128,11 +132,18 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
             int cx, cy, cz;
-            if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell
-                const int org_mask = ~((1 << a.shift) - 1);
-                cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
-                cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
-                cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
+            bool wide_cell = false;
+            if (GENERAL) {     // general layout: byte offsets from the origin of the record's region, or a wide record with absolute bounds
+                const int org_mask = int(~0u << gw.region_shift());
+                cx = (vx & org_mask) + sgx * int(__builtin_amdgcn_ubfe(ca.x, ox, 8u));
+                cy = (vy & org_mask) + sgy * int(__builtin_amdgcn_ubfe(ca.x, oy, 8u));
+                cz = (vz & org_mask) + sgz * int(__builtin_amdgcn_ubfe(ca.y, oz, 8u));
+                wide_cell = GenWalk<SLIM ? SLIM : 20>::is_wide(ca);
+                if (wide_cell) {
+                    const uint4 wr = GenWalk<SLIM ? SLIM : 20>::wide_at(a, ca);
+                    cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
+                    wide_begin = wr.w;
+                }
             } else if (SLIM) {     // byte offsets from the voxel the record belongs to
                 // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
@@ -147,17 +158,19 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             const int nz = texit == tcell.z ? cz + bz : int(ev.z);
             // never backwards: max with the current voxel along a positive direction, min along a negative one -- the median of
             // (new, current, +-infinity), one instruction per axis
+            if (GENERAL) { pvx = vx; pvy = vy; pvz = vz; }
             if (UNIFORM) { vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z); }
             else { vx = px ? max(nx, vx) : min(nx, vx); vy = py ? max(ny, vy) : min(ny, vy); vz = pz ? max(nz, vz) : min(nz, vz); }   // (the table layouts have no registers to spare)
             const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
 
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
-            if (!UNIFORM) {
+            if (!UNIFORM && !GENERAL) {
                 const int ntop = outside ? top_idx : top_index(vx, vy, vz);
                 if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
             }
-            uint4 na, nb = make_uint4(0u, 0u, 0u, 0u);
+            uint4 na = make_uint4(0u, 0u, 0u, 0u), nb = make_uint4(0u, 0u, 0u, 0u);
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
+            else if (GENERAL) { if (!outside) record(tab, vx, vy, vz, na, nb); }
             else record(tab, vx, vy, vz, na, nb);
 
             // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
@@ -176,12 +189,12 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                     if (o + n > 32) v |= w[i + 1] << (32 - o);
                     return n == 32 ? v : (v & ((1u << n) - 1u));
                 };
-                by_index = field(LAST, SLIM) == uint32_t(NONE - 1);
+                by_index = field(LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
                 ref = int(field(48, SLIM));
                 q1 = NI > 1 ? field(48 + SLIM, SLIM) : uint32_t(NONE);
                 q2 = NI > 2 ? field(48 + 2 * SLIM, SLIM) : uint32_t(NONE);
                 q3 = NI > 3 ? field(48 + 3 * SLIM, SLIM) : uint32_t(NONE);
-                li_begin = field(48, 32); li_count = field(80, 20);
+                li_begin = wide_cell ? wide_begin : field(48, 32); li_count = field(80, 20);
             } else {
                 by_index = int(ca.w) < 0;
                 q1 = cb.y; q2 = cb.z; q3 = cb.w;                            // inline: the ids still to test
@@ -227,6 +240,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;
+            if (GENERAL) gw.descend(a, ca, vx, vy, vz);
         }
     }
     nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
@@ -294,7 +308,7 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // triangle in the vector L1 and its L2 / HBM sector: the resources the incoherent and the beyond-cache batches are bound by (profiles/r4a).  It costs an LDS
 // round trip in front of every triangle round.
 template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false>
-__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kernel_tail(const TraverseArgs a) {
+__global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) traverse_kernel_tail(const TraverseArgs a) {
     static_assert(!REFILL || (UNIFORM && !DUAL && !TIMES), "refill: for the table-free layout, one id per round trip");
     __shared__ float4 ray_lds[REFILL ? 128 : 1];          // REFILL: the next 64 rays of the wavefront's pool, requested ahead (LDS-DMA)
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
@@ -381,22 +395,14 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
             alive = true;
         }
     }
-    uint32_t tab_off = 0u, tab_d = 0u;                     // table layout: block offset (records) and depth of the top-level cell the ray is in
-    int top_idx = -1;
-    auto load_record = [&](int x, int y, int z) -> uint4 {
+    GenWalk<SLIM> gw;                                      // general layout: the innermost block the ray's last look-up ended in
+    gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+    uint32_t wide_begin = 0u;                              // general layout: first reference index of the wide cell of this step
+    auto load_record = [&](int x, int y, int z) -> uint4 {          // uniform layout: the record of a voxel is arithmetic on the voxel
         const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
-        if (UNIFORM) {
-            const int d = a.shift, m = (1 << d) - 1;
-            const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-            return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
-        }
-        if (int(top) != top_idx) {
-            const uint2 t = gather32<uint2>(a.img_table, top << 3);
-            tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
-        }
-        const int d = int(tab_d), sh = a.shift - d, m = (1 << d) - 1;
-        const uint32_t idx = uint32_t((x >> sh) & m) + (uint32_t(((y >> sh) & m) + (((z >> sh) & m) << d)) << d);
-        return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
+        const int d = a.shift, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+        return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
     };
     auto tri_ptr = [&](int ref) -> const float4* {
         uint32_t r3, o;
@@ -437,10 +443,18 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
         } else {
-            const int org_mask = ~((1 << a.shift) - 1);
-            cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
-            cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
-            cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
+            // general layout: byte offsets from the origin of the record's region (2^s voxels wide) -- or, for the few cells that reach further, a wide
+            // record with absolute 16-bit bounds (one more dependent gather, in steps through the large cells of empty space only)
+            const int org_mask = int(~0u << gw.region_shift());
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx & org_mask));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy & org_mask));
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz & org_mask));
+            const bool wide = GenWalk<SLIM>::is_wide(rec);
+            if (__ballot(wide) != 0ull && wide) {
+                const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
+                cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
+                wide_begin = wr.w;
+            }
         }
         const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
         texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
@@ -448,17 +462,19 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
         const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
         const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
         const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
+        const int ovx = vx, ovy = vy, ovz = vz;
         vx = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000));
         vy = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000));
         vz = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000));
         outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
         uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
-        if (!outside) next = load_record(vx, vy, vz);
+        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, ovx, ovy, ovz);       // (general layout: possibly a link, resolved behind the tests)
         return next;
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
     auto test_list = [&](const uint4& rec) {
-        const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1);
+        const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(rec);
+        const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
         int ref = int(field(rec, 48, SLIM));
         uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
                  q3 = NI > 3 ? field(rec, 48 + 3 * SLIM, SLIM) : uint32_t(NONE);
@@ -512,7 +528,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
             }
         } else {
             if (by_index) {
-                q1 = field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);
+                q1 = wide_cell ? wide_begin : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);
                 ref = NONE;
                 if (q1 < q2) ref = ref_at(q1);
                 q1++;
@@ -539,7 +555,10 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
     };
 
     uint4 ca = make_uint4(0u, 0u, 0u, 0u);
-    if (alive) ca = load_record(vx, vy, vz);
+    if (alive) {
+        if (UNIFORM) ca = load_record(vx, vy, vz);
+        else { ca = gw.lookup(a, vx, vy, vz, vx, vy, vz); gw.descend(a, ca, vx, vy, vz); }
+    }
     unsigned long long live = __ballot(alive);
 
     if (quad_start) pending = valid && sub == 0;           // (the four lanes of a group hold the same ray: one of them stores its hit)
@@ -623,6 +642,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
                 test_list(ca);
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
+                if (!UNIFORM && alive) gw.descend(a, ca, vx, vy, vz);          // general layout: a link leads on to the child block (its first gather was in flight during the tests)
             }
             if (REFILL && joining) { alive = true; joining = false; }
             live = __ballot(alive);
@@ -650,7 +670,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
     tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
     vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
     ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
-    if (!UNIFORM) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
+    if (!UNIFORM) { gw.blk = uint32_t(pull_i(int(gw.blk))); gw.bks = uint32_t(pull_i(int(gw.bks))); }
     if (MAILBOX) {                                         // the mailbox moves with its ray: the group's first lane's slot holds it from here on
         const int4 m = mailbox[lanes_of[alive ? group : 0]];
         __syncthreads();                                   // (every slot is read before any is overwritten)
@@ -678,32 +698,50 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
         const uint32_t m_stride = ax == 0 ? 1u : (ax == 1 ? uint32_t(a.top_x) : uint32_t(a.top_xy)), m_lsh = uint32_t(ax * a.shift);
         int m_v = ax == 0 ? vx : (ax == 1 ? vy : vz);
         auto quad_sum = [&](uint32_t x) -> uint32_t { return x + uint32_t(quad_perm_i<9>(int(x))) + uint32_t(quad_perm_i<82>(int(x))); };
+        auto quad_or = [&](int o) -> bool { return (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0; };
+        // general layout, this lane's share of a child index: ((v >> s) & (2^k - 1)) << (axis * k)
+        auto child_share = [&](uint32_t v, uint32_t k, uint32_t s) -> uint32_t { return ((v >> s) & ((1u << k) - 1u)) << __umul24(uint32_t(ax), k); };
+        auto quad_descend = [&](uint4& rec) {          // GenWalk::descend with the voxel spread over the lanes of the group (all of them hold the same record)
+            while (GenWalk<SLIM>::is_link(rec)) {
+                const uint32_t k = (rec.z >> 16) & 3u, s = (gw.bks >> 2) - k;
+                gw.blk = GenWalk<SLIM>::word48(rec); gw.bks = k | s << 2;
+                rec = GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(uint32_t(m_v), k, s)));
+            }
+        };
         auto quad_step = [&](const uint4& rec) -> uint4 {
             int c;
             const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
             if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
-            else c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;             // table layout: bounds count from the top-level cell's origin
+            else {
+                // general layout: the byte counts from the origin of the record's region; a wide cell has absolute bounds in its wide record
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v & int(~0u << gw.region_shift())));
+                const bool wide = GenWalk<SLIM>::is_wide(rec);
+                if (__ballot(wide) != 0ull && wide) {
+                    const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
+                    c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
+                    wide_begin = wr.w;
+                }
+            }
             const float tc = (float(c) * m_cs + m_gmin - m_org) * m_inv;
             texit = detail::fmin2(detail::fmin2(tc, quad_perm_f<9>(tc)), quad_perm_f<82>(tc));
             const float ev = (texit * m_dir + m_org - m_gmin) * m_ginv;
             const int n_exit = c + (m_pos ? 0 : -1), n_other = int(ev);      // both, then one select: no divergent branch on the step's chain
             const int n = texit == tc ? n_exit : n_other;
+            const int o_v = m_v;
             m_v = med3_i32(n, m_v, m_pos ? 0x7fffffff : int(0x80000000));
-            const int o = uint32_t(m_v) >= uint32_t(m_dims) ? 1 : 0;
-            outside = (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0;
+            outside = quad_or(uint32_t(m_v) >= uint32_t(m_dims) ? 1 : 0);
             const uint32_t v = outside ? 0u : uint32_t(m_v);
             if (UNIFORM) {
                 const uint32_t d = uint32_t(a.shift);
                 const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh));
                 return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
             }
-            const uint32_t top = quad_sum(__umul24(v >> uint32_t(a.shift), m_stride));
-            if (int(top) != top_idx) {
-                const uint2 t = gather32<uint2>(a.img_table, top << 3);
-                tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
-            }
-            const uint32_t idx = quad_sum(((v >> (uint32_t(a.shift) - tab_d)) & ((1u << tab_d) - 1u)) << __umul24(uint32_t(ax), tab_d));
-            return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
+            if (outside) return make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t k = gw.bks & 3u, s = gw.bks >> 2;
+            // still inside the block of the last look-up (no axis left its region)?  then one gather; else from the top level again
+            if (gw.blk != ~0u && !quad_or(((uint32_t(m_v) ^ uint32_t(o_v)) >> (s + k)) != 0u ? 1 : 0)) return GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(v, k, s)));
+            gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+            return GenWalk<SLIM>::rec_at(a, quad_sum(__umul24(v >> uint32_t(a.shift), m_stride)));
         };
         const int my_word = (48 + (sub < NI ? sub : 0) * SLIM) >> 5;
         const uint32_t my_shift = uint32_t(48 + (sub < NI ? sub : 0) * SLIM) & 31u;
@@ -711,7 +749,8 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint4 na = quad_step(ca);
-                const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1);
+                const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(ca);
+                const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
                 // this lane's id: field `sub` of the 80 id bits from bit 48 on -- two words chosen by the lane's constants, one funnel shift
@@ -753,7 +792,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
                 } else {
                     // some list of the wavefront is given by index (more ids than a record holds): four ids per round as well, lane s takes
                     // ids s, s + 4, ...; the groups with inline lists take part in the first round
-                    const uint32_t li_begin = field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
+                    const uint32_t li_begin = wide_cell ? wide_begin : field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
                     int mine = inl;
                     if (uint32_t(sub) < li_count) mine = ref_at(li_begin + uint32_t(sub));
 #pragma unroll 1
@@ -774,6 +813,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : 8) traverse_kern
                 }
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
+                if (!UNIFORM && alive) quad_descend(ca);
             }
             live = __ballot(alive);
             if (COST) iters++;

@@ -212,7 +212,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const hagrid_ctx::RayHints* donor = nullptr;
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
-            if (donor) N.rowlen_seen = donor->rowlen_seen;
+            N.rows_from_origins = false;
+            if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
         }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
     }
@@ -259,7 +260,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             int* row_len = ctx->dscratch + 236 + hint_slot;
             const bool same = ctx->opt_row_cache && H.rowlen_rays == rays && H.rowlen_n == num_rays;
             if (same && H.rowlen_pending) {
-                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { H.rowlen_known = ctx->mailbox[300 + hint_slot]; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
+                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[300 + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rows_from_origins = (word & kRowsFromOrigins) != 0; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
             if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
@@ -312,9 +313,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow;
             // by default for launches of up to 25 rounds (2048^2, eight rounds: -8 %; 2560^2: -4.9 %, 3072^2, 18 rounds: -1.3 %, 4096^2, 32 rounds: +-0 -- the tiles
             // of a class of equal cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
-            // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch)
+            // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch).  Rays in image order WITHOUT coherent
+            // directions (the row length came from neighbouring origins: bounce rays) have nothing but their neighbours in the image to share lines with, and an
+            // order takes those away: up to 10 rounds only (round 5, 8M triangles: 8 rounds -3 %, 4 and 2 rounds +-0, 16 rounds +5 % slower -- the per-GPU share
+            // of configuration 5, which round 4's rule ordered; primary rays at the same time: 4.5 / 8 / 12.5 / 18 rounds -14 / -11 / -6.5 / -5.3 %).
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
-            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? ((rounds100 <= ctx->opt_tile_order_rounds && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
+            const int limit = H.rows_from_origins ? std::min(ctx->opt_tile_order_rounds, ctx->opt_tile_order_rounds_incoherent) : ctx->opt_tile_order_rounds;
+            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? ((rounds100 <= limit && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));

@@ -306,7 +306,8 @@ def test_config5_8M_triangles_compressed_bounce_rays():
 def test_clustered_scene_structure_and_hits_match_oracle():
     """A very non-uniform 1M-triangle scene (scene.make_clustered: six dense blobs in a sparse soup; grid shift 6, lists of
     up to ~20 references): grid arrays identical to the oracle's; primary and incoherent hits identical to the oracle's with
-    the construction-format kernel and with both image formats (nested blocks, by-index lists)."""
+    the construction-format kernel and with every image format (general layout of slim records: links, wide records, by-index lists; 32-byte records
+    with nested blocks; compact)."""
     from hagrid_amd import api
     from oracle import oracle as O
     tris = scene.make_clustered()
@@ -330,7 +331,18 @@ def test_clustered_scene_structure_and_hits_match_oracle():
         for image in (2, 1, 0):
             mem.set_option("traverse.image", image)
             assert same_hits(traverse(mem, grid, d_tris, rays), oh), f"traverse.image={image}"
-        mem.set_option("traverse.image", 2)
+        # the default image of a deep grid is the general layout of slim records, traversed by the tail kernel; the same image by the kernel without the
+        # tail mode, with ray binning, in the 26-bit id form, and the 32-byte records with their nested blocks
+        mem.set_option("traverse.image", 2); api.setup_traversal(grid)
+        fmt = mem.image_format(grid)
+        assert fmt["general"] and fmt["record_bytes"] == 16 and fmt["slim_id_bits"] == 20, fmt
+        for opts in ({"traverse.tail": 0}, {"binning": 1}, {"traverse.image_slim": 2}, {"traverse.image_slim": 0}):
+            for k, v in opts.items():
+                if k == "binning": mem.set_ray_binning(v)
+                else: mem.set_option(k, v)
+            assert same_hits(traverse(mem, grid, d_tris, rays), oh), opts
+            if "traverse.image_slim" in opts: assert mem.image_format(grid)["record_bytes"] == (16 if opts["traverse.image_slim"] else 32)
+            mem.set_ray_binning(0); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1)
         grid.free()
     finally:
         mem.close()

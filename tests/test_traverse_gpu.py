@@ -390,16 +390,11 @@ def _image_scenes():
             "compressed_long_lists": (np.concatenate([np.repeat(scene.make_soup(30, seed=15), 12, axis=0), scene.make_soup(6000, seed=16)]), dict(compress=True, top_density=0.3, snd_density=1.0))}
 
 
-# (traverse.image, traverse.image_slim): compact blocks (slot bytes + de-duplicated records); flat (a record per voxel) with slim
-# 16-byte records where the layout is uniform and they fit; flat with 32-byte records only; flat with the 26-bit form of the slim record
+# (traverse.image, traverse.image_slim): compact blocks (slot bytes + de-duplicated records); flat with slim 16-byte records -- a record per voxel where
+# every top-level cell has the full depth of at most three levels (uniform layout), else a record per voxel-map entry (general layout: any depth,
+# links to child blocks, wide records for cells whose bounds do not fit a byte); flat with 32-byte records only (blocks, nested blocks, deep links);
+# flat with the 26-bit form of the slim record
 _IMAGE_FORMATS = {"compact": (1, 1), "flat": (2, 1), "flat_fat": (2, 0), "flat_slim26": (2, 2)}
-
-
-def _slim_must_fit(G, slim):
-    """Slim records are built for flat images of grids with one to three levels when every bound fits its byte: at most 255 voxels
-    from each of the cell's voxels (table-free layout), within [-128, 127] of the origin of each top-level cell the cell overlaps
-    (table layout).  Both hold for certain when the virtual resolution is at most 128."""
-    return bool(slim) and 1 <= G.shift <= 3 and int((np.array(G.dims) << G.shift).max()) <= 128
 
 
 @pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
@@ -432,18 +427,28 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     by_index, deep = _check_records(got, want, begin)
     info = mem.image_format(grid)
     assert info["flat"] == (fmt == 2)
-    if fmt == 2 and _slim_must_fit(G, slim):
+    if fmt == 2 and slim:        # every grid here fits slim records: what a byte cannot say goes into wide records
         assert info["slim_id_bits"] == (26 if slim == 2 else 20) and info["record_bytes"] == 16, "slim records expected"
-    if fmt == 1 or not slim or not (1 <= G.shift <= 3):
-        assert info["slim_id_bits"] == 0 and info["record_bytes"] == 32
+        assert info["uniform"] != info["general"]
+        assert info["general"] or 1 <= G.shift <= 3
+    else:
+        assert info["slim_id_bits"] == 0 and info["record_bytes"] == 32 and not info["general"]
     if info["slim_id_bits"] and info["uniform"]:
         assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims))
+    if info["general"]:
+        assert nbytes.value >= 16 * G.num_entries and nbytes.value <= 16 * (G.num_entries + G.num_cells) + 256
     if name == "soup30k_shift3" and fmt == 2 and slim:
-        assert info["slim_id_bits"] and not info["uniform"], "the table layout with slim records is exercised"
+        assert info["general"], "the general layout on a grid of three levels is exercised"
     assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
-        assert (by_index & ~deep).any()
-    if name in ("deep", "sparse", "coincident", "compressed_deep"):
+        assert (by_index & ~deep).any() or info["general"]
+        assert by_index.any()
+    if info["general"]:
+        # bit 30 of the resolved record: the walk went through a link -- exactly where the top-level entry of the voxel is subdivided
+        t = vox.astype(np.int64) >> G.shift
+        top_inner = (G.entries[t[:, 0] + G.dims[0] * (t[:, 1] + G.dims[1] * t[:, 2])] & 3) != 0
+        assert (deep == top_inner).all()
+    elif name in ("deep", "sparse", "coincident", "compressed_deep"):
         assert G.shift > 3 and deep.any() and not deep.all()
     else:
         assert not deep.any()
@@ -491,9 +496,10 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
     grid.free(); mem.free(d_tris)
 
 
-def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
-    """A cell that reaches more than 255 voxels away from one of its voxels does not fit the byte offsets of a slim record: the
-    image is then built with 32-byte records, and the hits stay the oracle's.  The 26-bit id form gives the same hits."""
+def test_cells_too_long_for_a_byte_get_wide_records(mem):
+    """A cell that reaches more than 255 voxels away from one of its voxels does not fit the byte offsets of a slim record: the uniform layout
+    cannot hold it, the general layout gives it a WIDE record (absolute 16-bit bounds, one per cell), and the hits stay the oracle's.  The 26-bit
+    id form and 32-byte records give the same hits."""
     from oracle import oracle as O
     from hagrid_amd import api
     a = scene.make_soup(2000, seed=31).copy(); b = scene.make_soup(2000, seed=32).copy()
@@ -508,16 +514,23 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
     want, _ = G.traverse(tris, rays, nthreads=8)
     nb = C.c_int64(0)
     try:
-        for uniform in (2, 1):            # 2: the table-free layout whatever it costs (this grid is mostly empty); 1: the table layout here
+        for uniform in (2, 1):            # 2: the table-free layout whatever it costs (this grid is mostly empty) -- it does not fit; 1: not asked for
             mem.set_option("traverse.image_uniform", uniform)
             for slim in (1, 2, 0):
                 mem.set_option("traverse.image_slim", slim)
-                got = gpu_traverse(mem, grid, d_tris, rays)
-                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim)
+                for tail in (1, 0):
+                    mem.set_option("traverse.tail", tail)
+                    got = gpu_traverse(mem, grid, d_tris, rays)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim, tail)
+                mem.set_option("traverse.tail", 1)
                 info = mem.image_format(grid)
-                assert info["flat"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
                 assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
-                assert uniform == 1 or nb.value >= 32 * total
+                if slim:
+                    assert info["general"] and not info["uniform"] and info["record_bytes"] == 16, "the general layout with wide records expected"
+                    assert 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
+                else:
+                    assert info["flat"] and not info["general"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
+                    assert uniform == 1 or nb.value >= 32 * total
         mem.set_option("traverse.image_uniform", 2)
         # the same clusters close together: every cell fits, slim records in both id widths
         b[:, 0] -= np.float32(39.0)
@@ -534,10 +547,10 @@ def test_slim_records_fall_back_when_a_cell_is_too_long(mem):
             assert (got["id"] == want2["id"]).all() and (bits(got["t"]) == bits(want2["t"])).all(), slim
             assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
             assert nb.value == 16 * total2 + 8 * int(np.prod(G2.dims)), "slim records expected"
-            assert mem.image_format(grid2) == {"flat": True, "uniform": True, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
+            assert mem.image_format(grid2) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
         grid2.free(); mem.free(d_tris2)
     finally:
-        mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1)
+        mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.tail", 1)
     grid.free(); mem.free(d_tris)
 
 
@@ -612,19 +625,22 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
     in one round, replaying the acceptance in list order; the last tiles of a launch may start in that form ("traverse.quad_tail": four blocks
     of 16 rays per tile, a 4 x 4 pixel quadrant each).  Hits must stay the oracle's bit for bit: wavefronts that are sparse from the
     start (batches of 1 .. 17 rays, rays that miss the grid), that thin out on the way (64 coherent rays), lists longer than a record
-    holds (by index) met inside the tail phase, the 20- and 26-bit id forms, the table layout, binned batches -- and the kernel without
-    the tail mode for comparison."""
+    holds (by index) met inside the tail phase, the 20- and 26-bit id forms, the general layout (grids of three levels with top-level cells of
+    different depth, grids of five levels, wide records, compressed), binned batches -- and the kernel without the tail mode for comparison."""
     from oracle import oracle as O
     from hagrid_amd import api
     coincident = np.repeat(scene.make_soup(60, seed=41), 9, axis=0)          # nine copies of every triangle: equal t, lists of 9+ ids
     scenes = {"soup": (scene.make_soup(30000, seed=42), {}),
               "long_lists": (np.concatenate([coincident, scene.make_soup(4000, seed=43)]), dict(top_density=0.3, snd_density=1.0)),
-              "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0))}
+              "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),     # three levels, top-level cells of different depth: general layout
+              "deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),             # shift 5: links below the top level
+              "clustered": (scene.make_clustered(3000, 3, 4000), {}),                                          # shift 5, blobs in a sparse soup: wide records between them
+              "clustered_compressed": (scene.make_clustered(3000, 3, 4000), dict(compress=True))}
     try:
         mem.set_option("traverse.image_slim", slim)
         for name, (tris, params) in scenes.items():
             G = O.Grid.full(tris, **params)
-            assert 1 <= G.shift <= 3
+            assert (G.shift > 3) == (name in ("deep", "clustered", "clustered_compressed"))
             d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
             lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
             primary = scene.make_rays_primary(lo, hi, 64, 48)
@@ -633,7 +649,7 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             api.setup_traversal(grid)
             info = mem.image_format(grid)
             assert info["slim_id_bits"] == (26 if slim == 2 else 20), (name, info)
-            if name != "long_lists": assert info["uniform"] == (name == "soup"), (name, info)      # both slim layouts are exercised
+            if name != "long_lists": assert info["uniform"] == (name == "soup") and info["general"] == (name != "soup"), (name, info)      # both slim layouts are exercised
             # (tail mode, per cent of the tiles that START with four lanes per ray -- "traverse.quad_tail", 16 rays per wavefront)
             # ... and "traverse.tail_dual": two ids of an inline list per round trip in phase 1, the second triangle through LDS (forced on
             # for binned batches as well, where the default switches it off)
@@ -895,7 +911,7 @@ def test_wave_time_diagnostic_does_not_change_hits(mem):
     n = rays.shape[0]; nw = n // 64
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n); d_times = mem.alloc(16 * nw)
     api.setup_traversal(grid)
-    assert mem.image_format(grid) == {"flat": True, "uniform": True, "slim_id_bits": 20, "record_bytes": 16}
+    assert mem.image_format(grid) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 20, "record_bytes": 16}
     api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
     ref = mem.download(d_hits, api.HIT_DTYPE, n)
     d_order = mem.upload(np.arange(nw, dtype=np.int32)[::-1].copy())

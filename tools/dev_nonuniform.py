@@ -35,12 +35,13 @@ def steps_of(rays):
     return s, h
 
 
-def run(label, rays, images=(2, 0, 1, 2, 0), extra=None, repeats=9):
+def run(label, rays, images=(2, 3, 0, 1, 2, 3, 0), extra=None, repeats=9):
     rays = np.ascontiguousarray(rays.reshape(-1, 8)); n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     res = {"rays": label, "n": n}; res.update(extra or {}); ref = None
     for img in images:
-        mem.set_option("traverse.image", img); api.setup_traversal(grid)
+        # 2: the default flat image (general layout of slim records on this grid); 3: flat with 32-byte records (nested blocks); 1: compact; 0: construction format
+        mem.set_option("traverse.image", min(img, 2)); mem.set_option("traverse.image_slim", 0 if img == 3 else 1); api.setup_traversal(grid)
         if img: res[f"image{img}_MB"] = round(mem.image_bytes(grid) / 1e6, 1)
         for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
         t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(repeats))
