@@ -311,10 +311,11 @@ struct GenWalk {
         const uint32_t m = (1u << k) - 1u;
         return ((uint32_t(x) >> s) & m) + (((((uint32_t(y) >> s) & m)) + (((uint32_t(z) >> s) & m) << k)) << k);
     }
-    // the record of voxel (x, y, z) -- possibly a link: descend() before use; (px, py, pz): the voxel of the previous look-up
-    __device__ __forceinline__ uint4 lookup(const TraverseArgs& a, int x, int y, int z, int px, int py, int pz) {
+    // the record of voxel (x, y, z) -- possibly a link: descend() before use; moved: the bits in which the voxel differs from the voxel of the previous
+    // look-up, or-ed over the axes (nothing above the block's region changed: the voxel is still inside the block)
+    __device__ __forceinline__ uint4 lookup(const TraverseArgs& a, int x, int y, int z, uint32_t moved) {
         const uint32_t k = bks & 3u, s = bks >> 2;
-        if (blk != ~0u && (uint32_t((x ^ px) | (y ^ py) | (z ^ pz)) >> (s + k)) == 0u) return rec_at(a, blk + child(x, y, z, k, s));
+        if (blk != ~0u && (moved >> (s + k)) == 0u) return rec_at(a, blk + child(x, y, z, k, s));
         blk = ~0u; bks = uint32_t(a.shift) << 2;
         return rec_at(a, uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
     }

@@ -58,12 +58,11 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         constexpr bool GENERAL = SLIM != 0 && !UNIFORM;                         // one slim record per voxel-map entry (trav_common.h GenWalk)
         GenWalk<SLIM ? SLIM : 20> gw;
         gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-        int pvx = vx, pvy = vy, pvz = vz;                                       // general layout: the voxel of the previous look-up
         uint32_t wide_begin = 0u;
         uint32_t nest = ~0u;                                                    // innermost nested block the ray is inside (FLAT + NARROW, table layout)
         int nest_x = 0, nest_y = 0, nest_z = 0;                                 // ... and the voxel that led there
         // record of a voxel: FLAT + NARROW is one address computation off the scalar base
-        auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb) {
+        auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb, uint32_t moved = 0u) {
             if (UNIFORM) {
                 const int d = a.shift, m = (1 << d) - 1;
                 const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
@@ -72,7 +71,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 ra = p[0];
                 if (!SLIM) rb = p[1];
             } else if (FLAT && NARROW && SLIM) {          // general layout: from the block of the last look-up, or from the top level (a link is resolved behind the tests)
-                ra = gw.lookup(a, x, y, z, pvx, pvy, pvz);
+                ra = gw.lookup(a, x, y, z, moved);
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
@@ -158,7 +157,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             const int nz = texit == tcell.z ? cz + bz : int(ev.z);
             // never backwards: max with the current voxel along a positive direction, min along a negative one -- the median of
             // (new, current, +-infinity), one instruction per axis
-            if (GENERAL) { pvx = vx; pvy = vy; pvz = vz; }
+            const int pvx = vx, pvy = vy, pvz = vz;
             if (UNIFORM) { vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z); }
             else { vx = px ? max(nx, vx) : min(nx, vx); vy = py ? max(ny, vy) : min(ny, vy); vz = pz ? max(nz, vz) : min(nz, vz); }   // (the table layouts have no registers to spare)
             const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
@@ -170,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             uint4 na = make_uint4(0u, 0u, 0u, 0u), nb = make_uint4(0u, 0u, 0u, 0u);
             if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
-            else if (GENERAL) { if (!outside) record(tab, vx, vy, vz, na, nb); }
+            else if (GENERAL) { if (!outside) record(tab, vx, vy, vz, na, nb, uint32_t((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz))); }
             else record(tab, vx, vy, vz, na, nb);
 
             // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
@@ -307,8 +306,11 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // accepted: it either writes the same id and t again or is rejected -- so the hits stay bit-identical.  What it saves is the three lane accesses of the
 // triangle in the vector L1 and its L2 / HBM sector: the resources the incoherent and the beyond-cache batches are bound by (profiles/r4a).  It costs an LDS
 // round trip in front of every triangle round.
+#ifndef HG_GENERAL_WAVES
+#define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
+#endif
 template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false>
-__global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) traverse_kernel_tail(const TraverseArgs a) {
+__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : HG_GENERAL_WAVES)) traverse_kernel_tail(const TraverseArgs a) {
     static_assert(!REFILL || (UNIFORM && !DUAL && !TIMES), "refill: for the table-free layout, one id per round trip");
     __shared__ float4 ray_lds[REFILL ? 128 : 1];          // REFILL: the next 64 rays of the wavefront's pool, requested ahead (LDS-DMA)
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
@@ -397,7 +399,6 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
     }
     GenWalk<SLIM> gw;                                      // general layout: the innermost block the ray's last look-up ended in
     gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-    uint32_t wide_begin = 0u;                              // general layout: first reference index of the wide cell of this step
     auto load_record = [&](int x, int y, int z) -> uint4 {          // uniform layout: the record of a voxel is arithmetic on the voxel
         const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
         const int d = a.shift, m = (1 << d) - 1;
@@ -453,7 +454,6 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
             if (__ballot(wide) != 0ull && wide) {
                 const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                 cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
-                wide_begin = wr.w;
             }
         }
         const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
@@ -462,13 +462,13 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
         const int nx = texit == tcell.x ? cx + (px ? 0 : -1) : int(ev.x);
         const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
         const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
-        const int ovx = vx, ovy = vy, ovz = vz;
-        vx = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000));
-        vy = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000));
-        vz = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000));
+        uint32_t moved = 0u;                                       // general layout: the bits in which the voxel changes
+        { const int t = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved = uint32_t(t ^ vx); vx = t; }
+        { const int t = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved |= uint32_t(t ^ vy); vy = t; }
+        { const int t = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved |= uint32_t(t ^ vz); vz = t; }
         outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
         uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
-        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, ovx, ovy, ovz);       // (general layout: possibly a link, resolved behind the tests)
+        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, moved);       // (general layout: possibly a link, resolved behind the tests)
         return next;
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
             }
         } else {
             if (by_index) {
-                q1 = wide_cell ? wide_begin : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);
+                q1 = wide_cell ? GenWalk<SLIM>::wide_at(a, rec).w : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);      // (the wide record again: the kernel has no register to carry its list index across the step)
                 ref = NONE;
                 if (q1 < q2) ref = ref_at(q1);
                 q1++;
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
     uint4 ca = make_uint4(0u, 0u, 0u, 0u);
     if (alive) {
         if (UNIFORM) ca = load_record(vx, vy, vz);
-        else { ca = gw.lookup(a, vx, vy, vz, vx, vy, vz); gw.descend(a, ca, vx, vy, vz); }
+        else { ca = gw.lookup(a, vx, vy, vz, 0u); gw.descend(a, ca, vx, vy, vz); }
     }
     unsigned long long live = __ballot(alive);
 
@@ -719,7 +719,6 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
                 if (__ballot(wide) != 0ull && wide) {
                     const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                     c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
-                    wide_begin = wr.w;
                 }
             }
             const float tc = (float(c) * m_cs + m_gmin - m_org) * m_inv;
@@ -792,7 +791,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL || !UNIFORM) ? 7 : 8) t
                 } else {
                     // some list of the wavefront is given by index (more ids than a record holds): four ids per round as well, lane s takes
                     // ids s, s + 4, ...; the groups with inline lists take part in the first round
-                    const uint32_t li_begin = wide_cell ? wide_begin : field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
+                    const uint32_t li_begin = wide_cell ? GenWalk<SLIM>::wide_at(a, ca).w : field(ca, 48, 32), li_count = by_index ? field(ca, 80, 20) : 0u;
                     int mine = inl;
                     if (uint32_t(sub) < li_count) mine = ref_at(li_begin + uint32_t(sub));
 #pragma unroll 1

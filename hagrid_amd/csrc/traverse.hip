@@ -328,13 +328,17 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 int* report = ctx->mailbox + 304 + hint_slot;
                 if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && __atomic_load_n(report, __ATOMIC_ACQUIRE) == H.lpt_epoch) {
                     // A launch since the last sort found other rays in the buffer than the order was learned on (its first wavefront reported it): learn
-                    // again, from costs of the new rays only.  Three such orders in a row that lasted fewer than eight launches each: give up for 64 launches -- for twice as
-                    // many every time that happens again before an order has lasted through a refresh (a camera that keeps moving: up to 1024).
-                    H.relearn_streak = ctx->hint_clock - H.relearn_clock < 8 ? H.relearn_streak + 1 : 0;
+                    // again, from costs of the new rays only.  An order costs about a third of a launch to get (the launch that follows the stale one, the cost
+                    // bookkeeping of the launch that learns, two sorts) and returns about a sixth per launch it is followed: one that was stale within four launches
+                    // of the last time that happened was not worth it -- the rays change every launch (a moving camera) -- and the buffer gets no order for 64
+                    // launches, for twice as many every time that happens again before an order has lasted through a refresh (up to 1024).  (Round 4 gave up after
+                    // three such orders in a row that lasted fewer than eight launches: a camera at the viewer's speed then paid for nine launches of learning,
+                    // 0.192 against 0.184 ms per frame over its first 32 frames.)  A buffer refilled every 8th launch keeps its orders: they last six launches.
+                    const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
                     H.lpt_valid = false; H.lpt_age = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
-                    if (H.relearn_streak >= 3) { H.relearn_streak = 0; H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
+                    if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
                 if (H.cooldown > 0) { /* this launch and the next ones: default order, no costs */ }
                 else {
