@@ -91,6 +91,16 @@ def binding_limiter(resources: dict, top, top_frac):
     waiting = (resources.get("wave_time") or {}).get("waiting_for_memory", 0.0)
     return ("memory_latency" if (waiting >= 0.6 and top_frac is not None and top_frac < 0.95) else top), waiting
 
+def roofline_headline(algorithmic_gbps: float, traffic_bytes, kernel_ms: float):
+    """`achieved` / `frac` of the roofline block say ONE thing: the HBM rate -- bytes that crossed the fabric side of the L2s per launch (counter passes on these very
+    kernel sources) over the kernel time, against the HBM peak.  Without counters for these sources the algorithmic bytes stand in, and `frac_kind` says so: that figure
+    is not bounded by 1 for a cache-resident working set (configuration 3: 1.3)."""
+    if traffic_bytes is not None:
+        a = traffic_bytes / (kernel_ms * 1e6)
+        return round(a, 1), round(a / HBM_PEAK_GBPS, 4), "hbm_measured: fabric-side bytes of the L2s per launch (rocprofv3 --pmc passes, traffic_source) / kernel time / HBM peak"
+    return round(algorithmic_gbps, 1), round(algorithmic_gbps / HBM_PEAK_GBPS, 4), "algorithmic: bytes the kernel gathers (frac_image) -- no counter file for these kernel sources and this batch, see traffic_source"
+
+
 CONFIGS = {
     2: dict(baseline="1M-triangle synthetic scene, default densities, 1M primary rays on 1xMI355X", tris=1_000_000, rays="primary",
             width=1024, height=1024, scaling="weak", params={}),
@@ -100,7 +110,12 @@ CONFIGS = {
             tris=1_000_000, rays="incoherent", total=1 << 27, scaling="strong", params={}, bin_rays=1),
     5: dict(baseline="8M-triangle scene with --compress voxel map, 64M diffuse-bounce rays, 8xMI355X",
             tris=8_000_000, rays="bounce", width=8192, height=8192, scaling="strong", params=dict(compress=True)),
+    # not a BASELINE.json configuration: the non-uniform scene irregular grids exist for (main.cpp:246-275 loads such scenes) -- six dense blobs in a
+    # sparse soup, grid shift 6 -- `--config clustered`; `--rays aimed`: 1M incoherent rays aimed at the blobs
+    6: dict(baseline="(extension, not in BASELINE.json) clustered 1M-triangle scene (scene.make_clustered: six dense blobs in a sparse soup, six-level voxel map), 1M primary rays",
+            tris=1_000_000, scene="clustered", rays="primary", width=1024, height=1024, scaling="weak", params={}),
 }
+CONFIG_NAMES = {"clustered": 6}
 
 
 def log(*a):
@@ -126,12 +141,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.md configuration (config C = BASELINE.json configs[C - 1])")
+    ap.add_argument("--config", type=lambda v: CONFIG_NAMES.get(v) or int(v), default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.md configuration (config C = BASELINE.json configs[C - 1]); `clustered` (= 6): the non-uniform scene, an extension")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak for config 2, strong (one batch sharded over the ranks) for 3-5")
     ap.add_argument("--tris", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--rays", choices=["primary", "incoherent", "bounce"], default=None)
+    ap.add_argument("--rays", choices=["primary", "incoherent", "bounce", "aimed"], default=None, help="aimed: incoherent origins, directions towards the blobs of the clustered scene")
     ap.add_argument("--total-rays", type=int, default=None, help="size of the incoherent batch (config 4: 2^27)")
     ap.add_argument("--eye-dist", type=float, default=0.8, help="camera distance in scene diagonals (SURVEY proposed 1.5, where no ray reaches the grid within tmax = clip; DESIGN.md section 5)")
     ap.add_argument("--top-density", type=float, default=None)
@@ -211,8 +227,10 @@ def main():
     d_tris = 0
     t_bcast = 0.0
     tris_host = None
+    clustered = cfg.get("scene") == "clustered"
     if rank == 0 or ray_kind == "bounce":
-        tris_host = scene.make_soup(n_tris)             # bounce rays need the hit triangles' normals on every rank
+        tris_host = scene.make_clustered() if clustered else scene.make_soup(n_tris)             # bounce rays need the hit triangles' normals on every rank
+        n_tris = tris_host.shape[0]
     if rank == 0:
         d_tris = mem.upload(tris_host)
         build = lambda g=None: api.build_all(mem, d_tris, n_tris, top_density, snd_density, args.alpha, expansion, compress, g)
@@ -239,7 +257,7 @@ def main():
     # ---- this rank's rays ------------------------------------------------------------------------------------------------
     # weak: every rank traces a batch of the configuration's full size (primary: sub-pixel sample `rank` of `world` of the same
     # camera; incoherent / bounce: its own stretch of the sequence).  strong: the ONE batch is cut into contiguous ranges.
-    if ray_kind == "incoherent":
+    if ray_kind in ("incoherent", "aimed"):
         total = args.total_rays or cfg.get("total", width * height)
     else:
         total = width * height
@@ -255,19 +273,20 @@ def main():
         n_rays = end - first
         sample, nsamples = 0, 1
     else:
-        first, n_rays = (0, total) if ray_kind != "incoherent" else (rank * total, total)
+        first, n_rays = (0, total) if ray_kind not in ("incoherent", "aimed") else (rank * total, total)
         sample, nsamples = rank, world
     d_rays = mem.alloc(32 * n_rays)
     d_hits = mem.alloc(16 * n_rays)
     keep = min(n_rays, 1 << 20)                         # host copy of the first rays: CPU baseline + parity sample
     t_gen = time.perf_counter()
-    if ray_kind == "incoherent":
-        gen = lambda f, c: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, c, scene.RAY_SEED_BASE + 4, first=f)
+    if ray_kind in ("incoherent", "aimed"):
+        make = scene.make_rays_aimed if ray_kind == "aimed" else scene.make_rays_incoherent
+        gen = lambda f, c: make(grid.bbox_min, grid.bbox_max, c, scene.RAY_SEED_BASE + 4, first=f)
         rays_head = upload_generated(mem, d_rays, gen, first, n_rays, keep_host=keep)
     else:
         gen = lambda f, c: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, first=f, count=c, eye_dist=args.eye_dist, sample=sample, num_samples=nsamples)
         rays_head = upload_generated(mem, d_rays, gen, first, n_rays, chunk=1 << 22, keep_host=keep)
-    bin_rays = (cfg.get("bin_rays", 1 if ray_kind == "incoherent" else 0)) if args.bin_rays is None else args.bin_rays
+    bin_rays = (cfg.get("bin_rays", 1 if ray_kind in ("incoherent", "aimed") else 0)) if args.bin_rays is None else args.bin_rays
     mem.set_option("traverse.image", args.image)
     for kv in filter(None, args.opts.split(",")):                 # experiments: any hagrid_set_option key
         k, v = kv.split("="); mem.set_option(k, int(v))
@@ -347,7 +366,7 @@ def main():
             tile_order = {"ms_per_step_default_order": round(ms0, 5),
                           # the fractions of the roofline block on the default-order time (what a first launch over a new buffer reaches)
                           "walk_frac_default_order": round(ab["B_walk"] / (ms0 * 1e6) / HBM_PEAK_GBPS, 4),
-                          "frac_default_order": round(ab["B_image"] / (ms0 * 1e6) / HBM_PEAK_GBPS, 4), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
+                          "frac_image_default_order": round(ab["B_image"] / (ms0 * 1e6) / HBM_PEAK_GBPS, 4), "hits_identical": bool((hits0["id"] == hits["id"]).all() and
                           (hits0["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()),
                           "how": "`value` is the steady state of a renderer's loop: tiles dispatched longest first, by the costs the previous launches over the same ray "
                                  "buffer left (learned in the warm-up steps, refreshed every 32nd launch); ms_per_step_default_order = the "
@@ -374,13 +393,15 @@ def main():
                         mem.copy_h2d(d_rays, r)
                         ms.append(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays), mem))
                     return round(float(np.mean(ms[8:])), 5)
+                def pair(speed, refill=0):
+                    # the two policies in turn, twice (default order first: whichever loop runs first after a pause runs a few per cent slower)
+                    a0 = frames_ms(speed, 0, refill); a1 = frames_ms(speed, -1, refill); b0 = frames_ms(speed, 0, refill); b1 = frames_ms(speed, -1, refill)
+                    return {"ms_per_frame": round((a1 + b1) / 2, 5), "ms_per_frame_default_order": round((a0 + b0) / 2, 5), "runs": {"policy": [a1, b1], "default_order": [a0, b0]}}
                 tile_order["moving_camera"] = {
-                    "viewer_speed": {"ms_per_frame": frames_ms(1.0, -1), "ms_per_frame_default_order": frames_ms(1.0, 0)},
-                    "quarter_speed": {"ms_per_frame": frames_ms(0.25, -1), "ms_per_frame_default_order": frames_ms(0.25, 0)},
-                    "frozen": {"ms_per_frame": frames_ms(0.0, -1), "ms_per_frame_default_order": frames_ms(0.0, 0)},
-                    "refilled_every_8th_frame": {"ms_per_frame": frames_ms(0.0, -1, refill=8), "ms_per_frame_default_order": frames_ms(0.0, 0, refill=8)},
-                    "how": "mean traversal ms (HIP events) of frames 9-32 of a loop that writes each frame's rays into the one ray buffer and synchronises per frame; "
-                           "viewer speed = 0.005 rad turn + 0.005 scene diagonals sideways per frame (main.cpp:579-586: one mouse pixel, one key event)"}
+                    "viewer_speed": pair(1.0), "quarter_speed": pair(0.25), "frozen": pair(0.0), "refilled_every_8th_frame": pair(0.0, refill=8),
+                    "how": "mean traversal ms (HIP events) of frames 9-32 of a loop that writes each frame's rays into the one ray buffer and synchronises per frame, two loops per "
+                           "policy in turn; viewer speed = 0.005 rad turn + 0.005 scene diagonals sideways per frame (main.cpp:579-586: one mouse pixel, one key event).  An order that is "
+                           "stale again within four launches is given up at once (64 launches without, doubling): a moving camera runs in the default order"}
                 mem.copy_h2d(d_rays, scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist))      # the batch of the line again
         except Exception as e:                                       # (an option the library does not know: older build)
             log(f"[bench] tile order block skipped: {e}")
@@ -445,7 +466,7 @@ def main():
         src_hash = _build.source_hash()
         tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
         counters = None
-        std_shape = args.image == 2 and n_tris == cfg["tris"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
+        std_shape = args.image == 2 and n_tris == cfg["tris"] and ray_kind == cfg["rays"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
         if os.path.exists(tpath) and world == 1 and std_shape:
             try:
                 tj = json.load(open(tpath))
@@ -469,6 +490,7 @@ def main():
         # SURVEY 8(d) formula on the CONSTRUCTION format (entries + cells + ids + triangles, which this kernel never reads) is
         # carried next to it as `*_contract`.  Without an image the two are the same thing.
         ach = achieved_img if args.image else achieved
+        head_achieved, head_frac, head_kind = roofline_headline(ach, traffic, kernel_ms)
         cells_b = grid.num_cells * (16 if compressed else 32)
         image_b = mem.image_bytes(grid)
         out = {
@@ -476,8 +498,8 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['baseline']} -- soup-{n_tris} triangles, "
-                                   + (f"{ray_kind} rays, {total} in the batch" + (f" ({width}x{height})" if ray_kind != "incoherent" else ""))
+            "config": {"workload": (f"BASELINE.json configs[{args.config - 1}]: " if args.config <= 5 else "") + f"{cfg['baseline']} -- {'clustered' if clustered else 'soup'}-{n_tris} triangles, "
+                                   + (f"{ray_kind} rays, {total} in the batch" + (f" ({width}x{height})" if ray_kind not in ("incoherent", "aimed") else ""))
                                    + (f", rays [{first}, {first + n_rays}) = the share of rank {shard[0]} of {shard[1]}, on ONE GPU" if shard else f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
                        "baseline_config": args.config, "shard": args.shard, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
@@ -491,12 +513,14 @@ def main():
             "setup_traversal_ms": round(setup_ms, 3),
             "hits_sha256": hits_sha,
             "hit_fraction": round(tot_hits / total_rays, 4), "rays_entering_grid": round(tot_in / total_rays, 4),
-            # `achieved` / `frac`: the contract's figure -- ALGORITHMIC bytes (what the kernel gathers) over the kernel time against the HBM peak.  It is
-            # not a bound for a kernel whose working set is cache-resident (it can exceed 1: bytes served by L1 / L2 never reach HBM), so `binding` names
-            # what does bind, from the counters of this configuration measured on these kernel sources (tools/gpu_traffic_config.sh): every fraction
-            # there is against what the part delivers for that access pattern.
+            # `achieved` / `frac`: measured HBM bytes per launch over the kernel time against the HBM peak (roofline_headline above); `binding` names what
+            # does bind, from the counters of this configuration measured on these kernel sources (tools/gpu_traffic_config.sh): every fraction there is
+            # against what the part delivers for that access pattern.
             "roofline": {
-                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "bound": "hbm", "achieved": head_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": head_frac, "frac_kind": head_kind,
+                # the algorithmic figures next to it: what the kernel gathers (image records, triangles, ids of long lists) and the SURVEY.md 8(d) formula on the
+                # construction format (entries + cells + ids + triangles, which this kernel never reads); neither is a bound for a cache-resident working set
+                "achieved_image": round(ach, 1), "frac_image": round(ach / HBM_PEAK_GBPS, 4),
                 "bytes": "B_image: what the traversal-image kernel gathers (DESIGN.md 4.2)" if args.image else "B_ray: SURVEY.md 8(d) on the construction format",
                 "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / HBM_PEAK_GBPS, 4),     # SURVEY.md 8(d) formula, construction format
                 "traffic": traffic, "traffic_source": traffic_source,
@@ -505,7 +529,7 @@ def main():
                 "hbm_measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e6) / HBM_PEAK_GBPS, 4),
                 "l2_hit_rate": l2_hit,
                 "peak_measured": {"copy": round(peak["copy_GBps"], 1), "triad": round(peak["triad_GBps"], 1), "unit": "GB/s",
-                                  "frac_of_copy": round(ach / max(peak["copy_GBps"], 1e-9), 4)},
+                                  "frac_of_copy": round(head_achieved / max(peak["copy_GBps"], 1e-9), 4)},
                 "kernel": kernel_name, "kernel_ms": round(kernel_ms, 5), "kernel_sources": src_hash,
                 "bytes_per_ray": round((ab["B_image"] if args.image else ab["B_ray"]) / n_rays, 1),
                 "bytes_per_ray_contract": round(ab["B_ray"] / n_rays, 1),

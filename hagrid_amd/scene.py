@@ -94,6 +94,16 @@ def make_clustered(num_sparse: int = 100000, clusters: int = 6, per_cluster: int
     return np.ascontiguousarray(np.concatenate(parts), np.float32)
 
 
+def make_rays_aimed(bbox_min, bbox_max, num_rays: int, seed: int, first: int = 0) -> np.ndarray:
+    """Incoherent origins (make_rays_incoherent) with directions towards the blobs of make_clustered, with some spread: ray i aims at blob i % 6.  The rays
+    that end inside the dense parts of a very non-uniform scene (bench.py --config clustered --rays aimed; tests/test_fullsize_gpu.py)."""
+    rays = make_rays_incoherent(bbox_min, bbox_max, num_rays, seed, first=first).copy()
+    k = (np.arange(first, first + num_rays) % 6).astype(np.float32)
+    centre = np.stack([np.float32(0.17) + np.float32(0.14) * k, np.float32(0.32) + np.float32(0.08) * k, np.float32(0.22) + np.float32(0.1) * k], axis=1).astype(np.float32)
+    rays[:, 4:7] = centre - rays[:, 0:3] + np.float32(0.02) * rays[:, 4:7]
+    return np.ascontiguousarray(rays, np.float32)
+
+
 def tris_bbox(tris: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     """Scene bounding box over the three vertices (prims.h:27-31)."""
     v0 = tris[:, 0:3]; v1 = v0 - tris[:, 4:7]; v2 = v0 + tris[:, 8:11]

@@ -51,3 +51,21 @@ def test_limiter_rule():
     assert bench.binding_limiter(waiting, "fabric_fetch_rate", 0.89)[0] == "memory_latency"
     assert bench.binding_limiter(waiting, "hbm_bytes", 0.97)[0] == "hbm_bytes"          # saturated: the resource itself
     assert bench.binding_limiter({}, "valu_issue", 0.7)[0] == "valu_issue"               # no wave-time counters: the most used resource
+
+
+def test_roofline_headline_is_the_measured_hbm_rate():
+    """`roofline.achieved` / `frac` = measured HBM bytes per launch / kernel time / 8 TB/s when counters of these kernel sources exist; the algorithmic figure
+    stands in -- and says so -- when they do not."""
+    import bench
+    a, f, kind = bench.roofline_headline(6840.0, 306.9e6, 0.13468)
+    assert a == pytest.approx(2278.7, abs=0.5) and f == pytest.approx(0.2848, abs=1e-3) and kind.startswith("hbm_measured")
+    a, f, kind = bench.roofline_headline(6840.0, None, 0.13468)
+    assert a == 6840.0 and f == pytest.approx(0.855) and kind.startswith("algorithmic")
+
+
+def test_clustered_configuration_is_named():
+    import bench
+    assert bench.CONFIG_NAMES["clustered"] in bench.CONFIGS and bench.CONFIGS[bench.CONFIG_NAMES["clustered"]]["scene"] == "clustered"
+    from hagrid_amd import scene
+    r = scene.make_rays_aimed([0, 0, 0], [1, 1, 1], 12, 5)
+    assert r.shape == (12, 8) and (scene.make_rays_aimed([0, 0, 0], [1, 1, 1], 6, 5, first=6) == r[6:]).all()
