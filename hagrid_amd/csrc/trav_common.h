@@ -311,21 +311,15 @@ struct GenWalk {
         const uint32_t m = (1u << k) - 1u;
         return ((uint32_t(x) >> s) & m) + (((((uint32_t(y) >> s) & m)) + (((uint32_t(z) >> s) & m) << k)) << k);
     }
-    // The record of voxel (x, y, z): a cell (inline list, by index or wide), never a link.  moved: the bits in which the voxel differs from the voxel of the
-    // previous look-up, or-ed over the axes (nothing above the block's region changed: the voxel is still inside the block).  A look-up that starts at the top
-    // level waits for the top-level record -- those lie together at the front of the image and stay in the caches, as the table of the block layouts does --
-    // and requests the child at once, so that the tests of the current cell overlap the LAST gather of the walk (resolving links behind the tests instead
-    // exposes that gather in every iteration in which some lane of the wavefront changes its top-level cell: +25 % on configuration 3's grid).
+    // the record of voxel (x, y, z) -- possibly a link: descend() before use; moved: the bits in which the voxel differs from the voxel of the previous
+    // look-up, or-ed over the axes (nothing above the block's region changed: the voxel is still inside the block)
+    // (Measured, round 5: resolving the link INSIDE the look-up -- the wavefront waits for the top-level record, the tests overlap the child's gather, as the
+    // table of round 4's block layout had it -- is slower everywhere: configuration 3's grid at 4096^2 1.571 -> 1.615 ms, clustered scene 0.235 -> 0.246 ms.)
     __device__ __forceinline__ uint4 lookup(const TraverseArgs& a, int x, int y, int z, uint32_t moved) {
         const uint32_t k = bks & 3u, s = bks >> 2;
-        uint4 rec;
-        if (blk != ~0u && (moved >> (s + k)) == 0u) rec = rec_at(a, blk + child(x, y, z, k, s));
-        else {
-            blk = ~0u; bks = uint32_t(a.shift) << 2;
-            rec = rec_at(a, uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
-        }
-        descend(a, rec, x, y, z);
-        return rec;
+        if (blk != ~0u && (moved >> (s + k)) == 0u) return rec_at(a, blk + child(x, y, z, k, s));
+        blk = ~0u; bks = uint32_t(a.shift) << 2;
+        return rec_at(a, uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
     }
     __device__ __forceinline__ void descend(const TraverseArgs& a, uint4& rec, int x, int y, int z) {
         while (is_link(rec)) {

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         uint2 tab = (UNIFORM || GENERAL) ? make_uint2(0u, 0u) : table_at(top_idx);
         uint4 ca, cb = make_uint4(0u, 0u, 0u, 0u);
         record(tab, vx, vy, vz, ca, cb);
+        if (GENERAL) gw.descend(a, ca, vx, vy, vz);
 
         for (;;) {
             if (!UNIFORM && !SLIM && ca.w >= 0xfffffffeu) {                 // (the table-free layout and slim records need shift <= 3: every block resolves its cell fully)
@@ -238,7 +239,8 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
             ca = na; cb = nb;
-            }
+            if (GENERAL) gw.descend(a, ca, vx, vy, vz);
+        }
     }
     nt_store4(a.hits + id, __int_as_float(hit.id), hit.t, UVS ? hit.u : 0.0f, UVS ? hit.v : 0.0f);
 }
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
         { const int t = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved |= uint32_t(t ^ vz); vz = t; }
         outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
         uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
-        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, moved);
+        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, moved);       // (general layout: possibly a link, resolved behind the tests)
         return next;
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
     uint4 ca = make_uint4(0u, 0u, 0u, 0u);
     if (alive) {
         if (UNIFORM) ca = load_record(vx, vy, vz);
-        else ca = gw.lookup(a, vx, vy, vz, 0u);
+        else { ca = gw.lookup(a, vx, vy, vz, 0u); gw.descend(a, ca, vx, vy, vz); }
     }
     unsigned long long live = __ballot(alive);
 
@@ -640,6 +642,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
                 test_list(ca);
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
+                if (!UNIFORM && alive) gw.descend(a, ca, vx, vy, vz);          // general layout: a link leads on to the child block (its first gather was in flight during the tests)
             }
             if (REFILL && joining) { alive = true; joining = false; }
             live = __ballot(alive);
@@ -735,14 +738,9 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
             if (outside) return make_uint4(0u, 0u, 0u, 0u);
             const uint32_t k = gw.bks & 3u, s = gw.bks >> 2;
             // still inside the block of the last look-up (no axis left its region)?  then one gather; else from the top level again
-            uint4 next;
-            if (gw.blk != ~0u && !quad_or(((uint32_t(m_v) ^ uint32_t(o_v)) >> (s + k)) != 0u ? 1 : 0)) next = GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(v, k, s)));
-            else {
-                gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-                next = GenWalk<SLIM>::rec_at(a, quad_sum(__umul24(v >> uint32_t(a.shift), m_stride)));
-            }
-            quad_descend(next);
-            return next;
+            if (gw.blk != ~0u && !quad_or(((uint32_t(m_v) ^ uint32_t(o_v)) >> (s + k)) != 0u ? 1 : 0)) return GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(v, k, s)));
+            gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+            return GenWalk<SLIM>::rec_at(a, quad_sum(__umul24(v >> uint32_t(a.shift), m_stride)));
         };
         const int my_word = (48 + (sub < NI ? sub : 0) * SLIM) >> 5;
         const uint32_t my_shift = uint32_t(48 + (sub < NI ? sub : 0) * SLIM) & 31u;
@@ -814,6 +812,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
                 }
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
+                if (!UNIFORM && alive) quad_descend(ca);
             }
             live = __ballot(alive);
             if (COST) iters++;
