@@ -125,6 +125,7 @@ struct hagrid_ctx {
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
+    int opt_image_general = 1;  // flat image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: 32-byte records there (tests); 2: for every grid (tests)
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
 
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id

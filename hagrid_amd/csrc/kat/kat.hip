@@ -58,17 +58,17 @@ __global__ void kat_tile_slots(TraverseArgs a, int* out) {     // lane <-> ray a
     out[blockIdx.x * 64 + threadIdx.x] = tile_packet_slot(a, w, b, threadIdx.x);
 }
 
-__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat, int slim, int slim_uniform) {
+__global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_t* out, int flat, int slim, int slim_uniform, int general) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
     const int top = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
-    const uint2 tab = (slim && !slim_uniform) ? make_uint2(0u, 0u) : a.img_table[top];
+    const uint2 tab = general ? make_uint2(0u, 0u) : a.img_table[top];
     if (slim) {     // a slim record, brought into the form of the 32-byte record
         uint4 r;
         int region = a.shift;                   // general layout: log2 of the region the record's bound bytes count from
         uint32_t links = 0;
-        if (slim_uniform) {
+        if (!general) {
             const int d = int(tab.y & 3u), sh = a.shift - d, m = (1 << d) - 1;             // (uniform layout: d == shift)
             r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(tab.x) + size_t(((vx >> sh) & m) + ((((vy >> sh) & m) + (((vz >> sh) & m) << d)) << d))];
         } else {
@@ -95,6 +95,11 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
             o[0] = uint32_t(vx - int(field(0, 8))) | uint32_t(vx + int(field(8, 8))) << 16;
             o[1] = uint32_t(vy - int(field(16, 8))) | uint32_t(vy + int(field(24, 8))) << 16;
             o[2] = uint32_t(vz - int(field(32, 8))) | uint32_t(vz + int(field(40, 8))) << 16;
+        } else if (!general) {       // table layout: biased offsets from the origin of the top-level cell
+            const int om = ~((1 << a.shift) - 1);
+            o[0] = uint32_t((vx & om) + int(field(0, 8)) - 128) | uint32_t((vx & om) + int(field(8, 8)) - 128) << 16;
+            o[1] = uint32_t((vy & om) + int(field(16, 8)) - 128) | uint32_t((vy & om) + int(field(24, 8)) - 128) << 16;
+            o[2] = uint32_t((vz & om) + int(field(32, 8)) - 128) | uint32_t((vz & om) + int(field(40, 8)) - 128) << 16;
         } else {
             const int om = int(~0u << region);
             o[0] = uint32_t((vx & om) - int(field(0, 8))) | uint32_t((vx & om) + int(field(8, 8))) << 16;
@@ -102,7 +107,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
             o[2] = uint32_t((vz & om) - int(field(32, 8))) | uint32_t((vz & om) + int(field(40, 8))) << 16;
         }
         const uint32_t marker = field(48 + (ni - 1) * slim, slim);
-        const bool wide = !slim_uniform && marker == none - 3u;
+        const bool wide = general && marker == none - 3u;
         if (marker == none - 1u || wide) {
             const uint32_t cnt = field(80, 20);
             uint32_t first = field(48, 32);
@@ -244,7 +249,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim, ctx->image.uniform ? 1 : 0); HG_DBG(ctx);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim, ctx->image.uniform ? 1 : 0, ctx->image.general ? 1 : 0); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }
@@ -276,7 +281,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
-        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2},
+        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
         {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},

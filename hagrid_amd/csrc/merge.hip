@@ -416,14 +416,17 @@ __global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* _
 }
 
 // Control words of the mode (device): the dirty lists' lengths, the lists of a pass, its totals, the allocation cursor of its merged lists.
+// (Every counter on a cache line of its own: the L2 serialises the atomics of a line.)
+struct alignas(128) IpWord { int v; int pad[31]; };
 struct IpCtl {
-    int tail[3];          // entries in the dirty list of every axis
-    int evaluated;        // cells of the pass that found a partner (K1 -> K2)
-    int absorbers;        // cells of the pass that absorb their partner (K2 -> K3)
-    int need, merges, gone;   // totals of the pass: slots its merged lists need, merges, references that disappear
-    int alloc;            // slots handed out so far by the blocks of K3 (relative to the cursor books[0])
-    int ticket;           // blocks of K3 that are done: the last one closes the books
+    IpWord tail_[3];      // entries in the dirty list of every axis
+    IpWord evaluated_;    // cells of the pass that found a partner (K1 -> K2)
+    IpWord absorbers_;    // cells of the pass that absorb their partner (K2 -> K3)
+    IpWord need_, merges_, gone_;   // totals of the pass: slots its merged lists need, merges, references that disappear
+    IpWord alloc_;        // slots handed out so far by the blocks of K3 (relative to the cursor books[0])
+    IpWord ticket_;       // blocks of K3 that are done: the last one closes the books
 };
+#define IPW(ctl, name) ((ctl)->name##_.v)
 
 // A cell becomes dirty for an axis: its flag byte is set by an atomic on the word that holds it, and whoever finds the byte clear appends the cell to the axis'
 // list -- a cell is in the unconsumed part of a list at most once.  Every lane of the wavefront must call this (want = false: nothing to mark).
@@ -434,7 +437,7 @@ __device__ __forceinline__ void ip_mark_dirty(bool want, int axis, int id, unsig
         const uint32_t bit = 1u << (8u * uint32_t(at & 3));
         fresh = (atomicOr(reinterpret_cast<uint32_t*>(dirty + (at & ~size_t(3))), bit) & (0xffu << (8u * uint32_t(at & 3)))) == 0u;
     }
-    const int slot = wave_append(fresh ? 1 : 0, &ctl->tail[axis]);
+    const int slot = wave_append(fresh ? 1 : 0, &ctl->tail_[axis].v);
     if (fresh) lists[axis][slot] = id;
 }
 
@@ -442,11 +445,23 @@ struct IpLists { int* dirty[3]; int* evaluated; int* absorbers; };
 
 // the dirty lists from the flags ip_begin / ip_mark_entry set (entering the mode, or every cell when the mask lets merges through that it held back before)
 __global__ void __launch_bounds__(kBlock) ip_build_lists(const unsigned char* __restrict__ dirty, size_t dstride, int slots, IpLists L, IpCtl* __restrict__ ctl, int all) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
+    // a workgroup takes 4096 slots, 16 consecutive ones per thread, and draws the places of its cells in a list with ONE atomic
+    __shared__ int lds[kWaves];
+    __shared__ int base_of_block;
+    const int first = (blockIdx.x * kBlock + threadIdx.x) * 16;
     for (int axis = 0; axis < 3; axis++) {
-        const bool is = id < slots && (all || dirty[size_t(axis) * dstride + id]);
-        const int slot = wave_append(is ? 1 : 0, &ctl->tail[axis]);
-        if (is) L.dirty[axis][slot] = id;
+        uint32_t mask = 0;
+        for (int c = 0; c < 16; c++) if (first + c < slots && (all || dirty[size_t(axis) * dstride + first + c])) mask |= 1u << c;
+        const int count = __popc(mask), incl = wave_inclusive_scan(count);
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        int before = incl - count, total = 0;
+        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
+        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&ctl->tail_[axis].v, total) : 0;
+        __syncthreads();
+        int at = base_of_block + before;
+        for (int c = 0; c < 16; c++) if (mask & (1u << c)) L.dirty[axis][at++] = first + c;
+        __syncthreads();
     }
 }
 
@@ -456,7 +471,9 @@ __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const En
                                                     const int* __restrict__ refs, unsigned char* __restrict__ dirty_axis, IpLists L, IpCtl* __restrict__ ctl,
                                                     Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
                                                     unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
-    const int n = ctl->tail[axis];
+    __shared__ int lds[kWaves];
+    __shared__ int base_of_block;
+    const int n = ctl->tail_[axis].v;
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int i = base + threadIdx.x;
         bool found = false;
@@ -483,8 +500,16 @@ __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const En
                 }
             }
         }
-        const int slot = wave_append(found ? 1 : 0, &ctl->evaluated);
-        if (found) L.evaluated[slot] = id;
+        // (one atomic per workgroup and round: the counters' cache lines serialise)
+        const int incl = wave_inclusive_scan(found ? 1 : 0);
+        if (lane_id() == 63) lds[wave_id()] = incl;
+        __syncthreads();
+        int before = incl - (found ? 1 : 0), total = 0;
+        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
+        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, evaluated), total) : 0;
+        __syncthreads();
+        if (found) L.evaluated[base_of_block + before] = id;
+        __syncthreads();
     }
 }
 
@@ -495,8 +520,8 @@ __global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* 
                                                     const unsigned char* __restrict__ has_prev, const Int2* __restrict__ minfo, int pass_tag) {
     __shared__ int lds[kWaves];
     __shared__ int base_of_block;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->tail[axis] = 0;             // (K1 is done with it; K3 of this pass appends the cells that have to look again)
-    const int n = ctl->evaluated;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->tail_[axis].v = 0;             // (K1 is done with it; K3 of this pass appends the cells that have to look again)
+    const int n = IPW(ctl, evaluated);
     int need = 0, merges = 0, gone = 0;
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int i = base + threadIdx.x;
@@ -519,7 +544,7 @@ __global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* 
         __syncthreads();
         int before = incl - count, total = 0;
         for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&ctl->absorbers, total) : 0;
+        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, absorbers), total) : 0;
         __syncthreads();
         if (head >= 0) {
             int at = base_of_block + before;
@@ -533,7 +558,7 @@ __global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* 
         __syncthreads();                                                     // (lds / base_of_block are rewritten by the next round)
     }
     need = block_sum(need, lds); merges = block_sum(merges, lds); gone = block_sum(gone, lds);
-    if (threadIdx.x == 0 && merges) { atomicAdd(&ctl->need, need); atomicAdd(&ctl->merges, merges); atomicAdd(&ctl->gone, gone); }
+    if (threadIdx.x == 0 && merges) { atomicAdd(&IPW(ctl, need), need); atomicAdd(&IPW(ctl, merges), merges); atomicAdd(&IPW(ctl, gone), gone); }
 }
 
 // K3 -- merge (merge.cu:189-278), in place, for the absorbers of the pass, and who has to look again: the absorber for every axis and, per axis, the cell
@@ -546,9 +571,9 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
     __shared__ int lds[kWaves];
     __shared__ int base_of_block;
     __shared__ int last;
-    const int n = ctl->absorbers, cursor = books[0];
+    const int n = IPW(ctl, absorbers), cursor = books[0];
     const int overflow = __hip_atomic_load(books + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool fits = overflow == 0 && (long long)cursor + ctl->need <= (long long)capacity;       // (the same answer in every thread: none of the words changes before the books close)
+    const bool fits = overflow == 0 && (long long)cursor + IPW(ctl, need) <= (long long)capacity;       // (the same answer in every thread: none of the words changes before the books close)
     int* const lists[3] = {L.dirty[0], L.dirty[1], L.dirty[2]};
     if (fits) for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int i = base + threadIdx.x;
@@ -559,7 +584,7 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
         __syncthreads();
         int before = incl - m, total = 0;
         for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&ctl->alloc, total) : 0;
+        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, alloc), total) : 0;
         __syncthreads();
         ivec3 lo(0, 0, 0);
         if (id >= 0) {
@@ -585,13 +610,13 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
     }
     // the books of the pass: cursor, live cells, live references; the lists and totals of the next pass start empty
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&ctl->ticket, 1) == int(gridDim.x) - 1;
+    if (threadIdx.x == 0) last = atomicAdd(&IPW(ctl, ticket), 1) == int(gridDim.x) - 1;
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        if (fits) { books[0] += ctl->need; books[1] -= ctl->merges; books[2] -= ctl->gone; }
+        if (fits) { books[0] += IPW(ctl, need); books[1] -= IPW(ctl, merges); books[2] -= IPW(ctl, gone); }
         else if (overflow == 0) books[3] = 1 + axis;
         snap[0] = books[1]; snap[1] = books[2];
-        ctl->evaluated = 0; ctl->absorbers = 0; ctl->need = 0; ctl->merges = 0; ctl->gone = 0; ctl->alloc = 0; ctl->ticket = 0;
+        IPW(ctl, evaluated) = 0; IPW(ctl, absorbers) = 0; IPW(ctl, need) = 0; IPW(ctl, merges) = 0; IPW(ctl, gone) = 0; IPW(ctl, alloc) = 0; IPW(ctl, ticket) = 0;
     }
 }
 
@@ -707,9 +732,10 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     Int2* tile_sums = pool_alloc<Int2>(ctx, size_t(max_tiles) + 1);
     Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(max_tiles)) + 1);
     Int2* total = reinterpret_cast<Int2*>(ctx->dscratch);
+    IpCtl* ipc = pool_alloc<IpCtl>(ctx, 1);                                // control words of the in-place iterations (without them the merge compacts throughout)
     auto release = [&]() {
         hagrid_mem_free(ctx, merge_counts); hagrid_mem_free(ctx, nexts); hagrid_mem_free(ctx, prevs); hagrid_mem_free(ctx, cell_flags);
-        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, stamps_base);
+        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, stamps_base); hagrid_mem_free(ctx, ipc);
     };
     if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !tile_sums || !partials || !stamps) {
         release(); hagrid_mem_free(ctx, cells_b); hagrid_mem_free(ctx, refs_b);
@@ -748,7 +774,6 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references, overflow (1 + axis of the first pass that did not fit)
     int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
     Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
-    IpCtl* ipc = reinterpret_cast<IpCtl*>(ctx->dscratch + 32);
     const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
     const int ip_blocks = std::max(ctx->num_cus, 1) * 4;                  // the passes of the mode sweep their lists with this many workgroups
     size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the flags are set by word atomics)
@@ -758,7 +783,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         const auto r256 = [](size_t n) { return (n + 255) & ~size_t(255); };
         const size_t slots = size_t(num_cells), dstride = r256(slots), ints = r256(slots * sizeof(int));
         const size_t off_dirty = r256(slots * 8), off_eval = off_dirty + 3 * dstride, off_lists = off_eval + r256(slots);
-        if (off_lists + 5 * ints > nc0 * sizeof(Cell)) return false;
+        if (!ipc || off_lists + 5 * ints > nc0 * sizeof(Cell)) return false;
         ip_slots = num_cells; ip_dstride = dstride;
         char* scratch = static_cast<char*>(cells_other);
         minfo = reinterpret_cast<Int2*>(scratch);
@@ -773,7 +798,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2],
                                                                    evaluated, books, num_refs, ip_dstride); HG_DBG(ctx);
         if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2], ip_dstride); HG_DBG(ctx);
-        ip_build_lists<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 0); HG_DBG(ctx);
+        ip_build_lists<<<grid_blocks(ip_slots, 16 * kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 0); HG_DBG(ctx);
         in_place = true;
         return true;
     };
@@ -854,8 +879,8 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
             // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
             if (prev_mask & ~mask) {
                 (void)hipMemsetAsync(dirty, 1, 3 * ip_dstride, st);
-                (void)hipMemsetAsync(ipc->tail, 0, 3 * sizeof(int), st);
-                ip_build_lists<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 1); HG_DBG(ctx);
+                (void)hipMemsetAsync(ipc->tail_, 0, 3 * sizeof(IpWord), st);
+                ip_build_lists<<<grid_blocks(ip_slots, 16 * kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 1); HG_DBG(ctx);
             }
             const Entry* ent = reinterpret_cast<const Entry*>(entries);
             const int cap = ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity;

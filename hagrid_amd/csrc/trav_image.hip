@@ -325,21 +325,24 @@ __device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long l
     } else hi = (hi & ~(m << (pos - 64))) | (x << (pos - 64));
 }
 
-// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels (the uniform layout: block T holds (2^D)^3 records and
-// starts at T * (2^D)^3).  status: bit 0 = a bound does not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more
-// than IDB bits.
-template <int D, int IDB>
-__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status) {
+// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
+// not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
+// TABLE: the block of top-level cell T has depth metas[T] & 3 and starts at record offsets[T]; its bound bytes count from the origin
+// of the top-level cell, biased by 128.
+template <int D, int IDB, bool TABLE>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
+                                                      const uint32_t* __restrict__ metas, const int* __restrict__ offsets) {
     constexpr int NI = 80 / IDB;
     constexpr uint32_t NONE = (1u << IDB) - 1u;
     const int T = blockIdx.x, lane = threadIdx.x;
     const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
     const uint32_t topw = k.entries[T];
-    constexpr int V = 1 << (3 * D);
-    const size_t first = size_t(T) << (3 * D);
-    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(D) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
+    const int d = TABLE ? int(metas[T] & 3u) : D, sd = D - d, V = 1 << (3 * d);
+    const size_t first = TABLE ? size_t(offsets[T]) : size_t(T) << (3 * D);
+    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(d) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
     for (int f = lane; f < V; f += 64) {
-        const int rx = f & ((1 << D) - 1), ry = (f >> D) & ((1 << D) - 1), rz = f >> (2 * D);
+        // block voxel f at depth d -> its lowest finest-level voxel inside the top-level cell
+        const int rx = (f & ((1 << d) - 1)) << sd, ry = ((f >> d) & ((1 << d) - 1)) << sd, rz = (f >> (2 * d)) << sd;
         uint32_t w = topw;
         int depth = 0;
         while (w & 3u) {
@@ -362,11 +365,11 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
             lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
             begin = a.w; n = b.w - a.w;
         }
-        const int v[3] = {(tx << D) + rx, (ty << D) + ry, (tz << D) + rz};
+        const int v[3] = {(tx << D) + (TABLE ? 0 : rx), (ty << D) + (TABLE ? 0 : ry), (tz << D) + (TABLE ? 0 : rz)};
         unsigned long long rl = ~0ull << 48, rh = ~0ull;               // every id field "unused"
         int bad = 0;
         for (int ax = 0; ax < 3; ax++) {
-            const int dl = v[ax] - lo[ax], dh = hi[ax] - v[ax];
+            const int dl = TABLE ? lo[ax] - v[ax] + 128 : v[ax] - lo[ax], dh = TABLE ? hi[ax] - v[ax] + 128 : hi[ax] - v[ax];
             if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
             rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
         }
@@ -388,10 +391,22 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
     }
 }
 
-// The uniform layout with slim records.  Returns 1 when some cell does not fit a slim record.
+struct SlimSizeIn { const uint32_t* m; __device__ int operator()(int i) const { return 1 << (3 * int(m[i] & 3u)); } };
+struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
+
+// uniform: every block has (2^D)^3 records, block T starts at T * (2^D)^3; otherwise `metas` holds the depth of every block and the
+// offsets come from a scan over the block sizes.  Returns 1 when some cell does not fit a slim record.
 template <int D>
-int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table) {
-    const long long records = (long long)k.num_top << (3 * D);
+int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
+    long long records = (long long)k.num_top << (3 * D);
+    if (!uniform) {
+        int* total = ctx->dscratch + 227;
+        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
+        int h = 0;
+        const int rc = read_back(ctx, total, &h, sizeof(h));
+        if (rc != HAGRID_OK) return rc;
+        records = h;
+    }
     if (records <= 0 || records >= (1ll << 28)) return 1;               // record offsets of the narrow kernels: 32-bit byte offsets
     const size_t bytes = size_t(records) * 16u;
     uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
@@ -400,13 +415,18 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
     for (int idb : {20, 26}) {
         if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
         (void)hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream);
-        if (idb == 20) image_slim_fill<D, 20><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
-        else           image_slim_fill<D, 26><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status);
+        if (uniform) {
+            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
+            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
+        } else {
+            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
+            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
+        }
         HG_DBG(ctx);
         int h[2] = {0, 0};
         const int rc = read_back(ctx, status, h, sizeof(h));
         if (rc != HAGRID_OK) { hagrid_mem_free(ctx, recs); return rc; }
-        if (h[0]) break;                            // some cell does not fit a slim record: the general layout has wide records for those
+        if (h[0]) break;                            // some cell does not fit a slim record: 32-byte records
         if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
         if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
         img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
@@ -670,12 +690,20 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
     const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
     if (uniform) units = int(uniform_units);
     if (FLAT && ctx->opt_image_slim) {
-        // slim records: the uniform layout when every top-level cell has the full depth (three levels at most: no links), else -- or when some cell of it
-        // reaches further than a byte can say -- the general layout (a record per voxel-map entry)
+        // Slim records.  Grids of at most three levels: a block of (2^d)^3 records per top-level cell -- table-free when every top-level cell has the full depth
+        // (uniform layout), through the table otherwise (table layout) -- when every cell fits their bound bytes; the general layout (a record per voxel-map
+        // entry: links, wide records) for the cells that do not, and -- from trav_image_build directly -- for deeper grids.  (The general layout serves grids of
+        // three levels as well, at 20 % more instructions per cell step and seven instead of eight wavefronts per SIMD: configuration 3's grid 1.26 -> 1.57 ms
+        // at 4096^2, round 5 -- the table layout stays.)
         int rs = 1;
-        if (uniform) rs = build_slim<D>(ctx, k, img, table);
-        if (rs == HAGRID_OK) { release(); img.uniform = true; img.table = table; img.table_bytes = size_t(k.num_top) * 8u; return HAGRID_OK; }
-        if (rs == 1) {
+        if (D == k.shift && D >= 1) {
+            int* offs = nullptr;
+            if (!uniform) { offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1); if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; } }
+            rs = build_slim<D>(ctx, k, img, table, uniform, metas, offs, partials);
+            hagrid_mem_free(ctx, offs);
+            if (rs == HAGRID_OK) { release(); img.uniform = uniform; img.table = table; img.table_bytes = size_t(k.num_top) * 8u; return HAGRID_OK; }
+        }
+        if (rs == 1 && ctx->opt_image_general) {
             rs = build_general(ctx, k, img);
             if (rs == HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return HAGRID_OK; }
         }
@@ -770,7 +798,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     bool flat = ctx->opt_image == 2;
     // grids deeper than three levels: the general layout of slim records, without the sizing passes of the block layouts
     bool general = false;
-    if (flat && ctx->opt_image_slim && g->shift > 3) {
+    if (flat && ctx->opt_image_slim && ctx->opt_image_general && (g->shift > 3 || ctx->opt_image_general == 2)) {
         rc = build_general(ctx, k, img);
         if (rc < 0) return rc;
         general = rc == HAGRID_OK;

@@ -12,8 +12,9 @@ namespace hagrid_trav {
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
 // SLIM (with FLAT and NARROW, grids of at most three levels): 16-byte records, SLIM = bits per packed reference id (trav_image.hip,
 // "Slim records"); 0 = 32-byte records.  UNIFORM: bounds as offsets from the voxel; table layout: from the top-level cell's origin.
-template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0>
+template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0, bool GENERAL = false>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
+    static_assert(!GENERAL || (SLIM != 0 && !UNIFORM), "the general layout holds slim records");
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
     static_assert(SLIM == 0 || (FLAT && NARROW), "slim records are read by the flat narrow kernels only");
     constexpr int NONE = SLIM ? (1 << (SLIM ? SLIM : 1)) - 1 : -1;          // the id field of an unused list slot
@@ -55,7 +56,6 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
         };
         auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
-        constexpr bool GENERAL = SLIM != 0 && !UNIFORM;                         // one slim record per voxel-map entry (trav_common.h GenWalk)
         GenWalk<SLIM ? SLIM : 20> gw;
         gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
         uint32_t wide_begin = 0u;
@@ -70,8 +70,12 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
                 ra = p[0];
                 if (!SLIM) rb = p[1];
-            } else if (FLAT && NARROW && SLIM) {          // general layout: from the block of the last look-up, or from the top level (a link is resolved behind the tests)
+            } else if (GENERAL) {          // from the block of the last look-up, or from the top level (a link is resolved behind the tests)
                 ra = gw.lookup(a, x, y, z, moved);
+            } else if (FLAT && NARROW && SLIM) {          // table layout, no links: block offset in records, depth of the block
+                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
+                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+                ra = *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
             } else if (FLAT && NARROW) {
                 int d = int(tab.y & 3u), s = a.shift - d;
                 uint32_t base = tab.x;
@@ -143,6 +147,11 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                     cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
                     wide_begin = wr.w;
                 }
+            } else if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell
+                const int org_mask = ~((1 << a.shift) - 1);
+                cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
+                cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
+                cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
             } else if (SLIM) {     // byte offsets from the voxel the record belongs to
                 // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
@@ -309,8 +318,10 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 #ifndef HG_GENERAL_WAVES
 #define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
 #endif
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false>
-__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : HG_GENERAL_WAVES)) traverse_kernel_tail(const TraverseArgs a) {
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false>
+__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : 8)) traverse_kernel_tail(const TraverseArgs a) {
+    static_assert(!GENERAL || !UNIFORM, "a layout is uniform, table (blocks per top-level cell) or general (a record per voxel-map entry)");
+    constexpr bool TABLE = !UNIFORM && !GENERAL;
     static_assert(!REFILL || (UNIFORM && !DUAL && !TIMES), "refill: for the table-free layout, one id per round trip");
     __shared__ float4 ray_lds[REFILL ? 128 : 1];          // REFILL: the next 64 rays of the wavefront's pool, requested ahead (LDS-DMA)
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
@@ -399,11 +410,22 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
     }
     GenWalk<SLIM> gw;                                      // general layout: the innermost block the ray's last look-up ended in
     gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-    auto load_record = [&](int x, int y, int z) -> uint4 {          // uniform layout: the record of a voxel is arithmetic on the voxel
+    uint32_t tab_off = 0u, tab_d = 0u;                     // table layout: block offset (records) and depth of the top-level cell the ray is in
+    int top_idx = -1;
+    auto load_record = [&](int x, int y, int z) -> uint4 {          // uniform layout: the record of a voxel is arithmetic on the voxel; table layout: through the table entry of its top-level cell
         const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
-        const int d = a.shift, m = (1 << d) - 1;
-        const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-        return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+        if (UNIFORM) {
+            const int d = a.shift, m = (1 << d) - 1;
+            const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
+            return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
+        }
+        if (int(top) != top_idx) {
+            const uint2 t = gather32<uint2>(a.img_table, top << 3);
+            tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+        }
+        const int d = int(tab_d), sh = a.shift - d, m = (1 << d) - 1;
+        const uint32_t idx = uint32_t((x >> sh) & m) + (uint32_t(((y >> sh) & m) + (((z >> sh) & m) << d)) << d);
+        return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
     };
     auto tri_ptr = [&](int ref) -> const float4* {
         uint32_t r3, o;
@@ -443,6 +465,11 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz));
+        } else if (TABLE) {     // biased byte offsets from the origin of the top-level cell
+            const int org_mask = ~((1 << a.shift) - 1);
+            cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
+            cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
+            cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
         } else {
             // general layout: byte offsets from the origin of the record's region (2^s voxels wide) -- or, for the few cells that reach further, a wide
             // record with absolute 16-bit bounds (one more dependent gather, in steps through the large cells of empty space only)
@@ -463,17 +490,17 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
         const int ny = texit == tcell.y ? cy + (py ? 0 : -1) : int(ev.y);
         const int nz = texit == tcell.z ? cz + (pz ? 0 : -1) : int(ev.z);
         uint32_t moved = 0u;                                       // general layout: the bits in which the voxel changes
-        { const int t = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved = uint32_t(t ^ vx); vx = t; }
-        { const int t = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved |= uint32_t(t ^ vy); vy = t; }
-        { const int t = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000)); if (!UNIFORM) moved |= uint32_t(t ^ vz); vz = t; }
+        { const int t = med3_i32(nx, vx, px ? 0x7fffffff : int(0x80000000)); if (GENERAL) moved = uint32_t(t ^ vx); vx = t; }
+        { const int t = med3_i32(ny, vy, py ? 0x7fffffff : int(0x80000000)); if (GENERAL) moved |= uint32_t(t ^ vy); vy = t; }
+        { const int t = med3_i32(nz, vz, pz ? 0x7fffffff : int(0x80000000)); if (GENERAL) moved |= uint32_t(t ^ vz); vz = t; }
         outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
         uint4 next = make_uint4(0u, 0u, 0u, 0u);                  // a ray that left the grid requests nothing
-        if (!outside) next = UNIFORM ? load_record(vx, vy, vz) : gw.lookup(a, vx, vy, vz, moved);       // (general layout: possibly a link, resolved behind the tests)
+        if (!outside) next = GENERAL ? gw.lookup(a, vx, vy, vz, moved) : load_record(vx, vy, vz);       // (general layout: possibly a link, resolved behind the tests)
         return next;
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
     auto test_list = [&](const uint4& rec) {
-        const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(rec);
+        const bool wide_cell = GENERAL && GenWalk<SLIM>::is_wide(rec);
         const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
         int ref = int(field(rec, 48, SLIM));
         uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
@@ -556,8 +583,8 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
 
     uint4 ca = make_uint4(0u, 0u, 0u, 0u);
     if (alive) {
-        if (UNIFORM) ca = load_record(vx, vy, vz);
-        else { ca = gw.lookup(a, vx, vy, vz, 0u); gw.descend(a, ca, vx, vy, vz); }
+        if (GENERAL) { ca = gw.lookup(a, vx, vy, vz, 0u); gw.descend(a, ca, vx, vy, vz); }
+        else ca = load_record(vx, vy, vz);
     }
     unsigned long long live = __ballot(alive);
 
@@ -642,7 +669,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
                 test_list(ca);
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
-                if (!UNIFORM && alive) gw.descend(a, ca, vx, vy, vz);          // general layout: a link leads on to the child block (its first gather was in flight during the tests)
+                if (GENERAL && alive) gw.descend(a, ca, vx, vy, vz);          // general layout: a link leads on to the child block (its first gather was in flight during the tests)
             }
             if (REFILL && joining) { alive = true; joining = false; }
             live = __ballot(alive);
@@ -670,7 +697,8 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
     tmin = pull_f(tmin); hit_t = pull_f(hit_t); hit_id = pull_i(hit_id); id = pull_i(id);
     vx = pull_i(vx); vy = pull_i(vy); vz = pull_i(vz);
     ca = make_uint4(uint32_t(pull_i(int(ca.x))), uint32_t(pull_i(int(ca.y))), uint32_t(pull_i(int(ca.z))), uint32_t(pull_i(int(ca.w))));
-    if (!UNIFORM) { gw.blk = uint32_t(pull_i(int(gw.blk))); gw.bks = uint32_t(pull_i(int(gw.bks))); }
+    if (GENERAL) { gw.blk = uint32_t(pull_i(int(gw.blk))); gw.bks = uint32_t(pull_i(int(gw.bks))); }
+    if (TABLE) { tab_off = uint32_t(pull_i(int(tab_off))); tab_d = uint32_t(pull_i(int(tab_d))); top_idx = pull_i(top_idx); }
     if (MAILBOX) {                                         // the mailbox moves with its ray: the group's first lane's slot holds it from here on
         const int4 m = mailbox[lanes_of[alive ? group : 0]];
         __syncthreads();                                   // (every slot is read before any is overwritten)
@@ -712,6 +740,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
             int c;
             const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
             if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
+            else if (TABLE) c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;             // table layout: bounds count from the top-level cell's origin
             else {
                 // general layout: the byte counts from the origin of the record's region; a wide cell has absolute bounds in its wide record
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v & int(~0u << gw.region_shift())));
@@ -735,6 +764,15 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
                 const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh));
                 return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
             }
+            if (TABLE) {
+                const uint32_t top = quad_sum(__umul24(v >> uint32_t(a.shift), m_stride));
+                if (int(top) != top_idx) {
+                    const uint2 t = gather32<uint2>(a.img_table, top << 3);
+                    tab_off = t.x; tab_d = t.y & 3u; top_idx = int(top);
+                }
+                const uint32_t idx = quad_sum(((v >> (uint32_t(a.shift) - tab_d)) & ((1u << tab_d) - 1u)) << __umul24(uint32_t(ax), tab_d));
+                return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab_off + idx) << 4));
+            }
             if (outside) return make_uint4(0u, 0u, 0u, 0u);
             const uint32_t k = gw.bks & 3u, s = gw.bks >> 2;
             // still inside the block of the last look-up (no axis left its region)?  then one gather; else from the top level again
@@ -748,7 +786,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint4 na = quad_step(ca);
-                const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(ca);
+                const bool wide_cell = GENERAL && GenWalk<SLIM>::is_wide(ca);
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
@@ -812,7 +850,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (UNIFORM ? 8 : H
                 }
                 if (hit_t <= texit || outside) alive = false;
                 ca = na;
-                if (!UNIFORM && alive) quad_descend(ca);
+                if (GENERAL && alive) quad_descend(ca);
             }
             live = __ballot(alive);
             if (COST) iters++;

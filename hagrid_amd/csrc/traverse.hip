@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ 
 
 // the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
 template <unsigned MODE>
-bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, const TraverseArgs& a) {
+bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
     if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
     if (tail && MODE == 0 && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL)
         if (a.mailbox) {
@@ -41,7 +41,16 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
         }
         return true;
     }
-    if (tail && MODE == 0 && slim && !uniform) {
+    if (tail && MODE == 0 && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
+        if (a.tile_cost) {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
+    }
+    else if (tail && MODE == 0 && slim && !uniform) {
         // (the table layout has no registers to spare for the second request of "traverse.tail_dual", and keeps costs for the tile order only where asked to)
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -80,6 +89,8 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
     }
     else if (slim == 20 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
     else if (slim == 26 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
+    else if (slim == 20 && general) traverse_kernel_img<64, true, true, false, MODE, false, 20, true><<<blocks, 64, 0, st>>>(a);
+    else if (slim == 26 && general) traverse_kernel_img<64, true, true, false, MODE, false, 26, true><<<blocks, 64, 0, st>>>(a);
     else if (slim == 20)            traverse_kernel_img<64, true, true, false, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
     else if (slim == 26)            traverse_kernel_img<64, true, true, false, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
     else if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
@@ -90,12 +101,12 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
     else                           traverse_kernel_img<64, false, false, false, 0><<<blocks, 64, 0, st>>>(a);
     return true;
 }
-bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
+bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, bool general, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
     switch (mode & 3u) {
-        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, slim, tail, a);
-        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, slim, tail, a);
-        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, slim, tail, a);
-        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, slim, tail, a);
+        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
+        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
+        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
+        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
     }
 }
 
@@ -417,7 +428,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (refill_k > 1) {      // ("traverse.refill" above)
             a.refill = refill_k; a.tail_dual = 0; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);
         }
-        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.slim, ctx->opt_tail != 0, flags, a))
+        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (learn_order) { launch_tile_order(ctx, H, tiles, a); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {

@@ -390,11 +390,12 @@ def _image_scenes():
             "compressed_long_lists": (np.concatenate([np.repeat(scene.make_soup(30, seed=15), 12, axis=0), scene.make_soup(6000, seed=16)]), dict(compress=True, top_density=0.3, snd_density=1.0))}
 
 
-# (traverse.image, traverse.image_slim): compact blocks (slot bytes + de-duplicated records); flat with slim 16-byte records -- a record per voxel where
-# every top-level cell has the full depth of at most three levels (uniform layout), else a record per voxel-map entry (general layout: any depth,
-# links to child blocks, wide records for cells whose bounds do not fit a byte); flat with 32-byte records only (blocks, nested blocks, deep links);
-# flat with the 26-bit form of the slim record
-_IMAGE_FORMATS = {"compact": (1, 1), "flat": (2, 1), "flat_fat": (2, 0), "flat_slim26": (2, 2)}
+# (traverse.image, traverse.image_slim, traverse.image_general): compact blocks (slot bytes + de-duplicated records); flat with slim 16-byte records -- grids of
+# at most three levels whose cells fit the bound bytes: a block of records per top-level cell, table-free where every top-level cell has the full depth (uniform
+# layout), through the table otherwise (table layout); every other grid a record per voxel-map entry (general layout: any depth, links to child blocks, wide
+# records for cells whose bounds do not fit a byte); flat with 32-byte records only (blocks, nested blocks, deep links); flat with the 26-bit form of the slim
+# record; the general layout forced on grids the block layouts would serve
+_IMAGE_FORMATS = {"compact": (1, 1, 1), "flat": (2, 1, 1), "flat_fat": (2, 0, 1), "flat_slim26": (2, 2, 1), "flat_general": (2, 1, 2)}
 
 
 @pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
@@ -403,14 +404,14 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     """Every voxel of the virtual grid resolves, through the image's table / slot / record, to exactly the bounds, list
     length and reference ids that lookup_entry + cells + ref_ids give in the construction format."""
     from oracle import oracle as O
-    fmt, slim = _IMAGE_FORMATS[fmt_name]
+    fmt, slim, general = _IMAGE_FORMATS[fmt_name]
     tris, params = _image_scenes()[name]
     G = O.Grid.full(tris, **params)
     grid = upload_oracle_grid(mem, G)
     from hagrid_amd import api
-    mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim)
+    mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim); mem.set_option("traverse.image_general", general)
     api.setup_traversal(grid)
-    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_slim", 1)
+    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.image_general", 1)
     res = np.array(G.dims) << G.shift
     total = int(res[0]) * int(res[1]) * int(res[2])
     rng = np.random.default_rng(1)
@@ -429,8 +430,9 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     assert info["flat"] == (fmt == 2)
     if fmt == 2 and slim:        # every grid here fits slim records: what a byte cannot say goes into wide records
         assert info["slim_id_bits"] == (26 if slim == 2 else 20) and info["record_bytes"] == 16, "slim records expected"
-        assert info["uniform"] != info["general"]
+        assert not (info["uniform"] and info["general"])
         assert info["general"] or 1 <= G.shift <= 3
+        if general == 2 or G.shift > 3 or G.shift == 0: assert info["general"]
     else:
         assert info["slim_id_bits"] == 0 and info["record_bytes"] == 32 and not info["general"]
     if info["slim_id_bits"] and info["uniform"]:
@@ -438,7 +440,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     if info["general"]:
         assert nbytes.value >= 16 * G.num_entries and nbytes.value <= 16 * (G.num_entries + G.num_cells) + 256
     if name == "soup30k_shift3" and fmt == 2 and slim:
-        assert info["general"], "the general layout on a grid of three levels is exercised"
+        assert not info["uniform"] and info["general"] == (general == 2), "the table layout with slim records and the general layout on a grid of three levels are exercised"
     assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
         assert (by_index & ~deep).any() or info["general"]
@@ -467,7 +469,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
 def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
     from oracle import oracle as O
     from hagrid_amd import api
-    fmt, slim = _IMAGE_FORMATS[fmt_name]
+    fmt, slim, general = _IMAGE_FORMATS[fmt_name]
     if name == "compressed_deep" and fmt == 1:
         pytest.skip("no compact image for compressed grids deeper than three levels")
     tris, params = _image_scenes()[name]
@@ -478,7 +480,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
                            scene.make_rays_incoherent(G.bbox_min - 0.2, G.bbox_max + 0.2, 60001, 17)]).astype(np.float32)
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
-        mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim)
+        mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim); mem.set_option("traverse.image_general", general)
         for uniform in ((1, 0) if fmt == 2 and slim == 1 else (1,)):          # flat blocks: table-free layout allowed / not allowed
             mem.set_option("traverse.image_uniform", uniform)
             for variant in (4, 0, 2):
@@ -492,7 +494,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     finally:
         mem.set_ray_binning(0); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image", 2); mem.set_option("traverse.image_uniform", 1)
-        mem.set_option("traverse.image_slim", 1)
+        mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.image_general", 1)
     grid.free(); mem.free(d_tris)
 
 
@@ -632,7 +634,8 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
     coincident = np.repeat(scene.make_soup(60, seed=41), 9, axis=0)          # nine copies of every triangle: equal t, lists of 9+ ids
     scenes = {"soup": (scene.make_soup(30000, seed=42), {}),
               "long_lists": (np.concatenate([coincident, scene.make_soup(4000, seed=43)]), dict(top_density=0.3, snd_density=1.0)),
-              "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),     # three levels, top-level cells of different depth: general layout
+              "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),     # three levels, top-level cells of different depth: table layout
+              "general_shallow": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),  # the same grid in the general layout (forced)
               "deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),             # shift 5: links below the top level
               "clustered": (scene.make_clustered(3000, 3, 4000), {}),                                          # shift 5, blobs in a sparse soup: wide records between them
               "clustered_compressed": (scene.make_clustered(3000, 3, 4000), dict(compress=True))}
@@ -646,10 +649,11 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             primary = scene.make_rays_primary(lo, hi, 64, 48)
             rays = np.concatenate([primary, scene.make_rays_incoherent(lo - 0.3, hi + 0.3, 20011, 23)]).astype(np.float32)
             want, _ = G.traverse(tris, rays, nthreads=8)
+            mem.set_option("traverse.image_general", 2 if name == "general_shallow" else 1)
             api.setup_traversal(grid)
             info = mem.image_format(grid)
             assert info["slim_id_bits"] == (26 if slim == 2 else 20), (name, info)
-            if name != "long_lists": assert info["uniform"] == (name == "soup") and info["general"] == (name != "soup"), (name, info)      # both slim layouts are exercised
+            if name != "long_lists": assert info["uniform"] == (name == "soup") and info["general"] == (name not in ("soup", "table_layout")), (name, info)      # the three slim layouts are exercised
             # (tail mode, per cent of the tiles that START with four lanes per ray -- "traverse.quad_tail", 16 rays per wavefront)
             # ... and "traverse.tail_dual": two ids of an inline list per round trip in phase 1, the second triangle through LDS (forced on
             # for binned batches as well, where the default switches it off)
@@ -675,6 +679,7 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
     finally:
         mem.set_option("traverse.tail", 1); mem.set_option("traverse.quad_tail", -1); mem.set_option("traverse.tail_dual", -1)
         mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0); mem.set_option("traverse.tri_pad", -1); mem.set_option("traverse.mailbox", -1); mem.set_option("traverse.refill", -1)
+        mem.set_option("traverse.image_general", 1)
 
 
 def test_row_length_cache_never_changes_hits(mem):
