@@ -429,18 +429,7 @@ struct IpCtl {
 #define IPW(ctl, name) ((ctl)->name##_.v)
 
 // A cell becomes dirty for an axis: its flag byte is set by an atomic on the word that holds it, and whoever finds the byte clear appends the cell to the axis'
-// list -- a cell is in the unconsumed part of a list at most once.  Every lane of the wavefront must call this (want = false: nothing to mark).
-__device__ __forceinline__ void ip_mark_dirty(bool want, int axis, int id, unsigned char* __restrict__ dirty, size_t dstride, int* const* __restrict__ lists, IpCtl* __restrict__ ctl) {
-    bool fresh = false;
-    if (want) {
-        const size_t at = size_t(axis) * dstride + size_t(id);
-        const uint32_t bit = 1u << (8u * uint32_t(at & 3));
-        fresh = (atomicOr(reinterpret_cast<uint32_t*>(dirty + (at & ~size_t(3))), bit) & (0xffu << (8u * uint32_t(at & 3)))) == 0u;
-    }
-    const int slot = wave_append(fresh ? 1 : 0, &ctl->tail_[axis].v);
-    if (fresh) lists[axis][slot] = id;
-}
-
+// list -- a cell is in the unconsumed part of a list at most once (ip_apply).
 struct IpLists { int* dirty[3]; int* evaluated; int* absorbers; };
 
 // the dirty lists from the flags ip_begin / ip_mark_entry set (entering the mode, or every cell when the mask lets merges through that it held back before)
@@ -597,14 +586,31 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
             reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
         }
         // who has to look again (a cell found through a slot that another thread of this launch turns into a tombstone may be marked in its absorber's
-        // stead: that absorber marks itself for every axis)
+        // stead: that absorber marks itself for every axis).  The six flag atomics of a lane are independent, and so are the three list atomics of the
+        // wavefront: issued together, waited for once.
+        int who[6]; bool fresh[6];
         for (int ax = 0; ax < 3; ax++) {
-            ip_mark_dirty(id >= 0, ax, id, dirty, dstride, lists, ctl);
             ivec3 p = lo;
             if (ax == 0) p.x--; else if (ax == 1) p.y--; else p.z--;
             const bool behind = id >= 0 && comp(p, ax) >= 0;
-            const int b = behind ? ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p))) : 0;
-            ip_mark_dirty(behind, ax, b, dirty, dstride, lists, ctl);
+            who[2 * ax] = id; who[2 * ax + 1] = behind ? ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p))) : -1;
+        }
+        for (int j = 0; j < 6; j++) {
+            fresh[j] = false;
+            // (the cell behind the lower corner of axis a is never the absorber itself; two lanes may name the same cell: the flag decides)
+            if (who[j] >= 0) {
+                const size_t at = size_t(j >> 1) * dstride + size_t(who[j]);
+                const uint32_t sh = 8u * uint32_t(at & 3);
+                fresh[j] = (atomicOr(reinterpret_cast<uint32_t*>(dirty + (at & ~size_t(3))), 1u << sh) & (0xffu << sh)) == 0u;
+            }
+        }
+        int upto[3], cnt[3], basev[3] = {0, 0, 0};
+        for (int ax = 0; ax < 3; ax++) { cnt[ax] = int(fresh[2 * ax]) + int(fresh[2 * ax + 1]); upto[ax] = wave_inclusive_scan(cnt[ax]); }
+        if (lane_id() == 63) for (int ax = 0; ax < 3; ax++) if (upto[ax]) basev[ax] = atomicAdd(&ctl->tail_[ax].v, upto[ax]);
+        for (int ax = 0; ax < 3; ax++) {
+            int at = __shfl(basev[ax], 63, 64) + upto[ax] - cnt[ax];
+            if (fresh[2 * ax]) lists[ax][at++] = who[2 * ax];
+            if (fresh[2 * ax + 1]) lists[ax][at] = who[2 * ax + 1];
         }
         __syncthreads();
     }
@@ -775,7 +781,7 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
     Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
     const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
-    const int ip_blocks = std::max(ctx->num_cus, 1) * 4;                  // the passes of the mode sweep their lists with this many workgroups
+    const int ip_blocks = std::max(ctx->num_cus, 1) * 8;                  // the passes of the mode sweep their lists with this many workgroups (the resident set: their work is dependent gathers)
     size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the flags are set by word atomics)
     // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).  Returns false -- and the merge
     // goes on compacting -- when the scratch of the mode does not fit the idle cell buffer (32 bytes per cell of the un-merged grid; the mode needs 30 per slot).
