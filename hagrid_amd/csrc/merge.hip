@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* _
 struct alignas(128) IpWord { int v; int pad[31]; };
 struct IpCtl {
     IpWord tail_[3];      // entries in the dirty list of every axis
-    IpWord evaluated_;    // cells of the pass that found a partner (K1 -> K2)
+    IpWord swept_;        // entries of the axis' dirty list K1 swept (K2 sweeps them again for the tags K1 left)
     IpWord absorbers_;    // cells of the pass that absorb their partner (K2 -> K3)
     IpWord need_, merges_, gone_;   // totals of the pass: slots its merged lists need, merges, references that disappear
     IpWord alloc_;        // slots handed out so far by the blocks of K3 (relative to the cursor books[0])
@@ -430,7 +430,7 @@ struct IpCtl {
 
 // A cell becomes dirty for an axis: its flag byte is set by an atomic on the word that holds it, and whoever finds the byte clear appends the cell to the axis'
 // list -- a cell is in the unconsumed part of a list at most once (ip_apply).
-struct IpLists { int* dirty[3]; int* evaluated; int* absorbers; };
+struct IpLists { int* dirty[3]; int* absorbers; };
 
 // the dirty lists from the flags ip_begin / ip_mark_entry set (entering the mode, or every cell when the mask lets merges through that it held back before)
 __global__ void __launch_bounds__(kBlock) ip_build_lists(const unsigned char* __restrict__ dirty, size_t dstride, int slots, IpLists L, IpCtl* __restrict__ ctl, int all) {
@@ -454,51 +454,32 @@ __global__ void __launch_bounds__(kBlock) ip_build_lists(const unsigned char* __
     }
 }
 
-// K1 -- compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis: a grid-stride sweep over the axis' dirty list; a cell that finds a partner goes
-// into the list of the pass
+// K1 -- compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis: a grid-stride sweep over the axis' dirty list, every thread on its own (no
+// barrier, no atomic: the sweep is a chain of dependent gathers per cell -- voxel map, neighbour, both lists -- and a workgroup that waits for its slowest
+// chain in every round runs at half the rate).  A cell that finds a partner is tagged with the pass; K2 sweeps the same list for the tags.
 __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
                                                     const int* __restrict__ refs, unsigned char* __restrict__ dirty_axis, IpLists L, IpCtl* __restrict__ ctl,
                                                     Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
                                                     unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
-    __shared__ int lds[kWaves];
-    __shared__ int base_of_block;
     const int n = ctl->tail_[axis].v;
-    for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const int i = base + threadIdx.x;
-        bool found = false;
-        int id = 0;
-        if (i < n) {
-            id = L.dirty[axis][i];
-            dirty_axis[id] = 0;
-            if (!ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) {
-                const CellRec c1 = ip_load(cells, list_end, id);
-                const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
-                if (merge_allowed(k, empty_mask, comp(c1.lo, axis)) && comp(np, axis) < comp(k.dims, axis)) {
-                    const int next_id = ip_live(cells, int(lookup_entry(entries, k.shift, k.top, np)));
-                    const CellRec c2 = ip_load(cells, list_end, next_id);
-                    if (aligned(axis, c1, c2)) {
-                        const int m = merged_size_if_cheaper(k, axis, c1, c2, refs);
-                        if (m >= 0) {
-                            minfo[id] = Int2{ m, (c1.end - c1.begin) + (c2.end - c2.begin) - m };     // merged size, references that disappear
-                            nexts[id] = next_id;
-                            evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
-                            has_prev[next_id] = (unsigned char)pass_tag;
-                            found = true;
-                        }
-                    }
-                }
-            }
-        }
-        // (one atomic per workgroup and round: the counters' cache lines serialise)
-        const int incl = wave_inclusive_scan(found ? 1 : 0);
-        if (lane_id() == 63) lds[wave_id()] = incl;
-        __syncthreads();
-        int before = incl - (found ? 1 : 0), total = 0;
-        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, evaluated), total) : 0;
-        __syncthreads();
-        if (found) L.evaluated[base_of_block + before] = id;
-        __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) IPW(ctl, swept) = n;                 // K2 sweeps the same entries; the list itself starts anew there (K3 appends to it)
+    // (workgroups take their stretches of the list XCD by XCD -- wave_prims.h xcd_block: the list is in slot order where it is long, and a cell's partner is near it)
+    for (int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int id = L.dirty[axis][i];
+        dirty_axis[id] = 0;
+        if (ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) continue;
+        const CellRec c1 = ip_load(cells, list_end, id);
+        const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
+        if (!merge_allowed(k, empty_mask, comp(c1.lo, axis)) || comp(np, axis) >= comp(k.dims, axis)) continue;
+        const int next_id = ip_live(cells, int(lookup_entry(entries, k.shift, k.top, np)));
+        const CellRec c2 = ip_load(cells, list_end, next_id);
+        if (!aligned(axis, c1, c2)) continue;
+        const int m = merged_size_if_cheaper(k, axis, c1, c2, refs);
+        if (m < 0) continue;
+        minfo[id] = Int2{ m, (c1.end - c1.begin) + (c2.end - c2.begin) - m };     // merged size, references that disappear
+        nexts[id] = next_id;
+        evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
+        has_prev[next_id] = (unsigned char)pass_tag;
     }
 }
 
@@ -509,15 +490,15 @@ __global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* 
                                                     const unsigned char* __restrict__ has_prev, const Int2* __restrict__ minfo, int pass_tag) {
     __shared__ int lds[kWaves];
     __shared__ int base_of_block;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->tail_[axis].v = 0;             // (K1 is done with it; K3 of this pass appends the cells that have to look again)
-    const int n = IPW(ctl, evaluated);
+    const int n = IPW(ctl, swept);                                            // the entries K1 swept
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->tail_[axis].v = 0;         // (nobody reads the length any more; K3 of this pass appends the cells that have to look again)
     int need = 0, merges = 0, gone = 0;
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int i = base + threadIdx.x;
         int head = -1, count = 0;
         if (i < n) {
-            const int id = L.evaluated[i];
-            if (has_prev[id] != pass_tag) {
+            const int id = L.dirty[axis][i];
+            if (evaluated[id] == pass_tag && has_prev[id] != pass_tag) {
                 head = id;
                 for (int cur = id, pos = 0;; pos++) {
                     const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
@@ -557,8 +538,6 @@ __global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* 
 __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Entry* __restrict__ entries, void* cells, int* list_end, int* refs, IpLists L, IpCtl* ctl,
                                                    const Int2* __restrict__ minfo, const int* __restrict__ nexts, unsigned char* dirty, size_t dstride,
                                                    int* books /* cursor, live cells, live refs, overflow */, int* __restrict__ snap, int capacity) {
-    __shared__ int lds[kWaves];
-    __shared__ int base_of_block;
     __shared__ int last;
     const int n = IPW(ctl, absorbers), cursor = books[0];
     const int overflow = __hip_atomic_load(books + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -568,16 +547,14 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
         const int i = base + threadIdx.x;
         const int id = i < n ? L.absorbers[i] : -1;
         const int m = id >= 0 ? minfo[id].a : 0;
+        // the slots of a wavefront's 64 merged lists: one atomic (no barrier in this loop: every step below is a chain of dependent gathers)
         const int incl = wave_inclusive_scan(m);
-        if (lane_id() == 63) lds[wave_id()] = incl;
-        __syncthreads();
-        int before = incl - m, total = 0;
-        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, alloc), total) : 0;
-        __syncthreads();
+        int wbase = 0;
+        if (lane_id() == 63 && incl) wbase = atomicAdd(&IPW(ctl, alloc), incl);
+        const int before = __shfl(wbase, 63, 64) + incl - m;
         ivec3 lo(0, 0, 0);
         if (id >= 0) {
-            const int at = cursor + base_of_block + before, other = nexts[id];
+            const int at = cursor + before, other = nexts[id];
             const CellRec a = ip_load(cells, list_end, id), o = ip_load(cells, list_end, other);
             write_union(refs + a.begin, a.end - a.begin, refs + o.begin, o.end - o.begin, refs + at, m);
             lo = min(o.lo, a.lo);
@@ -612,7 +589,6 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
             if (fresh[2 * ax]) lists[ax][at++] = who[2 * ax];
             if (fresh[2 * ax + 1]) lists[ax][at] = who[2 * ax + 1];
         }
-        __syncthreads();
     }
     // the books of the pass: cursor, live cells, live references; the lists and totals of the next pass start empty
     __syncthreads();
@@ -622,7 +598,7 @@ __global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Ent
         if (fits) { books[0] += IPW(ctl, need); books[1] -= IPW(ctl, merges); books[2] -= IPW(ctl, gone); }
         else if (overflow == 0) books[3] = 1 + axis;
         snap[0] = books[1]; snap[1] = books[2];
-        IPW(ctl, evaluated) = 0; IPW(ctl, absorbers) = 0; IPW(ctl, need) = 0; IPW(ctl, merges) = 0; IPW(ctl, gone) = 0; IPW(ctl, alloc) = 0; IPW(ctl, ticket) = 0;
+        IPW(ctl, swept) = 0; IPW(ctl, absorbers) = 0; IPW(ctl, need) = 0; IPW(ctl, merges) = 0; IPW(ctl, gone) = 0; IPW(ctl, alloc) = 0; IPW(ctl, ticket) = 0;
     }
 }
 
@@ -784,20 +760,19 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     const int ip_blocks = std::max(ctx->num_cus, 1) * 8;                  // the passes of the mode sweep their lists with this many workgroups (the resident set: their work is dependent gathers)
     size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the flags are set by word atomics)
     // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).  Returns false -- and the merge
-    // goes on compacting -- when the scratch of the mode does not fit the idle cell buffer (32 bytes per cell of the un-merged grid; the mode needs 30 per slot).
+    // goes on compacting -- when the scratch of the mode does not fit the idle cell buffer (32 bytes per cell of the un-merged grid; the mode needs 28 per slot).
     auto ip_enter = [&]() -> bool {
         const auto r256 = [](size_t n) { return (n + 255) & ~size_t(255); };
         const size_t slots = size_t(num_cells), dstride = r256(slots), ints = r256(slots * sizeof(int));
         const size_t off_dirty = r256(slots * 8), off_eval = off_dirty + 3 * dstride, off_lists = off_eval + r256(slots);
-        if (!ipc || off_lists + 5 * ints > nc0 * sizeof(Cell)) return false;
+        if (!ipc || off_lists + 4 * ints > nc0 * sizeof(Cell)) return false;
         ip_slots = num_cells; ip_dstride = dstride;
         char* scratch = static_cast<char*>(cells_other);
         minfo = reinterpret_cast<Int2*>(scratch);
         dirty = reinterpret_cast<unsigned char*>(scratch + off_dirty);
         evaluated = reinterpret_cast<unsigned char*>(scratch + off_eval);
         for (int a = 0; a < 3; a++) ipl.dirty[a] = reinterpret_cast<int*>(scratch + off_lists + size_t(a) * ints);
-        ipl.evaluated = reinterpret_cast<int*>(scratch + off_lists + 3 * ints);
-        ipl.absorbers = reinterpret_cast<int*>(scratch + off_lists + 4 * ints);
+        ipl.absorbers = reinterpret_cast<int*>(scratch + off_lists + 3 * ints);
         // dirty cells: the ones made after the last evaluation of the axis (their stamps say so) and the cells behind their lower corners
         const unsigned char* stp = have_stamps ? stamps : nullptr;
         (void)hipMemsetAsync(ipc, 0, sizeof(IpCtl), st);
