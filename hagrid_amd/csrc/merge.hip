@@ -381,11 +381,11 @@ __device__ __forceinline__ int ip_compact_tile(uint32_t mask4 /* bit 8c: slot id
 // its lower corner (ip_mark_entry).  Without stamps every cell is dirty.
 __global__ void __launch_bounds__(kBlock) ip_begin(const void* __restrict__ cells, int slots, int* __restrict__ list_end, unsigned char* __restrict__ dirty,
                                                    const unsigned char* __restrict__ stamps, int since_x, int since_y, int since_z,
-                                                   unsigned char* __restrict__ evaluated, int* __restrict__ books, int num_refs, size_t dstride) {
+                                                   unsigned char* __restrict__ evaluated, unsigned char* __restrict__ absorbs, int* __restrict__ books, int num_refs, size_t dstride) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id == 0) { books[0] = num_refs; books[1] = slots; books[2] = num_refs; books[3] = 0; }      // cursor, live cells, live references, overflow
     if (id >= slots) return;
-    evaluated[id] = 0;                                                        // the tags of the mode's passes
+    evaluated[id] = 0; absorbs[id] = 0;                                       // the tags of the mode's passes
     list_end[id] = int(reinterpret_cast<const uint4*>(cells)[size_t(id) + 1].w);
     const int st = stamps ? stamps[id] : 255;
     dirty[id] = st >= since_x; dirty[dstride + id] = st >= since_y; dirty[2 * dstride + id] = st >= since_z;
@@ -415,190 +415,143 @@ __global__ void __launch_bounds__(kBlock) ip_mark_entry(MergeK k, const Entry* _
     }
 }
 
-// Control words of the mode (device): the dirty lists' lengths, the lists of a pass, its totals, the allocation cursor of its merged lists.
-// (Every counter on a cache line of its own: the L2 serialises the atomics of a line.)
-struct alignas(128) IpWord { int v; int pad[31]; };
-struct IpCtl {
-    IpWord tail_[3];      // entries in the dirty list of every axis
-    IpWord swept_;        // entries of the axis' dirty list K1 swept (K2 sweeps them again for the tags K1 left)
-    IpWord absorbers_;    // cells of the pass that absorb their partner (K2 -> K3)
-    IpWord need_, merges_, gone_;   // totals of the pass: slots its merged lists need, merges, references that disappear
-    IpWord alloc_;        // slots handed out so far by the blocks of K3 (relative to the cursor books[0])
-    IpWord ticket_;       // blocks of K3 that are done: the last one closes the books
-};
-#define IPW(ctl, name) ((ctl)->name##_.v)
-
-// A cell becomes dirty for an axis: its flag byte is set by an atomic on the word that holds it, and whoever finds the byte clear appends the cell to the axis'
-// list -- a cell is in the unconsumed part of a list at most once (ip_apply).
-struct IpLists { int* dirty[3]; int* absorbers; };
-
-// the dirty lists from the flags ip_begin / ip_mark_entry set (entering the mode, or every cell when the mask lets merges through that it held back before)
-__global__ void __launch_bounds__(kBlock) ip_build_lists(const unsigned char* __restrict__ dirty, size_t dstride, int slots, IpLists L, IpCtl* __restrict__ ctl, int all) {
-    // a workgroup takes 4096 slots, 16 consecutive ones per thread, and draws the places of its cells in a list with ONE atomic
-    __shared__ int lds[kWaves];
-    __shared__ int base_of_block;
-    const int first = (blockIdx.x * kBlock + threadIdx.x) * 16;
-    for (int axis = 0; axis < 3; axis++) {
-        uint32_t mask = 0;
-        for (int c = 0; c < 16; c++) if (first + c < slots && (all || dirty[size_t(axis) * dstride + first + c])) mask |= 1u << c;
-        const int count = __popc(mask), incl = wave_inclusive_scan(count);
-        if (lane_id() == 63) lds[wave_id()] = incl;
-        __syncthreads();
-        int before = incl - count, total = 0;
-        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&ctl->tail_[axis].v, total) : 0;
-        __syncthreads();
-        int at = base_of_block + before;
-        for (int c = 0; c < 16; c++) if (mask & (1u << c)) L.dirty[axis][at++] = first + c;
-        __syncthreads();
-    }
+// compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis
+__device__ __forceinline__ void ip_count_one(int id, int axis, const MergeK& k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
+                                             const int* __restrict__ refs, Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
+                                             unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
+    if (ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) return;
+    const CellRec c1 = ip_load(cells, list_end, id);
+    const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
+    if (!merge_allowed(k, empty_mask, comp(c1.lo, axis)) || comp(np, axis) >= comp(k.dims, axis)) return;
+    const int next_id = ip_live(cells, int(lookup_entry(entries, k.shift, k.top, np)));
+    const CellRec c2 = ip_load(cells, list_end, next_id);
+    if (!aligned(axis, c1, c2)) return;
+    const int n = merged_size_if_cheaper(k, axis, c1, c2, refs);
+    if (n < 0) return;
+    minfo[id] = Int2{ n, (c1.end - c1.begin) + (c2.end - c2.begin) - n };     // merged size, references that disappear
+    nexts[id] = next_id;
+    evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
+    has_prev[next_id] = (unsigned char)pass_tag;
 }
-
-// K1 -- compute_merge_counts (merge.cu:91-142) for the dirty cells of the axis: a grid-stride sweep over the axis' dirty list, every thread on its own (no
-// barrier, no atomic: the sweep is a chain of dependent gathers per cell -- voxel map, neighbour, both lists -- and a workgroup that waits for its slowest
-// chain in every round runs at half the rate).  A cell that finds a partner is tagged with the pass; K2 sweeps the same list for the tags.
 __global__ void __launch_bounds__(kBlock) ip_counts(int axis, MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const int* __restrict__ list_end,
-                                                    const int* __restrict__ refs, unsigned char* __restrict__ dirty_axis, IpLists L, IpCtl* __restrict__ ctl,
+                                                    const int* __restrict__ refs, int slots, unsigned char* __restrict__ dirty_axis,
                                                     Int2* __restrict__ minfo, int* __restrict__ nexts, unsigned char* __restrict__ evaluated,
                                                     unsigned char* __restrict__ has_prev, int pass_tag, int empty_mask) {
-    const int n = ctl->tail_[axis].v;
-    if (blockIdx.x == 0 && threadIdx.x == 0) IPW(ctl, swept) = n;                 // K2 sweeps the same entries; the list itself starts anew there (K3 appends to it)
-    // (workgroups take their stretches of the list XCD by XCD -- wave_prims.h xcd_block: the list is in slot order where it is long, and a cell's partner is near it)
-    for (int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int id = L.dirty[axis][i];
-        dirty_axis[id] = 0;
-        if (ip_is_tomb(reinterpret_cast<const uint4*>(cells)[id])) continue;
-        const CellRec c1 = ip_load(cells, list_end, id);
-        const ivec3 np = next_cell_pos(axis, c1.lo, c1.hi);
-        if (!merge_allowed(k, empty_mask, comp(c1.lo, axis)) || comp(np, axis) >= comp(k.dims, axis)) continue;
-        const int next_id = ip_live(cells, int(lookup_entry(entries, k.shift, k.top, np)));
-        const CellRec c2 = ip_load(cells, list_end, next_id);
-        if (!aligned(axis, c1, c2)) continue;
-        const int m = merged_size_if_cheaper(k, axis, c1, c2, refs);
-        if (m < 0) continue;
-        minfo[id] = Int2{ m, (c1.end - c1.begin) + (c2.end - c2.begin) - m };     // merged size, references that disappear
-        nexts[id] = next_id;
-        evaluated[id] = (unsigned char)pass_tag;                                 // nexts[id] / minfo[id] belong to this pass
-        has_prev[next_id] = (unsigned char)pass_tag;
+    __shared__ int list[kIpTile];
+    __shared__ int count;
+    const int id4 = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * kIpPer;
+    uint32_t mask = 0;
+    if (id4 < slots) {
+        const uint32_t f = ip_flags4(dirty_axis, id4, slots);
+        for (int c = 0; c < 4; c++) if ((f >> (8 * c)) & 0xffu) { mask |= 1u << (8 * c); dirty_axis[id4 + c] = 0; }
+    }
+    const int n = ip_compact_tile(mask, id4, list, &count);
+    for (int i = threadIdx.x; i < n; i += kBlock)
+        ip_count_one(list[i], axis, k, entries, cells, list_end, refs, minfo, nexts, evaluated, has_prev, pass_tag, empty_mask);
+}
+
+// compute_cell_flags (merge.cu:145-170): chain heads name the absorbers of their chain (every second cell, while it has a successor)
+__global__ void __launch_bounds__(kBlock) ip_chains(int slots, const int* __restrict__ nexts, const unsigned char* __restrict__ evaluated,
+                                                    const unsigned char* __restrict__ has_prev, unsigned char* __restrict__ absorbs, int pass_tag) {
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    if (id4 >= slots) return;
+    const uint32_t heads = ip_match4(ip_flags4(evaluated, id4, slots), pass_tag) & ~ip_match4(ip_flags4(has_prev, id4, slots), pass_tag);
+    if (!heads) return;
+    for (int c = 0; c < 4; c++) {
+        if (!(heads & (1u << (8 * c)))) continue;
+        int cur = id4 + c, pos = 0;
+        for (;;) {
+            const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
+            if (nxt < 0) break;
+            if (!(pos & 1)) absorbs[cur] = (unsigned char)pass_tag;
+            cur = nxt; pos++;
+        }
     }
 }
 
-// K2 -- compute_cell_flags (merge.cu:145-170): the heads of the chains name the absorbers of their chain (every second cell, while it has a successor).  The
-// absorbers of a workgroup's 256 list entries get their places in the absorber list by one atomic (a first walk counts them, a second one writes them); the
-// totals of the pass by one set of atomics per workgroup.  Thread 0 also hands the consumed dirty list back.
-__global__ void __launch_bounds__(kBlock) ip_chains(int axis, IpLists L, IpCtl* __restrict__ ctl, const int* __restrict__ nexts, const unsigned char* __restrict__ evaluated,
-                                                    const unsigned char* __restrict__ has_prev, const Int2* __restrict__ minfo, int pass_tag) {
+// per tile of kIpTile slots: {slots its merged lists need, merges} for the scan (its total closes the books of the pass), and on the side the
+// references that disappear (sums of a pass kept by atomics on a handful of words of one cache line cost 115 us per pass: the L2 serialises them)
+__global__ void __launch_bounds__(kBlock) ip_tile_sums(const unsigned char* __restrict__ absorbs, int pass_tag, const Int2* __restrict__ minfo, int slots,
+                                                       Int2* __restrict__ sums, int* __restrict__ removed) {
     __shared__ int lds[kWaves];
-    __shared__ int base_of_block;
-    const int n = IPW(ctl, swept);                                            // the entries K1 swept
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->tail_[axis].v = 0;         // (nobody reads the length any more; K3 of this pass appends the cells that have to look again)
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
     int need = 0, merges = 0, gone = 0;
-    for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const int i = base + threadIdx.x;
-        int head = -1, count = 0;
-        if (i < n) {
-            const int id = L.dirty[axis][i];
-            if (evaluated[id] == pass_tag && has_prev[id] != pass_tag) {
-                head = id;
-                for (int cur = id, pos = 0;; pos++) {
-                    const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
-                    if (nxt < 0) break;
-                    if (!(pos & 1)) count++;
-                    cur = nxt;
-                }
-            }
-        }
-        // exclusive scan of the counts over the workgroup; one atomic for its absorbers
-        const int incl = wave_inclusive_scan(count);
-        if (lane_id() == 63) lds[wave_id()] = incl;
-        __syncthreads();
-        int before = incl - count, total = 0;
-        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) before += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) base_of_block = total ? atomicAdd(&IPW(ctl, absorbers), total) : 0;
-        __syncthreads();
-        if (head >= 0) {
-            int at = base_of_block + before;
-            for (int cur = head, pos = 0;; pos++) {
-                const int nxt = evaluated[cur] == pass_tag ? nexts[cur] : -1;
-                if (nxt < 0) break;
-                if (!(pos & 1)) { L.absorbers[at++] = cur; const Int2 v = minfo[cur]; need += v.a; merges++; gone += v.b; }
-                cur = nxt;
-            }
-        }
-        __syncthreads();                                                     // (lds / base_of_block are rewritten by the next round)
+    if (id4 < slots) {
+        const uint32_t m = ip_match4(ip_flags4(absorbs, id4, slots), pass_tag);
+        for (int c = 0; c < 4; c++) if (m & (1u << (8 * c))) { const Int2 v = minfo[id4 + c]; need += v.a; merges++; gone += v.b; }
     }
     need = block_sum(need, lds); merges = block_sum(merges, lds); gone = block_sum(gone, lds);
-    if (threadIdx.x == 0 && merges) { atomicAdd(&IPW(ctl, need), need); atomicAdd(&IPW(ctl, merges), merges); atomicAdd(&IPW(ctl, gone), gone); }
+    if (threadIdx.x == 0) { sums[blockIdx.x] = Int2{need, merges}; removed[blockIdx.x] = gone; }
 }
 
-// K3 -- merge (merge.cu:189-278), in place, for the absorbers of the pass, and who has to look again: the absorber for every axis and, per axis, the cell
-// behind its lower corner.  The merged lists are appended behind the live references in the SAME buffer (its tail is free once the first iterations have
-// shrunk the lists): a workgroup draws the slots of its 256 absorbers with one atomic.  A pass whose lists do not fit is not applied at all, nor is any later
-// pass of the iteration (books[3] = 1 + its axis, sticky): the host compacts and runs those passes the compacting way.  The last workgroup closes the books.
-__global__ void __launch_bounds__(kBlock) ip_apply(int axis, MergeK k, const Entry* __restrict__ entries, void* cells, int* list_end, int* refs, IpLists L, IpCtl* ctl,
-                                                   const Int2* __restrict__ minfo, const int* __restrict__ nexts, unsigned char* dirty, size_t dstride,
-                                                   int* books /* cursor, live cells, live refs, overflow */, int* __restrict__ snap, int capacity) {
-    __shared__ int last;
-    const int n = IPW(ctl, absorbers), cursor = books[0];
+// merge (merge.cu:189-278), in place.
+// The merged lists are appended behind the live references in the SAME buffer (its tail is free once the first iterations have shrunk the lists).
+// A pass whose lists do not fit is not applied at all, nor is any later pass of the iteration (books[3] = 1 + its axis, sticky): the host compacts and
+// runs those passes the compacting way.
+__global__ void __launch_bounds__(kBlock) ip_apply(void* cells, int* list_end, int* refs, const unsigned char* __restrict__ absorbs, int pass_tag,
+                                                   const Int2* __restrict__ minfo, const int* __restrict__ nexts, const Int2* __restrict__ tile_prefix,
+                                                   int slots, int* __restrict__ books, const Int2* __restrict__ pass_total, int capacity, int axis) {
+    __shared__ int lds[kWaves];
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    const int* cursor = books;
     const int overflow = __hip_atomic_load(books + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool fits = overflow == 0 && (long long)cursor + IPW(ctl, need) <= (long long)capacity;       // (the same answer in every thread: none of the words changes before the books close)
-    int* const lists[3] = {L.dirty[0], L.dirty[1], L.dirty[2]};
-    if (fits) for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const int i = base + threadIdx.x;
-        const int id = i < n ? L.absorbers[i] : -1;
-        const int m = id >= 0 ? minfo[id].a : 0;
-        // the slots of a wavefront's 64 merged lists: one atomic (no barrier in this loop: every step below is a chain of dependent gathers)
-        const int incl = wave_inclusive_scan(m);
-        int wbase = 0;
-        if (lane_id() == 63 && incl) wbase = atomicAdd(&IPW(ctl, alloc), incl);
-        const int before = __shfl(wbase, 63, 64) + incl - m;
-        ivec3 lo(0, 0, 0);
-        if (id >= 0) {
-            const int at = cursor + before, other = nexts[id];
-            const CellRec a = ip_load(cells, list_end, id), o = ip_load(cells, list_end, other);
-            write_union(refs + a.begin, a.end - a.begin, refs + o.begin, o.end - o.begin, refs + at, m);
-            lo = min(o.lo, a.lo);
-            CellFmt<true>::store(cells, id, lo, at, max(o.hi, a.hi), 0);
-            list_end[id] = at + m;
-            reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
-        }
-        // who has to look again (a cell found through a slot that another thread of this launch turns into a tombstone may be marked in its absorber's
-        // stead: that absorber marks itself for every axis).  The six flag atomics of a lane are independent, and so are the three list atomics of the
-        // wavefront: issued together, waited for once.
-        int who[6]; bool fresh[6];
-        for (int ax = 0; ax < 3; ax++) {
-            ivec3 p = lo;
-            if (ax == 0) p.x--; else if (ax == 1) p.y--; else p.z--;
-            const bool behind = id >= 0 && comp(p, ax) >= 0;
-            who[2 * ax] = id; who[2 * ax + 1] = behind ? ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p))) : -1;
-        }
-        for (int j = 0; j < 6; j++) {
-            fresh[j] = false;
-            // (the cell behind the lower corner of axis a is never the absorber itself; two lanes may name the same cell: the flag decides)
-            if (who[j] >= 0) {
-                const size_t at = size_t(j >> 1) * dstride + size_t(who[j]);
-                const uint32_t sh = 8u * uint32_t(at & 3);
-                fresh[j] = (atomicOr(reinterpret_cast<uint32_t*>(dirty + (at & ~size_t(3))), 1u << sh) & (0xffu << sh)) == 0u;
-            }
-        }
-        int upto[3], cnt[3], basev[3] = {0, 0, 0};
-        for (int ax = 0; ax < 3; ax++) { cnt[ax] = int(fresh[2 * ax]) + int(fresh[2 * ax + 1]); upto[ax] = wave_inclusive_scan(cnt[ax]); }
-        if (lane_id() == 63) for (int ax = 0; ax < 3; ax++) if (upto[ax]) basev[ax] = atomicAdd(&ctl->tail_[ax].v, upto[ax]);
-        for (int ax = 0; ax < 3; ax++) {
-            int at = __shfl(basev[ax], 63, 64) + upto[ax] - cnt[ax];
-            if (fresh[2 * ax]) lists[ax][at++] = who[2 * ax];
-            if (fresh[2 * ax + 1]) lists[ax][at] = who[2 * ax + 1];
+    if (overflow > 0 || (long long)*cursor + pass_total->a > (long long)capacity) {       // (the same answer in every thread: books[0] and the total do not change in this kernel)
+        if (id4 == 0 && overflow <= 0) __hip_atomic_store(books + 3, -(1 + axis), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // negative: "this pass"; ip_mark makes it sticky
+        return;
+    }
+    const uint32_t mine = id4 < slots ? ip_match4(ip_flags4(absorbs, id4, slots), pass_tag) : 0u;
+    int m[4], total = 0;
+    for (int c = 0; c < 4; c++) { m[c] = (mine & (1u << (8 * c))) ? minfo[id4 + c].a : 0; total += m[c]; }
+    const int incl = wave_inclusive_scan(total);
+    if (lane_id() == 63) lds[wave_id()] = incl;
+    __syncthreads();
+    if (!mine) return;
+    int at = *cursor + tile_prefix[blockIdx.x].a + incl - total;
+    for (int w = 0; w < wave_id(); w++) at += lds[w];
+    for (int c = 0; c < 4; c++) {
+        if (!(mine & (1u << (8 * c)))) continue;
+        const int id = id4 + c, other = nexts[id];
+        const CellRec a = ip_load(cells, list_end, id), n = ip_load(cells, list_end, other);
+        write_union(refs + a.begin, a.end - a.begin, refs + n.begin, n.end - n.begin, refs + at, m[c]);
+        CellFmt<true>::store(cells, id, min(n.lo, a.lo), at, max(n.hi, a.hi), 0);
+        list_end[id] = at + m[c];
+        reinterpret_cast<uint4*>(cells)[other] = make_uint4(kTombLo, 0u, 0u, uint32_t(id));
+        at += m[c];
+    }
+}
+
+// who has to look again: the absorber for every axis and, per axis, the cell behind its lower corner; block 0 closes the books of the pass
+__global__ void __launch_bounds__(kBlock) ip_mark(MergeK k, const Entry* __restrict__ entries, const void* __restrict__ cells, const unsigned char* __restrict__ absorbs,
+                                                  int pass_tag, int slots, unsigned char* __restrict__ dirty, const Int2* __restrict__ pass_total,
+                                                  const int* __restrict__ removed, int num_tiles, int* __restrict__ books /* cursor, live cells, live refs, overflow */,
+                                                  int* __restrict__ snap, size_t dstride) {
+    __shared__ int lds[kWaves];
+    const int id4 = (blockIdx.x * kBlock + threadIdx.x) * kIpPer;
+    const int overflow = books[3];                    // (written by the previous kernel at the latest; this kernel's thread 0 only changes its sign)
+    if (blockIdx.x == 0) {                            // the books of the pass: cursor, live cells, live references
+        int gone = 0;
+        for (int i = threadIdx.x; i < num_tiles; i += kBlock) gone += removed[i];
+        gone = block_sum(gone, lds);
+        if (threadIdx.x == 0) {
+            if (overflow == 0) { books[0] += pass_total->a; books[1] -= pass_total->b; books[2] -= gone; }
+            else if (overflow < 0) books[3] = -overflow;
+            snap[0] = books[1]; snap[1] = books[2];
         }
     }
-    // the books of the pass: cursor, live cells, live references; the lists and totals of the next pass start empty
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&IPW(ctl, ticket), 1) == int(gridDim.x) - 1;
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        if (fits) { books[0] += IPW(ctl, need); books[1] -= IPW(ctl, merges); books[2] -= IPW(ctl, gone); }
-        else if (overflow == 0) books[3] = 1 + axis;
-        snap[0] = books[1]; snap[1] = books[2];
-        IPW(ctl, swept) = 0; IPW(ctl, absorbers) = 0; IPW(ctl, need) = 0; IPW(ctl, merges) = 0; IPW(ctl, gone) = 0; IPW(ctl, alloc) = 0; IPW(ctl, ticket) = 0;
+    __shared__ int list[kIpTile];
+    __shared__ int count;
+    const uint32_t mine = (overflow == 0 && id4 < slots) ? ip_match4(ip_flags4(absorbs, id4, slots), pass_tag) : 0u;
+    const int n = ip_compact_tile(mine, id4, list, &count);
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int id = list[i];
+        const CellRec cell = CellFmt<true>::load(cells, id);
+        for (int axis = 0; axis < 3; axis++) {
+            dirty[size_t(axis) * dstride + id] = 1;
+            ivec3 p = cell.lo;
+            if (axis == 0) p.x--; else if (axis == 1) p.y--; else p.z--;
+            if (comp(p, axis) < 0) continue;
+            dirty[size_t(axis) * dstride + ip_live(cells, int(lookup_entry(entries, k.shift, k.top, p)))] = 1;
+        }
     }
 }
 
@@ -714,10 +667,9 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     Int2* tile_sums = pool_alloc<Int2>(ctx, size_t(max_tiles) + 1);
     Int2* partials = pool_alloc<Int2>(ctx, size_t(scan_num_tiles(max_tiles)) + 1);
     Int2* total = reinterpret_cast<Int2*>(ctx->dscratch);
-    IpCtl* ipc = pool_alloc<IpCtl>(ctx, 1);                                // control words of the in-place iterations (without them the merge compacts throughout)
     auto release = [&]() {
         hagrid_mem_free(ctx, merge_counts); hagrid_mem_free(ctx, nexts); hagrid_mem_free(ctx, prevs); hagrid_mem_free(ctx, cell_flags);
-        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, stamps_base); hagrid_mem_free(ctx, ipc);
+        hagrid_mem_free(ctx, tile_sums); hagrid_mem_free(ctx, partials); hagrid_mem_free(ctx, stamps_base);
     };
     if (!cells_b || !refs_b || !merge_counts || !nexts || !prevs || !cell_flags || !tile_sums || !partials || !stamps) {
         release(); hagrid_mem_free(ctx, cells_b); hagrid_mem_free(ctx, refs_b);
@@ -752,34 +704,30 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
     int ip_slots = 0, ip_iters = 0, prev_mask = 0;
     int* list_end = merge_counts;
     Int2* minfo = nullptr; unsigned char* dirty = nullptr; unsigned char* evaluated = nullptr;
-    IpLists ipl = {};                                                     // the dirty list of every axis, the lists of a pass
     int* books = ctx->dscratch + 16;                                      // cursor, live cells, live references, overflow (1 + axis of the first pass that did not fit)
     int* snap = ctx->dscratch + 20;                                       // live cells / references behind each of the three passes
     Int2* ip_total = reinterpret_cast<Int2*>(ctx->dscratch + 26);
+    int* tile_removed = nullptr;                                          // references that disappear, per tile of the pass
     const int ip_capacity = int(std::min<size_t>(nr0, 0x7fffffff));       // both reference buffers hold nr0 ints
-    const int ip_blocks = std::max(ctx->num_cus, 1) * 8;                  // the passes of the mode sweep their lists with this many workgroups (the resident set: their work is dependent gathers)
-    size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the flags are set by word atomics)
-    // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).  Returns false -- and the merge
-    // goes on compacting -- when the scratch of the mode does not fit the idle cell buffer (32 bytes per cell of the un-merged grid; the mode needs 28 per slot).
+    // Enters the mode behind a compacting iteration (cells: num_cells working records, refs: num_refs references, compact).
+    size_t ip_dstride = 0;                                                // bytes between the dirty flags of two axes (a multiple of 256: the sweeps load four flags at a time)
+    // (returns false -- and the merge goes on compacting -- when the scratch of the mode does not fit the idle cell buffer: grids of a few dozen cells)
     auto ip_enter = [&]() -> bool {
         const auto r256 = [](size_t n) { return (n + 255) & ~size_t(255); };
-        const size_t slots = size_t(num_cells), dstride = r256(slots), ints = r256(slots * sizeof(int));
-        const size_t off_dirty = r256(slots * 8), off_eval = off_dirty + 3 * dstride, off_lists = off_eval + r256(slots);
-        if (!ipc || off_lists + 4 * ints > nc0 * sizeof(Cell)) return false;
+        const size_t slots = size_t(num_cells), dstride = r256(slots);
+        const size_t off_dirty = r256(slots * 8), off_eval = off_dirty + 3 * dstride, off_removed = off_eval + r256(slots);
+        if (off_removed + r256(size_t(grid_blocks(num_cells, kIpTile)) * sizeof(int)) > nc0 * sizeof(Cell)) return false;
         ip_slots = num_cells; ip_dstride = dstride;
-        char* scratch = static_cast<char*>(cells_other);
+        char* scratch = static_cast<char*>(cells_other);                   // 32 bytes per cell of the un-merged grid: 12 per slot are used
         minfo = reinterpret_cast<Int2*>(scratch);
         dirty = reinterpret_cast<unsigned char*>(scratch + off_dirty);
         evaluated = reinterpret_cast<unsigned char*>(scratch + off_eval);
-        for (int a = 0; a < 3; a++) ipl.dirty[a] = reinterpret_cast<int*>(scratch + off_lists + size_t(a) * ints);
-        ipl.absorbers = reinterpret_cast<int*>(scratch + off_lists + 3 * ints);
+        tile_removed = reinterpret_cast<int*>(scratch + off_removed);
         // dirty cells: the ones made after the last evaluation of the axis (their stamps say so) and the cells behind their lower corners
         const unsigned char* stp = have_stamps ? stamps : nullptr;
-        (void)hipMemsetAsync(ipc, 0, sizeof(IpCtl), st);
         ip_begin<<<grid_blocks(ip_slots, kBlock), kBlock, 0, st>>>(cells, ip_slots, list_end, dirty, stp, since[0], since[1], since[2],
-                                                                   evaluated, books, num_refs, ip_dstride); HG_DBG(ctx);
+                                                                   evaluated, cell_flags /* the mode's `absorbs` tags */, books, num_refs, ip_dstride); HG_DBG(ctx);
         if (stp) ip_mark_entry<<<grid_blocks(ip_slots, kIpTile), kBlock, 0, st>>>(k, reinterpret_cast<const Entry*>(entries), cells, ip_slots, dirty, stp, since[0], since[1], since[2], ip_dstride); HG_DBG(ctx);
-        ip_build_lists<<<grid_blocks(ip_slots, 16 * kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 0); HG_DBG(ctx);
         in_place = true;
         return true;
     };
@@ -858,25 +806,22 @@ extern "C" int hagrid_merge_grid(hagrid_ctx* ctx, hagrid_grid* grid, float alpha
         int first_compacting_axis = 0;
         if (in_place) {
             // every cell looks again when the mask lets merges through that it held back before (merge.cu:361: from the fifth iteration on)
-            if (prev_mask & ~mask) {
-                (void)hipMemsetAsync(dirty, 1, 3 * ip_dstride, st);
-                (void)hipMemsetAsync(ipc->tail_, 0, 3 * sizeof(IpWord), st);
-                ip_build_lists<<<grid_blocks(ip_slots, 16 * kBlock), kBlock, 0, st>>>(dirty, ip_dstride, ip_slots, ipl, ipc, 1); HG_DBG(ctx);
-            }
+            if (prev_mask & ~mask) (void)hipMemsetAsync(dirty, 1, 3 * ip_dstride, st);
+            const int blocks = grid_blocks(ip_slots, kIpTile), tiles = blocks;
             const Entry* ent = reinterpret_cast<const Entry*>(entries);
-            const int cap = ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity;
             for (int axis = 0; axis < 3 && rc == HAGRID_OK; axis++) {
                 global_pass++;
                 if (++pass_tag == 256) {                                   // tags are bytes
                     pass_tag = 1;
-                    (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st);
+                    (void)hipMemsetAsync(prevs, 0, nc0, st); (void)hipMemsetAsync(evaluated, 0, size_t(ip_slots), st); (void)hipMemsetAsync(cell_flags, 0, size_t(ip_slots), st);
                 }
-                // three launches per pass, each a grid-stride sweep over a LIST (the dirty cells of the axis, the cells that found a partner, the absorbers):
-                // a late pass touches a few thousand cells and costs its launches.  (Round 4 swept a flag byte per slot in six launches per pass: 36 launches
-                // and 0.55 ms for the two in-place iterations of the 1M-triangle soup, which merge 3 % of the cells.)
-                ip_counts<<<ip_blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, dirty + size_t(axis) * ip_dstride, ipl, ipc, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
-                ip_chains<<<ip_blocks, kBlock, 0, st>>>(axis, ipl, ipc, nexts, evaluated, prevs, minfo, pass_tag); HG_DBG(ctx);
-                ip_apply<<<ip_blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ipl, ipc, minfo, nexts, dirty, ip_dstride, books, snap + 2 * axis, cap); HG_DBG(ctx);
+                ip_counts<<<blocks, kBlock, 0, st>>>(axis, k, ent, cells, list_end, refs, ip_slots, dirty + size_t(axis) * ip_dstride, minfo, nexts, evaluated, prevs, pass_tag, mask); HG_DBG(ctx);
+                ip_chains<<<blocks, kBlock, 0, st>>>(ip_slots, nexts, evaluated, prevs, cell_flags, pass_tag); HG_DBG(ctx);
+                ip_tile_sums<<<tiles, kBlock, 0, st>>>(cell_flags, pass_tag, minfo, ip_slots, tile_sums, tile_removed); HG_DBG(ctx);
+                if (!ctx_scan<Int2>(ctx, SumsIn{tile_sums}, SumsOut{tile_sums}, tiles, partials, (const Int2*)nullptr, ip_total)) { rc = HAGRID_ENOMEM; break; }
+                ip_apply<<<tiles, kBlock, 0, st>>>(cells, list_end, refs, cell_flags, pass_tag, minfo, nexts, tile_sums, ip_slots, books, ip_total,
+                                                    ctx->opt_merge_inplace_room > 0 ? std::min(ip_capacity, ctx->opt_merge_inplace_room) : ip_capacity, axis); HG_DBG(ctx);
+                ip_mark<<<blocks, kBlock, 0, st>>>(k, ent, cells, cell_flags, pass_tag, ip_slots, dirty, ip_total, tile_removed, tiles, books, snap + 2 * axis, ip_dstride); HG_DBG(ctx);
             }
             if (rc != HAGRID_OK) break;
             int h[10];                                                     // books (4), the three snapshots
