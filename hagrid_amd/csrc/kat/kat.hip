@@ -107,7 +107,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
             o[2] = uint32_t((vz & om) - int(field(32, 8))) | uint32_t((vz & om) + int(field(40, 8))) << 16;
         }
         const uint32_t marker = field(48 + (ni - 1) * slim, slim);
-        const bool wide = general && marker == none - 3u;
+        const bool wide = !slim_uniform && marker == none - 3u;
         if (marker == none - 1u || wide) {
             const uint32_t cnt = field(80, 20);
             uint32_t first = field(48, 32);

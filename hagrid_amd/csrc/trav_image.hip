@@ -325,117 +325,6 @@ __device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long l
     } else hi = (hi & ~(m << (pos - 64))) | (x << (pos - 64));
 }
 
-// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
-// not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
-// TABLE: the block of top-level cell T has depth metas[T] & 3 and starts at record offsets[T]; its bound bytes count from the origin
-// of the top-level cell, biased by 128.
-template <int D, int IDB, bool TABLE>
-__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
-                                                      const uint32_t* __restrict__ metas, const int* __restrict__ offsets) {
-    constexpr int NI = 80 / IDB;
-    constexpr uint32_t NONE = (1u << IDB) - 1u;
-    const int T = blockIdx.x, lane = threadIdx.x;
-    const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
-    const uint32_t topw = k.entries[T];
-    const int d = TABLE ? int(metas[T] & 3u) : D, sd = D - d, V = 1 << (3 * d);
-    const size_t first = TABLE ? size_t(offsets[T]) : size_t(T) << (3 * D);
-    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(d) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
-    for (int f = lane; f < V; f += 64) {
-        // block voxel f at depth d -> its lowest finest-level voxel inside the top-level cell
-        const int rx = (f & ((1 << d) - 1)) << sd, ry = ((f >> d) & ((1 << d) - 1)) << sd, rz = (f >> (2 * d)) << sd;
-        uint32_t w = topw;
-        int depth = 0;
-        while (w & 3u) {
-            const int kk = int(w & 3u);
-            depth += kk;
-            const int s = D - depth, m = (1 << kk) - 1;
-            w = k.entries[int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk)];
-        }
-        const int c = int(w >> 2);
-        int lo[3], hi[3], begin, n;
-        if (k.small_cells) {
-            const uint4 sc = k.small_cells[c];
-            lo[0] = int(sc.x & 0xffffu); lo[1] = int(sc.x >> 16); lo[2] = int(sc.y & 0xffffu);
-            hi[0] = int(sc.y >> 16); hi[1] = int(sc.z & 0xffffu); hi[2] = int(sc.z >> 16);
-            begin = int(sc.w); n = 0;
-            if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
-            else begin = 0;
-        } else {
-            const int4 a = k.cells[2 * size_t(c)], b = k.cells[2 * size_t(c) + 1];
-            lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
-            begin = a.w; n = b.w - a.w;
-        }
-        const int v[3] = {(tx << D) + (TABLE ? 0 : rx), (ty << D) + (TABLE ? 0 : ry), (tz << D) + (TABLE ? 0 : rz)};
-        unsigned long long rl = ~0ull << 48, rh = ~0ull;               // every id field "unused"
-        int bad = 0;
-        for (int ax = 0; ax < 3; ax++) {
-            const int dl = TABLE ? lo[ax] - v[ax] + 128 : v[ax] - lo[ax], dh = TABLE ? hi[ax] - v[ax] + 128 : hi[ax] - v[ax];
-            if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
-            rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
-        }
-        // an id that does not fit the field (the kernel takes NONE for the end of a list, wherever the id came from): the whole image
-        // needs the wider field
-        bool wide = false;
-        for (int i = 0; i < n; i++) wide = wide || uint32_t(k.refs[begin + i]) >= NONE - 1u;
-        if (wide) atomicAdd(status + 1, 1);
-        if (n <= NI && !wide) {
-            for (int i = 0; i < n; i++) put_bits(rl, rh, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
-        } else {
-            if (n >= (1 << 20)) bad |= 2;
-            put_bits(rl, rh, 48, 32, uint32_t(begin));
-            put_bits(rl, rh, 80, 20, uint32_t(n));
-            put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
-        }
-        if (bad) atomicOr(status, bad);
-        recs[first + f] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
-    }
-}
-
-struct SlimSizeIn { const uint32_t* m; __device__ int operator()(int i) const { return 1 << (3 * int(m[i] & 3u)); } };
-struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
-
-// uniform: every block has (2^D)^3 records, block T starts at T * (2^D)^3; otherwise `metas` holds the depth of every block and the
-// offsets come from a scan over the block sizes.  Returns 1 when some cell does not fit a slim record.
-template <int D>
-int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
-    long long records = (long long)k.num_top << (3 * D);
-    if (!uniform) {
-        int* total = ctx->dscratch + 227;
-        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
-        int h = 0;
-        const int rc = read_back(ctx, total, &h, sizeof(h));
-        if (rc != HAGRID_OK) return rc;
-        records = h;
-    }
-    if (records <= 0 || records >= (1ll << 28)) return 1;               // record offsets of the narrow kernels: 32-bit byte offsets
-    const size_t bytes = size_t(records) * 16u;
-    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
-    if (!recs) return HAGRID_ENOMEM;
-    int* status = ctx->dscratch + 228;
-    for (int idb : {20, 26}) {
-        if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
-        (void)hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream);
-        if (uniform) {
-            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
-            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr);
-        } else {
-            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
-            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets);
-        }
-        HG_DBG(ctx);
-        int h[2] = {0, 0};
-        const int rc = read_back(ctx, status, h, sizeof(h));
-        if (rc != HAGRID_OK) { hagrid_mem_free(ctx, recs); return rc; }
-        if (h[0]) break;                            // some cell does not fit a slim record: 32-byte records
-        if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
-        if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
-        img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
-        return HAGRID_OK;
-    }
-    hagrid_mem_free(ctx, recs);
-    return 1;
-}
-
 // ---- general layout: one slim record per voxel-map ENTRY ---------------------------------------------------------------------------
 // Grids whose top-level cells differ in depth, and grids deeper than three levels (non-uniform scenes; the reference advertises N-level maps, README.md:12).
 // The image is the voxel map itself with every 4-byte entry widened to a 16-byte slim record at the SAME index: a leaf entry becomes its cell (bounds, ids
@@ -552,7 +441,7 @@ __global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, uint
 }
 // records that name a wide cell get the index of its wide record; the wide records themselves
 template <int IDB>
-__global__ void __launch_bounds__(kBlock) image_general_patch(uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim) {
+__global__ void __launch_bounds__(kBlock) image_general_patch(uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim, int first_wide) {
     constexpr int NI = 80 / IDB, LAST = 48 + (NI - 1) * IDB;
     constexpr uint32_t NONE = (1u << IDB) - 1u;
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -562,7 +451,7 @@ __global__ void __launch_bounds__(kBlock) image_general_patch(uint4* __restrict_
     const uint32_t last = uint32_t(rh >> (LAST - 64)) & NONE;
     if (last != NONE - 3u) return;
     const uint32_t c = uint32_t(rl >> 48) | uint32_t(rh & 0xffffu) << 16;
-    put_bits(rl, rh, 48, 32, uint32_t(claim[c]));
+    put_bits(rl, rh, 48, 32, uint32_t(first_wide + claim[c]));
     recs[i] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
 }
 __global__ void __launch_bounds__(kBlock) image_general_wide(const ImgK k, int num_cells, const int* __restrict__ claim, uint4* __restrict__ wide) {
@@ -623,8 +512,8 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
         uint4* wide = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(std::max(h[2], 1)) * 16u));
         if (!wide) { rc = HAGRID_ENOMEM; break; }
         if (h[2] > 0) {
-            if (idb == 20) image_general_patch<20><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim);
-            else           image_general_patch<26><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim);
+            if (idb == 20) image_general_patch<20><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim, 0);
+            else           image_general_patch<26><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim, 0);
             HG_DBG(ctx);
             image_general_wide<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(k, num_cells, claim, wide); HG_DBG(ctx);
         }
@@ -636,6 +525,144 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     release();
     if (rc != HAGRID_OK) hagrid_mem_free(ctx, recs);
     return rc;
+}
+
+// One wavefront per top-level cell of a grid whose top-level cells all resolve `shift` = D levels.  status: bit 0 = a bound does
+// not fit a byte, bit 1 = a by-index list is too long; word 1 counts the lists that hold an id of more than IDB bits.
+// TABLE: the block of top-level cell T has depth metas[T] & 3 and starts at record offsets[T]; its bound bytes count from the origin
+// of the top-level cell, biased by 128.
+// TABLE only: a cell whose bounds do not fit the bytes (the large cells of empty space) gets a WIDE record, as in the general layout below: the record names the
+// cell (image_general_patch replaces it by the index of the cell's wide record), status word 2 counts the wide records, claim[c] holds their indices.
+template <int D, int IDB, bool TABLE>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
+                                                      const uint32_t* __restrict__ metas, const int* __restrict__ offsets, int* __restrict__ claim) {
+    constexpr int NI = 80 / IDB;
+    constexpr uint32_t NONE = (1u << IDB) - 1u;
+    const int T = blockIdx.x, lane = threadIdx.x;
+    const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
+    const uint32_t topw = k.entries[T];
+    const int d = TABLE ? int(metas[T] & 3u) : D, sd = D - d, V = 1 << (3 * d);
+    const size_t first = TABLE ? size_t(offsets[T]) : size_t(T) << (3 * D);
+    if (lane == 0) table[T] = make_uint2(uint32_t(first), uint32_t(d) | 8u | 16u | (uint32_t(V) << 8));   // offset in records; bit 4: slim
+    for (int f = lane; f < V; f += 64) {
+        // block voxel f at depth d -> its lowest finest-level voxel inside the top-level cell
+        const int rx = (f & ((1 << d) - 1)) << sd, ry = ((f >> d) & ((1 << d) - 1)) << sd, rz = (f >> (2 * d)) << sd;
+        uint32_t w = topw;
+        int depth = 0;
+        while (w & 3u) {
+            const int kk = int(w & 3u);
+            depth += kk;
+            const int s = D - depth, m = (1 << kk) - 1;
+            w = k.entries[int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk)];
+        }
+        const int c = int(w >> 2);
+        int lo[3], hi[3], begin, n;
+        if (k.small_cells) {
+            const uint4 sc = k.small_cells[c];
+            lo[0] = int(sc.x & 0xffffu); lo[1] = int(sc.x >> 16); lo[2] = int(sc.y & 0xffffu);
+            hi[0] = int(sc.y >> 16); hi[1] = int(sc.z & 0xffffu); hi[2] = int(sc.z >> 16);
+            begin = int(sc.w); n = 0;
+            if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
+            else begin = 0;
+        } else {
+            const int4 a = k.cells[2 * size_t(c)], b = k.cells[2 * size_t(c) + 1];
+            lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+            begin = a.w; n = b.w - a.w;
+        }
+        const int v[3] = {(tx << D) + (TABLE ? 0 : rx), (ty << D) + (TABLE ? 0 : ry), (tz << D) + (TABLE ? 0 : rz)};
+        unsigned long long rl = ~0ull << 48, rh = ~0ull;               // every id field "unused"
+        int bad = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            const int dl = TABLE ? lo[ax] - v[ax] + 128 : v[ax] - lo[ax], dh = TABLE ? hi[ax] - v[ax] + 128 : hi[ax] - v[ax];
+            if (dl < 0 || dl > 255 || dh < 0 || dh > 255) bad |= 1;
+            rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
+        }
+        // an id that does not fit the field (the kernel takes NONE for the end of a list, wherever the id came from): the whole image
+        // needs the wider field
+        bool wide = false;
+        for (int i = 0; i < n; i++) wide = wide || uint32_t(k.refs[begin + i]) >= NONE - (TABLE ? 3u : 1u);
+        if (wide) atomicAdd(status + 1, 1);
+        if (TABLE && (bad & 1)) {
+            bad &= ~1;
+            if (atomicCAS(claim + c, -1, -2) == -1) claim[c] = atomicAdd(status + 2, 1);
+            if (n >= (1 << 20)) bad |= 2;
+            put_bits(rl, rh, 48, 32, uint32_t(c));
+            put_bits(rl, rh, 80, 20, uint32_t(n));
+            put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 3u);
+        } else if (n <= NI && !wide) {
+            for (int i = 0; i < n; i++) put_bits(rl, rh, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
+        } else {
+            if (n >= (1 << 20)) bad |= 2;
+            put_bits(rl, rh, 48, 32, uint32_t(begin));
+            put_bits(rl, rh, 80, 20, uint32_t(n));
+            put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
+        }
+        if (bad) atomicOr(status, bad);
+        recs[first + f] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
+    }
+}
+
+struct SlimSizeIn { const uint32_t* m; __device__ int operator()(int i) const { return 1 << (3 * int(m[i] & 3u)); } };
+struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
+
+// uniform: every block has (2^D)^3 records, block T starts at T * (2^D)^3; otherwise `metas` holds the depth of every block and the
+// offsets come from a scan over the block sizes.  Returns 1 when some cell does not fit a slim record.
+template <int D>
+int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
+    long long records = (long long)k.num_top << (3 * D);
+    if (!uniform) {
+        int* total = ctx->dscratch + 227;
+        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
+        int h = 0;
+        const int rc = read_back(ctx, total, &h, sizeof(h));
+        if (rc != HAGRID_OK) return rc;
+        records = h;
+    }
+    if (records <= 0 || records >= (1ll << 28)) return 1;               // record offsets of the narrow kernels: 32-bit byte offsets
+    const size_t bytes = size_t(records) * 16u;
+    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, bytes));
+    if (!recs) return HAGRID_ENOMEM;
+    int* claim = uniform ? nullptr : pool_alloc<int>(ctx, size_t(k.num_cells));       // table layout: the wide record of every cell that needs one
+    if (!uniform && !claim) { hagrid_mem_free(ctx, recs); return HAGRID_ENOMEM; }
+    int* status = ctx->dscratch + 228;
+    int result = 1;
+    for (int idb : {20, 26}) {
+        if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
+        (void)hipMemsetAsync(status, 0, 3 * sizeof(int), ctx->stream);
+        if (claim) (void)hipMemsetAsync(claim, 0xFF, size_t(k.num_cells) * sizeof(int), ctx->stream);
+        if (uniform) {
+            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr, nullptr);
+            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr, nullptr);
+        } else {
+            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets, claim);
+            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets, claim);
+        }
+        HG_DBG(ctx);
+        int h[3] = {0, 0, 0};
+        const int rc = read_back(ctx, status, h, sizeof(h));
+        if (rc != HAGRID_OK) { result = rc; break; }
+        if (h[0]) break;                            // uniform layout: some cell does not fit a slim record (the table layout has wide records for those); a list of 2^20 ids
+        if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
+        if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
+        if (h[2] > 0) {
+            // wide records behind the table, in ONE buffer (the kernels know one more pointer than the records): 16-byte units from the table's start
+            const size_t table16 = (size_t(k.num_top) * 8u + 15u) / 16u;
+            uint4* both = static_cast<uint4*>(hagrid_mem_alloc(ctx, (table16 + size_t(h[2])) * 16u));
+            if (!both) { result = HAGRID_ENOMEM; break; }
+            (void)hipMemcpyAsync(both, table, size_t(k.num_top) * 8u, hipMemcpyDeviceToDevice, ctx->stream);
+            if (idb == 20) image_general_patch<20><<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(recs, int(records), claim, int(table16));
+            else           image_general_patch<26><<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(recs, int(records), claim, int(table16));
+            HG_DBG(ctx);
+            image_general_wide<<<grid_blocks(k.num_cells, kBlock), kBlock, 0, ctx->stream>>>(k, k.num_cells, claim, both + table16); HG_DBG(ctx);
+            img.table = both; img.table_bytes = (table16 + size_t(h[2])) * 16u;      // (the caller's table is released with its other temporaries)
+        } else { img.table = nullptr; img.table_bytes = size_t(k.num_top) * 8u; }
+        img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
+        result = HAGRID_OK;
+        break;
+    }
+    hagrid_mem_free(ctx, claim);
+    if (result != HAGRID_OK) hagrid_mem_free(ctx, recs);
+    return result;
 }
 
 struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
@@ -697,11 +724,21 @@ int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
         // at 4096^2, round 5 -- the table layout stays.)
         int rs = 1;
         if (D == k.shift && D >= 1) {
-            int* offs = nullptr;
-            if (!uniform) { offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1); if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; } }
-            rs = build_slim<D>(ctx, k, img, table, uniform, metas, offs, partials);
-            hagrid_mem_free(ctx, offs);
-            if (rs == HAGRID_OK) { release(); img.uniform = uniform; img.table = table; img.table_bytes = size_t(k.num_top) * 8u; return HAGRID_OK; }
+            uint2* own_table = nullptr;                  // (the table layout with wide records brings a table of its own: table + wide records in one buffer)
+            if (uniform) rs = build_slim<D>(ctx, k, img, table, true, metas, nullptr, partials);
+            bool is_uniform = rs == HAGRID_OK;
+            if (rs == 1) {                               // top-level cells of different depth, or a cell the uniform layout's bytes cannot hold
+                int* offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
+                if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+                rs = build_slim<D>(ctx, k, img, table, false, metas, offs, partials);
+                hagrid_mem_free(ctx, offs);
+                own_table = static_cast<uint2*>(img.table);
+            }
+            if (rs == HAGRID_OK) {
+                release(); img.uniform = is_uniform;
+                if (own_table) hagrid_mem_free(ctx, table); else img.table = table;
+                return HAGRID_OK;
+            }
         }
         if (rs == 1 && ctx->opt_image_general) {
             rs = build_general(ctx, k, img);
@@ -818,7 +855,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     }
     img.flat = flat;
     if (rc != HAGRID_OK) return rc;
-    img.valid = img.table != nullptr;
+    img.valid = img.blocks != nullptr;
     img.standalone = img.general || (flat && g->shift <= 6);            // the general layout never links back; blocks + nested blocks resolve six levels, only deeper grids keep `deep` links
     img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
     img.cell_bytes = g->small_cells ? 16 : 32;

@@ -147,11 +147,17 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                     cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
                     wide_begin = wr.w;
                 }
-            } else if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell
+            } else if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell, or a wide record
                 const int org_mask = ~((1 << a.shift) - 1);
                 cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
                 cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
                 cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
+                wide_cell = GenWalk<SLIM ? SLIM : 20>::is_wide(ca);
+                if (wide_cell) {
+                    const uint4 wr = GenWalk<SLIM ? SLIM : 20>::wide_at(a, ca);
+                    cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
+                    wide_begin = wr.w;
+                }
             } else if (SLIM) {     // byte offsets from the voxel the record belongs to
                 // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
@@ -470,6 +476,11 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
             cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
             cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
+            const bool wide = GenWalk<SLIM>::is_wide(rec);          // a cell the bytes cannot hold: absolute bounds in its wide record (the large cells of empty space)
+            if (__ballot(wide) != 0ull && wide) {
+                const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
+                cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
+            }
         } else {
             // general layout: byte offsets from the origin of the record's region (2^s voxels wide) -- or, for the few cells that reach further, a wide
             // record with absolute 16-bit bounds (one more dependent gather, in steps through the large cells of empty space only)
@@ -500,7 +511,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
     auto test_list = [&](const uint4& rec) {
-        const bool wide_cell = GENERAL && GenWalk<SLIM>::is_wide(rec);
+        const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(rec);
         const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
         int ref = int(field(rec, 48, SLIM));
         uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
@@ -740,8 +751,14 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             int c;
             const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
             if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
-            else if (TABLE) c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;             // table layout: bounds count from the top-level cell's origin
-            else {
+            else if (TABLE) {             // table layout: bounds count from the top-level cell's origin; a wide cell has absolute bounds in its wide record
+                c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;
+                const bool wide = GenWalk<SLIM>::is_wide(rec);
+                if (__ballot(wide) != 0ull && wide) {
+                    const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
+                    c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
+                }
+            } else {
                 // general layout: the byte counts from the origin of the record's region; a wide cell has absolute bounds in its wide record
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v & int(~0u << gw.region_shift())));
                 const bool wide = GenWalk<SLIM>::is_wide(rec);
@@ -786,7 +803,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint4 na = quad_step(ca);
-                const bool wide_cell = GENERAL && GenWalk<SLIM>::is_wide(ca);
+                const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(ca);
                 const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;

@@ -500,8 +500,8 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
 
 def test_cells_too_long_for_a_byte_get_wide_records(mem):
     """A cell that reaches more than 255 voxels away from one of its voxels does not fit the byte offsets of a slim record: the uniform layout
-    cannot hold it, the general layout gives it a WIDE record (absolute 16-bit bounds, one per cell), and the hits stay the oracle's.  The 26-bit
-    id form and 32-byte records give the same hits."""
+    cannot hold it, the table layout and the general layout give it a WIDE record (absolute 16-bit bounds, one per cell), and the hits stay the
+    oracle's.  The 26-bit id form and 32-byte records give the same hits."""
     from oracle import oracle as O
     from hagrid_amd import api
     a = scene.make_soup(2000, seed=31).copy(); b = scene.make_soup(2000, seed=32).copy()
@@ -528,8 +528,15 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
                 info = mem.image_format(grid)
                 assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
                 if slim:
-                    assert info["general"] and not info["uniform"] and info["record_bytes"] == 16, "the general layout with wide records expected"
-                    assert 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
+                    assert not info["general"] and not info["uniform"] and info["record_bytes"] == 16, "the table layout with wide records expected"
+                    assert 16 * G.num_cells / 8 < nb.value < 32 * total
+                    mem.set_option("traverse.image_general", 2)                      # the same grid in the general layout: wide records there as well
+                    got = gpu_traverse(mem, grid, d_tris, rays)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim, "general")
+                    info = mem.image_format(grid)
+                    assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
+                    assert info["general"] and 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
+                    mem.set_option("traverse.image_general", 1)
                 else:
                     assert info["flat"] and not info["general"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
                     assert uniform == 1 or nb.value >= 32 * total
@@ -552,7 +559,7 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
             assert mem.image_format(grid2) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
         grid2.free(); mem.free(d_tris2)
     finally:
-        mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.tail", 1)
+        mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_general", 1)
     grid.free(); mem.free(d_tris)
 
 
