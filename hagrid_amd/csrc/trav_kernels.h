@@ -464,8 +464,16 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     // One cell step of the ray in this lane (traverse.cu:61-78): exit plane of the cell `rec` describes, next voxel, next record.
     float texit = 0.0f;
     bool outside = false;
+    // The form of the current cell's list, found once per step: by index (more ids than a record holds) -- or, in the table and general layouts, a WIDE cell, whose
+    // list is by index as well -- in this lane, and in any lane of the wavefront.  Wide cells are looked for only in steps in which some lane is by index:
+    // the common step (inline lists everywhere) pays one OR for them.
+    bool bi_cur = false;
+    unsigned long long bi_any = 0ull;
     auto cell_step = [&](const uint4& rec, const vec3& inv_dir) -> uint4 {
         const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
+        const uint32_t marker = field(rec, LAST, SLIM);
+        bi_cur = UNIFORM ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide
+        bi_any = __ballot(bi_cur);
         int cx, cy, cz;
         if (UNIFORM) {
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx));
@@ -476,8 +484,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
             cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
             cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
-            const bool wide = GenWalk<SLIM>::is_wide(rec);          // a cell the bytes cannot hold: absolute bounds in its wide record (the large cells of empty space)
-            if (__ballot(wide) != 0ull && wide) {
+            if (bi_any != 0ull && marker == uint32_t(NONE - 3)) {          // a cell the bytes cannot hold: absolute bounds in its wide record (the large cells of empty space)
                 const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                 cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
             }
@@ -488,8 +495,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx & org_mask));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy & org_mask));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz & org_mask));
-            const bool wide = GenWalk<SLIM>::is_wide(rec);
-            if (__ballot(wide) != 0ull && wide) {
+            if (bi_any != 0ull && marker == uint32_t(NONE - 3)) {
                 const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                 cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
             }
@@ -511,12 +517,11 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     };
     // The list of the cell `rec` describes, tested front to back by this lane alone (the plain loop of traverse_kernel_img).
     auto test_list = [&](const uint4& rec) {
-        const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(rec);
-        const bool by_index = field(rec, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
+        const bool by_index = bi_cur;                          // (cell_step of this record has looked)
         int ref = int(field(rec, 48, SLIM));
         uint32_t q1 = NI > 1 ? field(rec, 48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(rec, 48 + 2 * SLIM, SLIM) : uint32_t(NONE),
                  q3 = NI > 3 ? field(rec, 48 + 3 * SLIM, SLIM) : uint32_t(NONE);
-        if (DUAL && __ballot(by_index) == 0ull) {
+        if (DUAL && bi_any == 0ull) {
             // Two ids per round trip.  A list is tested front to back and every test waits for its triangle; with 64 registers a lane
             // has room for one triangle, so the SECOND id of a round is requested straight into the lane's slots of `tri_lds`
             // (global_load_lds: no registers) together with the first one's ordinary loads, and read from there when the first test is
@@ -547,7 +552,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
                 hit_t = h.t; hit_id = h.id;
                 ref = int(q2); q1 = q3; q2 = uint32_t(NONE); q3 = uint32_t(NONE);
             }
-        } else if (__ballot(by_index) == 0ull) {
+        } else if (bi_any == 0ull) {
 #pragma unroll 1
             while (ref != NONE) {
                 bool fresh = true;
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             }
         } else {
             if (by_index) {
-                q1 = wide_cell ? GenWalk<SLIM>::wide_at(a, rec).w : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);      // (the wide record again: the kernel has no register to carry its list index across the step)
+                q1 = (!UNIFORM && GenWalk<SLIM>::is_wide(rec)) ? GenWalk<SLIM>::wide_at(a, rec).w : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);      // (the wide record again: the kernel has no register to carry its list index across the step)
                 ref = NONE;
                 if (q1 < q2) ref = ref_at(q1);
                 q1++;
@@ -747,22 +752,20 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
                 rec = GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(uint32_t(m_v), k, s)));
             }
         };
-        auto quad_step = [&](const uint4& rec) -> uint4 {
+        auto quad_step = [&](const uint4& rec, bool maybe_wide /* some lane of the wavefront holds a list by index: wave-uniform */) -> uint4 {
             int c;
             const uint32_t bound = __builtin_amdgcn_ubfe(ax == 2 ? rec.y : rec.x, m_bit, 8u);
             if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
             else if (TABLE) {             // table layout: bounds count from the top-level cell's origin; a wide cell has absolute bounds in its wide record
                 c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;
-                const bool wide = GenWalk<SLIM>::is_wide(rec);
-                if (__ballot(wide) != 0ull && wide) {
+                if (maybe_wide && GenWalk<SLIM>::is_wide(rec)) {
                     const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                     c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
                 }
             } else {
                 // general layout: the byte counts from the origin of the record's region; a wide cell has absolute bounds in its wide record
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v & int(~0u << gw.region_shift())));
-                const bool wide = GenWalk<SLIM>::is_wide(rec);
-                if (__ballot(wide) != 0ull && wide) {
+                if (maybe_wide && GenWalk<SLIM>::is_wide(rec)) {
                     const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                     c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
                 }
@@ -802,9 +805,11 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         live = __ballot(alive);
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
-                const uint4 na = quad_step(ca);
-                const bool wide_cell = !UNIFORM && GenWalk<SLIM>::is_wide(ca);
-                const bool by_index = field(ca, LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
+                const uint32_t marker = field(ca, LAST, SLIM);
+                const bool by_index = UNIFORM ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide (by index as well)
+                const unsigned long long any_by_index = __ballot(by_index);
+                const uint4 na = quad_step(ca, any_by_index != 0ull);
+                const bool wide_cell = !UNIFORM && marker == uint32_t(NONE - 3);
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
                 // this lane's id: field `sub` of the 80 id bits from bit 48 on -- two words chosen by the lane's constants, one funnel shift
@@ -814,7 +819,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
                 auto accept = [&](int ok, float t, float ad, int ref) {            // prims.h:284-292 with the tmax of this moment
                     if (ok && ad * hit_t > t) { const float inv_det = 1.0f / ad; hit_t = t * inv_det; hit_id = ref; }
                 };
-                if (__ballot(by_index) == 0ull) {
+                if (any_by_index == 0ull) {
                     // the common step: inline lists only, one round
                     TriCand cd; cd.t = 0.0f; cd.abs_det = 0.0f; cd.ok = false;
                     int mine_now = inl;
