@@ -29,6 +29,7 @@ namespace hagrid_impl {
 struct TravImageCache {
     void* table = nullptr;          // uint2 per top-level cell; general layout: the wide records (16 bytes each)
     size_t table_bytes = 0;
+    int wide_records = 0;           // table and general layouts: cells whose bounds the records' bytes cannot hold (a 16-byte wide record each, behind the table)
     void* blocks = nullptr;         // 128-byte aligned blocks: local voxel map + 32-byte cell records
     size_t block_bytes = 0;
     bool valid = false;

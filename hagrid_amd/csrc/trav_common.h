@@ -41,6 +41,7 @@ struct TraverseArgs {
     unsigned long long* __restrict__ wave_times; // TIMES instantiations only: start / end of every wavefront, 100 MHz wall clock
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
+    int img_wide;                 // host side only: the image holds wide records (which instantiation of the table-layout kernel is launched)
     size_t bin_working_set;       // host only: bytes a batch gathers from (traversal image or cells + entries, references, triangles): ray binning picks its bin count by it
     int num_rays;
     int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)

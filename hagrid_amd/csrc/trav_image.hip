@@ -518,7 +518,7 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
             image_general_wide<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(k, num_cells, claim, wide); HG_DBG(ctx);
         }
         img.blocks = recs; img.block_bytes = size_t(k.num_entries) * 16u; img.table = wide; img.table_bytes = size_t(std::max(h[2], 1)) * 16u;
-        img.slim = idb; img.general = true; img.uniform = false;
+        img.slim = idb; img.general = true; img.uniform = false; img.wide_records = h[2];
         rc = HAGRID_OK;
         break;
     }
@@ -654,8 +654,8 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
             else           image_general_patch<26><<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(recs, int(records), claim, int(table16));
             HG_DBG(ctx);
             image_general_wide<<<grid_blocks(k.num_cells, kBlock), kBlock, 0, ctx->stream>>>(k, k.num_cells, claim, both + table16); HG_DBG(ctx);
-            img.table = both; img.table_bytes = (table16 + size_t(h[2])) * 16u;      // (the caller's table is released with its other temporaries)
-        } else { img.table = nullptr; img.table_bytes = size_t(k.num_top) * 8u; }
+            img.table = both; img.table_bytes = (table16 + size_t(h[2])) * 16u; img.wide_records = h[2];      // (the caller's table is released with its other temporaries)
+        } else { img.table = nullptr; img.table_bytes = size_t(k.num_top) * 8u; img.wide_records = 0; }
         img.blocks = recs; img.block_bytes = bytes; img.slim = idb;
         result = HAGRID_OK;
         break;

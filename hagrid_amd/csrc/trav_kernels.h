@@ -324,8 +324,10 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 #ifndef HG_GENERAL_WAVES
 #define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
 #endif
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false>
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false, bool WIDE = GENERAL>
 __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : 8)) traverse_kernel_tail(const TraverseArgs a) {
+    // WIDE: the image holds wide records (always possible in the general layout; a table-layout image without any runs the instantiation without the checks)
+    static_assert(!WIDE || !UNIFORM, "the uniform layout has no wide records");
     static_assert(!GENERAL || !UNIFORM, "a layout is uniform, table (blocks per top-level cell) or general (a record per voxel-map entry)");
     constexpr bool TABLE = !UNIFORM && !GENERAL;
     static_assert(!REFILL || (UNIFORM && !DUAL && !TIMES), "refill: for the table-free layout, one id per round trip");
@@ -472,7 +474,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     auto cell_step = [&](const uint4& rec, const vec3& inv_dir) -> uint4 {
         const bool px = dir.x >= 0.0f, py = dir.y >= 0.0f, pz = dir.z >= 0.0f;
         const uint32_t marker = field(rec, LAST, SLIM);
-        bi_cur = UNIFORM ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide
+        bi_cur = !WIDE ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide
         bi_any = __ballot(bi_cur);
         int cx, cy, cz;
         if (UNIFORM) {
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)) - 128;
             cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)) - 128;
             cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)) - 128;
-            if (bi_any != 0ull && marker == uint32_t(NONE - 3)) {          // a cell the bytes cannot hold: absolute bounds in its wide record (the large cells of empty space)
+            if (WIDE && bi_any != 0ull && marker == uint32_t(NONE - 3)) {          // a cell the bytes cannot hold: absolute bounds in its wide record (the large cells of empty space)
                 const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                 cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
             }
@@ -495,7 +497,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(px ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, px ? 8u : 0u, 8u)), "v"(vx & org_mask));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(py ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.x, py ? 24u : 16u, 8u)), "v"(vy & org_mask));
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(pz ? 1 : -1), "v"(__builtin_amdgcn_ubfe(rec.y, pz ? 8u : 0u, 8u)), "v"(vz & org_mask));
-            if (bi_any != 0ull && marker == uint32_t(NONE - 3)) {
+            if (WIDE && bi_any != 0ull && marker == uint32_t(NONE - 3)) {
                 const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                 cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
             }
@@ -571,7 +573,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             }
         } else {
             if (by_index) {
-                q1 = (!UNIFORM && GenWalk<SLIM>::is_wide(rec)) ? GenWalk<SLIM>::wide_at(a, rec).w : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);      // (the wide record again: the kernel has no register to carry its list index across the step)
+                q1 = (WIDE && GenWalk<SLIM>::is_wide(rec)) ? GenWalk<SLIM>::wide_at(a, rec).w : field(rec, 48, 32); q2 = q1 + field(rec, 80, 20);      // (the wide record again: the kernel has no register to carry its list index across the step)
                 ref = NONE;
                 if (q1 < q2) ref = ref_at(q1);
                 q1++;
@@ -758,7 +760,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             if (UNIFORM) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(c) : "v"(m_pos ? 1 : -1), "v"(bound), "v"(m_v));
             else if (TABLE) {             // table layout: bounds count from the top-level cell's origin; a wide cell has absolute bounds in its wide record
                 c = (m_v & ~((1 << a.shift) - 1)) + int(bound) - 128;
-                if (maybe_wide && GenWalk<SLIM>::is_wide(rec)) {
+                if (WIDE && maybe_wide && GenWalk<SLIM>::is_wide(rec)) {
                     const uint4 wr = GenWalk<SLIM>::wide_at(a, rec);
                     c = int(__builtin_amdgcn_ubfe(ax == 0 ? wr.x : (ax == 1 ? wr.y : wr.z), m_pos ? 16u : 0u, 16u));
                 }
@@ -806,10 +808,10 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         while (live) {
             if (alive) {                                                   // (whole groups: the four lanes of a ray finish together)
                 const uint32_t marker = field(ca, LAST, SLIM);
-                const bool by_index = UNIFORM ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide (by index as well)
+                const bool by_index = !WIDE ? marker == uint32_t(NONE - 1) : (marker | 2u) == uint32_t(NONE - 1);        // NONE - 1: by index, NONE - 3: wide (by index as well)
                 const unsigned long long any_by_index = __ballot(by_index);
                 const uint4 na = quad_step(ca, any_by_index != 0ull);
-                const bool wide_cell = !UNIFORM && marker == uint32_t(NONE - 3);
+                const bool wide_cell = WIDE && marker == uint32_t(NONE - 3);
                 const int i0 = int(field(ca, 48, SLIM)), i1 = NI > 1 ? int(field(ca, 48 + SLIM, SLIM)) : NONE,
                           i2 = NI > 2 ? int(field(ca, 48 + 2 * SLIM, SLIM)) : NONE, i3 = NI > 3 ? int(field(ca, 48 + 3 * SLIM, SLIM)) : NONE;
                 // this lane's id: field `sub` of the 80 id bits from bit 48 on -- two words chosen by the lane's constants, one funnel shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One-off experiment (round 5, job 10): the list form of a step looked at once (by index / wide); headline and configuration 3 against round 4's library (B).
+# One-off experiment (round 5, job 11): the table layout with / without wide records as two instantiations; configuration 3 against round 4's library (B).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-exp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" || exit 1
@@ -12,10 +12,7 @@ ab() {  # batch, env
   done; done
   cp /tmp/libA.so hagrid_amd/libhagrid_amd.so
 }
-ab "primary 1024^2" "X=1" 200
-ab "primary 4096^2" "X=1" 20
 ab "config3 4096^2" "X=1" 20
-ab "incoherent 4M binned" "X=1" 20
+ab "primary 1024^2" "TD=0.15 SD=3.0"
 cp /tmp/libA.so hagrid_amd/libhagrid_amd.so
 SD=5.0 timeout 600 python tools/dev_option_sweep.py traverse.tile_order 0 --batch "primary 4096^2" --reps 1 --launches 20 2>&1 | tail -1 | cut -c1-300
-timeout 600 python tools/dev_nonuniform.py frames > $OUT/nonuniform_frames.txt 2>&1; grep "primary 1024\|incoherent" $OUT/nonuniform_frames.txt | cut -c1-300
