@@ -163,9 +163,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="after the timed region (never part of `value`): the same K steps with this many independent calls in flight, "
                     "one context = one stream each over ONE traversal image (hagrid_share_traversal); reported as `pipelined`; 0 or 1: skip")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-cores baseline sample")
-    ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off, 1 compact, 2 flat (default)")
+    ap.add_argument("--image", type=int, default=2, choices=[0, 1, 2], help="traversal image built by setup_traversal: 0 off (construction format), 1 / 2 on (default)")
     ap.add_argument("--hits-hash", action="store_true", help="experiments: `hits_sha256` of this rank's whole hit buffer after the timed steps in the line")
-    ap.add_argument("--opts", default="", help="experiments: comma-separated key=value pairs for hagrid_set_option, e.g. traverse.image_slim=0")
+    ap.add_argument("--opts", default="", help="experiments: comma-separated key=value pairs for hagrid_set_option, e.g. traverse.tile_order=0")
     ap.add_argument("--bin-rays", type=int, default=None, help="ray binning before traversal (extension): default 1 for incoherent, 0 otherwise")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
@@ -503,7 +503,7 @@ def main():
                                    + (f", rays [{first}, {first + n_rays}) = the share of rank {shard[0]} of {shard[1]}, on ONE GPU" if shard else f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
                        "baseline_config": args.config, "shard": args.shard, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
-                       "traversal_image": {0: "off (construction format)", 1: "compact blocks", 2: f"flat blocks: one {record_bytes}-byte record per voxel, built by setup_traversal"}[args.image],
+                       "traversal_image": "off (construction format)" if not args.image else (lambda f: f"{record_bytes}-byte slim records, " + ("uniform layout (a record per voxel, table-free)" if f.get("uniform") else "general layout (a record per voxel-map entry: links, wide records)" if f.get("general") else "table layout (a block of records per top-level cell)") + ", built by setup_traversal")(mem.image_format(grid)),
                        "ray_packets": "8x8 pixel tiles, row length detected on the device (kept per ray buffer, looked for again every 16th call; buffer stays in image order); from the second launch over a buffer on the tiles are dispatched longest first, by the costs the previous launches left (`tile_order`)",
                        "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",
                        "grid": grid.summary(), "device": info},

@@ -94,7 +94,7 @@ struct hagrid_ctx {
     int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
-    int opt_image_uniform = 1;  // flat image: use the table-free uniform layout when it is not much bigger
+    int opt_image_uniform = 1;  // traversal image: use the table-free uniform layout when it is not much bigger than the table layout (2: whatever it costs; 0: never)
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
     // What the context remembers about a ray buffer it has traversed (traverse.hip): the row length found for it and the order of its tiles.  A few
     // buffers are remembered at once (a renderer that alternates between two or three ray buffers keeps the hints of each); the least recently used
@@ -125,9 +125,9 @@ struct hagrid_ctx {
     int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
-    int opt_image_slim = 1;     // uniform flat image: 16-byte records (bounds as byte offsets from the voxel, ids packed) when every record fits; 2: always with 26-bit ids
+    int opt_image_slim = 1;     // traversal image: 1: reference ids packed in 20 bits where every id fits, else 26; 2: always 26 bits (tests)
     int opt_image_general = 1;  // flat image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: 32-byte records there (tests); 2: for every grid (tests)
-    int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (compact / flat, trav_image.hip) and traverse_grid uses it
+    int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (trav_image.hip; the two values are one since round 5) and traverse_grid uses it
 
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
 

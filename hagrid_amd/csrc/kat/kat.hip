@@ -64,7 +64,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
     const int vx = vox[3 * i], vy = vox[3 * i + 1], vz = vox[3 * i + 2];
     const int top = (vx >> a.shift) + a.top_x * ((vy >> a.shift) + a.top_y * (vz >> a.shift));
     const uint2 tab = general ? make_uint2(0u, 0u) : a.img_table[top];
-    if (slim) {     // a slim record, brought into the form of the 32-byte record
+    {     // the slim record, brought into an explicit form: bounds lo | hi << 16 per axis, list length (bit 31: by index, bit 30: through a link), ids or first index
         uint4 r;
         int region = a.shift;                   // general layout: log2 of the region the record's bound bytes count from
         uint32_t links = 0;
@@ -130,11 +130,6 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
         }
         return;
     }
-    const uint4* rec = flat ? image_record<true>(a, tab, vx, vy, vz) : image_record<false>(a, tab, vx, vy, vz);
-    uint4 ra = rec[0], rb = rec[1];
-    if (ra.w >= 0xfffffffeu) { uint32_t off, meta; image_resolve_links(a, vx, vy, vz, ra, rb, off, meta); ra.w |= 0x40000000u; }     // bit 30: came through a nested block or a deep link
-    uint32_t* o = out + 8 * size_t(i);
-    o[0] = ra.x; o[1] = ra.y; o[2] = ra.z; o[3] = ra.w; o[4] = rb.x; o[5] = rb.y; o[6] = rb.z; o[7] = rb.w;
 }
 
 struct Staged {   // host array staged on the device through the pool
@@ -269,7 +264,7 @@ extern "C" int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* gri
     a.row_len_hint = row_len; a.wave_times = times_dev; a.tile_order = tile_order_dev;
     const int blocks = grid_blocks(num_rays, 64);
     if (tail) traverse_kernel_tail<20, true><<<blocks, 64, 0, ctx->stream>>>(a);
-    else      traverse_kernel_img<64, true, true, true, 0, true, 20><<<blocks, 64, 0, ctx->stream>>>(a);
+    else      traverse_kernel_img<0, 20, 0, true><<<blocks, 64, 0, ctx->stream>>>(a);
     HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return HAGRID_OK;
@@ -281,7 +276,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
-        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 0, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2},
+        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
         {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},

@@ -233,61 +233,6 @@ __device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
     return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
 }
 
-// ---- records of the traversal image (trav_image.hip) ----------------------------------------------------------------------
-// Same ray arithmetic as v1 / v2 / the oracle; the cell comes from the traversal image (trav_image.hip): the table entry
-// of the top-level cell (kept in registers while the ray stays inside it), one slot byte, one 32-byte record that carries
-// the bounds and -- for lists of up to four -- the reference ids themselves.  The next cell's slot + record are fetched
-// before the current cell's triangles are tested, as in v2.
-template <bool FLAT>
-__device__ __forceinline__ const uint4* image_record(const TraverseArgs& a, uint2 tab, int vx, int vy, int vz) {
-    const uint32_t meta = tab.y;
-    const int d = int(meta & 3u), w = int((meta >> 2) & 1u);
-    const unsigned char* base = a.img_blocks + size_t(tab.x) * 128u;
-    const int s = a.shift - d, m = (1 << d) - 1;
-    const int idx = ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << d)) << d);   // 0 when d == 0
-    if (FLAT) return reinterpret_cast<const uint4*>(base + uint32_t(idx) * 32u);             // the record itself: one gather per step
-    uint32_t slot = base[idx << w];                                                           // d == 0: a byte of the record, ignored
-    if (w) slot |= uint32_t(base[(idx << 1) + 1]) << 8;
-    uint32_t ebytes = (1u << (3 * d)) << w;
-    ebytes = d ? (ebytes < 32u ? 32u : ebytes) : 0u;
-    if (!d) slot = 0;
-    return reinterpret_cast<const uint4*>(base + ebytes + slot * 32u);
-}
-
-// A `deep` record: the block does not resolve this voxel; continue the walk of the construction format at the entry the
-// record names and bring the cell into record form (list by index, never inline).
-__device__ __forceinline__ void image_resolve_deep(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb) {
-    uint32_t w = a.entries[cb.x];
-    int depth = int(cb.y);
-    while (w & 3u) {
-        const int k = int(w & 3u);
-        depth += k;
-        const int s = a.shift - depth, m = (1 << k) - 1;
-        w = a.entries[(w >> 2) + ((vx >> s) & m) + ((((vy >> s) & m) + (((vz >> s) & m) << k)) << k)];
-    }
-    const int4* p = reinterpret_cast<const int4*>(a.cells) + 2 * size_t(w >> 2);
-    const int4 lo = p[0], hi = p[1];
-    ca.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
-    ca.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
-    ca.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
-    ca.w = uint32_t(hi.w - lo.w) | 0x80000000u;
-    cb.x = uint32_t(lo.w);
-}
-
-// Records that are links: 0xfffffffe = nested block (three more levels of the same flat form), 0xffffffff = deep (construction
-// format).  Dense spots of very non-uniform scenes only; the common record never gets here.
-__device__ __forceinline__ void image_resolve_links(const TraverseArgs& a, int vx, int vy, int vz, uint4& ca, uint4& cb, uint32_t& nest_off, uint32_t& nest_meta) {
-    while (ca.w == 0xfffffffeu) {
-        nest_off = cb.x; nest_meta = cb.y;
-        const int d = int(cb.y & 3u), s = a.shift - int(cb.y >> 8) - d, m = (1 << d) - 1;
-        const uint32_t idx = uint32_t((vx >> s) & m) + (uint32_t(((vy >> s) & m) + (((vz >> s) & m) << d)) << d);
-        const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + size_t(cb.x) * 128u + size_t(idx) * 32u);
-        ca = p[0]; cb = p[1];
-    }
-    if (ca.w == 0xffffffffu) image_resolve_deep(a, vx, vy, vz, ca, cb);
-}
-
-
 // ---- the general layout of slim records (trav_image.hip): one record per voxel-map entry, at the entry's index -------------------------------------
 // The walk to the record of a voxel is the reference's lookup_entry (grid.h:103-116) over 16-byte records: the top-level record of the voxel's top-level cell,
 // then -- while the record is a LINK -- the child the voxel selects in the block the link names.  A ray keeps the innermost block its last look-up ended in

@@ -1,45 +1,29 @@
 // trav_image.hip -- the traversal image: the finished grid re-laid-out for the vector L1 of gfx950.
 //
-// No reference counterpart.  The reference traverses the construction format directly (traverse.cu:27-95): per cell
-// step a top-level entry, a second-level entry, a 32-byte cell, then per reference a 4-byte id and a 48-byte triangle,
-// each in a different region of memory.  On MI355X a divergent gather costs one 128-byte line fill of the vector L1
-// (64 B/clk/CU) however few bytes are used (tools/micro/l1_gather.hip: 2.4 CU-cycles per record for 4, 16 or 32
-// bytes), so what bounds the traversal is the number of distinct lines a ray touches, not its bytes.  The image puts
-// what a ray needs while it crosses one top-level cell into one contiguous, 128-byte aligned block:
-//
-//   table[T]  (uint2 per top-level cell)   x = block offset in 128-byte units
-//                                          y = depth d | wide << 2 | count << 8
-//   block     [ (2^d)^3 local slots, u8 (u16 if wide), padded to >= 32 B ]   only if d > 0
-//             [ count records of 32 bytes ]
-//   record    u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | u32 n | the reference ids inline (unused = -1)          n <= 4
-//             u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | u32 n | 1 << 31 | first reference index into ref_ids    n  > 4
-//             (one word per axis: the traversal takes lo or hi with a single bit-field extract)
-//             0 0 0 | 0xffffffff | entry index, depth of that entry                                        deep
-//
-// d is the deepest subdivision inside the top-level cell, capped at 3 (512 slots); a slot names one of the cells that
-// overlap the top-level cell (a cell spanning several top-level cells has a record in each), and a reference list of
-// up to four ids travels with its cell.  Where the construction format subdivides further than the block resolves, the
-// record is a `deep` link to the voxel-map entry at which the walk of the construction format continues for that step
-// (dense spots of very non-uniform scenes; everything else never touches the construction format).  A cell step is
-// then [table entry, only when the top-level cell changes] -> slot byte -> record, typically inside one or two lines
-// that neighbouring rays share, and the reference-id gather disappears for short lists.  Cell bounds, reference order
-// and every value the traversal arithmetic uses are copied unchanged: hits are identical to the traversal of the
-// construction format (tests/test_traverse_gpu.py).
-//
-// Slim records (uniform layout only, `traverse.image_slim`): 16 bytes per voxel instead of 32 -- ONE gather instruction per cell
-// step, half the lane-lines, half the image (it fits the 256 MB memory-side cache again).  The bounds travel as byte offsets
-// from the record's own voxel (voxel - lo, hi - voxel), the ids as packed fields of IDB bits:
-//   bits   0..47   lo.x hi.x lo.y hi.y lo.z hi.z offsets, one byte each (lo and hi of an axis in neighbouring bytes)
+// No reference counterpart.  The reference traverses the construction format directly (traverse.cu:27-95): per cell step a top-level entry, a
+// second-level entry, a 32-byte cell, then per reference a 4-byte id and a 48-byte triangle, each in a different region of memory.  On MI355X a
+// divergent gather costs one 128-byte line fill of the vector L1 (64 B/clk/CU) however few bytes are used (tools/micro/l1_gather.hip: 2.4
+// CU-cycles per record for 4, 16 or 32 bytes), so what bounds the traversal is the number of distinct lines a ray touches and the number of
+// dependent round trips, not its bytes.  The image is ONE 16-byte "slim" record per cell step that carries the cell's bounds and -- for lists of
+// up to four -- the reference ids themselves:
+//   bits   0..47   lo.x hi.x lo.y hi.y lo.z hi.z as byte offsets (lo and hi of an axis in neighbouring bytes; from where: see the layouts)
 //   bits  48..127  80 / IDB reference ids of IDB bits (IDB = 20: four, IDB = 26: three); unused = all ones
 //   by index       the LAST id field = all ones - 1; bits 48..79 first reference index, bits 80..99 list length
-// Grids of at most three levels whose top-level cells differ in depth (table layout) get slim records as well: the block of a
-// top-level cell is (2^d)^3 records of 16 bytes, the table gives its offset in records, and the bound bytes are biased offsets from
-// the ORIGIN OF THE TOP-LEVEL CELL (bound - origin + 128: a coarse block voxel has no single finest-level voxel to count from).
-// An image whose cells do not all fit (an offset outside the byte, a by-index list of 2^20 ids or more) is built with 32-byte records.
-//
-// Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal state), owned by
-// the context, dropped when the source arrays are freed, overwritten or rebuilt.  Covers uncompressed grids and compressed grids of up to three levels, with a
-// virtual resolution below 65536 per axis; otherwise traversal reads the construction format.
+//   (table and general layouts) last id field = all ones - 3: WIDE, the cell's bounds do not fit a byte -- bits 48..79 index of a 16-byte wide record
+//                  (lo | hi << 16 per axis in absolute finest-level voxels, first reference index), bits 80..99 list length;
+//   (general layout) last id field = all ones - 2: LINK to a block of child records, bits 48..79 first child, bits 80..81 log2 of its edge
+// in one of three layouts:
+//   uniform   grids of at most three levels in which (nearly) every top-level cell has the full depth: (2^shift)^3 records per top-level cell, block T at
+//             T * (2^shift)^3 -- the record of a voxel is arithmetic on the voxel; bounds count from the record's own voxel (voxel - lo, hi - voxel)
+//   table     grids of at most three levels otherwise: per top-level cell a block of (2^d)^3 records, d its own depth, found through a table
+//             (uint2 per top-level cell: offset in records, d); bounds count from the top-level cell's origin, biased by 128
+//   general   any depth: the voxel map itself with every 4-byte entry widened to a record at the SAME index (below)
+// Cell bounds, reference order and every value the traversal arithmetic uses are copied unchanged: hits are identical to the traversal of the
+// construction format (tests/test_traverse_gpu.py).  Built by hagrid_setup_traversal (traverse.cu:97-109 is where the reference prepares its traversal
+// state), owned by the context, dropped when the source arrays are freed, overwritten or rebuilt.  Grids no layout describes -- a virtual resolution of
+// 65536 and more per axis, ids beyond 26 bits, a list of 2^20 ids, 2^28 records -- are traversed in the construction format (trav_plain.hip).
+// (Rounds 1-4 also had 32-byte records -- blocks, nested blocks three levels deeper, links back into the construction format -- and a compact form with
+// de-duplicated records behind slot bytes; the general layout serves every grid those served, at half the bytes and one gather per step at any depth.)
 #include "ctx.h"
 
 #include <algorithm>
@@ -60,260 +44,32 @@ struct ImgK {
     int top_x, top_y, num_top;
     int shift, num_entries, num_cells;
     long long source_bytes;                // entries + cells of the construction format
-    // nested blocks (flat form, grids deeper than three levels): the entries at which a block stops resolving become roots
-    int* claim;                            // per entry: -1, or the index of its root
-    int2* roots;                           // (entry index, depth of that entry)
-    int* num_roots;
-    const int* nested_off;                 // fill pass: block offset of every root, in 128-byte units, relative to nested_base
-    const int* nested_d;                   // fill pass: depth of every root's block
-    int nested_base;
 };
 
-__host__ __device__ __forceinline__ uint32_t slot_bytes(int d, bool wide) {
-    if (d == 0) return 0u;
-    const uint32_t b = (1u << (3 * d)) << (wide ? 1 : 0);
-    return b < 32u ? 32u : b;
-}
-
-// One wavefront per top-level cell.  D = min(shift, 3) is the finest resolution a block can have.
-// FILL = false: sizes[T] (128-byte units) and metas[T]; FILL = true: the block.
-// FLAT: no slot bytes and no de-duplication -- the block is (2^d)^3 records indexed by the voxel, so a cell step is ONE
-// dependent gather (table entry cached per top-level cell -> record) instead of two, at 1.8x the memory.
-template <int D, bool FILL, bool FLAT>
-__global__ void __launch_bounds__(64) image_top_cell(const ImgK k, int* __restrict__ sizes, uint32_t* __restrict__ metas,
-                                                     const int* __restrict__ offsets, uint2* __restrict__ table, unsigned char* __restrict__ blocks,
-                                                     int uniform) {
-    constexpr int SHIFT = D;                 // index arithmetic inside the block
-    constexpr int V = 1 << (3 * D), P = (V + 63) / 64, M = (1 << D) - 1;
-    __shared__ unsigned long long rep_mask[P];
-    __shared__ int rep_prefix[P];
-    __shared__ int ids[V];
-    const int T = blockIdx.x, lane = threadIdx.x;
+// The deepest subdivision inside every top-level cell (at most D = shift <= 3 levels): the edge of its block in the table layout, and what decides
+// between the table and the uniform layout.  One wavefront per top-level cell, a lane per finest-level voxel (strided).
+template <int D>
+__global__ void __launch_bounds__(64) image_depths(const ImgK k, uint32_t* __restrict__ metas) {
+    constexpr int V = 1 << (3 * D), M = (1 << D) - 1;
+    const int T = blockIdx.x;
     const uint32_t topw = k.entries[T];
-    const int up = k.shift - D;              // block voxel -> finest-level voxel inside the top-level cell
-
-    // what every block voxel resolves to: a leaf cell (id >= 0) or, where the construction format subdivides beyond
-    // depth D, the entry at which its walk has to continue (id = -1 - entry index)
-    int cell[P], rep[P], dep[P];
     int depth_max = 0;
-    #pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int f = p * 64 + lane;
-        cell[p] = -1; rep[p] = -1; dep[p] = 0;
-        if (f < V) {
-            const int rx = (f & M) << up, ry = ((f >> SHIFT) & M) << up, rz = (f >> (2 * SHIFT)) << up;
-            uint32_t w = topw;
-            int depth = 0, eidx = T;
-            while ((w & 3u) && depth + int(w & 3u) <= D) {
-                const int kk = int(w & 3u);
-                depth += kk;
-                const int s = k.shift - depth, m = (1 << kk) - 1;
-                eidx = int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk);
-                w = k.entries[eidx];
-            }
-            cell[p] = (w & 3u) ? -1 - eidx : int(w >> 2);
-            dep[p] = depth;
-            ids[f] = cell[p];
-            depth_max = max(depth_max, depth);
-        }
-    }
-    // uniform: every block has the full resolution D and block T starts at T * (2^D)^3 records -- no table needed to find it
-    const int d = uniform ? D : wave_max(depth_max);
-    const int sd = D - d;
-    __syncthreads();
-
-    // The voxels that name one cell form a box (the cell before expand_grid stretched its bounds; the voxel map is not
-    // touched by the expansion).  Its representative is the lowest corner of that box inside this block, found by walking
-    // the runs of equal ids down x, then y, then z until nothing moves: the walk ends on a voxel that is its own representative
-    // and names the same cell as the voxel it started from, so a region that is not a box (hand-made voxel maps) only costs
-    // duplicate records.
-    int count = 0;
-    #pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int f = p * 64 + lane;
-        bool is_rep = false;
-        if (f < V) {
-            const int fx = f & M, fy = (f >> SHIFT) & M, fz = f >> (2 * SHIFT);
-            if (((fx | fy | fz) & ((1 << sd) - 1)) == 0) {                           // a voxel of depth d
-                const int step = 1 << sd, c = cell[p];
-                int x = fx, y = fy, z = fz;
-                for (;;) {                                        // to a fixed point: a voxel with no equal neighbour below it on any axis
-                    const int x0 = x, y0 = y, z0 = z;
-                    while (x > 0 && ids[(x - step) + (y << SHIFT) + (z << (2 * SHIFT))] == c) x -= step;
-                    while (y > 0 && ids[x + ((y - step) << SHIFT) + (z << (2 * SHIFT))] == c) y -= step;
-                    while (z > 0 && ids[x + (y << SHIFT) + ((z - step) << (2 * SHIFT))] == c) z -= step;
-                    if (x == x0 && y == y0 && z == z0) break;
-                }
-                rep[p] = x + (y << SHIFT) + (z << (2 * SHIFT));
-                is_rep = rep[p] == f;
-            }
-        }
-        const unsigned long long mask = __ballot(is_rep);
-        if (lane == 0) { rep_mask[p] = mask; rep_prefix[p] = count; }
-        count += __popcll(mask);
-    }
-    if (FLAT && !FILL && k.claim) {
-        // every entry a voxel of this block stops at becomes the root of a nested block; the first voxel to claim it registers it
-        #pragma unroll
-        for (int p = 0; p < P; p++) {
-            const bool want = (p * 64 + lane) < V && cell[p] < 0 && atomicCAS(k.claim + (-1 - cell[p]), -1, -2) == -1;
-            const unsigned long long m = __ballot(want);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(k.num_roots, __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (want) {
-                const int r = base + __popcll(m & ((1ull << lane) - 1ull));
-                k.roots[r] = make_int2(-1 - cell[p], dep[p]);
-                k.claim[-1 - cell[p]] = r;
-            }
-        }
-    }
-    if (FLAT) count = 1 << (3 * d);
-    const bool wide = !FLAT && count > 255;
-    const uint32_t meta = uint32_t(d) | (wide ? 4u : 0u) | (FLAT ? 8u : 0u) | (uint32_t(count) << 8);
-    const uint32_t ebytes = FLAT ? 0u : slot_bytes(d, wide);
-    if (!FILL) {
-        if (lane == 0) { sizes[T] = int((ebytes + 32u * uint32_t(count) + 127u) >> 7); metas[T] = meta; }
-        return;
-    }
-    __syncthreads();
-    const uint32_t off = uniform ? uint32_t(T) * uint32_t((32u << (3 * D)) >> 7) : uint32_t(offsets[T]);
-    if (lane == 0) table[T] = make_uint2(off, meta);
-    unsigned char* base = blocks + size_t(off) * 128u;
-    #pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int f = p * 64 + lane;
-        if (f >= V || rep[p] < 0) continue;
-        int g = rep[p];
-        int slot = rep_prefix[g >> 6] + __popcll(rep_mask[g >> 6] & ((1ull << (g & 63)) - 1ull));
-        {
-            const int fx = f & M, fy = (f >> SHIFT) & M, fz = f >> (2 * SHIFT);
-            const int idx = (fx >> sd) + (((fy >> sd) + ((fz >> sd) << d)) << d);
-            if (FLAT) { slot = idx; g = f; }               // every voxel writes its own record
-            else if (d > 0) {
-                if (wide) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)slot;
-                else      base[idx] = (unsigned char)slot;
-            }
-        }
-        if (g == f && cell[p] < 0) {
-            uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
-            const int root = (FLAT && k.claim) ? k.claim[-1 - cell[p]] : -1;
-            if (root >= 0) {     // nested block: offset | its depth, depth of the entry it resolves
-                rec[0] = make_uint4(0u, 0u, 0u, 0xfffffffeu);
-                rec[1] = make_uint4(uint32_t(k.nested_base + k.nested_off[root]), uint32_t(k.nested_d[root]) | (uint32_t(dep[p]) << 8), 0u, 0u);
-            } else {
-                rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu);
-                rec[1] = make_uint4(uint32_t(-1 - cell[p]), uint32_t(dep[p]), 0u, 0u);
-            }
-        } else if (g == f) {
-            int begin, n;
-            uint4 a, b;
-            if (k.small_cells) {
-                const uint4 sc = k.small_cells[cell[p]];        // the u16 bounds are packed exactly as the record packs them
-                // SmallCell: min.x min.y | min.z max.x | max.y max.z  ->  record: one word per axis, lo | hi << 16
-                a.x = (sc.x & 0xffffu) | (sc.y & 0xffff0000u);
-                a.y = (sc.x >> 16) | (sc.z << 16);
-                a.z = (sc.y & 0xffffu) | (sc.z & 0xffff0000u);
-                begin = int(sc.w); n = 0;
-                if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
-                else begin = 0;
-            } else {
-                const int4 lo = k.cells[2 * size_t(cell[p])], hi = k.cells[2 * size_t(cell[p]) + 1];
-                begin = lo.w; n = hi.w - lo.w;
-                a.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
-                a.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
-                a.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
-            }
-            a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
-            if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }
-            else {
-                b.x = n > 0 ? uint32_t(k.refs[begin]) : ~0u;
-                b.y = n > 1 ? uint32_t(k.refs[begin + 1]) : ~0u;
-                b.z = n > 2 ? uint32_t(k.refs[begin + 2]) : ~0u;
-                b.w = n > 3 ? uint32_t(k.refs[begin + 3]) : ~0u;
-            }
-            uint4* rec = reinterpret_cast<uint4*>(base + ebytes + size_t(slot) * 32u);
-            rec[0] = a; rec[1] = b;
-        }
-    }
-}
-
-// the 32-byte record of a leaf cell
-__device__ __forceinline__ void write_cell_record(const ImgK& k, int c, uint4* rec) {
-    int begin, n;
-    uint4 a, b;
-    if (k.small_cells) {
-        const uint4 sc = k.small_cells[c];
-        a.x = (sc.x & 0xffffu) | (sc.y & 0xffff0000u);
-        a.y = (sc.x >> 16) | (sc.z << 16);
-        a.z = (sc.y & 0xffffu) | (sc.z & 0xffff0000u);
-        begin = int(sc.w); n = 0;
-        if (begin >= 0) while (k.refs[begin + n] >= 0) n++;
-        else begin = 0;
-    } else {
-        const int4 lo = k.cells[2 * size_t(c)], hi = k.cells[2 * size_t(c) + 1];
-        begin = lo.w; n = hi.w - lo.w;
-        a.x = uint32_t(lo.x) | (uint32_t(hi.x) << 16);
-        a.y = uint32_t(lo.y) | (uint32_t(hi.y) << 16);
-        a.z = uint32_t(lo.z) | (uint32_t(hi.z) << 16);
-    }
-    a.w = uint32_t(n) | (n > 4 ? 0x80000000u : 0u);
-    if (n > 4) { b = make_uint4(uint32_t(begin), 0u, 0u, 0u); }
-    else {
-        b.x = n > 0 ? uint32_t(k.refs[begin]) : ~0u;
-        b.y = n > 1 ? uint32_t(k.refs[begin + 1]) : ~0u;
-        b.z = n > 2 ? uint32_t(k.refs[begin + 2]) : ~0u;
-        b.w = n > 3 ? uint32_t(k.refs[begin + 3]) : ~0u;
-    }
-    rec[0] = a; rec[1] = b;
-}
-
-// Nested blocks: one wavefront per root (an entry at depth `dep` whose subtree the block above does not resolve).  The block
-// resolves up to three more levels below the root; what lies deeper still is a `deep` link into the construction format.
-template <bool FILL>
-__global__ void __launch_bounds__(64) image_nested(const ImgK k, int num_roots, int* __restrict__ sizes, int* __restrict__ depths,
-                                                   const int* __restrict__ offsets, unsigned char* __restrict__ blocks) {
-    const int r = blockIdx.x, lane = threadIdx.x;
-    if (r >= num_roots) return;
-    const int2 root = k.roots[r];
-    const int dep0 = root.y, Dr = min(3, k.shift - dep0), V = 1 << (3 * Dr), up = k.shift - dep0 - Dr, M = (1 << Dr) - 1;
-    const uint32_t w0 = k.entries[root.x];
-    auto resolve = [&](int f, int& depth, int& eidx) -> uint32_t {
-        const int rx = (f & M) << up, ry = ((f >> Dr) & M) << up, rz = (f >> (2 * Dr)) << up;
-        uint32_t w = w0;
-        depth = dep0; eidx = root.x;
-        while ((w & 3u) && (depth - dep0) + int(w & 3u) <= Dr) {
+    for (int f = threadIdx.x; f < V; f += 64) {
+        const int rx = f & M, ry = (f >> D) & M, rz = f >> (2 * D);
+        uint32_t w = topw;
+        int depth = 0;
+        while (w & 3u) {
             const int kk = int(w & 3u);
             depth += kk;
-            const int s = k.shift - depth, m = (1 << kk) - 1;
-            eidx = int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk);
-            w = k.entries[eidx];
+            if (depth > D) break;                 // (a map deeper than its shift says: not a grid; the fill finds out)
+            const int s = D - depth, m = (1 << kk) - 1;
+            w = k.entries[int(w >> 2) + ((rx >> s) & m) + ((((ry >> s) & m) + (((rz >> s) & m) << kk)) << kk)];
         }
-        return w;
-    };
-    int d;
-    if (!FILL) {
-        int dmax = 0;
-        for (int f = lane; f < V; f += 64) { int depth, eidx; (void)resolve(f, depth, eidx); dmax = max(dmax, depth - dep0); }
-        d = wave_max(dmax);
-        if (lane == 0) { sizes[r] = ((32 << (3 * d)) + 127) >> 7; depths[r] = d; }
-        return;
+        depth_max = max(depth_max, min(depth, D));
     }
-    d = depths[r];
-    const int sd = Dr - d;
-    unsigned char* base = blocks + size_t(offsets[r]) * 128u;
-    for (int f = lane; f < V; f += 64) {
-        const int fx = f & M, fy = (f >> Dr) & M, fz = f >> (2 * Dr);
-        if ((fx | fy | fz) & ((1 << sd) - 1)) continue;                       // not a voxel of depth d
-        int depth, eidx;
-        const uint32_t w = resolve(f, depth, eidx);
-        const int idx = (fx >> sd) + (((fy >> sd) + ((fz >> sd) << d)) << d);
-        uint4* rec = reinterpret_cast<uint4*>(base + size_t(idx) * 32u);
-        if (w & 3u) { rec[0] = make_uint4(0u, 0u, 0u, 0xffffffffu); rec[1] = make_uint4(uint32_t(eidx), uint32_t(depth), 0u, 0u); }
-        else write_cell_record(k, int(w >> 2), rec);
-    }
+    depth_max = wave_max(depth_max);
+    if (threadIdx.x == 0) metas[T] = uint32_t(depth_max);
 }
-
 
 // ---- slim records -------------------------------------------------------------------------------------------------------
 // bits [pos, pos + n) of the 128-bit record {lo, hi} := v   (n <= 32)
@@ -610,11 +366,9 @@ struct SlimSizeOut { int* v; __device__ void operator()(int i, int s) const { v[
 template <int D>
 int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table, bool uniform, const uint32_t* metas, int* offsets, int* partials) {
     long long records = (long long)k.num_top << (3 * D);
-    if (!uniform) {
-        int* total = ctx->dscratch + 227;
-        if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offsets}, k.num_top, partials, (const int*)nullptr, total)) return HAGRID_ENOMEM;
+    if (!uniform) {              // (the caller scanned the block sizes into `offsets`; the total stands in its scratch word)
         int h = 0;
-        const int rc = read_back(ctx, total, &h, sizeof(h));
+        const int rc = read_back(ctx, ctx->dscratch + 224, &h, sizeof(h));
         if (rc != HAGRID_OK) return rc;
         records = h;
     }
@@ -665,99 +419,39 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
     return result;
 }
 
-struct SizeIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
-struct SizeOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
-
-template <int D, bool FLAT>
-int build_image(hagrid_ctx* ctx, const ImgK& k0, TravImageCache& img) {
-    hipStream_t st = ctx->stream;
-    ImgK k = k0;
-    const bool nest = FLAT && k.shift > 3;                     // blocks resolve three levels; deeper grids get nested blocks
-    int* sizes = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
-    uint32_t* metas = pool_alloc<uint32_t>(ctx, size_t(k.num_top) + 1);   // lives until the fill pass re-derives it
-    int* partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(std::max(k.num_top, k.num_entries))) + 1);
+// Grids of at most three levels: the uniform layout, else the table layout.  Returns 1 when neither describes the grid (the general layout is tried next).
+template <int D>
+int build_blocks(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
+    uint32_t* metas = pool_alloc<uint32_t>(ctx, size_t(k.num_top) + 1);
+    int* offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
+    int* partials = pool_alloc<int>(ctx, size_t(scan_num_tiles(k.num_top)) + 1);
     uint2* table = pool_alloc<uint2>(ctx, size_t(k.num_top));
-    int* claim = nest ? pool_alloc<int>(ctx, size_t(k.num_entries)) : nullptr;
-    int2* roots = nest ? pool_alloc<int2>(ctx, size_t(k.num_entries)) : nullptr;
-    int* sizes1 = nullptr; int* depths1 = nullptr;
-    auto release = [&]() {
-        hagrid_mem_free(ctx, sizes); hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, partials);
-        hagrid_mem_free(ctx, claim); hagrid_mem_free(ctx, roots); hagrid_mem_free(ctx, sizes1); hagrid_mem_free(ctx, depths1);
-    };
-    if (!sizes || !metas || !partials || !table || (nest && (!claim || !roots))) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    int* total = ctx->dscratch + 224;          // [0] level-0 units, [1] roots, [2] nested units
-    if (nest) {
-        (void)hipMemsetAsync(claim, 0xFF, size_t(k.num_entries) * sizeof(int), st);
-        (void)hipMemsetAsync(total + 1, 0, sizeof(int), st);
-        k.claim = claim; k.roots = roots; k.num_roots = total + 1;
+    auto release = [&]() { hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, offs); hagrid_mem_free(ctx, partials); };
+    if (!metas || !offs || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    image_depths<D><<<k.num_top, 64, 0, ctx->stream>>>(k, metas); HG_DBG(ctx);
+    int* total = ctx->dscratch + 224;
+    if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offs}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
+    int table_records = 0;
+    int rc = read_back(ctx, total, &table_records, sizeof(int));
+    if (rc != HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return rc; }
+    // An image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed; "traverse.image_max_mb" sets the limit); the uniform
+    // layout when it costs at most a quarter more records than the table layout (every top-level cell subdivided to the full depth, as in evenly
+    // filled scenes): the record of a voxel is then found by arithmetic alone.
+    const long long limit = ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes);
+    const long long uniform_records = (long long)k.num_top << (3 * D);
+    const bool uniform = ctx->opt_image_uniform && (uniform_records * 4 <= (long long)table_records * 5 || ctx->opt_image_uniform == 2) && uniform_records * 16 <= limit;
+    int rs = 1;
+    uint2* own_table = nullptr;                  // (the table layout with wide records brings a table of its own: table + wide records in one buffer)
+    if (uniform) rs = build_slim<D>(ctx, k, img, table, true, metas, nullptr, partials);
+    const bool is_uniform = rs == HAGRID_OK;
+    if (rs == 1 && (long long)table_records * 16 <= limit) {       // top-level cells of different depth, or a cell the uniform layout's bytes cannot hold
+        rs = build_slim<D>(ctx, k, img, table, false, metas, offs, partials);
+        own_table = static_cast<uint2*>(img.table);
     }
-    image_top_cell<D, false, FLAT><<<k.num_top, 64, 0, st>>>(k, sizes, metas, nullptr, nullptr, nullptr, 0); HG_DBG(ctx);
-    if (!ctx_scan<int>(ctx, SizeIn{sizes}, SizeOut{sizes}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    int h[2] = {0, 0};
-    int rc = read_back(ctx, total, h, sizeof(h));
-    int units = h[0];
-    const int num_roots = nest ? h[1] : 0;
-    if (rc != HAGRID_OK || units <= 0) { release(); hagrid_mem_free(ctx, table); return rc; }
-    int units1 = 0;
-    if (num_roots > 0) {
-        sizes1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
-        depths1 = pool_alloc<int>(ctx, size_t(num_roots) + 1);
-        if (!sizes1 || !depths1) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-        image_nested<false><<<num_roots, 64, 0, st>>>(k, num_roots, sizes1, depths1, nullptr, nullptr); HG_DBG(ctx);
-        if (!ctx_scan<int>(ctx, SizeIn{sizes1}, SizeOut{sizes1}, num_roots, partials, (const int*)nullptr, total + 2)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-        rc = read_back(ctx, total + 2, &units1, sizeof(int));
-        if (rc != HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return rc; }
-    }
-    // a flat image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed): beyond that the
-    // compact form is built
-    if (FLAT && ((long long)units + units1) * 128 > (ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes))) { release(); hagrid_mem_free(ctx, table); return 1; }
-    // Uniform layout when it costs at most a quarter more memory than the adaptive one (every top-level cell subdivided to the
-    // full depth, as in evenly filled scenes): the record of a voxel is then found by arithmetic alone.
-    const long long uniform_units = (long long)k.num_top * ((32ll << (3 * D)) >> 7);
-    const bool uniform = FLAT && D >= 1 && D == k.shift && ctx->opt_image_uniform && (uniform_units * 4 <= (long long)units * 5 || ctx->opt_image_uniform == 2) && uniform_units < (1ll << 31);
-    if (uniform) units = int(uniform_units);
-    if (FLAT && ctx->opt_image_slim) {
-        // Slim records.  Grids of at most three levels: a block of (2^d)^3 records per top-level cell -- table-free when every top-level cell has the full depth
-        // (uniform layout), through the table otherwise (table layout) -- when every cell fits their bound bytes; the general layout (a record per voxel-map
-        // entry: links, wide records) for the cells that do not, and -- from trav_image_build directly -- for deeper grids.  (The general layout serves grids of
-        // three levels as well, at 20 % more instructions per cell step and seven instead of eight wavefronts per SIMD: configuration 3's grid 1.26 -> 1.57 ms
-        // at 4096^2, round 5 -- the table layout stays.)
-        int rs = 1;
-        if (D == k.shift && D >= 1) {
-            uint2* own_table = nullptr;                  // (the table layout with wide records brings a table of its own: table + wide records in one buffer)
-            if (uniform) rs = build_slim<D>(ctx, k, img, table, true, metas, nullptr, partials);
-            bool is_uniform = rs == HAGRID_OK;
-            if (rs == 1) {                               // top-level cells of different depth, or a cell the uniform layout's bytes cannot hold
-                int* offs = pool_alloc<int>(ctx, size_t(k.num_top) + 1);
-                if (!offs) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-                rs = build_slim<D>(ctx, k, img, table, false, metas, offs, partials);
-                hagrid_mem_free(ctx, offs);
-                own_table = static_cast<uint2*>(img.table);
-            }
-            if (rs == HAGRID_OK) {
-                release(); img.uniform = is_uniform;
-                if (own_table) hagrid_mem_free(ctx, table); else img.table = table;
-                return HAGRID_OK;
-            }
-        }
-        if (rs == 1 && ctx->opt_image_general) {
-            rs = build_general(ctx, k, img);
-            if (rs == HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return HAGRID_OK; }
-        }
-        if (rs != 1) { release(); hagrid_mem_free(ctx, table); return rs; }
-    }
-    if ((long long)units + units1 >= (1ll << 31)) { release(); hagrid_mem_free(ctx, table); return 1; }
-    unsigned char* blocks = static_cast<unsigned char*>(hagrid_mem_alloc(ctx, (size_t(units) + size_t(units1)) * 128u));
-    if (!blocks) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    k.nested_off = sizes1; k.nested_d = depths1; k.nested_base = units;
-    if (num_roots == 0) k.claim = nullptr;
-    image_top_cell<D, true, FLAT><<<k.num_top, 64, 0, st>>>(k, nullptr, nullptr, sizes, table, blocks, uniform ? 1 : 0); HG_DBG(ctx);
-    if (num_roots > 0) image_nested<true><<<num_roots, 64, 0, st>>>(k, num_roots, nullptr, depths1, sizes1, blocks + size_t(units) * 128u);
-    img.uniform = uniform;
-    hipError_t e = hipGetLastError();
     release();
-    if (e != hipSuccess) { hagrid_mem_free(ctx, table); hagrid_mem_free(ctx, blocks); return fail(ctx, HAGRID_EHIP, __FILE__, __LINE__, hipGetErrorString(e)); }
-    img.table = table; img.table_bytes = size_t(k.num_top) * 8u; img.blocks = blocks; img.block_bytes = (size_t(units) + size_t(units1)) * 128u;
+    if (rs != HAGRID_OK) { hagrid_mem_free(ctx, table); return rs; }
+    img.uniform = is_uniform;
+    if (own_table) hagrid_mem_free(ctx, table); else img.table = table;
     return HAGRID_OK;
 }
 
@@ -812,9 +506,6 @@ __global__ void __launch_bounds__(kBlock) max_ref_kernel(const int* __restrict__
 int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     trav_image_drop(ctx);
     if (!ctx->opt_image || !g->entries || (!g->cells && !g->small_cells) || !g->ref_ids || g->num_cells <= 0) return HAGRID_OK;
-    // deep links (below six levels, or below three in the compact form) resolve through 32-byte cells only: a compressed grid
-    // gets an image when blocks + nested blocks cover it
-    const bool compressed_deep = g->small_cells && g->shift > 3;
     if (g->shift < 0 || g->shift > 15) return HAGRID_OK;
     for (int i = 0; i < 3; i++)
         if (g->dims[i] <= 0 || (long long)g->dims[i] << g->shift > 65535) return HAGRID_OK;
@@ -829,34 +520,23 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     k.top_x = g->dims[0]; k.top_y = g->dims[1]; k.num_top = int(num_top); k.shift = g->shift;
     k.source_bytes = 4ll * g->num_entries + (g->small_cells ? 16ll : 32ll) * g->num_cells;
     k.num_entries = g->num_entries; k.num_cells = g->num_cells;
-    k.claim = nullptr; k.roots = nullptr; k.num_roots = nullptr; k.nested_off = nullptr; k.nested_d = nullptr; k.nested_base = 0;
     TravImageCache img;
-    int rc = HAGRID_OK;
-    bool flat = ctx->opt_image == 2;
-    // grids deeper than three levels: the general layout of slim records, without the sizing passes of the block layouts
-    bool general = false;
-    if (flat && ctx->opt_image_slim && ctx->opt_image_general && (g->shift > 3 || ctx->opt_image_general == 2)) {
-        rc = build_general(ctx, k, img);
-        if (rc < 0) return rc;
-        general = rc == HAGRID_OK;
-        rc = HAGRID_OK;
-    }
-    if (compressed_deep && !general && (g->shift > 6 || ctx->opt_image != 2)) return HAGRID_OK;
-    while (!general) {
-        switch (g->shift < 3 ? g->shift : 3) {
-            case 0: rc = flat ? build_image<0, true>(ctx, k, img) : build_image<0, false>(ctx, k, img); break;
-            case 1: rc = flat ? build_image<1, true>(ctx, k, img) : build_image<1, false>(ctx, k, img); break;
-            case 2: rc = flat ? build_image<2, true>(ctx, k, img) : build_image<2, false>(ctx, k, img); break;
-            default: rc = flat ? build_image<3, true>(ctx, k, img) : build_image<3, false>(ctx, k, img); break;
+    // Grids of at most three levels: a block of records per top-level cell (uniform or table layout); deeper grids, and grids those layouts cannot hold: the
+    // general layout.  ("traverse.image_general" = 2 of the test library: the general layout for every grid; 0: never.)
+    int rc = 1;
+    if (g->shift >= 1 && g->shift <= 3 && ctx->opt_image_general != 2) {
+        switch (g->shift) {
+            case 1: rc = build_blocks<1>(ctx, k, img); break;
+            case 2: rc = build_blocks<2>(ctx, k, img); break;
+            default: rc = build_blocks<3>(ctx, k, img); break;
         }
-        if (rc == 1 && flat && compressed_deep) return HAGRID_OK;   // too big, and the compact form cannot describe it: no image
-        if (rc == 1 && flat) { flat = false; continue; }     // too big as a flat image: compact form
-        break;
     }
-    img.flat = flat;
+    if (rc == 1 && ctx->opt_image_general) rc = build_general(ctx, k, img);
+    if (rc == 1) return HAGRID_OK;                 // no layout describes this grid (or fits the size limit): traversal reads the construction format
     if (rc != HAGRID_OK) return rc;
+    img.flat = true;
     img.valid = img.blocks != nullptr;
-    img.standalone = img.general || (flat && g->shift <= 6);            // the general layout never links back; blocks + nested blocks resolve six levels, only deeper grids keep `deep` links
+    img.standalone = true;                         // no record links back into the construction format
     img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
     img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;

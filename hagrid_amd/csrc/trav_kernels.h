@@ -1,5 +1,5 @@
-// trav_kernels.h -- the kernels that traverse the traversal image: traverse_kernel_img (every layout, any-hit / barycentric variants)
-// and traverse_kernel_tail (slim records, nearest hit: the default of every BASELINE configuration).  Templates, instantiated by
+// trav_kernels.h -- the kernels that traverse the traversal image (16-byte slim records in three layouts, trav_image.hip): traverse_kernel_img (any-hit /
+// barycentric variants, and the nearest hit without the tail mode) and traverse_kernel_tail (nearest hit: the default of every BASELINE configuration).  Templates, instantiated by
 // traverse.hip (the product) and, with TIMES = true, by kat/kat.hip (wavefront timelines for tools/dev_wave_timeline.py).
 #pragma once
 
@@ -7,26 +7,27 @@
 
 namespace hagrid_trav {
 
-// NARROW: 32-bit offsets off scalar bases as in v2 (the host checks that image, triangles, entries and cells are < 4 GB)
-// UNIFORM (with FLAT and NARROW): every block has (2^shift)^3 records and block T starts at T * (2^shift)^3 -- no table
+// Every gather is base (scalar registers) + unsigned 32-bit byte offset: the host launches these kernels when image, triangles and references are below 4 GB
+// and the top-level resolution fits 23 bits per axis (traverse.hip; larger grids are traversed in the construction format).
+// LAYOUT: 0 uniform (record of a voxel by arithmetic; bounds as offsets from the voxel), 1 table (blocks per top-level cell through the table; bounds from the
+// top-level cell's origin; wide records), 2 general (a record per voxel-map entry: trav_common.h GenWalk; links, wide records) -- trav_image.hip
+// SLIM: bits per packed reference id (20 or 26)
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-// SLIM (with FLAT and NARROW, grids of at most three levels): 16-byte records, SLIM = bits per packed reference id (trav_image.hip,
-// "Slim records"); 0 = 32-byte records.  UNIFORM: bounds as offsets from the voxel; table layout: from the top-level cell's origin.
-template <int BLOCK, bool FLAT, bool NARROW, bool UNIFORM, unsigned MODE, bool TIMES = false, int SLIM = 0, bool GENERAL = false>
-__global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseArgs a) {
-    static_assert(!GENERAL || (SLIM != 0 && !UNIFORM), "the general layout holds slim records");
+template <unsigned MODE, int SLIM, int LAYOUT, bool TIMES = false>
+__global__ void __launch_bounds__(64, 8) traverse_kernel_img(const TraverseArgs a) {
     constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
-    static_assert(SLIM == 0 || (FLAT && NARROW), "slim records are read by the flat narrow kernels only");
-    constexpr int NONE = SLIM ? (1 << (SLIM ? SLIM : 1)) - 1 : -1;          // the id field of an unused list slot
+    constexpr bool UNIFORM = LAYOUT == 0, TABLE = LAYOUT == 1, GENERAL = LAYOUT == 2;
+    constexpr int NONE = (1 << SLIM) - 1;          // the id field of an unused list slot
+    constexpr int NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     struct Stamp {
         unsigned long long* p;
         __device__ Stamp(unsigned long long* q) : p(q) { if (TIMES && threadIdx.x == 0) p[0] = wall_clock64(); }
         __device__ ~Stamp() { if (TIMES) { const unsigned long long t = wall_clock64(); atomicMax(p + 1, t); } }   // the last lane to leave
     } stamp(TIMES ? a.wave_times + 2 * size_t(blockIdx.x) : nullptr);
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
-    const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
+    const int w = !perm ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
-    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, threadIdx.x) : b * BLOCK + threadIdx.x;
+    const int slot = w ? tile_packet_slot(a, w, (TIMES && a.tile_order) ? a.tile_order[b] : b, threadIdx.x) : b * 64 + threadIdx.x;
     if (slot >= a.num_rays) return;
     const int id = perm ? perm[slot] : slot;
 
@@ -52,49 +53,24 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
         int vz = min(max(int(fv.z), 0), a.dims_z - 1);
 
         auto top_index = [&](int x, int y, int z) -> int {
-            if (NARROW) return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
-            return (x >> a.shift) + a.top_x * ((y >> a.shift) + a.top_y * (z >> a.shift));
+            return int(uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
         };
-        auto table_at = [&](int t) -> uint2 { return NARROW ? gather32<uint2>(a.img_table, uint32_t(t) << 3) : a.img_table[t]; };
-        GenWalk<SLIM ? SLIM : 20> gw;
+        auto table_at = [&](int t) -> uint2 { return gather32<uint2>(a.img_table, uint32_t(t) << 3); };
+        GenWalk<SLIM> gw;
         gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-        uint32_t wide_begin = 0u;
-        uint32_t nest = ~0u;                                                    // innermost nested block the ray is inside (FLAT + NARROW, table layout)
-        int nest_x = 0, nest_y = 0, nest_z = 0;                                 // ... and the voxel that led there
-        // record of a voxel: FLAT + NARROW is one address computation off the scalar base
-        auto record = [&](uint2 tab, int x, int y, int z, uint4& ra, uint4& rb, uint32_t moved = 0u) {
+        // record of a voxel: one address computation off the scalar base
+        auto record = [&](uint2 tab, int x, int y, int z, uint32_t moved = 0u) -> uint4 {
             if (UNIFORM) {
                 const int d = a.shift, m = (1 << d) - 1;
                 const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-                const uint32_t o = ((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << (SLIM ? 4 : 5);
-                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                ra = p[0];
-                if (!SLIM) rb = p[1];
-            } else if (GENERAL) {          // from the block of the last look-up, or from the top level (a link is resolved behind the tests)
-                ra = gw.lookup(a, x, y, z, moved);
-            } else if (FLAT && NARROW && SLIM) {          // table layout, no links: block offset in records, depth of the block
-                const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;
-                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                ra = *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
-            } else if (FLAT && NARROW) {
-                int d = int(tab.y & 3u), s = a.shift - d;
-                uint32_t base = tab.x;
-                if (nest != ~0u) {
-                    const int sr = a.shift - int(nest >> 27);               // finest-level voxels per root cell of the nested block, log2
-                    if ((((x ^ nest_x) | (y ^ nest_y) | (z ^ nest_z)) >> sr) == 0) { d = int((nest >> 25) & 3u); s = sr - d; base = nest & 0x1ffffffu; }
-                }
-                const int m = (1 << d) - 1;
-                const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
-                const uint32_t o = (base << 7) + (idx << 5);
-                const uint4* p = reinterpret_cast<const uint4*>(a.img_blocks + o);
-                ra = p[0]; rb = p[1];
-            } else {
-                const uint4* p = image_record<FLAT>(a, tab, x, y, z);
-                ra = p[0]; rb = p[1];
+                return *reinterpret_cast<const uint4*>(a.img_blocks + (((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 4));
             }
+            if (GENERAL) return gw.lookup(a, x, y, z, moved);          // from the block of the last look-up, or from the top level (a link is resolved behind the tests)
+            const int d = int(tab.y & 3u), s = a.shift - d, m = (1 << d) - 1;          // table layout: block offset in records, depth of the block
+            const uint32_t idx = uint32_t((x >> s) & m) + (uint32_t(((y >> s) & m) + (((z >> s) & m) << d)) << d);
+            return *reinterpret_cast<const uint4*>(a.img_blocks + ((tab.x + idx) << 4));
         };
         auto tri_at = [&](int ref) -> Tri {
-            if (!NARROW) return load_tri(a.tris, ref);
             uint32_t r3, o;
             asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
             asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
@@ -102,68 +78,52 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             const float4 p0 = p[0], p1 = p[1], p2 = p[2];
             return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
         };
-
         auto tri_for = [&](int ref) -> Tri {
-            if (HG_SOLO && NARROW) {
+            if (HG_SOLO) {
                 const int r0 = __builtin_amdgcn_readfirstlane(ref);
                 const unsigned long long others = __ballot(ref != r0);
                 if (others == 0ull) return load_tri_scalar(a.tris, r0);
             }
             return tri_at(ref);
         };
-        // which half of a bounds word is the exit plane (slim records: which byte, and the direction the offset counts in)
-        const uint32_t ox = SLIM ? (px ? 8u : 0u) : (px ? 16u : 0u), oy = SLIM ? (py ? 24u : 16u) : (py ? 16u : 0u), oz = SLIM ? (pz ? 8u : 0u) : (pz ? 16u : 0u);
+        // which byte of the bounds is the exit plane, and the direction the offset counts in
+        const uint32_t ox = px ? 8u : 0u, oy = py ? 24u : 16u, oz = pz ? 8u : 0u;
         const int sgx = px ? 1 : -1, sgy = py ? 1 : -1, sgz = pz ? 1 : -1;
         const int bx = px ? 0 : -1, by = py ? 0 : -1, bz = pz ? 0 : -1;               // the voxel just past it
         const int lim_x = px ? 0x7fffffff : int(0x80000000), lim_y = py ? 0x7fffffff : int(0x80000000), lim_z = pz ? 0x7fffffff : int(0x80000000);
-        int top_idx = (UNIFORM || GENERAL) ? 0 : top_index(vx, vy, vz);
-        uint2 tab = (UNIFORM || GENERAL) ? make_uint2(0u, 0u) : table_at(top_idx);
-        uint4 ca, cb = make_uint4(0u, 0u, 0u, 0u);
-        record(tab, vx, vy, vz, ca, cb);
+        int top_idx = TABLE ? top_index(vx, vy, vz) : 0;
+        uint2 tab = TABLE ? table_at(top_idx) : make_uint2(0u, 0u);
+        uint4 ca = record(tab, vx, vy, vz);
         if (GENERAL) gw.descend(a, ca, vx, vy, vz);
 
         for (;;) {
-            if (!UNIFORM && !SLIM && ca.w >= 0xfffffffeu) {                 // (the table-free layout and slim records need shift <= 3: every block resolves its cell fully)
-                // remember the innermost nested block and the voxel that led there: while the ray stays inside that block's root
-                // cell the next records are fetched from it directly (one gather per step again)
-                uint32_t off = ~0u, meta = 0u;
-                image_resolve_links(a, vx, vy, vz, ca, cb, off, meta);
-                if (!UNIFORM && FLAT && NARROW && off != ~0u) {
-                    nest = off | (meta & 3u) << 25 | (meta >> 8) << 27;        // offset < 2^25 units (NARROW), depth of the block, depth of its root
-                    nest_x = vx; nest_y = vy; nest_z = vz;
-                }
-            }
-            // lo or hi of every axis: one bit-field extract per axis (offset 0 or 16, fixed per ray)
             int cx, cy, cz;
             bool wide_cell = false;
-            if (GENERAL) {     // general layout: byte offsets from the origin of the record's region, or a wide record with absolute bounds
-                const int org_mask = int(~0u << gw.region_shift());
-                cx = (vx & org_mask) + sgx * int(__builtin_amdgcn_ubfe(ca.x, ox, 8u));
-                cy = (vy & org_mask) + sgy * int(__builtin_amdgcn_ubfe(ca.x, oy, 8u));
-                cz = (vz & org_mask) + sgz * int(__builtin_amdgcn_ubfe(ca.y, oz, 8u));
-                wide_cell = GenWalk<SLIM ? SLIM : 20>::is_wide(ca);
-                if (wide_cell) {
-                    const uint4 wr = GenWalk<SLIM ? SLIM : 20>::wide_at(a, ca);
-                    cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
-                    wide_begin = wr.w;
-                }
-            } else if (SLIM && !UNIFORM) {     // table layout: biased byte offsets from the origin of the top-level cell, or a wide record
-                const int org_mask = ~((1 << a.shift) - 1);
-                cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
-                cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
-                cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
-                wide_cell = GenWalk<SLIM ? SLIM : 20>::is_wide(ca);
-                if (wide_cell) {
-                    const uint4 wr = GenWalk<SLIM ? SLIM : 20>::wide_at(a, ca);
-                    cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
-                    wide_begin = wr.w;
-                }
-            } else if (SLIM) {     // byte offsets from the voxel the record belongs to
+            uint32_t wide_begin = 0u;
+            if (UNIFORM) {     // byte offsets from the voxel the record belongs to
                 // voxel +- offset as ONE multiply-add with the ray's sign (the compiler expands a plain multiply by +-1 into negate + select)
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cx) : "v"(sgx), "v"(__builtin_amdgcn_ubfe(ca.x, ox, 8u)), "v"(vx));
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cy) : "v"(sgy), "v"(__builtin_amdgcn_ubfe(ca.x, oy, 8u)), "v"(vy));
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(cz) : "v"(sgz), "v"(__builtin_amdgcn_ubfe(ca.y, oz, 8u)), "v"(vz));
-            } else { cx = int(__builtin_amdgcn_ubfe(ca.x, ox, 16u)); cy = int(__builtin_amdgcn_ubfe(ca.y, oy, 16u)); cz = int(__builtin_amdgcn_ubfe(ca.z, oz, 16u)); }
+            } else {
+                if (GENERAL) {     // byte offsets from the origin of the record's region
+                    const int org_mask = int(~0u << gw.region_shift());
+                    cx = (vx & org_mask) + sgx * int(__builtin_amdgcn_ubfe(ca.x, ox, 8u));
+                    cy = (vy & org_mask) + sgy * int(__builtin_amdgcn_ubfe(ca.x, oy, 8u));
+                    cz = (vz & org_mask) + sgz * int(__builtin_amdgcn_ubfe(ca.y, oz, 8u));
+                } else {           // table layout: biased byte offsets from the origin of the top-level cell
+                    const int org_mask = ~((1 << a.shift) - 1);
+                    cx = (vx & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, ox, 8u)) - 128;
+                    cy = (vy & org_mask) + int(__builtin_amdgcn_ubfe(ca.x, oy, 8u)) - 128;
+                    cz = (vz & org_mask) + int(__builtin_amdgcn_ubfe(ca.y, oz, 8u)) - 128;
+                }
+                wide_cell = GenWalk<SLIM>::is_wide(ca);          // a cell the bytes cannot hold: absolute bounds in its wide record
+                if (wide_cell) {
+                    const uint4 wr = GenWalk<SLIM>::wide_at(a, ca);
+                    cx = int(__builtin_amdgcn_ubfe(wr.x, px ? 16u : 0u, 16u)); cy = int(__builtin_amdgcn_ubfe(wr.y, py ? 16u : 0u, 16u)); cz = int(__builtin_amdgcn_ubfe(wr.z, pz ? 16u : 0u, 16u));
+                    wide_begin = wr.w;
+                }
+            }
             const vec3 tcell = (vec3(float(cx), float(cy), float(cz)) * csize + gmin - org) * inv_dir;
             const float texit = detail::fmin2(tcell.x, detail::fmin2(tcell.y, tcell.z));
             const vec3 ev = (texit * dir + org - gmin) * ginv;
@@ -173,48 +133,33 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
             // never backwards: max with the current voxel along a positive direction, min along a negative one -- the median of
             // (new, current, +-infinity), one instruction per axis
             const int pvx = vx, pvy = vy, pvz = vz;
-            if (UNIFORM) { vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z); }
-            else { vx = px ? max(nx, vx) : min(nx, vx); vy = py ? max(ny, vy) : min(ny, vy); vz = pz ? max(nz, vz) : min(nz, vz); }   // (the table layouts have no registers to spare)
+            vx = med3_i32(nx, vx, lim_x); vy = med3_i32(ny, vy, lim_y); vz = med3_i32(nz, vz, lim_z);
             const bool outside = (uint32_t(vx) >= uint32_t(a.dims_x)) | (uint32_t(vy) >= uint32_t(a.dims_y)) | (uint32_t(vz) >= uint32_t(a.dims_z));
 
             // next cell: table entry (only when the top-level cell changes) -> record, in flight during the tests below
-            if (!UNIFORM && !GENERAL) {
+            if (TABLE) {
                 const int ntop = outside ? top_idx : top_index(vx, vy, vz);
                 if (ntop != top_idx) { tab = table_at(ntop); top_idx = ntop; }
             }
-            uint4 na = make_uint4(0u, 0u, 0u, 0u), nb = make_uint4(0u, 0u, 0u, 0u);
-            if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; record(tab, sx, sy, sz, na, nb); }
-            else if (GENERAL) { if (!outside) record(tab, vx, vy, vz, na, nb, uint32_t((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz))); }
-            else record(tab, vx, vy, vz, na, nb);
+            uint4 na = make_uint4(0u, 0u, 0u, 0u);
+            if (UNIFORM) { const int sx = outside ? 0 : vx, sy = outside ? 0 : vy, sz = outside ? 0 : vz; na = record(tab, sx, sy, sz); }
+            else if (!outside) na = record(tab, vx, vy, vz, uint32_t((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz)));
 
-            // Lists: inline ids (up to four, unused slots -1) are consumed front to back; a list given by index (bit 31: more
-            // than four ids, deep cells) fetches the id of the next test one test ahead, as v2 does.
-            auto ref_at = [&](uint32_t i) -> int { return NARROW ? gather32<int>(a.refs, i << 2) : a.refs[i]; };
-            bool by_index;
-            uint32_t q1, q2, q3, li_begin, li_count;
-            int ref;
-            if (SLIM) {
-                // id fields of SLIM bits from bit 48 on; the last field = NONE - 1 marks a list given by index
-                constexpr int NI = 80 / (SLIM ? SLIM : 80), LAST = 48 + (NI - 1) * SLIM;
-                auto field = [&](int pos, int n) -> uint32_t {              // pos, n are constants after inlining
-                    const uint32_t w[4] = {ca.x, ca.y, ca.z, ca.w};
-                    const int i = pos >> 5, o = pos & 31;
-                    uint32_t v = w[i] >> o;
-                    if (o + n > 32) v |= w[i + 1] << (32 - o);
-                    return n == 32 ? v : (v & ((1u << n) - 1u));
-                };
-                by_index = field(LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
-                ref = int(field(48, SLIM));
-                q1 = NI > 1 ? field(48 + SLIM, SLIM) : uint32_t(NONE);
-                q2 = NI > 2 ? field(48 + 2 * SLIM, SLIM) : uint32_t(NONE);
-                q3 = NI > 3 ? field(48 + 3 * SLIM, SLIM) : uint32_t(NONE);
-                li_begin = wide_cell ? wide_begin : field(48, 32); li_count = field(80, 20);
-            } else {
-                by_index = int(ca.w) < 0;
-                q1 = cb.y; q2 = cb.z; q3 = cb.w;                            // inline: the ids still to test
-                ref = int(cb.x);                                            // inline: the first id, or -1 for an empty list
-                li_begin = cb.x; li_count = ca.w & 0x7fffffffu;
-            }
+            // Lists: inline ids (up to four, unused fields NONE) are consumed front to back; a list given by index (more ids than a record holds, wide cells)
+            // fetches the id of the next test one test ahead, as v2 does.
+            auto ref_at = [&](uint32_t i) -> int { return gather32<int>(a.refs, i << 2); };
+            auto field = [&](int pos, int n) -> uint32_t {              // pos, n are constants after inlining
+                const uint32_t wd[4] = {ca.x, ca.y, ca.z, ca.w};
+                const int i = pos >> 5, o = pos & 31;
+                uint32_t v = wd[i] >> o;
+                if (o + n > 32) v |= wd[i + 1] << (32 - o);
+                return n == 32 ? v : (v & ((1u << n) - 1u));
+            };
+            const bool by_index = field(LAST, SLIM) == uint32_t(NONE - 1) || wide_cell;
+            int ref = int(field(48, SLIM));
+            uint32_t q1 = NI > 1 ? field(48 + SLIM, SLIM) : uint32_t(NONE), q2 = NI > 2 ? field(48 + 2 * SLIM, SLIM) : uint32_t(NONE),
+                     q3 = NI > 3 ? field(48 + 3 * SLIM, SLIM) : uint32_t(NONE);
+            const uint32_t li_begin = wide_cell ? wide_begin : field(48, 32), li_count = field(80, 20);
             if (UNIFORM && __ballot(by_index) == 0ull) {
                 // shallow grids: lists of more than four ids are rare (1.5 % of the visited cells of the 1M-triangle soup), so a
                 // wavefront normally holds inline lists only and runs this loop: no index bookkeeping, no masked branches
@@ -253,7 +198,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_img(const TraverseAr
                 }
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
-            ca = na; cb = nb;
+            ca = na;
             if (GENERAL) gw.descend(a, ca, vx, vy, vz);
         }
     }

@@ -27,18 +27,13 @@ __global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ 
     out[i + t] = tris[i];                            // piece p of triangle t: 4 t + p = i + t
 }
 
-// the image kernel: plain traversal for every layout, the any-hit / barycentric variants for the flat narrow layouts
+// the kernels of the traversal image: the tail kernel for the nearest hit, the image kernel for any-hit / barycentrics (and with "traverse.tail" = 0)
 template <unsigned MODE>
-bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
-    if (slim && !(flat && narrow && (slim == 20 || slim == 26))) return false;          // slim records are read by the flat narrow kernels only
-    if (tail && MODE == 0 && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL)
-        if (a.mailbox) {
-            if (a.tri64) { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a); }
-            else         { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a); }
-        } else {
-            if (a.tri64) { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a); }
-            else         { if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a); else traverse_kernel_tail<26, false, true, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a); }
-        }
+bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
+    if (!narrow || (slim != 20 && slim != 26)) return false;          // (32-bit offsets: the caller sends larger grids to the construction-format kernels)
+    if (tail && MODE == 0 && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL; always with the mailbox, never on padded triangles)
+        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        else            traverse_kernel_tail<26, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         return true;
     }
     if (tail && MODE == 0 && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
@@ -96,26 +91,23 @@ bool launch_img_mode(hipStream_t st, int blocks, bool flat, bool narrow, bool un
             else            traverse_kernel_tail<26><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
-    else if (slim == 20 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
-    else if (slim == 26 && uniform) traverse_kernel_img<64, true, true, true, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
-    else if (slim == 20 && general) traverse_kernel_img<64, true, true, false, MODE, false, 20, true><<<blocks, 64, 0, st>>>(a);
-    else if (slim == 26 && general) traverse_kernel_img<64, true, true, false, MODE, false, 26, true><<<blocks, 64, 0, st>>>(a);
-    else if (slim == 20)            traverse_kernel_img<64, true, true, false, MODE, false, 20><<<blocks, 64, 0, st>>>(a);
-    else if (slim == 26)            traverse_kernel_img<64, true, true, false, MODE, false, 26><<<blocks, 64, 0, st>>>(a);
-    else if (flat && narrow && uniform) traverse_kernel_img<64, true, true, true, MODE><<<blocks, 64, 0, st>>>(a);
-    else if (flat && narrow)       traverse_kernel_img<64, true, true, false, MODE><<<blocks, 64, 0, st>>>(a);
-    else if (MODE != 0)            return false;
-    else if (flat)                 traverse_kernel_img<64, true, false, false, 0><<<blocks, 64, 0, st>>>(a);
-    else if (narrow)               traverse_kernel_img<64, false, true, false, 0><<<blocks, 64, 0, st>>>(a);
-    else                           traverse_kernel_img<64, false, false, false, 0><<<blocks, 64, 0, st>>>(a);
+    else if (slim == 20) {
+        if (uniform)      traverse_kernel_img<MODE, 20, 0><<<blocks, 64, 0, st>>>(a);
+        else if (general) traverse_kernel_img<MODE, 20, 2><<<blocks, 64, 0, st>>>(a);
+        else              traverse_kernel_img<MODE, 20, 1><<<blocks, 64, 0, st>>>(a);
+    } else {
+        if (uniform)      traverse_kernel_img<MODE, 26, 0><<<blocks, 64, 0, st>>>(a);
+        else if (general) traverse_kernel_img<MODE, 26, 2><<<blocks, 64, 0, st>>>(a);
+        else              traverse_kernel_img<MODE, 26, 1><<<blocks, 64, 0, st>>>(a);
+    }
     return true;
 }
-bool launch_img(hipStream_t st, int blocks, bool flat, bool narrow, bool uniform, bool general, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
+bool launch_img(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
     switch (mode & 3u) {
-        case 0: return launch_img_mode<0>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
-        case 1: return launch_img_mode<1>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
-        case 2: return launch_img_mode<2>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
-        default: return launch_img_mode<3>(st, blocks, flat, narrow, uniform, general, slim, tail, a);
+        case 0: return launch_img_mode<0>(st, blocks, narrow, uniform, general, slim, tail, a);
+        case 1: return launch_img_mode<1>(st, blocks, narrow, uniform, general, slim, tail, a);
+        case 2: return launch_img_mode<2>(st, blocks, narrow, uniform, general, slim, tail, a);
+        default: return launch_img_mode<3>(st, blocks, narrow, uniform, general, slim, tail, a);
     }
 }
 
@@ -427,7 +419,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
             const long long n_tris = (long long)ctx->image.max_ref + 1;
             const bool want = ctx->opt_tri_pad < 0 ? (perm != nullptr && (long long)num_rays >= 4 * n_tris) : ctx->opt_tri_pad != 0;
-            if (want) {
+            if (want && refill_k <= 1) {          // (a refilled launch reads the caller's triangles: its default never meets a binned batch)
                 float4* padded = tmp.get<float4>(size_t(n_tris) * 4);
                 if (padded) {
                     pad_triangles<<<grid_blocks(3 * n_tris, 256), 256, 0, ctx->stream>>>(a.tris, int(3 * n_tris), padded); HG_DBG(ctx);
@@ -436,9 +428,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             }
         }
         if (refill_k > 1) {      // ("traverse.refill" above)
-            a.refill = refill_k; a.tail_dual = 0; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);
+            a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
-        if (!launch_img(ctx->stream, blocks, ctx->image.flat, narrow, ctx->image.flat && ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
+        if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (learn_order) { launch_tile_order(ctx, H, tiles, a); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {

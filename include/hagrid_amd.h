@@ -184,17 +184,17 @@ int hagrid_grid_broadcast(hagrid_ctx* ctx, void* comm, int rank, int root, hagri
 /* ---- traversal (traverse.h:11-14) ------------------------------------------------------------------- */
 /* setup_traversal (traverse.cu:97-109): prepares the traversal state of `grid`.  The reference uploads constants; here
  * the constants travel with every launch and this call builds the TRAVERSAL IMAGE of the grid in the context (one per
- * context: the grid of the last call).  Default form ("traverse.image" = 2, flat): per top-level cell one 128-byte aligned
- * block of (2^d)^3 records of 32 bytes, indexed by the voxel -- u16 cell bounds, list length and the reference ids of lists
- * of up to four inline -- so that a cell step is ONE dependent gather (the block's table entry is kept while the ray stays in
- * the top-level cell) instead of entry -> entry -> cell, and the reference-id gather disappears for short lists; blocks
- * resolve three levels, deeper subdivisions are links to nested blocks of the same form (three more levels each; below
- * six levels a link back into the construction format).  Grids of at most three levels get SLIM records of 16 bytes instead
- * ("traverse.image_slim", on by default: bounds as byte offsets from the record's voxel -- from the top-level cell's origin in
- * the table layout --, four reference ids of 20 bits or three of 26 bits; one gather instruction per cell step, half the
- * image) unless a cell reaches further than a byte can say, in which case the 32-byte records are kept.  "traverse.image" = 1 is the compact
- * form (one byte per voxel + de-duplicated records: half the memory, two gathers per step), 0 builds nothing.  A flat
- * image that would exceed max(1 GB, 8x the entries + cells it replaces) ("traverse.image_max_mb") is built in the compact form.
+ * context: the grid of the last call): ONE 16-byte record per cell step -- the cell's bounds as byte offsets, the reference ids of
+ * lists of up to four (20-bit ids) or three (26-bit ids) inline -- so that a cell step is one dependent gather instead of
+ * entry -> entry -> cell, and the reference-id gather disappears for short lists.  Three layouts (hagrid_amd/csrc/trav_image.hip):
+ * grids of at most three levels get a block of records per top-level cell, indexed by the voxel -- found by arithmetic where
+ * (nearly) every top-level cell has the full depth (uniform layout), through a table otherwise (table layout); every other grid
+ * gets a record per voxel-map entry at the entry's index (general layout: inner entries are links to their child blocks, and the
+ * kernel keeps the innermost block a ray is in -- one gather per step at any depth).  Cells whose bounds a byte cannot hold (the
+ * large cells of empty space) get a wide record in the table and general layouts.  "traverse.image" = 0 builds nothing (traversal
+ * reads the construction format); 1 and 2 build the image (1 was round 1-4's compact form and is kept as a value).  An image that
+ * would exceed max(1 GB, 8x the entries + cells it replaces) ("traverse.image_max_mb") is not built, nor is one for a grid no layout
+ * describes (a virtual resolution of 65536 per axis, reference ids beyond 26 bits, a list of 2^20 ids).
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
  * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
  * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for

@@ -111,7 +111,7 @@ def test_config2_loop_over_one_buffer_learned_tile_order_matches_oracle(world):
 
 def test_config3_dense_grid_16M_primary_rays(world):
     """configs[2]: soup-1M, --top-density 0.15 --snd-density 3.0 --expansion 3, 4096 x 4096 primary rays.  Grid arrays identical
-    to the oracle's; identical hits from the flat image, the compact image and the construction format; the oracle on a strided
+    to the oracle's; identical hits from the table layout of the image, the general layout and the construction format; the oracle on a strided
     1M-ray sample; a brute force over all triangles on 1024 rays."""
     import os
     from hagrid_amd import api
@@ -128,12 +128,13 @@ def test_config3_dense_grid_16M_primary_rays(world):
     n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     got = {}
-    for image in (2, 1, 0):
-        mem.set_option("traverse.image", image)
+    for image, general in ((2, 1), (1, 2), (0, 1)):          # the table layout (this grid's default), the general layout forced, the construction format
+        mem.set_option("traverse.image", image); mem.set_option("traverse.image_general", general)
         api.setup_traversal(grid)
+        if image: assert mem.image_format(grid)["general"] == (general == 2) and not mem.image_format(grid)["uniform"]
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
         got[image] = mem.download(d_hits, api.HIT_DTYPE, n)
-    mem.set_option("traverse.image", 2)
+    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_general", 1)
     assert same_hits(got[2], got[1]) and same_hits(got[2], got[0])
     hits = got[2]
     assert (hits["id"] >= 0).mean() > 0.7
@@ -306,8 +307,7 @@ def test_config5_8M_triangles_compressed_bounce_rays():
 def test_clustered_scene_structure_and_hits_match_oracle():
     """A very non-uniform 1M-triangle scene (scene.make_clustered: six dense blobs in a sparse soup; grid shift 6, lists of
     up to ~20 references): grid arrays identical to the oracle's; primary and incoherent hits identical to the oracle's with
-    the construction-format kernel and with every image format (general layout of slim records: links, wide records, by-index lists; 32-byte records
-    with nested blocks; compact)."""
+    the construction-format kernel and with the traversal image (general layout of slim records: links, wide records, by-index lists)."""
     from hagrid_amd import api
     from oracle import oracle as O
     tris = scene.make_clustered()
@@ -328,20 +328,19 @@ def test_clustered_scene_structure_and_hits_match_oracle():
                                scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 18, 11), aimed]).astype(np.float32)
         oh, _ = G.traverse(tris, rays, nthreads=8)
         assert (oh["id"] >= 1_00_000).sum() > 1000            # rays that end inside a blob
-        for image in (2, 1, 0):
+        for image in (2, 0):
             mem.set_option("traverse.image", image)
             assert same_hits(traverse(mem, grid, d_tris, rays), oh), f"traverse.image={image}"
-        # the default image of a deep grid is the general layout of slim records, traversed by the tail kernel; the same image by the kernel without the
-        # tail mode, with ray binning, in the 26-bit id form, and the 32-byte records with their nested blocks
+        # the image of a deep grid is the general layout of slim records, traversed by the tail kernel; the same image by the kernel without the
+        # tail mode, with ray binning, in the 26-bit id form
         mem.set_option("traverse.image", 2); api.setup_traversal(grid)
         fmt = mem.image_format(grid)
         assert fmt["general"] and fmt["record_bytes"] == 16 and fmt["slim_id_bits"] == 20, fmt
-        for opts in ({"traverse.tail": 0}, {"binning": 1}, {"traverse.image_slim": 2}, {"traverse.image_slim": 0}):
+        for opts in ({"traverse.tail": 0}, {"binning": 1}, {"traverse.image_slim": 2}):
             for k, v in opts.items():
                 if k == "binning": mem.set_ray_binning(v)
                 else: mem.set_option(k, v)
             assert same_hits(traverse(mem, grid, d_tris, rays), oh), opts
-            if "traverse.image_slim" in opts: assert mem.image_format(grid)["record_bytes"] == (16 if opts["traverse.image_slim"] else 32)
             mem.set_ray_binning(0); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1)
         grid.free()
     finally:

@@ -390,12 +390,12 @@ def _image_scenes():
             "compressed_long_lists": (np.concatenate([np.repeat(scene.make_soup(30, seed=15), 12, axis=0), scene.make_soup(6000, seed=16)]), dict(compress=True, top_density=0.3, snd_density=1.0))}
 
 
-# (traverse.image, traverse.image_slim, traverse.image_general): compact blocks (slot bytes + de-duplicated records); flat with slim 16-byte records -- grids of
-# at most three levels whose cells fit the bound bytes: a block of records per top-level cell, table-free where every top-level cell has the full depth (uniform
-# layout), through the table otherwise (table layout); every other grid a record per voxel-map entry (general layout: any depth, links to child blocks, wide
-# records for cells whose bounds do not fit a byte); flat with 32-byte records only (blocks, nested blocks, deep links); flat with the 26-bit form of the slim
-# record; the general layout forced on grids the block layouts would serve
-_IMAGE_FORMATS = {"compact": (1, 1, 1), "flat": (2, 1, 1), "flat_fat": (2, 0, 1), "flat_slim26": (2, 2, 1), "flat_general": (2, 1, 2)}
+# (traverse.image, traverse.image_slim, traverse.image_general): the traversal image holds 16-byte slim records in one of three layouts -- grids of at most three
+# levels: a block of records per top-level cell, table-free where (nearly) every top-level cell has the full depth (uniform layout), through the table otherwise
+# (table layout; wide records for cells whose bounds do not fit a byte); every other grid a record per voxel-map entry (general layout: any depth, links to child
+# blocks, wide records).  "image1": the value 1 of the option (round 1-4's compact form) builds the same image as 2; the 26-bit form of the record; the general
+# layout forced on grids the block layouts would serve
+_IMAGE_FORMATS = {"flat": (2, 1, 1), "image1": (1, 1, 1), "flat_slim26": (2, 2, 1), "flat_general": (2, 1, 2)}
 
 
 @pytest.mark.parametrize("fmt_name", list(_IMAGE_FORMATS))
@@ -419,39 +419,29 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     vox = np.stack([flat % res[0], (flat // res[0]) % res[1], flat // (res[0] * res[1])], axis=1).astype(np.int32)
     got = np.zeros((len(vox), 8), np.uint32); nbytes = C.c_int64(0)
     rc = mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), vox.ctypes.data_as(C.c_void_p), len(vox), got.ctypes.data_as(C.c_void_p), C.byref(nbytes))
-    if name == "compressed_deep" and fmt == 1:         # the compact form would need deep links, which resolve through 32-byte cells only
-        assert rc != 0
-        grid.free()
-        return
     assert rc == 0
     want, begin = _expected_records(G, vox.astype(np.int64))
     by_index, deep = _check_records(got, want, begin)
     info = mem.image_format(grid)
-    assert info["flat"] == (fmt == 2)
-    if fmt == 2 and slim:        # every grid here fits slim records: what a byte cannot say goes into wide records
-        assert info["slim_id_bits"] == (26 if slim == 2 else 20) and info["record_bytes"] == 16, "slim records expected"
-        assert not (info["uniform"] and info["general"])
-        assert info["general"] or 1 <= G.shift <= 3
-        if general == 2 or G.shift > 3 or G.shift == 0: assert info["general"]
-    else:
-        assert info["slim_id_bits"] == 0 and info["record_bytes"] == 32 and not info["general"]
-    if info["slim_id_bits"] and info["uniform"]:
+    # every grid here fits slim records: what a byte cannot say goes into wide records
+    assert info["flat"] and info["slim_id_bits"] == (26 if slim == 2 else 20) and info["record_bytes"] == 16, "slim records expected"
+    assert not (info["uniform"] and info["general"])
+    assert info["general"] == (general == 2 or G.shift > 3 or G.shift == 0)
+    if info["uniform"]:
         assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims))
     if info["general"]:
         assert nbytes.value >= 16 * G.num_entries and nbytes.value <= 16 * (G.num_entries + G.num_cells) + 256
-    if name == "soup30k_shift3" and fmt == 2 and slim:
-        assert not info["uniform"] and info["general"] == (general == 2), "the table layout with slim records and the general layout on a grid of three levels are exercised"
-    assert nbytes.value >= 32 * G.num_cells / 64 and nbytes.value < (64 if fmt == 1 else 600) * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
+    if name == "soup30k_shift3":
+        assert not info["uniform"] and info["general"] == (general == 2), "the table layout and the general layout on a grid of three levels are exercised"
+    assert nbytes.value >= 16 * G.num_cells / 64 and nbytes.value < 600 * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
-        assert (by_index & ~deep).any() or info["general"]
         assert by_index.any()
     if info["general"]:
         # bit 30 of the resolved record: the walk went through a link -- exactly where the top-level entry of the voxel is subdivided
         t = vox.astype(np.int64) >> G.shift
         top_inner = (G.entries[t[:, 0] + G.dims[0] * (t[:, 1] + G.dims[1] * t[:, 2])] & 3) != 0
         assert (deep == top_inner).all()
-    elif name in ("deep", "sparse", "coincident", "compressed_deep"):
-        assert G.shift > 3 and deep.any() and not deep.all()
+        if name in ("deep", "sparse", "coincident", "compressed_deep"): assert G.shift > 3 and deep.any() and not deep.all()
     else:
         assert not deep.any()
     if name == "dense_wide":
@@ -459,7 +449,7 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
         top = vox >> 3
         per_top = {}
         key = (top[:, 0] + G.dims[0] * (top[:, 1] + G.dims[1] * top[:, 2])).astype(np.int64) * (G.num_cells + 1) + _np_lookup(G, vox.astype(np.int64))
-        assert np.bincount(np.unique(key) // (G.num_cells + 1)).max() > 255        # the u16 slot form is exercised
+        assert np.bincount(np.unique(key) // (G.num_cells + 1)).max() > 255        # (a top-level cell with more than 255 cells)
     grid.free()
     assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) != 0      # the image went with the grid
 
@@ -470,8 +460,6 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
     from oracle import oracle as O
     from hagrid_amd import api
     fmt, slim, general = _IMAGE_FORMATS[fmt_name]
-    if name == "compressed_deep" and fmt == 1:
-        pytest.skip("no compact image for compressed grids deeper than three levels")
     tris, params = _image_scenes()[name]
     G = O.Grid.full(tris, **params)
     d_tris = mem.upload(tris)
@@ -481,7 +469,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
     want, _ = G.traverse(tris, rays, nthreads=8)
     try:
         mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim); mem.set_option("traverse.image_general", general)
-        for uniform in ((1, 0) if fmt == 2 and slim == 1 else (1,)):          # flat blocks: table-free layout allowed / not allowed
+        for uniform in ((1, 0) if slim == 1 and general == 1 else (1,)):          # blocks: table-free layout allowed / not allowed
             mem.set_option("traverse.image_uniform", uniform)
             for variant in (4, 0, 2):
                 mem.set_option("traverse.variant", variant)
@@ -501,7 +489,7 @@ def test_image_kernel_gives_the_oracle_hits(mem, name, fmt_name):
 def test_cells_too_long_for_a_byte_get_wide_records(mem):
     """A cell that reaches more than 255 voxels away from one of its voxels does not fit the byte offsets of a slim record: the uniform layout
     cannot hold it, the table layout and the general layout give it a WIDE record (absolute 16-bit bounds, one per cell), and the hits stay the
-    oracle's.  The 26-bit id form and 32-byte records give the same hits."""
+    oracle's.  The 26-bit id form gives the same hits."""
     from oracle import oracle as O
     from hagrid_amd import api
     a = scene.make_soup(2000, seed=31).copy(); b = scene.make_soup(2000, seed=32).copy()
@@ -518,7 +506,7 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
     try:
         for uniform in (2, 1):            # 2: the table-free layout whatever it costs (this grid is mostly empty) -- it does not fit; 1: not asked for
             mem.set_option("traverse.image_uniform", uniform)
-            for slim in (1, 2, 0):
+            for slim in (1, 2):
                 mem.set_option("traverse.image_slim", slim)
                 for tail in (1, 0):
                     mem.set_option("traverse.tail", tail)
@@ -527,19 +515,15 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
                 mem.set_option("traverse.tail", 1)
                 info = mem.image_format(grid)
                 assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
-                if slim:
-                    assert not info["general"] and not info["uniform"] and info["record_bytes"] == 16, "the table layout with wide records expected"
-                    assert 16 * G.num_cells / 8 < nb.value < 32 * total
-                    mem.set_option("traverse.image_general", 2)                      # the same grid in the general layout: wide records there as well
-                    got = gpu_traverse(mem, grid, d_tris, rays)
-                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim, "general")
-                    info = mem.image_format(grid)
-                    assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
-                    assert info["general"] and 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
-                    mem.set_option("traverse.image_general", 1)
-                else:
-                    assert info["flat"] and not info["general"] and info["uniform"] == (uniform == 2) and info["record_bytes"] == 32, "32-byte records expected"
-                    assert uniform == 1 or nb.value >= 32 * total
+                assert not info["general"] and not info["uniform"] and info["record_bytes"] == 16, "the table layout with wide records expected"
+                assert 16 * G.num_cells / 8 < nb.value < 32 * total
+                mem.set_option("traverse.image_general", 2)                      # the same grid in the general layout: wide records there as well
+                got = gpu_traverse(mem, grid, d_tris, rays)
+                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim, "general")
+                info = mem.image_format(grid)
+                assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
+                assert info["general"] and 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
+                mem.set_option("traverse.image_general", 1)
         mem.set_option("traverse.image_uniform", 2)
         # the same clusters close together: every cell fits, slim records in both id widths
         b[:, 0] -= np.float32(39.0)
@@ -580,7 +564,7 @@ def test_image_lifetime(mem):
         got = mem.download(d_hits, api.HIT_DTYPE, rays.shape[0])
         assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
     try:
-        api.setup_traversal(grid); assert has_image(grid)          # built by default (flat blocks)
+        api.setup_traversal(grid); assert has_image(grid)          # built by default
         mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid)
         mem.set_option("traverse.image", 1)
         mem.set_option("traverse.variant", 4)
@@ -604,20 +588,19 @@ def test_image_lifetime(mem):
         # switched off: setup_traversal builds nothing
         mem.set_option("traverse.image", 0); api.setup_traversal(grid); assert not has_image(grid); check()
         mem.set_option("traverse.image", 1); api.setup_traversal(grid); assert has_image(grid); check()
-        # a flat image above the size limit is replaced by the compact form
+        # an image above the size limit is not built: traversal reads the construction format
         mem.set_option("traverse.image", 2); mem.set_option("traverse.image_max_mb", 1)
         big = O.Grid.full(scene.make_soup(40000, seed=22)); gb = upload_oracle_grid(mem, big)
         nb = C.c_int64(0)
-        api.setup_traversal(gb)
-        assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value < (7 << 20)
-        mem.set_option("traverse.image_max_mb", 0); mem.set_option("traverse.image_slim", 0); api.setup_traversal(gb)
-        assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and nb.value > (8 << 20)
-        mem.set_option("traverse.image_slim", 1); api.setup_traversal(gb)        # 16-byte records: half of it
+        api.setup_traversal(gb); assert not has_image(gb)
+        mem.set_option("traverse.image_max_mb", 0); api.setup_traversal(gb)
         assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(gb.pod), None, 0, None, C.byref(nb)) == 0 and (4 << 20) < nb.value < (5 << 20)
+        mem.set_option("traverse.image_max_mb", 5); api.setup_traversal(gb); assert has_image(gb)          # (it fits five megabytes)
+        mem.set_option("traverse.image_max_mb", 0)
         gb.free(); mem.set_option("traverse.image", 1)
-        # compressed grids get one as well (shift <= 3)
+        # compressed grids get one as well
         Gc = O.Grid.full(tris, compress=True); gc = upload_oracle_grid(mem, Gc)
-        api.setup_traversal(gc); assert has_image(gc) == (Gc.shift <= 3); gc.free()
+        api.setup_traversal(gc); assert has_image(gc); gc.free()
         api.setup_traversal(grid); assert has_image(grid)
         grid.free()                                          # freeing a source array drops the image
         assert not mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, None) == 0
@@ -985,8 +968,8 @@ def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
         assert mem.download(d_hits, api.HIT_DTYPE, n).tobytes() == want[0].tobytes()
         mem.free(d_rays); mem.free(d_hits); grid.free()
-    # the compact image still walks the voxel map: not releasable
-    mem.set_option("traverse.image", 1)
+    # without an image there is nothing that could stand for the construction format
+    mem.set_option("traverse.image", 0)
     grid = api.build_all(mem, d_tris, tris.shape[0])
     api.setup_traversal(grid)
     with pytest.raises(api.HagridError):
@@ -1025,9 +1008,8 @@ def test_hit_id_can_carry_the_reference_kernels_step_count():
 
 def test_image_of_a_voxel_map_with_non_box_regions(mem):
     """A voxel map whose voxels of ONE cell do not form a box (hand-edited maps, grids uploaded from elsewhere): in many blocks the
-    three voxels (0,0,0), (1,0,0), (0,1,0) are redirected to one cell -- an L.  The compact image de-duplicates records through a
-    representative voxel per region; both image forms and the construction-format kernel must still agree with the oracle's
-    traversal of the very same arrays (the representative walk has to reach a fixed point)."""
+    three voxels (0,0,0), (1,0,0), (0,1,0) are redirected to one cell -- an L.  The image (block layouts: a record per voxel; general layout: a record
+    per entry) and the construction-format kernels must still agree with the oracle's traversal of the very same arrays."""
     from hagrid_amd import api
     from oracle import oracle as O
     tris = scene.make_soup(30_000)
@@ -1059,10 +1041,10 @@ def test_image_of_a_voxel_map_with_non_box_regions(mem):
     d_tris = mem.upload(tris)
     grid = api.Grid.upload(mem, entries, refs, cells, None, G0.bbox_min, G0.bbox_max, G0.dims, G0.shift, G0.offsets)
     try:
-        for fmt, variant in ((1, 4), (2, 4), (0, 2), (0, 1)):
-            mem.set_option("traverse.image", fmt); mem.set_option("traverse.variant", variant)
+        for fmt, variant, general in ((2, 4, 1), (2, 4, 2), (0, 2, 1), (0, 1, 1)):
+            mem.set_option("traverse.image", fmt); mem.set_option("traverse.variant", variant); mem.set_option("traverse.image_general", general)
             got = gpu_traverse(mem, grid, d_tris, rays)
-            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (fmt, variant)
+            assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (fmt, variant, general)
     finally:
-        mem.set_option("traverse.image", 2); mem.set_option("traverse.variant", 0)
+        mem.set_option("traverse.image", 2); mem.set_option("traverse.variant", 0); mem.set_option("traverse.image_general", 1)
         grid.free(); mem.free(d_tris)

@@ -1,5 +1,5 @@
 """DEV TOOL: the very non-uniform scene (scene.make_clustered: six dense blobs in a sparse soup, grid shift 6) -- traversal image
-formats (2 flat, 1 compact, 0 construction format) on different batches.  Prints JSON lines; hits are compared across formats.
+(2: the traversal image -- the general layout of slim records on this grid; 0: the construction format) on different batches.  Prints JSON lines; hits are compared across formats.
 
     python tools/dev_nonuniform.py frames            whole 1024^2 frame, the image rows that see blobs / do not, 1M incoherent rays
     python tools/dev_nonuniform.py bands             the frame in 8 bands of 128 rows and growing prefixes
@@ -35,13 +35,12 @@ def steps_of(rays):
     return s, h
 
 
-def run(label, rays, images=(2, 3, 0, 1, 2, 3, 0), extra=None, repeats=9):
+def run(label, rays, images=(2, 0, 2, 0), extra=None, repeats=9):
     rays = np.ascontiguousarray(rays.reshape(-1, 8)); n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     res = {"rays": label, "n": n}; res.update(extra or {}); ref = None
     for img in images:
-        # 2: the default flat image (general layout of slim records on this grid); 3: flat with 32-byte records (nested blocks); 1: compact; 0: construction format
-        mem.set_option("traverse.image", min(img, 2)); mem.set_option("traverse.image_slim", 0 if img == 3 else 1); api.setup_traversal(grid)
+        mem.set_option("traverse.image", img); api.setup_traversal(grid)
         if img: res[f"image{img}_MB"] = round(mem.image_bytes(grid) / 1e6, 1)
         for _ in range(2): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
         t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)) for _ in range(repeats))
