@@ -34,6 +34,11 @@
 using namespace hagrid;
 using namespace hagrid_impl;
 
+#ifdef HG_BRICK
+#include "trav_common.h"
+using hagrid_trav::brick_index;
+#endif
+
 namespace {
 
 struct ImgK {
@@ -354,6 +359,9 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
             put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
         }
         if (bad) atomicOr(status, bad);
+#ifdef HG_BRICK
+        if (!TABLE) { recs[first + brick_index(uint32_t(rx), uint32_t(ry), uint32_t(rz), uint32_t(D))] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32)); continue; }
+#endif
         recs[first + f] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
     }
 }
