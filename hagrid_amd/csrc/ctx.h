@@ -30,14 +30,12 @@ struct TravImageCache {
     void* table = nullptr;          // uint2 per top-level cell; general layout: the wide records (16 bytes each)
     size_t table_bytes = 0;
     int wide_records = 0;           // table and general layouts: cells whose bounds the records' bytes cannot hold (a 16-byte wide record each, behind the table)
-    void* blocks = nullptr;         // 128-byte aligned blocks: local voxel map + 32-byte cell records
+    void* blocks = nullptr;         // the slim records, 16 bytes each (uniform / table layout: a block per top-level cell; general layout: one per voxel-map entry)
     size_t block_bytes = 0;
     bool valid = false;
-    bool flat = false;              // records indexed by the voxel (no slot bytes)
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
     bool general = false;           // flat, one slim record per voxel-map entry at the entry's index (links to child blocks, wide records): any depth
-    int slim = 0;                   // uniform layout with 16-byte records: bits per inline reference id (20: four ids, 26: three), 0 = 32-byte records
-    bool standalone = false;        // no record links back into the construction format: traversal needs neither entries nor cells
+    int slim = 0;                   // bits per inline reference id of the slim records (20: four ids, 26: three)
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
     bool borrowed = false;          // hagrid_share_traversal: table and blocks belong to another context's pool, never freed here
     // Set by the context that built the image, cleared when THAT context drops it (new setup, construction pass, a source array
@@ -93,7 +91,7 @@ struct hagrid_ctx {
     int opt_super_log2 = 3;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside); round-3 sweep: 3 (profiles/dev_r3_tile_params.txt)
     int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
-    int opt_image_max_mb = 0;   // flat image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built
+    int opt_image_max_mb = 0;   // traversal image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); an image beyond it is not built
     int opt_image_uniform = 1;  // traversal image: use the table-free uniform layout when it is not much bigger than the table layout (2: whatever it costs; 0: never)
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
     // What the context remembers about a ray buffer it has traversed (traverse.hip): the row length found for it and the order of its tiles.  A few
@@ -126,7 +124,7 @@ struct hagrid_ctx {
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // traversal image: 1: reference ids packed in 20 bits where every id fits, else 26; 2: always 26 bits (tests)
-    int opt_image_general = 1;  // flat image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: 32-byte records there (tests); 2: for every grid (tests)
+    int opt_image_general = 1;  // traversal image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: 32-byte records there (tests); 2: for every grid (tests)
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (trav_image.hip; the two values are one since round 5) and traverse_grid uses it
 
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id

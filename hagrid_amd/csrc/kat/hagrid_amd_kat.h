@@ -41,7 +41,7 @@ int hagrid_kat_tile_slots(hagrid_ctx* ctx, int num_rays, int row_len, int super_
 int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris, const void* rays, void* hits, int num_rays,
                               int row_len, int tail, unsigned long long* times_dev, const int* tile_order_dev);
 /* Traversal image (hagrid_setup_traversal): the 8 words of the record that each voxel (finest-level coordinates)
- * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a deep link | the
+ * resolves to -- u16 lo.x hi.x | lo.y hi.y | lo.z hi.z | n, bit 31 = list given by index, bit 30 = reached through a link of the general layout | the
  * reference ids (n <= 4, bit 31 clear) or the first reference index -- and the size of the image in bytes.
  * HAGRID_EINVAL when the context holds no image of this grid. */
 int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int32_t* voxels3, int n, uint32_t* records8, int64_t* image_bytes);
@@ -51,8 +51,9 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "traverse.variant"   0 = choose (the traversal-image kernel when the grid has an image, else v2), 1 = the reference-shaped kernel, 2 = v2 on the
  *                        construction format, 4 = the traversal-image kernel (an error without an image); 3 no longer exists
  *   "traverse.narrow"    1 (default) = 32-bit offsets / 24-bit multiplies when every gathered array is below 4 GB, 0 = 64-bit addressing
- *   "traverse.image_uniform" / "traverse.image_slim"   flat image: table-free layout when it is not much bigger (1) / 16-byte records where every
- *                        cell fits them (1), 32-byte records (0), the 26-bit id form even where 20 bits would do (2)
+ *   "traverse.image_uniform" / "traverse.image_slim" / "traverse.image_general"   traversal image: table-free layout when it is not much bigger (1), whatever it
+ *                        costs (2), never (0) / reference ids of 20 bits where they fit (1), the 26-bit form even where 20 bits would do (2) / the general
+ *                        layout where the block layouts do not fit (1), for every grid (2), never (0)
  *   "traverse.tail"      1 (default) = slim-record images are traversed by the kernel with the tail mode, 0 = one ray per lane throughout
  *   "traverse.quad_tail" per cent of the tiles, the last in dispatch order, that start with four lanes per ray; -1 (default) = by launch size
  *   "traverse.tail_dual" 1 = phase 1 of the tail kernel tests two ids of an inline list per round trip; -1 (default) = 1 unless the batch is binned

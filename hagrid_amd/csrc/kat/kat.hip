@@ -115,7 +115,7 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
                 const uint4 wr = reinterpret_cast<const uint4*>(a.img_table)[first];
                 o[0] = wr.x; o[1] = wr.y; o[2] = wr.z; first = wr.w;
             }
-            // lists of at most four ids are inline in the 32-byte record: read them through the index
+            // (the explicit form holds lists of at most four ids inline: read them through the index)
             o[3] = cnt | (cnt > 4 ? 0x80000000u : 0u) | (links ? 0x40000000u : 0u);
             if (cnt > 4) { o[4] = first; o[5] = o[6] = o[7] = 0u; }
             else for (uint32_t j = 0; j < 4; j++) o[4 + j] = j < cnt ? uint32_t(a.refs[first + j]) : ~0u;
@@ -244,7 +244,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
-    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, ctx->image.flat ? 1 : 0, ctx->image.slim, ctx->image.uniform ? 1 : 0, ctx->image.general ? 1 : 0); HG_DBG(ctx);
+    kat_image_records<<<grid_blocks(n, 64), 64, 0, ctx->stream>>>(a, (const int*)v.d, n, (uint32_t*)o.d, 1, ctx->image.slim, ctx->image.uniform ? 1 : 0, ctx->image.general ? 1 : 0); HG_DBG(ctx);
     HG_HIP(ctx, hipGetLastError());
     return o.fetch(records8);
 }
@@ -255,7 +255,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
 extern "C" int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* grid, const void* tris, const void* rays, void* hits, int num_rays,
                                          int row_len, int tail, unsigned long long* times_dev, const int* tile_order_dev) {
     if (!ctx || !grid || !times_dev || num_rays <= 0) return HAGRID_EINVAL;
-    if (!trav_image_matches(ctx, grid) || !(ctx->image.flat && ctx->image.uniform && ctx->image.slim == 20))
+    if (!trav_image_matches(ctx, grid) || !(ctx->image.uniform && ctx->image.slim == 20))
         HG_FAIL(ctx, HAGRID_EINVAL, "kat_traverse_timed: needs the table-free image with 20-bit slim records of this grid");
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));

@@ -233,12 +233,6 @@ __device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
     return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
 }
 
-// EXPERIMENT (round 5, -DHG_BRICK builds ab/lib<NAME>.so only; never defined in the product): the records of a uniform-layout block in BRICK order -- the
-// eight records of a 2 x 2 x 2 group of voxels in one 128-byte line -- instead of x-major rows (eight records along x per line).  profiles/NOTES.md "Round 5".
-__host__ __device__ __forceinline__ uint32_t brick_index(uint32_t x, uint32_t y, uint32_t z, uint32_t d) {      // x, y, z < 2^d, d >= 1
-    return ((x & 1u) | (y & 1u) << 1 | (z & 1u) << 2) | ((x >> 1) + (((y >> 1) + ((z >> 1) << (d - 1u))) << (d - 1u))) << 3;
-}
-
 // ---- the general layout of slim records (trav_image.hip): one record per voxel-map entry, at the entry's index -------------------------------------
 // The walk to the record of a voxel is the reference's lookup_entry (grid.h:103-116) over 16-byte records: the top-level record of the voxel's top-level cell,
 // then -- while the record is a LINK -- the child the voxel selects in the block the link names.  A ray keeps the innermost block its last look-up ended in

@@ -34,11 +34,6 @@
 using namespace hagrid;
 using namespace hagrid_impl;
 
-#ifdef HG_BRICK
-#include "trav_common.h"
-using hagrid_trav::brick_index;
-#endif
-
 namespace {
 
 struct ImgK {
@@ -231,7 +226,7 @@ __global__ void __launch_bounds__(kBlock) image_general_wide(const ImgK k, int n
     wide[claim[c]] = w;
 }
 
-// Returns 1 when the grid does not fit the general layout (ids beyond 26 bits, a list of 2^20 ids, 2^28 records): 32-byte records then.
+// Returns 1 when the grid does not fit the general layout (ids beyond 26 bits, a list of 2^20 ids, 2^28 records, the size limit): no image then.
 int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     const int num_cells = k.num_cells;
     hipStream_t st = ctx->stream;
@@ -269,7 +264,7 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
         rc = read_back(ctx, status, h, sizeof(h));
         if (rc != HAGRID_OK) break;
         if (h[0] || n > 0) { rc = 1; break; }       // a list of 2^20 ids, a map deeper than 16 levels
-        if (h[1]) { rc = 1; if (idb == 20) continue; break; }       // ids of more than 20 bits: three ids of 26 bits per record; of more than 26: 32-byte records
+        if (h[1]) { rc = 1; if (idb == 20) continue; break; }       // ids of more than 20 bits: three ids of 26 bits per record; of more than 26: no image
         uint4* wide = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(std::max(h[2], 1)) * 16u));
         if (!wide) { rc = HAGRID_ENOMEM; break; }
         if (h[2] > 0) {
@@ -359,9 +354,6 @@ __global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __res
             put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 1u);
         }
         if (bad) atomicOr(status, bad);
-#ifdef HG_BRICK
-        if (!TABLE) { recs[first + brick_index(uint32_t(rx), uint32_t(ry), uint32_t(rz), uint32_t(D))] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32)); continue; }
-#endif
         recs[first + f] = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
     }
 }
@@ -405,7 +397,7 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
         if (rc != HAGRID_OK) { result = rc; break; }
         if (h[0]) break;                            // uniform layout: some cell does not fit a slim record (the table layout has wide records for those); a list of 2^20 ids
         if (h[1] && idb == 20) continue;            // ids of more than 20 bits: three ids of 26 bits per record
-        if (h[1]) break;                            // ... of more than 26 bits: 32-byte records
+        if (h[1]) break;                            // ... of more than 26 bits: no image
         if (h[2] > 0) {
             // wide records behind the table, in ONE buffer (the kernels know one more pointer than the records): 16-byte units from the table's start
             const size_t table16 = (size_t(k.num_top) * 8u + 15u) / 16u;
@@ -542,9 +534,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     if (rc == 1 && ctx->opt_image_general) rc = build_general(ctx, k, img);
     if (rc == 1) return HAGRID_OK;                 // no layout describes this grid (or fits the size limit): traversal reads the construction format
     if (rc != HAGRID_OK) return rc;
-    img.flat = true;
     img.valid = img.blocks != nullptr;
-    img.standalone = true;                         // no record links back into the construction format
     img.entries = g->entries; img.cells = g->small_cells ? g->small_cells : g->cells; img.refs = g->ref_ids;
     img.cell_bytes = g->small_cells ? 16 : 32;
     img.num_cells = g->num_cells; img.num_entries = g->num_entries; img.num_refs = g->num_refs; img.shift = g->shift;
@@ -565,7 +555,6 @@ extern "C" int hagrid_grid_release_for_traversal(hagrid_ctx* ctx, hagrid_grid* g
     TravImageCache& img = ctx->image;
     if (!trav_image_matches(ctx, grid) || img.detached) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: call hagrid_setup_traversal for this grid first");
     if (img.borrowed) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: this context only borrows the traversal image (hagrid_share_traversal); release the grid in the context that built it");
-    if (!img.standalone) HG_FAIL(ctx, HAGRID_EINVAL, "release_for_traversal: the traversal image of this grid still refers to the voxel map (compact form, or more than six levels)");
     void* entries = grid->entries;
     void* cells = grid->cells ? grid->cells : grid->small_cells;
     img.entries = nullptr; img.cells = nullptr; img.detached = true;      // the frees below must not take the image with them
@@ -591,7 +580,7 @@ extern "C" int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* g
     if (!ctx || !grid) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
     const TravImageCache& img = ctx->image;
-    if (format4) { format4[0] = img.general ? 2 : (img.flat ? 1 : 0); format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
+    if (format4) { format4[0] = img.general ? 2 : 1; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
     if (image_bytes) *image_bytes = (int64_t)img.block_bytes + (int64_t)img.table_bytes;
     return HAGRID_OK;
 }

@@ -62,11 +62,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_img(const TraverseArgs 
         auto record = [&](uint2 tab, int x, int y, int z, uint32_t moved = 0u) -> uint4 {
             if (UNIFORM) {
                 const int d = a.shift, m = (1 << d) - 1;
-#ifdef HG_BRICK
-                const uint32_t idx = brick_index(uint32_t(x & m), uint32_t(y & m), uint32_t(z & m), uint32_t(d));
-#else
                 const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-#endif
                 return *reinterpret_cast<const uint4*>(a.img_blocks + (((uint32_t(top_index(x, y, z)) << (3 * d)) + idx) << 4));
             }
             if (GENERAL) return gw.lookup(a, x, y, z, moved);          // from the block of the last look-up, or from the top level (a link is resolved behind the tests)
@@ -373,11 +369,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         const uint32_t top = uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift));
         if (UNIFORM) {
             const int d = a.shift, m = (1 << d) - 1;
-#ifdef HG_BRICK
-            const uint32_t idx = brick_index(uint32_t(x & m), uint32_t(y & m), uint32_t(z & m), uint32_t(d));
-#else
             const uint32_t idx = uint32_t(x & m) + (uint32_t((y & m) + ((z & m) << d)) << d);
-#endif
             return *reinterpret_cast<const uint4*>(a.img_blocks + (((top << (3 * d)) + idx) << 4));
         }
         if (int(top) != top_idx) {
@@ -736,12 +728,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             const uint32_t v = outside ? 0u : uint32_t(m_v);
             if (UNIFORM) {
                 const uint32_t d = uint32_t(a.shift);
-#ifdef HG_BRICK
-                const uint32_t vm = v & ((1u << d) - 1u);
-                const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + (((vm & 1u) << uint32_t(ax)) | ((vm >> 1) << (3u + uint32_t(ax) * (d - 1u)))));
-#else
                 const uint32_t rec_idx = quad_sum((__umul24(v >> d, m_stride) << (3u * d)) + ((v & ((1u << d) - 1u)) << m_lsh));
-#endif
                 return *reinterpret_cast<const uint4*>(a.img_blocks + (rec_idx << 4));
             }
             if (TABLE) {

@@ -234,7 +234,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // batch; without one the latency-oriented v2 walks the construction format (trav_plain.hip).
     // hagrid_set_option("traverse.variant", 1|2|4) forces the reference-shaped kernel, v2 or the image kernel (tests, experiments).
     const bool have_image = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
-    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant != 4) || (flags && !ctx->image.flat)))
+    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant != 4) || false))
         HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal, only the traversal-image kernel can serve it");
     if (ctx->opt_variant == 4 && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
     int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : 2);
@@ -243,7 +243,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                             ctx->image.block_bytes < (size_t(1) << 32) && size_t(grid->num_cells) * 32 < (size_t(1) << 32) &&
                             size_t(grid->num_entries) * 4 < (size_t(1) << 32) && size_t(grid->num_refs) * 4 < (size_t(1) << 32);
     // any-hit / barycentrics: the flat narrow image kernels and v2 have these variants
-    if (flags && !(variant == 4 && ctx->image.flat && img_narrow)) {
+    if (flags && !(variant == 4 && img_narrow)) {
         if (ctx->image.detached && have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: any-hit / barycentrics on a released grid need the narrow image kernel (arrays below 4 GB)");
         variant = 2;
     }
@@ -315,7 +315,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // tile order (its rule misfires on such launches anyway: -5.3 % on that share) and starts no tile with four lanes per ray.  Hits do not depend on it.
         int refill_k = 0;
         {
-            const bool can = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow;
+            const bool can = ctx->opt_tail && !flags && ctx->image.uniform && narrow;
             const bool first_touch = a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 && size_t(num_rays) * 64 < a.bin_working_set;
             refill_k = !can ? 0 : (ctx->opt_refill < 0 ? ((!perm && first_touch) ? 2 : 0) : ctx->opt_refill);
         }
@@ -323,7 +323,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
         {
-            const bool tail_kernel = ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow;
+            const bool tail_kernel = ctx->opt_tail && !flags && narrow;
             // by default for launches of up to 25 rounds (2048^2, eight rounds: -8 %; 2560^2: -4.9 %, 3072^2, 18 rounds: -1.3 %, 4096^2, 32 rounds: +-0 -- the tiles
             // of a class of equal cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
             // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch).  Rays in image order WITHOUT coherent
@@ -406,7 +406,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // per ray (256^2 ... 960 x 540: -8 ... -23 % against the shares above in the default order), none of a larger one
             if (a.tile_order && !shared) quad_pct = r100 <= 100 ? 100 : 0;
         }
-        if (quad_pct > 0 && ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && narrow) {
+        if (quad_pct > 0 && ctx->opt_tail && !flags && narrow) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
@@ -416,7 +416,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // a binned incoherent batch a quarter more requests from the vector L1s to L2 than it needs (profiles/r4a).  Measured (NOTES "Round 4"): +2.4 % on
         // the 16M-ray share of configuration 4, nothing on image-ordered batches, -13 % where the copy (112 bytes per triangle) is not small against the
         // launch.  -1 (default): for binned batches of at least four rays per triangle the grid refers to.
-        if (ctx->opt_tail && !flags && ctx->image.slim && ctx->image.flat && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
+        if (ctx->opt_tail && !flags && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
             const long long n_tris = (long long)ctx->image.max_ref + 1;
             const bool want = ctx->opt_tri_pad < 0 ? (perm != nullptr && (long long)num_rays >= 4 * n_tris) : ctx->opt_tri_pad != 0;
             if (want && refill_k <= 1) {          // (a refilled launch reads the caller's triangles: its default never meets a binned batch)

@@ -197,11 +197,10 @@ int hagrid_grid_broadcast(hagrid_ctx* ctx, void* comm, int rank, int root, hagri
  * describes (a virtual resolution of 65536 per axis, reference ids beyond 26 bits, a list of 2^20 ids).
  * hagrid_traverse_grid uses the image when it is called with the same grid (same arrays, same counts); the image is
  * dropped when a construction pass runs in this context or when one of the grid's arrays is freed or overwritten through
- * this API; without an image traversal reads the construction format.  Hits are identical either way.  Not built for
- * a virtual resolution above 65535 per axis or for compressed grids deeper than six levels (three in the compact form).  Synchronous (size / fit read-backs); 0.19 ms and 129 MB for
- * the 1M-triangle scene of BASELINE.md (257 MB with 32-byte records). */
+ * this API; without an image traversal reads the construction format.  Hits are identical either way.  Synchronous (size / fit
+ * read-backs); 0.3 ms and 129 MB for the 1M-triangle scene of BASELINE.md. */
 int hagrid_setup_traversal(hagrid_ctx* ctx, const hagrid_grid* grid);
-/* Extension: after hagrid_setup_traversal built a self-contained image of `grid` (the flat form of a grid of at most six levels), the
+/* Extension: after hagrid_setup_traversal built the image of `grid` (no layout refers to the voxel map), the
  * caller may give the construction format up: entries and cells | small_cells are released to the pool and set to NULL in the
  * descriptor, the image answers for them (1M-triangle scene: 166 MB of 365 MB).  hagrid_traverse_grid[_ex] keep working with that
  * descriptor; what reads the construction format (construction passes, hagrid_traverse_grid_stats, hagrid_grid_pack, forced kernel
@@ -249,9 +248,8 @@ int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* grid, const v
 int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
 
 /* Options: behaviour a caller may want to change; the defaults are the reference's behaviour at the tuned speed.  Keys:
- * "traverse.image": what hagrid_setup_traversal builds -- 2 (default) = the flat traversal image (one record per voxel), 1 = the compact one,
- *   0 = nothing (traversal walks the construction format);
- * "traverse.image_max_mb": size limit of the flat image in MB (0, default = max(1 GB, 8x the arrays it replaces)); beyond it the compact form is built;
+ * "traverse.image": what hagrid_setup_traversal builds -- 2 (default) and 1 = the traversal image, 0 = nothing (traversal walks the construction format);
+ * "traverse.image_max_mb": size limit of the image in MB (0, default = max(1 GB, 8x the arrays it replaces)); an image beyond it is not built;
  * "traverse.image_width": tile packets -- a batch in image order (ray y * w + x, as gen_rays of main.cpp:55-66 writes it) is traversed with
  *   one 8 x 8 pixel tile per wavefront instead of a 64 x 1 strip; 0 (default) = the row length w is looked for on the device (constant
  *   (origin, direction) step along a row; for batches of 4M rays or more also from the origins alone -- bounce rays in the image order of

@@ -1057,6 +1057,7 @@ static inline int clampi(int a, int b, int c) { return imin(c, imax(b, a)); } /*
 static __thread unsigned char* g_trace = NULL;
 static __thread int g_trace_cap = 0, g_trace_len = 0;
 static __thread int* g_trace_ids = NULL;
+static __thread short* g_trace_vox = NULL;        /* dev analysis: the voxel of every look-up, 3 shorts per step (same capacity as g_trace) */
 static __thread int g_trace_ids_cap = 0, g_trace_ids_len = 0;
 
 static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, const ORay* rp, OHit* out, int* steps_out, OStats* st) {
@@ -1080,6 +1081,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
         for (;;) {
             int words = 0;
             uint32_t entry = orc_lookup_entry(g->entries, k->shift, &k->top, &voxel, &words);
+            const oivec3 look = voxel;                 /* (dev analysis: the voxel of this look-up) */
             oivec3 cmin, cmax; int cbegin, cend = 0;
             if (g->small_cells) {
                 OSmallCell sc = g->small_cells[entry];
@@ -1129,7 +1131,7 @@ static void traverse_one(const TravConsts* k, const OGrid* g, const OTri* tris, 
                 if (st) { st->refs += nrefs; if (nrefs > 4) st->long_list_refs += nrefs; }
             }
             steps += 1 + nrefs;
-            if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (unsigned char)(nrefs > 255 ? 255 : nrefs); g_trace_len++; }
+            if (g_trace) { if (g_trace_len < g_trace_cap) { g_trace[g_trace_len] = (unsigned char)(nrefs > 255 ? 255 : nrefs); if (g_trace_vox) { g_trace_vox[3 * g_trace_len] = (short)look.x; g_trace_vox[3 * g_trace_len + 1] = (short)look.y; g_trace_vox[3 * g_trace_len + 2] = (short)look.z; } } g_trace_len++; }
             if (st) { st->cells++; st->entry_words += words; }
             /* traverse.cu:85-89 */
             if (found_any || hit.t <= texit ||
@@ -1146,6 +1148,18 @@ void orc_traverse_grid(const OGrid* grid, const OTri* tris, const ORay* rays, OH
     TravConsts k; setup_consts(grid, &k);
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t i = 0; i < n; i++) traverse_one(&k, grid, tris, &rays[i], &hits[i], steps ? &steps[i] : NULL, stats);
+}
+
+/* dev analysis: as orc_traverse_trace, plus vox[(i * cap + s) * 3 ..] = the voxel of the s-th look-up of ray i */
+void orc_traverse_trace_voxels(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t n, int cap, unsigned char* lens, int* num_cells, short* vox) {
+    TravConsts k; setup_consts(grid, &k);
+    for (int64_t i = 0; i < n; i++) {
+        OHit hit;
+        g_trace = lens + i * cap; g_trace_cap = cap; g_trace_len = 0; g_trace_vox = vox + i * cap * 3;
+        traverse_one(&k, grid, tris, &rays[i], &hit, NULL, NULL);
+        num_cells[i] = g_trace_len;
+    }
+    g_trace = NULL; g_trace_vox = NULL;
 }
 
 void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t n, int cap, unsigned char* lens, int* num_cells,

@@ -118,6 +118,8 @@ void orc_traverse_grid_ex(const OGrid* grid, const OTri* tris, const ORay* rays,
 /* dev analysis: lens[i*cap + s] = list length of the s-th cell ray i visits (clamped to 255), num_cells[i] = cells visited */
 void orc_traverse_trace(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t num_rays, int cap, unsigned char* lens, int* num_cells,
                         int ids_cap, int* ids /* may be NULL: tested reference ids in order */, int* num_ids);
+/* dev analysis: as orc_traverse_trace, plus vox[(i * cap + s) * 3 ..] = the voxel of the s-th look-up of ray i */
+void orc_traverse_trace_voxels(const OGrid* grid, const OTri* tris, const ORay* rays, int64_t num_rays, int cap, unsigned char* lens, int* num_cells, short* vox);
 /* nearest hit over all triangles with orc_intersect_prim_ray, ascending id order */
 void orc_brute_force(const OTri* tris, int num_tris, const ORay* rays, OHit* hits, int64_t num_rays, int nthreads);
 
