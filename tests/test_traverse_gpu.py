@@ -922,20 +922,24 @@ def test_wave_time_diagnostic_does_not_change_hits(mem):
 
 
 def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
-    """Extension hagrid_grid_release_for_traversal: once setup_traversal has built a self-contained (flat) image, entries and cells
+    """Extension hagrid_grid_release_for_traversal: once setup_traversal has built the image (any of its three layouts), entries and cells
     go back to the pool, traversal (nearest hit, any-hit, barycentrics, binned) gives the same hits from the image alone; what
     needs the construction format is refused without harming the image."""
     from hagrid_amd import api
-    tris = scene.make_soup(200_000)
     mem = api.MemManager(keep=False)
-    d_tris = mem.upload(tris)
-    for compress in (False, True):
-        grid = api.build_all(mem, d_tris, tris.shape[0], compress=compress)
+    soup = scene.make_soup(200_000); clustered = scene.make_clustered(20000, 3, 30000)
+    # every layout of the image: uniform (the soup), table (the soup at other densities), general (the clustered scene: five levels, wide records)
+    for tris, params, compress, layout in ((soup, {}, False, "uniform"), (soup, {}, True, "uniform"), (soup, dict(top_density=0.15, snd_density=3.0), False, "table"),
+                                           (clustered, {}, False, "general"), (clustered, {}, True, "general")):
+        d_tris = mem.upload(tris)
+        grid = api.build_all(mem, d_tris, tris.shape[0], compress=compress, **params)
         rays = np.concatenate([scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 256, 256),
                                scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 150_000, 21)]).astype(np.float32)
         n = rays.shape[0]
         d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
         api.setup_traversal(grid)
+        fmt = mem.image_format(grid)
+        assert (fmt["uniform"], fmt["general"]) == (layout == "uniform", layout == "general"), (layout, fmt)
         want = {}
         for flags in (0, api.ANY_HIT, api.UVS):
             api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
@@ -951,7 +955,7 @@ def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
                 mem.zero(d_hits, 16 * n)
                 api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
                 got = mem.download(d_hits, api.HIT_DTYPE, n)
-                assert got.tobytes() == want[flags].tobytes(), (compress, binning, flags)
+                assert got.tobytes() == want[flags].tobytes(), (layout, compress, binning, flags)
         mem.set_ray_binning(0)
         api.setup_traversal(grid)                                   # nothing to rebuild, nothing lost
         with pytest.raises(api.HagridError):
@@ -967,9 +971,10 @@ def test_release_for_traversal_keeps_hits_and_frees_the_construction_format():
         mem.set_option("traverse.variant", 0)
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
         assert mem.download(d_hits, api.HIT_DTYPE, n).tobytes() == want[0].tobytes()
-        mem.free(d_rays); mem.free(d_hits); grid.free()
+        mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
     # without an image there is nothing that could stand for the construction format
     mem.set_option("traverse.image", 0)
+    tris = soup; d_tris = mem.upload(tris)
     grid = api.build_all(mem, d_tris, tris.shape[0])
     api.setup_traversal(grid)
     with pytest.raises(api.HagridError):
