@@ -63,7 +63,7 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "traverse.row_cache" 1 (default) = a row length found for a ray buffer is kept for the next 15 calls, 0 = looked for at every call
  *   "traverse.lds_pad"   bytes of dynamic LDS per workgroup of the tail kernel (limits the resident wavefronts: profiles/dev_r3_quad_tail.txt)
  *   "merge.narrow_cells" 1 (default) = 16-byte working cell records between the merge passes when the virtual resolution is below 65536
- *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss, 0 = three kernels */
+ *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss (the three-kernel form exists in hagrid_kat_scan only) */
 int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 
 #ifdef __cplusplus

@@ -3,6 +3,7 @@
 // The scans replace cub::DeviceScan::ExclusiveSum of the reference (parallel.cuh:31-42); the construction passes only ever
 // exercise them indirectly, so tests/test_scan_gpu.py drives them directly: tile-boundary sizes, the device carry chain and
 // the two-word (Int2) publish of the look-back form.
+#define HG_SCAN_THREE_KERNELS              // the reduce / spine / apply form next to the look-back form: instantiated here only
 #include "../ctx.h"
 #include "../wave_prims.h"
 #include "hagrid_amd_kat.h"

@@ -50,6 +50,7 @@ struct TraverseArgs {
     int refill;                   // tail kernel (REFILL instantiations): tiles per wavefront whose lanes take new rays as they finish (0: off)
     int tri64;                    // host side only: `tris` is the copy padded to 64 bytes per triangle (instantiations with TRI64)
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
+    unsigned mode;                // v2 and the image kernel: HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS of this call (read at run time)
     int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
     int shift;
     int dims_x, dims_y, dims_z;   // virtual resolution dims << shift
@@ -283,7 +284,7 @@ int make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tris, const voi
 // bytes from p to the end of the device allocation that holds it (all bits set if the runtime does not know the pointer)
 size_t buffer_bytes_from(const void* p);
 // trav_plain.hip: 256 threads per block (reference-shaped kernel), one wavefront per block (v2)
-void launch_plain(hipStream_t st, int num_rays, bool small, bool stats, const TraverseArgs& a);
+void launch_plain(hipStream_t st, int num_rays, bool small, const TraverseArgs& a);
 void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a);
 // ray_order.hip: row length of an image-ordered batch -> row_len[0] on the device (0: none); nobody waits for it
 constexpr int kOriginMinRays = 1 << 22;

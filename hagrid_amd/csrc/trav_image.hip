@@ -48,9 +48,9 @@ struct ImgK {
 
 // The deepest subdivision inside every top-level cell (at most D = shift <= 3 levels): the edge of its block in the table layout, and what decides
 // between the table and the uniform layout.  One wavefront per top-level cell, a lane per finest-level voxel (strided).
-template <int D>
-__global__ void __launch_bounds__(64) image_depths(const ImgK k, uint32_t* __restrict__ metas) {
-    constexpr int V = 1 << (3 * D), M = (1 << D) - 1;
+// (Set-up kernels take the depth D and the id width IDB as ARGUMENTS: they run once per grid and stream; an instantiation per value bought nothing.)
+__global__ void __launch_bounds__(64) image_depths(const ImgK k, const int D, uint32_t* __restrict__ metas) {
+    const int V = 1 << (3 * D), M = (1 << D) - 1;
     const int T = blockIdx.x;
     const uint32_t topw = k.entries[T];
     int depth_max = 0;
@@ -95,10 +95,9 @@ __device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long l
 // children (it knows their origins) and lists the inner ones for the next launch.  Wide records are per CELL (a large cell is named by many entries).
 struct GenItem { int entry; uint32_t oxy, ozs; int pad; };           // inner entry, origin of its region (x | y << 16, z | s << 16)
 
-template <int IDB>
-__device__ __forceinline__ bool general_record(const ImgK& k, uint32_t word, int ox, int oy, int oz, uint4* __restrict__ rec, int* __restrict__ claim, int* __restrict__ status) {
-    constexpr int NI = 80 / IDB;
-    constexpr uint32_t NONE = (1u << IDB) - 1u;
+__device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uint32_t word, int ox, int oy, int oz, uint4* __restrict__ rec, int* __restrict__ claim, int* __restrict__ status) {
+    const int NI = 80 / IDB;
+    const uint32_t NONE = (1u << IDB) - 1u;
     unsigned long long rl = ~0ull << 48, rh = ~0ull;               // no bounds, every id field "unused"
     if (word & 3u) {
         rl &= ~(0xffffffffull << 48);
@@ -156,8 +155,7 @@ __device__ __forceinline__ bool general_record(const ImgK& k, uint32_t word, int
 }
 
 // the top level: one thread per entry
-template <int IDB>
-__global__ void __launch_bounds__(kBlock) image_general_top(const ImgK k, uint4* __restrict__ recs, GenItem* __restrict__ items, int* __restrict__ num_items,
+__global__ void __launch_bounds__(kBlock) image_general_top(const ImgK k, const int IDB, uint4* __restrict__ recs, GenItem* __restrict__ items, int* __restrict__ num_items,
                                                             int* __restrict__ claim, int* __restrict__ status) {
     const int T = blockIdx.x * kBlock + threadIdx.x;
     bool inner = false;
@@ -165,15 +163,14 @@ __global__ void __launch_bounds__(kBlock) image_general_top(const ImgK k, uint4*
     if (T < k.num_top) {
         ox = (T % k.top_x) << k.shift; oy = ((T / k.top_x) % k.top_y) << k.shift; oz = (T / (k.top_x * k.top_y)) << k.shift;
         const uint32_t w = k.entries[T];
-        inner = general_record<IDB>(k, w, ox, oy, oz, recs + T, claim, status);
+        inner = general_record(k, IDB, w, ox, oy, oz, recs + T, claim, status);
         if (inner && k.shift < int(w & 3u)) { atomicOr(status, 4); inner = false; }
     }
     const int at = wave_append(inner ? 1 : 0, num_items);
     if (inner) items[at] = GenItem{T, uint32_t(ox) | uint32_t(oy) << 16, uint32_t(oz) | uint32_t(k.shift) << 16, 0};
 }
 // one level down: one wavefront per inner entry of the level above
-template <int IDB>
-__global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, uint4* __restrict__ recs, const GenItem* __restrict__ in, const int* __restrict__ num_in,
+__global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, const int IDB, uint4* __restrict__ recs, const GenItem* __restrict__ in, const int* __restrict__ num_in,
                                                               GenItem* __restrict__ items, int* __restrict__ num_items, int* __restrict__ claim, int* __restrict__ status) {
     const int i = blockIdx.x * kWaves + wave_id();
     if (i >= *num_in) return;
@@ -188,7 +185,7 @@ __global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, uint
         if (c < (1 << (3 * kk))) {
             cx = ox + ((c & m) << s); cy = oy + (((c >> kk) & m) << s); cz = oz + ((c >> (2 * kk)) << s);
             const uint32_t w = k.entries[first + c];
-            inner = general_record<IDB>(k, w, cx, cy, cz, recs + first + c, claim, status);
+            inner = general_record(k, IDB, w, cx, cy, cz, recs + first + c, claim, status);
             if (inner && s < int(w & 3u)) { atomicOr(status, 4); inner = false; }       // a map deeper than its shift says: not a grid
         }
         const int at = wave_append(inner ? 1 : 0, num_items);
@@ -196,10 +193,9 @@ __global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, uint
     }
 }
 // records that name a wide cell get the index of its wide record; the wide records themselves
-template <int IDB>
-__global__ void __launch_bounds__(kBlock) image_general_patch(uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim, int first_wide) {
-    constexpr int NI = 80 / IDB, LAST = 48 + (NI - 1) * IDB;
-    constexpr uint32_t NONE = (1u << IDB) - 1u;
+__global__ void __launch_bounds__(kBlock) image_general_patch(const int IDB, uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim, int first_wide) {
+    const int NI = 80 / IDB, LAST = 48 + (NI - 1) * IDB;
+    const uint32_t NONE = (1u << IDB) - 1u;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_entries) return;
     uint4 r = recs[i];
@@ -245,15 +241,13 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
         if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
         (void)hipMemsetAsync(status, 0, 24 * sizeof(int), st);
         (void)hipMemsetAsync(claim, 0xFF, size_t(num_cells) * sizeof(int), st);
-        if (idb == 20) image_general_top<20><<<grid_blocks(k.num_top, kBlock), kBlock, 0, st>>>(k, recs, items[0], counts, claim, status);
-        else           image_general_top<26><<<grid_blocks(k.num_top, kBlock), kBlock, 0, st>>>(k, recs, items[0], counts, claim, status);
+        image_general_top<<<grid_blocks(k.num_top, kBlock), kBlock, 0, st>>>(k, idb, recs, items[0], counts, claim, status);
         HG_DBG(ctx);
         int level = 0, n = 0;
         rc = read_back(ctx, counts, &n, sizeof(int));
         while (rc == HAGRID_OK && n > 0 && level < 16) {
             GenItem* in = items[level & 1]; GenItem* out = items[(level + 1) & 1];
-            if (idb == 20) image_general_level<20><<<grid_blocks(n, kWaves), kBlock, 0, st>>>(k, recs, in, counts + level, out, counts + level + 1, claim, status);
-            else           image_general_level<26><<<grid_blocks(n, kWaves), kBlock, 0, st>>>(k, recs, in, counts + level, out, counts + level + 1, claim, status);
+            image_general_level<<<grid_blocks(n, kWaves), kBlock, 0, st>>>(k, idb, recs, in, counts + level, out, counts + level + 1, claim, status);
             HG_DBG(ctx);
             level++;
             rc = read_back(ctx, counts + level, &n, sizeof(int));
@@ -268,8 +262,7 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
         uint4* wide = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(std::max(h[2], 1)) * 16u));
         if (!wide) { rc = HAGRID_ENOMEM; break; }
         if (h[2] > 0) {
-            if (idb == 20) image_general_patch<20><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim, 0);
-            else           image_general_patch<26><<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(recs, k.num_entries, claim, 0);
+            image_general_patch<<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(idb, recs, k.num_entries, claim, 0);
             HG_DBG(ctx);
             image_general_wide<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(k, num_cells, claim, wide); HG_DBG(ctx);
         }
@@ -289,11 +282,11 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
 // of the top-level cell, biased by 128.
 // TABLE only: a cell whose bounds do not fit the bytes (the large cells of empty space) gets a WIDE record, as in the general layout below: the record names the
 // cell (image_general_patch replaces it by the index of the cell's wide record), status word 2 counts the wide records, claim[c] holds their indices.
-template <int D, int IDB, bool TABLE>
-__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
+template <bool TABLE>
+__global__ void __launch_bounds__(64) image_slim_fill(const ImgK k, const int D, const int IDB, uint4* __restrict__ recs, uint2* __restrict__ table, int* __restrict__ status,
                                                       const uint32_t* __restrict__ metas, const int* __restrict__ offsets, int* __restrict__ claim) {
-    constexpr int NI = 80 / IDB;
-    constexpr uint32_t NONE = (1u << IDB) - 1u;
+    const int NI = 80 / IDB;
+    const uint32_t NONE = (1u << IDB) - 1u;
     const int T = blockIdx.x, lane = threadIdx.x;
     const int tx = T % k.top_x, ty = (T / k.top_x) % k.top_y, tz = T / (k.top_x * k.top_y);
     const uint32_t topw = k.entries[T];
@@ -384,13 +377,8 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
         if (idb == 20 && ctx->opt_image_slim == 2) continue;           // "traverse.image_slim" = 2: the 26-bit form whatever the ids (tests)
         (void)hipMemsetAsync(status, 0, 3 * sizeof(int), ctx->stream);
         if (claim) (void)hipMemsetAsync(claim, 0xFF, size_t(k.num_cells) * sizeof(int), ctx->stream);
-        if (uniform) {
-            if (idb == 20) image_slim_fill<D, 20, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr, nullptr);
-            else           image_slim_fill<D, 26, false><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, nullptr, nullptr, nullptr);
-        } else {
-            if (idb == 20) image_slim_fill<D, 20, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets, claim);
-            else           image_slim_fill<D, 26, true><<<k.num_top, 64, 0, ctx->stream>>>(k, recs, table, status, metas, offsets, claim);
-        }
+        if (uniform) image_slim_fill<false><<<k.num_top, 64, 0, ctx->stream>>>(k, D, idb, recs, table, status, nullptr, nullptr, nullptr);
+        else         image_slim_fill<true><<<k.num_top, 64, 0, ctx->stream>>>(k, D, idb, recs, table, status, metas, offsets, claim);
         HG_DBG(ctx);
         int h[3] = {0, 0, 0};
         const int rc = read_back(ctx, status, h, sizeof(h));
@@ -404,8 +392,7 @@ int build_slim(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img, uint2* table
             uint4* both = static_cast<uint4*>(hagrid_mem_alloc(ctx, (table16 + size_t(h[2])) * 16u));
             if (!both) { result = HAGRID_ENOMEM; break; }
             (void)hipMemcpyAsync(both, table, size_t(k.num_top) * 8u, hipMemcpyDeviceToDevice, ctx->stream);
-            if (idb == 20) image_general_patch<20><<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(recs, int(records), claim, int(table16));
-            else           image_general_patch<26><<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(recs, int(records), claim, int(table16));
+            image_general_patch<<<grid_blocks(records, kBlock), kBlock, 0, ctx->stream>>>(idb, recs, int(records), claim, int(table16));
             HG_DBG(ctx);
             image_general_wide<<<grid_blocks(k.num_cells, kBlock), kBlock, 0, ctx->stream>>>(k, k.num_cells, claim, both + table16); HG_DBG(ctx);
             img.table = both; img.table_bytes = (table16 + size_t(h[2])) * 16u; img.wide_records = h[2];      // (the caller's table is released with its other temporaries)
@@ -428,7 +415,7 @@ int build_blocks(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     uint2* table = pool_alloc<uint2>(ctx, size_t(k.num_top));
     auto release = [&]() { hagrid_mem_free(ctx, metas); hagrid_mem_free(ctx, offs); hagrid_mem_free(ctx, partials); };
     if (!metas || !offs || !partials || !table) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
-    image_depths<D><<<k.num_top, 64, 0, ctx->stream>>>(k, metas); HG_DBG(ctx);
+    image_depths<<<k.num_top, 64, 0, ctx->stream>>>(k, D, metas); HG_DBG(ctx);
     int* total = ctx->dscratch + 224;
     if (!ctx_scan<int>(ctx, SlimSizeIn{metas}, SlimSizeOut{offs}, k.num_top, partials, (const int*)nullptr, total)) { release(); hagrid_mem_free(ctx, table); return HAGRID_ENOMEM; }
     int table_records = 0;

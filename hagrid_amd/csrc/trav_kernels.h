@@ -13,9 +13,10 @@ namespace hagrid_trav {
 // top-level cell's origin; wide records), 2 general (a record per voxel-map entry: trav_common.h GenWalk; links, wide records) -- trav_image.hip
 // SLIM: bits per packed reference id (20 or 26)
 // TIMES: diagnostic instantiation that records the wall clock at the start and the end of every wavefront (tools/dev_wave_timeline.py)
-template <unsigned MODE, int SLIM, int LAYOUT, bool TIMES = false>
+// UVS: barycentrics stored with the hit (HAGRID_TRAVERSE_UVS: two more registers); the any-hit rule (HAGRID_TRAVERSE_ANY_HIT) is a uniform flag of the call, a.mode
+template <bool UVS, int SLIM, int LAYOUT, bool TIMES = false>
 __global__ void __launch_bounds__(64, 8) traverse_kernel_img(const TraverseArgs a) {
-    constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
+    const bool ANY = (a.mode & HAGRID_TRAVERSE_ANY_HIT) != 0;
     constexpr bool UNIFORM = LAYOUT == 0, TABLE = LAYOUT == 1, GENERAL = LAYOUT == 2;
     constexpr int NONE = (1 << SLIM) - 1;          // the id field of an unused list slot
     constexpr int NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;

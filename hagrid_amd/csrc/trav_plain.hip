@@ -12,8 +12,10 @@ using namespace hagrid_trav;
 
 namespace {
 
-template <bool SMALL, bool STATS>
+// One instantiation per cell format: the counters are kept in registers whether or not the caller asked for them (a.steps / a.stats null, "traverse.variant" = 1).
+template <bool SMALL>
 __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
+    constexpr bool STATS = true;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= a.num_rays) return;
 
@@ -130,9 +132,11 @@ __global__ void __launch_bounds__(256) traverse_kernel(const TraverseArgs a) {
 //   * one wavefront per workgroup (a finished wave frees its slot at once) and an XCD-aware block -> ray-range map:
 //     consecutive ray ranges run on the same XCD, so each of the 8 private L2s caches one band of the scene.
 // Same arithmetic per ray as v1 (and the oracle): identical hits.
-template <bool SMALL, int BLOCK, bool NARROW, unsigned MODE>
+// a.mode (HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS) is read at run time: the barycentrics are computed with every accepted hit (two multiplies; id and t are
+// the same operations either way) and stored where asked for -- one instantiation per cell format and addressing instead of four.
+template <bool SMALL, int BLOCK, bool NARROW>
 __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArgs a) {
-    constexpr bool ANY = (MODE & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (MODE & HAGRID_TRAVERSE_UVS) != 0;
+    const bool ANY = (a.mode & HAGRID_TRAVERSE_ANY_HIT) != 0, UVS = (a.mode & HAGRID_TRAVERSE_UVS) != 0;
     const int* perm = (a.perm && (!a.perm_flag || __builtin_amdgcn_readfirstlane(*a.perm_flag))) ? a.perm : nullptr;
     const int w = (BLOCK == 64 && !perm) ? tile_packet_row_len(a) : 0;
     const int b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk_log2) : xcd_split(blockIdx.x, gridDim.x);
@@ -239,8 +243,7 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
             while (ref >= 0) {
                 const int next = SMALL ? ref_at(cur) : (cur < c.end ? ref_at(cur) : -1);
                 cur++;
-                const bool got = UVS ? intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit)
-                                     : intersect_prim_ray(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
+                const bool got = intersect_prim_ray_uvs(tri_at(ref), Ray(org, tmin, dir, hit.t), ref, hit);
                 ref = (ANY && got) ? -1 : next;
             }
             if ((ANY && hit.id >= 0) || hit.t <= texit || outside) break;
@@ -251,25 +254,18 @@ __global__ void __launch_bounds__(BLOCK, 8) traverse_kernel_v2(const TraverseArg
 }
 
 
-template <bool SMALL, bool NARROW>
-void launch_v2_mode(hipStream_t st, int blocks, unsigned mode, const TraverseArgs& a) {
-    switch (mode & 3u) {
-        case 0: traverse_kernel_v2<SMALL, 64, NARROW, 0><<<blocks, 64, 0, st>>>(a); break;
-        case 1: traverse_kernel_v2<SMALL, 64, NARROW, 1><<<blocks, 64, 0, st>>>(a); break;
-        case 2: traverse_kernel_v2<SMALL, 64, NARROW, 2><<<blocks, 64, 0, st>>>(a); break;
-        default: traverse_kernel_v2<SMALL, 64, NARROW, 3><<<blocks, 64, 0, st>>>(a); break;
-    }
-}
 } // namespace
 
-void hagrid_trav::launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a) {
-    if (small) { if (narrow) launch_v2_mode<true, true>(st, blocks, mode, a); else launch_v2_mode<true, false>(st, blocks, mode, a); }
-    else       { if (narrow) launch_v2_mode<false, true>(st, blocks, mode, a); else launch_v2_mode<false, false>(st, blocks, mode, a); }
+void hagrid_trav::launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a0) {
+    TraverseArgs a = a0;
+    a.mode = mode & 3u;
+    if (small) { if (narrow) traverse_kernel_v2<true, 64, true><<<blocks, 64, 0, st>>>(a); else traverse_kernel_v2<true, 64, false><<<blocks, 64, 0, st>>>(a); }
+    else       { if (narrow) traverse_kernel_v2<false, 64, true><<<blocks, 64, 0, st>>>(a); else traverse_kernel_v2<false, 64, false><<<blocks, 64, 0, st>>>(a); }
 }
 
 
-void hagrid_trav::launch_plain(hipStream_t st, int num_rays, bool small, bool stats, const TraverseArgs& a) {
+void hagrid_trav::launch_plain(hipStream_t st, int num_rays, bool small, const TraverseArgs& a) {
     const int blocks = grid_blocks(num_rays, 256);
-    if (small) { if (stats) traverse_kernel<true, true><<<blocks, 256, 0, st>>>(a); else traverse_kernel<true, false><<<blocks, 256, 0, st>>>(a); }
-    else       { if (stats) traverse_kernel<false, true><<<blocks, 256, 0, st>>>(a); else traverse_kernel<false, false><<<blocks, 256, 0, st>>>(a); }
+    if (small) traverse_kernel<true><<<blocks, 256, 0, st>>>(a);
+    else       traverse_kernel<false><<<blocks, 256, 0, st>>>(a);
 }

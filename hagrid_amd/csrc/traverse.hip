@@ -28,15 +28,15 @@ __global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ 
 }
 
 // the kernels of the traversal image: the tail kernel for the nearest hit, the image kernel for any-hit / barycentrics (and with "traverse.tail" = 0)
-template <unsigned MODE>
+template <bool UVS>
 bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
     if (!narrow || (slim != 20 && slim != 26)) return false;          // (32-bit offsets: the caller sends larger grids to the construction-format kernels)
-    if (tail && MODE == 0 && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL; always with the mailbox, never on padded triangles)
+    if (tail && a.mode == 0u && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL; always with the mailbox, never on padded triangles)
         if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         else            traverse_kernel_tail<26, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         return true;
     }
-    if (tail && MODE == 0 && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
+    if (tail && a.mode == 0u && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -45,7 +45,7 @@ bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool
             else            traverse_kernel_tail<26, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
-    else if (tail && MODE == 0 && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
+    else if (tail && a.mode == 0u && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, true, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -54,7 +54,7 @@ bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool
             else            traverse_kernel_tail<26, false, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
-    else if (tail && MODE == 0 && slim && !uniform) {
+    else if (tail && a.mode == 0u && slim && !uniform) {
         // (the table layout has no registers to spare for the second request of "traverse.tail_dual", and keeps costs for the tile order only where asked to)
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -64,25 +64,15 @@ bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool
             else            traverse_kernel_tail<26, false, false><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
-    else if (tail && MODE == 0 && uniform && slim && a.mailbox) {          // (one id per round trip: the mailbox sits in front of every round)
-        if (a.tri64) {
-            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        } else {
-            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        }
+    else if (tail && a.mode == 0u && uniform && slim && a.mailbox) {          // (one id per round trip: the mailbox sits in front of every round; the caller's triangles)
+        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        else            traverse_kernel_tail<26, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
     }
-    else if (tail && MODE == 0 && uniform && slim && a.tri64) {
-        if (a.tail_dual) {
-            if (slim == 20) traverse_kernel_tail<20, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, true, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        } else {
-            if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        }
+    else if (tail && a.mode == 0u && uniform && slim && a.tri64) {            // (padded triangles are for binned batches: one id per round trip)
+        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        else            traverse_kernel_tail<26, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
     }
-    else if (tail && MODE == 0 && uniform && slim) {
+    else if (tail && a.mode == 0u && uniform && slim) {
         if (a.tail_dual) {
             if (slim == 20) traverse_kernel_tail<20, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
@@ -92,23 +82,21 @@ bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool
         }
     }
     else if (slim == 20) {
-        if (uniform)      traverse_kernel_img<MODE, 20, 0><<<blocks, 64, 0, st>>>(a);
-        else if (general) traverse_kernel_img<MODE, 20, 2><<<blocks, 64, 0, st>>>(a);
-        else              traverse_kernel_img<MODE, 20, 1><<<blocks, 64, 0, st>>>(a);
+        if (uniform)      traverse_kernel_img<UVS, 20, 0><<<blocks, 64, 0, st>>>(a);
+        else if (general) traverse_kernel_img<UVS, 20, 2><<<blocks, 64, 0, st>>>(a);
+        else              traverse_kernel_img<UVS, 20, 1><<<blocks, 64, 0, st>>>(a);
     } else {
-        if (uniform)      traverse_kernel_img<MODE, 26, 0><<<blocks, 64, 0, st>>>(a);
-        else if (general) traverse_kernel_img<MODE, 26, 2><<<blocks, 64, 0, st>>>(a);
-        else              traverse_kernel_img<MODE, 26, 1><<<blocks, 64, 0, st>>>(a);
+        if (uniform)      traverse_kernel_img<UVS, 26, 0><<<blocks, 64, 0, st>>>(a);
+        else if (general) traverse_kernel_img<UVS, 26, 2><<<blocks, 64, 0, st>>>(a);
+        else              traverse_kernel_img<UVS, 26, 1><<<blocks, 64, 0, st>>>(a);
     }
     return true;
 }
-bool launch_img(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, unsigned mode, const TraverseArgs& a) {
-    switch (mode & 3u) {
-        case 0: return launch_img_mode<0>(st, blocks, narrow, uniform, general, slim, tail, a);
-        case 1: return launch_img_mode<1>(st, blocks, narrow, uniform, general, slim, tail, a);
-        case 2: return launch_img_mode<2>(st, blocks, narrow, uniform, general, slim, tail, a);
-        default: return launch_img_mode<3>(st, blocks, narrow, uniform, general, slim, tail, a);
-    }
+bool launch_img(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, unsigned mode, const TraverseArgs& a0) {
+    TraverseArgs a = a0;
+    a.mode = mode & 3u;             // (the any-hit rule is read at run time, the barycentrics are an instantiation: two more registers)
+    return (mode & HAGRID_TRAVERSE_UVS) ? launch_img_mode<true>(st, blocks, narrow, uniform, general, slim, tail, a)
+                                        : launch_img_mode<false>(st, blocks, narrow, uniform, general, slim, tail, a);
 }
 
 } // namespace
@@ -147,7 +135,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -186,7 +174,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // (traverse.cu:80,93) and its viewer colours by it (main.cpp:100-107).  Served by the reference-shaped kernel.
         if (!grid->entries) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: traverse.id_is_steps needs the construction format (grid released for traversal)");
         a.id_is_steps = 1;
-        launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, true, a);
+        launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
         HG_DBG(ctx);
         HG_HIP(ctx, hipGetLastError());
         return HAGRID_OK;
@@ -419,11 +407,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (ctx->opt_tail && !flags && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
             const long long n_tris = (long long)ctx->image.max_ref + 1;
             const bool want = ctx->opt_tri_pad < 0 ? (perm != nullptr && (long long)num_rays >= 4 * n_tris) : ctx->opt_tri_pad != 0;
-            if (want && refill_k <= 1) {          // (a refilled launch reads the caller's triangles: its default never meets a binned batch)
+            if (want && refill_k <= 1 && !a.mailbox) {          // (the refill and mailbox instantiations read the caller's triangles: their defaults never meet a binned batch of four rays per triangle)
                 float4* padded = tmp.get<float4>(size_t(n_tris) * 4);
                 if (padded) {
                     pad_triangles<<<grid_blocks(3 * n_tris, 256), 256, 0, ctx->stream>>>(a.tris, int(3 * n_tris), padded); HG_DBG(ctx);
-                    a.tris = padded; a.tri64 = 1;
+                    a.tris = padded; a.tri64 = 1; a.tail_dual = 0;          // (one instantiation on padded triangles: one id per round trip, the default of a binned batch)
                 }
             }
         }
@@ -434,7 +422,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (learn_order) { launch_tile_order(ctx, H, tiles, a); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
-        launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, false, a);
+        launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
     } else {
         const int blocks = grid_blocks(num_rays, 64);
         // 32-bit offsets are enough when every gathered array is smaller than 4 GB
@@ -498,7 +486,7 @@ extern "C" int hagrid_traverse_grid_stats(hagrid_ctx* ctx, const hagrid_grid* gr
     }
     a.steps = static_cast<int*>(steps);
     a.stats = dstats;
-    launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, true, a);
+    launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
     HG_HIP(ctx, hipGetLastError());
     if (stats) {
         unsigned long long h[8];

@@ -16,14 +16,15 @@ batches = [("primary 1024^2", lambda: scene.make_rays_primary(grid.bbox_min, gri
            ("incoherent 1M", lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4), 0),
            ("incoherent 4M binned", lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4), 1)]
 only = os.environ.get("BATCH")
+flags = int(os.environ.get("FLAGS", "0"))          # api.ANY_HIT = 1, api.UVS = 2
 for name, gen, binning in batches:
     if only and name not in only.split(";"): continue
     rays = gen(); n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     mem.set_ray_binning(binning)
-    for _ in range(3): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
-    t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n), mem) for _ in range(21))
+    for _ in range(3): api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+    t = sorted(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags), mem) for _ in range(21))
     h = mem.download(d_hits, api.HIT_DTYPE, n)
-    print(json.dumps({"batch": name, "ms_median": round(t[10], 4), "ms_min": round(t[0], 4), "Grays/s": round(n / t[10] / 1e6, 2),
+    print(json.dumps({"batch": name, "flags": flags, "ms_median": round(t[10], 4), "ms_min": round(t[0], 4), "Grays/s": round(n / t[10] / 1e6, 2),
                       "hits_crc": zlib.crc32(h.tobytes())}), flush=True)
     mem.set_ray_binning(0); mem.free(d_rays); mem.free(d_hits)
