@@ -36,6 +36,8 @@ struct TravImageCache {
     bool uniform = false;           // flat, every block at the full resolution: block T starts at T * (2^shift)^3 records
     bool general = false;           // flat, one slim record per voxel-map entry at the entry's index (links to child blocks, wide records): any depth
     int slim = 0;                   // bits per inline reference id of the slim records (20: four ids, 26: three)
+    int vtop_k = 0;                 // general layout: levels between the voxel map's top level and the image's virtual top level (0: none, 1)
+    uint32_t vtop_base = 0;         // general layout: index of the first record of the virtual top level (behind the records of the entries)
     bool detached = false;          // hagrid_grid_release_for_traversal freed entries and cells; the image stands for them
     bool borrowed = false;          // hagrid_share_traversal: table and blocks belong to another context's pool, never freed here
     // Set by the context that built the image, cleared when THAT context drops it (new setup, construction pass, a source array
@@ -92,6 +94,7 @@ struct hagrid_ctx {
     int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // traversal image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); an image beyond it is not built
+    int opt_image_vtop = 1;     // traversal image, general layout: records of a virtual top level one level below the map's (0: look-ups start at the map's top level, rounds 1-5a)
     int opt_image_uniform = 1;  // traversal image: use the table-free uniform layout when it is not much bigger than the table layout (2: whatever it costs; 0: never)
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
     // What the context remembers about a ray buffer it has traversed (traverse.hip): the row length found for it and the order of its tiles.  A few

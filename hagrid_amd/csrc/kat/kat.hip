@@ -74,10 +74,12 @@ __global__ void kat_image_records(TraverseArgs a, const int* vox, int n, uint32_
         } else {
             // general layout: from the top-level record down through the links, as lookup_entry walks the voxel map (grid.h:103-116)
             const uint32_t none_ = (1u << slim) - 1u; const int last_ = 48 + (80 / slim - 1) * slim;
-            r = reinterpret_cast<const uint4*>(a.img_blocks)[top];
+            // (from the image's virtual top level, where the kernels' look-ups start: a.gen_*)
+            region = a.gen_shift;
+            r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(a.gen_base) + size_t(vx >> region) + size_t(a.gen_x) * size_t(vy >> region) + size_t(a.gen_xy) * size_t(vz >> region)];
             while (((r.w >> (last_ - 96)) & none_) == none_ - 2u) {
                 const int k = int((r.z >> 16) & 3u), m = (1 << k) - 1;
-                region -= k; links++;
+                region += int((r.z >> 18) & 3u) - k; links++;
                 const uint32_t first = (r.y >> 16) | (r.z << 16);
                 r = reinterpret_cast<const uint4*>(a.img_blocks)[size_t(first) + size_t(((vx >> region) & m) + ((((vy >> region) & m) + (((vz >> region) & m) << k)) << k))];
             }
@@ -239,8 +241,7 @@ extern "C" int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid
     if (n == 0) return HAGRID_OK;
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, nullptr, nullptr, nullptr, 0, a));
-    a.img_table = static_cast<const uint2*>(ctx->image.table);
-    a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
+    image_args(ctx, a);
     // staging must not disturb the image: these buffers are not grid arrays
     Staged v(ctx, voxels3, size_t(n) * 12), o(ctx, nullptr, size_t(n) * 32);
     if (!v.d || !o.d) return HAGRID_ENOMEM;
@@ -259,8 +260,7 @@ extern "C" int hagrid_kat_traverse_timed(hagrid_ctx* ctx, const hagrid_grid* gri
         HG_FAIL(ctx, HAGRID_EINVAL, "kat_traverse_timed: needs the table-free image with 20-bit slim records of this grid");
     TraverseArgs a;
     HG_TRY(make_args(ctx, grid, tris, rays, hits, num_rays, a));
-    a.img_table = static_cast<const uint2*>(ctx->image.table);
-    a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
+    image_args(ctx, a);
     a.row_len_hint = row_len; a.wave_times = times_dev; a.tile_order = tile_order_dev;
     const int blocks = grid_blocks(num_rays, 64);
     if (tail) traverse_kernel_tail<20, true><<<blocks, 64, 0, ctx->stream>>>(a);
@@ -276,7 +276,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
-        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2},
+        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2}, {"traverse.image_vtop", &ctx->opt_image_vtop, 0, 1},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
         {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},

@@ -42,6 +42,9 @@ struct TraverseArgs {
     const uint2* __restrict__ img_table;     // traversal image (trav_image.hip) or null
     const unsigned char* __restrict__ img_blocks;
     int img_wide;                 // host side only: the image holds wide records (which instantiation of the table-layout kernel is launched)
+    // general layout: where a look-up that left its block starts again -- the image's VIRTUAL top level, `shift - gen_shift` (0 or 1) levels below the voxel map's
+    // (trav_image.hip image_general_vtop): record gen_base + x' + gen_x * y' + gen_xy * z' with x' = x >> gen_shift
+    int gen_shift, gen_x, gen_xy; uint32_t gen_base;
     size_t bin_working_set;       // host only: bytes a batch gathers from (traversal image or cells + entries, references, triangles): ray binning picks its bin count by it
     int num_rays;
     int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
@@ -239,6 +242,11 @@ __device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
 // then -- while the record is a LINK -- the child the voxel selects in the block the link names.  A ray keeps the innermost block its last look-up ended in
 // (`blk`: its first record, `bks`: k | s << 2 with (2^k)^3 records of 2^s finest-level voxels each); while the next voxel lies inside that block's region the
 // look-up is one gather.  Per record form: LAST id field = NONE - 1 by index, NONE - 2 link, NONE - 3 wide (bounds in a.img_table as 16-byte wide records).
+// A look-up that left its block starts at the image's VIRTUAL TOP LEVEL (round 5): a dense array of records one level below the voxel map's top level, each
+// the record the walk from the top would have reached there -- on the oracle's traces of the clustered scene 74 % of a primary ray's look-ups start again and
+// 58 % of those met a top-level link first (1.43 dependent gathers per step; with the virtual level 1.007, tests/analysis/general_walk_model.py).  A link
+// names its block's first record and k (bits 80..81) and how many levels the block's region lies ABOVE the region the link was found in (`up`, bits 82..83:
+// 1 for a top-level block of more than 2^3 entries seen from the virtual level, else 0).
 template <int SLIM>
 struct GenWalk {
     static constexpr int NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
@@ -262,21 +270,32 @@ struct GenWalk {
     // look-up, or-ed over the axes (nothing above the block's region changed: the voxel is still inside the block)
     // (Measured, round 5: resolving the link INSIDE the look-up -- the wavefront waits for the top-level record, the tests overlap the child's gather, as the
     // table of round 4's block layout had it -- is slower everywhere: configuration 3's grid at 4096^2 1.571 -> 1.615 ms, clustered scene 0.235 -> 0.246 ms.)
+    __device__ __forceinline__ void restart(const TraverseArgs& a) { blk = ~0u; bks = uint32_t(a.gen_shift) << 2; }
+    __device__ __forceinline__ static uint32_t link_region(const uint4& rec, uint32_t bks) { return (bks >> 2) + ((rec.z >> 18) & 3u) - ((rec.z >> 16) & 3u); }   // s of the link's block
     __device__ __forceinline__ uint4 lookup(const TraverseArgs& a, int x, int y, int z, uint32_t moved) {
         const uint32_t k = bks & 3u, s = bks >> 2;
         if (blk != ~0u && (moved >> (s + k)) == 0u) return rec_at(a, blk + child(x, y, z, k, s));
-        blk = ~0u; bks = uint32_t(a.shift) << 2;
-        return rec_at(a, uint32_t(x >> a.shift) + __umul24(uint32_t(a.top_x), uint32_t(y >> a.shift)) + __umul24(uint32_t(a.top_xy), uint32_t(z >> a.shift)));
+        restart(a);
+        return rec_at(a, a.gen_base + uint32_t(x >> a.gen_shift) + __umul24(uint32_t(a.gen_x), uint32_t(y >> a.gen_shift)) + __umul24(uint32_t(a.gen_xy), uint32_t(z >> a.gen_shift)));
     }
     __device__ __forceinline__ void descend(const TraverseArgs& a, uint4& rec, int x, int y, int z) {
         while (is_link(rec)) {
-            const uint32_t k = (rec.z >> 16) & 3u, s = (bks >> 2) - k;
+            const uint32_t k = (rec.z >> 16) & 3u, s = link_region(rec, bks);
             blk = word48(rec); bks = k | s << 2;
             rec = rec_at(a, blk + child(x, y, z, k, s));
         }
     }
     __device__ __forceinline__ static uint4 wide_at(const TraverseArgs& a, const uint4& rec) { return reinterpret_cast<const uint4*>(a.img_table)[word48(rec)]; }
 };
+
+// the traversal image of the context as kernel arguments (traverse.hip, kat/kat.hip)
+inline void image_args(const hagrid_ctx* ctx, TraverseArgs& a) {
+    const TravImageCache& im = ctx->image;
+    a.img_table = static_cast<const uint2*>(im.table);
+    a.img_blocks = static_cast<const unsigned char*>(im.blocks);
+    a.img_wide = im.wide_records > 0;
+    a.gen_shift = a.shift - im.vtop_k; a.gen_x = a.top_x << im.vtop_k; a.gen_xy = (a.top_x << im.vtop_k) * (a.top_y << im.vtop_k); a.gen_base = im.vtop_base;
+}
 
 // ---- host entry points of the translation units ------------------------------------------------------------------------------
 // traverse.hip: the argument block of a grid (setup_traversal's constants, traverse.cu:97-109); tris / rays / hits may be null when num_rays == 0

@@ -95,7 +95,8 @@ __device__ __forceinline__ void put_bits(unsigned long long& lo, unsigned long l
 // children (it knows their origins) and lists the inner ones for the next launch.  Wide records are per CELL (a large cell is named by many entries).
 struct GenItem { int entry; uint32_t oxy, ozs; int pad; };           // inner entry, origin of its region (x | y << 16, z | s << 16)
 
-__device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uint32_t word, int ox, int oy, int oz, uint4* __restrict__ rec, int* __restrict__ claim, int* __restrict__ status) {
+__device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uint32_t word, int ox, int oy, int oz, uint4* __restrict__ rec, int* __restrict__ claim, int* __restrict__ status,
+                                               uint32_t up = 0u) {
     const int NI = 80 / IDB;
     const uint32_t NONE = (1u << IDB) - 1u;
     unsigned long long rl = ~0ull << 48, rh = ~0ull;               // no bounds, every id field "unused"
@@ -103,6 +104,7 @@ __device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uin
         rl &= ~(0xffffffffull << 48);
         put_bits(rl, rh, 48, 32, word >> 2);
         put_bits(rl, rh, 80, 2, word & 3u);
+        put_bits(rl, rh, 82, 2, up);                                  // levels between the region the link is found in and the region of its block (virtual top level: 1)
         put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 2u);
         *rec = make_uint4(uint32_t(rl), uint32_t(rl >> 32), uint32_t(rh), uint32_t(rh >> 32));
         return true;
@@ -192,6 +194,22 @@ __global__ void __launch_bounds__(kBlock) image_general_level(const ImgK k, cons
         if (inner) items[at] = GenItem{first + c, uint32_t(cx) | uint32_t(cy) << 16, uint32_t(cz) | uint32_t(s) << 16, 0};
     }
 }
+// The VIRTUAL TOP LEVEL, one level below the voxel map's: record v of a dense (2 top_x) x (2 top_y) x (2 top_z) array is what the walk from the top level
+// reaches for the half-size region v of its top-level cell -- the cell (bounds from the region's origin), the child's link, or, where the top-level block has
+// more than 2^3 entries, that block's link seen from one level further down (up = 1).  A look-up that left its block starts here (trav_common.h GenWalk):
+// a top-level cell with eight leaf children costs it one gather instead of two.  One thread per record.
+__global__ void __launch_bounds__(kBlock) image_general_vtop(const ImgK k, const int IDB, uint4* __restrict__ recs, int* __restrict__ claim, int* __restrict__ status) {
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= 8 * k.num_top) return;
+    const int wx = 2 * k.top_x, wy = 2 * k.top_y;
+    const int x = v % wx, y = (v / wx) % wy, z = v / (wx * wy);
+    const int T = (x >> 1) + k.top_x * ((y >> 1) + k.top_y * (z >> 1)), oct = (x & 1) | (y & 1) << 1 | (z & 1) << 2;
+    const int s = k.shift - 1, ox = x << s, oy = y << s, oz = z << s;
+    const uint32_t e = k.entries[T];
+    uint4* rec = recs + size_t(k.num_entries) + v;
+    if ((e & 3u) == 1u) general_record(k, IDB, k.entries[(e >> 2) + oct], ox, oy, oz, rec, claim, status);      // the child: its cell or its link
+    else general_record(k, IDB, e, ox, oy, oz, rec, claim, status, 1u);                                           // a leaf (its cell from here), or a larger block from one level down
+}
 // records that name a wide cell get the index of its wide record; the wide records themselves
 __global__ void __launch_bounds__(kBlock) image_general_patch(const int IDB, uint4* __restrict__ recs, int num_entries, const int* __restrict__ claim, int first_wide) {
     const int NI = 80 / IDB, LAST = 48 + (NI - 1) * IDB;
@@ -227,9 +245,13 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     const int num_cells = k.num_cells;
     hipStream_t st = ctx->stream;
     if (k.num_entries <= 0 || k.num_entries >= (1 << 28) || k.shift > 15) return 1;
-    if (ctx->opt_image_max_mb > 0 && size_t(k.num_entries) * 16u > (size_t(ctx->opt_image_max_mb) << 20)) return 1;      // ("traverse.image_max_mb")
+    // the virtual top level (image_general_vtop): where the map has a level below its top level and the record index stays within the kernels' 24-bit products
+    const int top_z = k.num_top / std::max(k.top_x * k.top_y, 1);
+    const bool vtop = ctx->opt_image_vtop && k.shift >= 1 && 4ll * k.top_x * k.top_y < (1 << 23) && 2ll * top_z < (1 << 23) && (long long)k.num_entries + 8ll * k.num_top < (1ll << 28);
+    const size_t records = size_t(k.num_entries) + (vtop ? 8u * size_t(k.num_top) : 0u);
+    if (ctx->opt_image_max_mb > 0 && records * 16u > (size_t(ctx->opt_image_max_mb) << 20)) return 1;      // ("traverse.image_max_mb")
     const size_t cap = size_t(std::max(k.num_top, k.num_entries / 8)) + 1;
-    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(k.num_entries) * 16u));
+    uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, records * 16u));
     GenItem* items[2] = {pool_alloc<GenItem>(ctx, cap), pool_alloc<GenItem>(ctx, cap)};
     int* claim = pool_alloc<int>(ctx, size_t(num_cells));
     auto release = [&]() { hagrid_mem_free(ctx, items[0]); hagrid_mem_free(ctx, items[1]); hagrid_mem_free(ctx, claim); };
@@ -254,6 +276,7 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
             if (size_t(n) > cap) { rc = 1; break; }                       // (cannot happen for a voxel map whose blocks are disjoint)
         }
         if (rc != HAGRID_OK) break;
+        if (vtop) { image_general_vtop<<<grid_blocks(8ll * k.num_top, kBlock), kBlock, 0, st>>>(k, idb, recs, claim, status); HG_DBG(ctx); }
         int h[3] = {0, 0, 0};
         rc = read_back(ctx, status, h, sizeof(h));
         if (rc != HAGRID_OK) break;
@@ -262,11 +285,12 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
         uint4* wide = static_cast<uint4*>(hagrid_mem_alloc(ctx, size_t(std::max(h[2], 1)) * 16u));
         if (!wide) { rc = HAGRID_ENOMEM; break; }
         if (h[2] > 0) {
-            image_general_patch<<<grid_blocks(k.num_entries, kBlock), kBlock, 0, st>>>(idb, recs, k.num_entries, claim, 0);
+            image_general_patch<<<grid_blocks((long long)records, kBlock), kBlock, 0, st>>>(idb, recs, int(records), claim, 0);
             HG_DBG(ctx);
             image_general_wide<<<grid_blocks(num_cells, kBlock), kBlock, 0, st>>>(k, num_cells, claim, wide); HG_DBG(ctx);
         }
-        img.blocks = recs; img.block_bytes = size_t(k.num_entries) * 16u; img.table = wide; img.table_bytes = size_t(std::max(h[2], 1)) * 16u;
+        img.vtop_k = vtop ? 1 : 0; img.vtop_base = vtop ? uint32_t(k.num_entries) : 0u;
+        img.blocks = recs; img.block_bytes = records * 16u; img.table = wide; img.table_bytes = size_t(std::max(h[2], 1)) * 16u;
         img.slim = idb; img.general = true; img.uniform = false; img.wide_records = h[2];
         rc = HAGRID_OK;
         break;

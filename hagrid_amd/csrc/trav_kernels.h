@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64, 8) traverse_kernel_img(const TraverseArgs 
         };
         auto table_at = [&](int t) -> uint2 { return gather32<uint2>(a.img_table, uint32_t(t) << 3); };
         GenWalk<SLIM> gw;
-        gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+        gw.restart(a);
         // record of a voxel: one address computation off the scalar base
         auto record = [&](uint2 tab, int x, int y, int z, uint32_t moved = 0u) -> uint4 {
             if (UNIFORM) {
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         }
     }
     GenWalk<SLIM> gw;                                      // general layout: the innermost block the ray's last look-up ended in
-    gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
+    gw.restart(a);
     uint32_t tab_off = 0u, tab_d = 0u;                     // table layout: block offset (records) and depth of the top-level cell the ray is in
     int top_idx = -1;
     auto load_record = [&](int x, int y, int z) -> uint4 {          // uniform layout: the record of a voxel is arithmetic on the voxel; table layout: through the table entry of its top-level cell
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         const int m_dims = ax == 0 ? a.dims_x : (ax == 1 ? a.dims_y : a.dims_z);
         const bool m_pos = m_dir >= 0.0f;
         const uint32_t m_bit = (ax == 1 ? 16u : 0u) + (m_pos ? 8u : 0u);                       // where the record holds this axis' bound byte
-        const uint32_t m_stride = ax == 0 ? 1u : (ax == 1 ? uint32_t(a.top_x) : uint32_t(a.top_xy)), m_lsh = uint32_t(ax * a.shift);
+        const uint32_t m_stride = ax == 0 ? 1u : (ax == 1 ? uint32_t(GENERAL ? a.gen_x : a.top_x) : uint32_t(GENERAL ? a.gen_xy : a.top_xy)), m_lsh = uint32_t(ax * a.shift);
         int m_v = ax == 0 ? vx : (ax == 1 ? vy : vz);
         auto quad_sum = [&](uint32_t x) -> uint32_t { return x + uint32_t(quad_perm_i<9>(int(x))) + uint32_t(quad_perm_i<82>(int(x))); };
         auto quad_or = [&](int o) -> bool { return (o | quad_perm_i<9>(o) | quad_perm_i<82>(o)) != 0; };
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
         auto child_share = [&](uint32_t v, uint32_t k, uint32_t s) -> uint32_t { return ((v >> s) & ((1u << k) - 1u)) << __umul24(uint32_t(ax), k); };
         auto quad_descend = [&](uint4& rec) {          // GenWalk::descend with the voxel spread over the lanes of the group (all of them hold the same record)
             while (GenWalk<SLIM>::is_link(rec)) {
-                const uint32_t k = (rec.z >> 16) & 3u, s = (gw.bks >> 2) - k;
+                const uint32_t k = (rec.z >> 16) & 3u, s = GenWalk<SLIM>::link_region(rec, gw.bks);
                 gw.blk = GenWalk<SLIM>::word48(rec); gw.bks = k | s << 2;
                 rec = GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(uint32_t(m_v), k, s)));
             }
@@ -745,8 +745,8 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
             const uint32_t k = gw.bks & 3u, s = gw.bks >> 2;
             // still inside the block of the last look-up (no axis left its region)?  then one gather; else from the top level again
             if (gw.blk != ~0u && !quad_or(((uint32_t(m_v) ^ uint32_t(o_v)) >> (s + k)) != 0u ? 1 : 0)) return GenWalk<SLIM>::rec_at(a, gw.blk + quad_sum(child_share(v, k, s)));
-            gw.blk = ~0u; gw.bks = uint32_t(a.shift) << 2;
-            return GenWalk<SLIM>::rec_at(a, quad_sum(__umul24(v >> uint32_t(a.shift), m_stride)));
+            gw.restart(a);                   // from the image's virtual top level
+            return GenWalk<SLIM>::rec_at(a, a.gen_base + quad_sum(__umul24(v >> uint32_t(a.gen_shift), m_stride)));
         };
         const int my_word = (48 + (sub < NI ? sub : 0) * SLIM) >> 5;
         const uint32_t my_shift = uint32_t(48 + (sub < NI ? sub : 0) * SLIM) & 31u;

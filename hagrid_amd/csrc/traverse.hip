@@ -134,7 +134,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // +1.9 % with eleven (a square in-flight block), -2 % with 22; primary batches of 8 and 32 rounds +-0 with four, -1 ... -2 % with eleven; a 1024^2
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
-    a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0;
+    a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0; a.gen_shift = g->shift; a.gen_x = g->dims[0]; a.gen_xy = 0; a.gen_base = 0u;
     a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
@@ -241,9 +241,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         variant = 2;
     }
     if (variant == 4) {
-        a.img_table = static_cast<const uint2*>(ctx->image.table);
-        a.img_blocks = static_cast<const unsigned char*>(ctx->image.blocks);
-        a.img_wide = ctx->image.wide_records > 0;
+        image_args(ctx, a);
     }
     // Tile packets (v2 and the image kernel, not for binned batches): "traverse.image_width" > 0 gives the row length, 0
     // (default) looks for one on the device, -1 switches the feature off.  The kernel reads the answer from device memory,

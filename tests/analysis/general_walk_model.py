@@ -22,6 +22,7 @@ entries = G.entries; shift = G.shift; dims = G.dims
 steps = restarts = links = 0; parent_hits = 0; links_saved = 0
 gathers = 0
 hist = np.zeros(8, np.int64)
+K0 = (0, 1, 2, 3); gathers_k0 = {k0: 0 for k0 in K0}        # a VIRTUAL top level k0 levels below the map's: the first gather of a restart resolves every link that ends at depth <= k0
 for i in range(n):
     m = min(int(nc[i]), CAP)
     blk = None          # (first record, k, s) of the innermost block; parent likewise
@@ -42,13 +43,25 @@ for i in range(n):
             restarts += 1
             t = (int(v[0]) >> shift) + dims[0] * ((int(v[1]) >> shift) + dims[1] * (int(v[2]) >> shift))
             w = int(entries[t]); s_cur = shift; blk = None; parent = None
+            ww, d, chain = w, 0, []
+            while ww & 3:
+                kk = ww & 3; d += kk; chain.append(d); ss = shift - d
+                ww = int(entries[(ww >> 2) + ((int(v[0]) >> ss) & ((1 << kk) - 1)) + ((((int(v[1]) >> ss) & ((1 << kk) - 1)) + (((int(v[2]) >> ss) & ((1 << kk) - 1)) << kk)) << kk)])
+            for k0 in K0: gathers_k0[k0] += 1 + sum(1 for dd in chain if dd > k0)
+            restart_now = True
         while w & 3:
             k = w & 3; s_cur -= k; first = w >> 2
             parent = blk; blk = (first, k, s_cur)
             w = int(entries[first + ((int(v[0]) >> s_cur) & ((1 << k) - 1)) + ((((int(v[1]) >> s_cur) & ((1 << k) - 1)) + (((int(v[2]) >> s_cur) & ((1 << k) - 1)) << k)) << k)])
             links += 1; g += 1
         gathers += g; hist[min(g, 7)] += 1
+        if not locals().get("restart_now", False):
+            for k0 in K0: gathers_k0[k0] += g
+        restart_now = False
         pv = v
 print(f"{kind}: rays {n}, cell steps {steps} ({steps / n:.1f} per ray); look-ups that start at the top level {restarts / steps:.1%}; links followed {links / steps:.2f} per step; "
       f"gathers per step {gathers / steps:.2f}; restarts a remembered PARENT block would have served {parent_hits / max(restarts, 1):.1%}")
 print("steps by number of dependent gathers (1 = inside the block):", {g: f"{hist[g] / steps:.1%}" for g in range(1, 8) if hist[g]})
+top = int(dims[0]) * int(dims[1]) * int(dims[2])
+print("gathers per step with a virtual top level k0 levels down (image + top * 8^k0 records of 16 bytes):",
+      {k0: f"{gathers_k0[k0] / steps:.3f} (+{top * 8 ** k0 * 16 / 2 ** 20:.0f} MB)" for k0 in K0})

@@ -376,6 +376,17 @@ def _check_records(got, want, begin):
     return by_index, deep
 
 
+def _walk_meets_link(G, vox, vtop):
+    """general layout: does the walk to the voxel's record go through a link?  From the map's top level: where the top-level entry is subdivided.  From the
+    image's virtual top level (one level down): where the top-level block has more than 2^3 entries, or the voxel's child of it is subdivided again."""
+    t = vox.astype(np.int64) >> G.shift
+    e = G.entries[t[:, 0] + G.dims[0] * (t[:, 1] + G.dims[1] * t[:, 2])].astype(np.int64)
+    if not vtop or G.shift == 0: return (e & 3) != 0
+    h = (vox.astype(np.int64) >> (G.shift - 1)) & 1
+    child = G.entries[np.where((e & 3) == 1, (e >> 2) + h[:, 0] + 2 * h[:, 1] + 4 * h[:, 2], 0)].astype(np.int64)
+    return ((e & 3) > 1) | (((e & 3) == 1) & ((child & 3) != 0))
+
+
 def _image_scenes():
     sparse = scene.make_soup(3000, seed=5).copy()                      # two clusters far apart: top-level cells without subdivision
     sparse[:1500, 0:3] *= np.float32(0.2); sparse[1500:, 0:3] = sparse[1500:, 0:3] * np.float32(0.2) + np.float32(3.0)
@@ -430,17 +441,15 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     if info["uniform"]:
         assert nbytes.value == 16 * total + 8 * int(np.prod(G.dims))
     if info["general"]:
-        assert nbytes.value >= 16 * G.num_entries and nbytes.value <= 16 * (G.num_entries + G.num_cells) + 256
+        assert nbytes.value >= 16 * G.num_entries and nbytes.value <= 16 * (G.num_entries + G.num_cells + 8 * int(np.prod(G.dims))) + 256       # (entries, wide records, virtual top level)
     if name == "soup30k_shift3":
         assert not info["uniform"] and info["general"] == (general == 2), "the table layout and the general layout on a grid of three levels are exercised"
     assert nbytes.value >= 16 * G.num_cells / 64 and nbytes.value < 600 * 32 * G.num_cells + 128 * np.prod(G.dims) + 4096
     if name == "coincident":
         assert by_index.any()
     if info["general"]:
-        # bit 30 of the resolved record: the walk went through a link -- exactly where the top-level entry of the voxel is subdivided
-        t = vox.astype(np.int64) >> G.shift
-        top_inner = (G.entries[t[:, 0] + G.dims[0] * (t[:, 1] + G.dims[1] * t[:, 2])] & 3) != 0
-        assert (deep == top_inner).all()
+        # bit 30 of the resolved record: the walk went through a link -- from the image's virtual top level, one level below the map's
+        assert (deep == _walk_meets_link(G, vox, True)).all()
         if name in ("deep", "sparse", "coincident", "compressed_deep"): assert G.shift > 3 and deep.any()
     else:
         assert not deep.any()
@@ -522,7 +531,7 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
                 assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (uniform, slim, "general")
                 info = mem.image_format(grid)
                 assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), None, 0, None, C.byref(nb)) == 0
-                assert info["general"] and 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells)
+                assert info["general"] and 16 * G.num_entries + 16 <= nb.value <= 16 * (G.num_entries + G.num_cells + 8 * int(np.prod(G.dims)))      # (+ the virtual top level)
                 mem.set_option("traverse.image_general", 1)
         mem.set_option("traverse.image_uniform", 2)
         # the same clusters close together: every cell fits, slim records in both id widths
@@ -545,6 +554,53 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
     finally:
         mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_general", 1)
     grid.free(); mem.free(d_tris)
+
+
+def test_general_layout_virtual_top_level_on_and_off(mem):
+    """The general layout's virtual top level ("traverse.image_vtop", trav_image.hip image_general_vtop: eight records per top-level cell, where look-ups that left
+    their block start again) only shortens the walk: with it and without it every kernel gives the oracle's hits, and every voxel resolves to its cell."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    scenes = {"deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),       # shift 5, top-level blocks of more than 2^3 entries (links seen from one level down)
+              "clustered": (scene.make_clustered(3000, 3, 4000), {}),
+              "shallow": (scene.make_soup(20000, seed=11), dict(top_density=0.15, snd_density=3.0)),    # three levels, general layout forced
+              "one_level": (scene.make_soup(300, seed=5), dict(top_density=0.12, snd_density=0.01))}   # shift 0: no level below the top level, no virtual one
+    nb = C.c_int64(0)
+    try:
+        for name, (tris, params) in scenes.items():
+            G = O.Grid.full(tris, **params)
+            assert (G.shift == 0) == (name == "one_level"), (name, G.shift)
+            d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+            lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+            rays = np.concatenate([scene.make_rays_primary(lo, hi, 96, 64), scene.make_rays_incoherent(lo - 0.3, hi + 0.3, 20011, 29)]).astype(np.float32)
+            want, _ = G.traverse(tris, rays, nthreads=8)
+            rng = np.random.default_rng(3); total = np.array(G.dims) << G.shift
+            vox = np.ascontiguousarray(np.stack([rng.integers(0, total[c], 50000) for c in range(3)], axis=1).astype(np.int32))
+            mem.set_option("traverse.image_general", 2)
+            size = {}
+            for vtop in (1, 0):
+                mem.set_option("traverse.image_vtop", vtop)
+                for tail in (1, 0):
+                    mem.set_option("traverse.tail", tail)
+                    for flags in (0, api.ANY_HIT):
+                        if flags and tail: continue
+                        got = gpu_traverse(mem, grid, d_tris, rays) if not flags else None
+                        if got is not None: assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (name, vtop, tail)
+                mem.set_option("traverse.tail", 1)
+                assert mem.image_format(grid)["general"]
+                recs = np.zeros((vox.shape[0], 8), np.uint32)
+                assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid.pod), vox.ctypes.data_as(C.c_void_p), vox.shape[0], recs.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
+                size[vtop] = nb.value
+                # every voxel's record resolves to the cell (bounds, list) the construction format gives, through links exactly where the walk meets one
+                rec_want, begin = _expected_records(G, vox.astype(np.int64))
+                _, deep = _check_records(recs, rec_want, begin)
+                assert (deep == _walk_meets_link(G, vox, vtop == 1)).all(), (name, vtop)
+                if name == "clustered": assert deep.any() and not deep.all()
+                if name == "deep": assert deep.all()                                  # top-level blocks of 8^3 entries: a link either way (seen from one level down: up = 1)
+            assert size[1] - size[0] == (128 * int(np.prod(G.dims)) if G.shift >= 1 else 0), (name, size)
+            grid.free(); mem.free(d_tris)
+    finally:
+        mem.set_option("traverse.image_vtop", 1); mem.set_option("traverse.image_general", 1); mem.set_option("traverse.tail", 1)
 
 
 def test_image_lifetime(mem):

@@ -1,20 +1,21 @@
 #!/bin/bash
-# One-off experiment (round 5, job 14): the whole GPU suite after the second prune (119 kernels: scans in the look-back form only, any-hit as a run-time flag,
-# image builders with depth and id width as arguments, one construction-format kernel per cell format); same-box A/B against the library before it (ab/libOLD.so).
+# One-off experiment (round 5, job 15): the general layout's virtual top level (trav_image.hip image_general_vtop) -- traversal tests, then the clustered scene and
+# configuration 3's grid forced into the general layout, with ("traverse.image_vtop" = 1, default) and without it.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-exp}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" || exit 1
-timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; tail -8 $OUT/pytest.log | cut -c1-300
-cp hagrid_amd/libhagrid_amd.so /tmp/libNEW.so
+timeout 1500 python -m pytest tests/test_traverse_gpu.py -m gpu -q -x > $OUT/pytest.log 2>&1; tail -8 $OUT/pytest.log | cut -c1-300
+B="python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --inflight 0 --no-order-compare --hits-hash"
 for round in 1 2; do
-for v in NEW OLD; do
-  cp $( [ $v = NEW ] && echo /tmp/libNEW.so || echo ab/lib$v.so ) hagrid_amd/libhagrid_amd.so; touch hagrid_amd/libhagrid_amd.so
-  echo "== $v (round $round)"
-  timeout 600 python tools/dev_traverse_time.py 2>&1 | cut -c1-200
-  [ $round = 1 ] && BATCH="primary 1024^2;incoherent 4M binned" FLAGS=1 timeout 600 python tools/dev_traverse_time.py 2>&1 | cut -c1-200
-  [ $round = 1 ] && BATCH="primary 1024^2;incoherent 4M binned" FLAGS=2 timeout 600 python tools/dev_traverse_time.py 2>&1 | cut -c1-200
-  [ $round = 1 ] && BATCH="primary 1024^2;incoherent 1M" OPTS=traverse.image=0 timeout 600 python tools/dev_traverse_time.py 2>&1 | cut -c1-200
-  [ $round = 1 ] && timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --config clustered --no-cpu-baseline --inflight 0 --no-order-compare 2> $OUT/c.err | cut -c1-260
+for vt in 1 0; do
+  for what in "--config clustered" "--config clustered --rays aimed" "--config 3 --opts traverse.image_general=2,traverse.image_vtop=$vt"; do
+    case "$what" in *opts*) W="$what";; *) W="$what --opts traverse.image_vtop=$vt";; esac
+    timeout 900 $B $W > $OUT/x.json 2> $OUT/x.err; python - $OUT/x.json "vtop=$vt $what" <<'PY'
+import json, sys
+try:
+    j = json.load(open(sys.argv[1])); print(f"{sys.argv[2][:70]:70s} ms_per_step {j['ms_per_step']:8.4f}  kernel_ms {j['roofline']['kernel_ms']:8.4f}  Mrays/s {j['value']:8.1f}  hits {j['hits_sha256'][:12]}  image {j['memory']['traversal_image']}")
+except Exception as e: print(sys.argv[2], "FAILED", e, open(sys.argv[1][:-5] + ".err").read()[-600:])
+PY
+  done
 done
 done
-cp /tmp/libNEW.so hagrid_amd/libhagrid_amd.so
