@@ -6,12 +6,19 @@
 //
 // How it differs from the reference's pipeline (not a port):
 //  * Only the ORDER OF CELLS is part of the result; the final reference list of a cell is the ascending
-//    list of primitive ids.  So references never go through ordered scans, a flagged partition or a radix
-//    sort: kept and split references are appended with one atomic per wavefront (wave_append), per-cell
-//    reference counts are accumulated with atomics while the levels are built, the final scatter uses a
-//    per-cell cursor, and each (short) list is sorted in place.  Ordered scans run over cells only.
-//  * Per level there is ONE host round trip (new cells, children, kept) instead of four; the bounding box,
-//    the reference count and the shift cost two more; concat costs one.
+//    list of primitive ids.  So references never go through an ordered scan, a flagged partition or a radix
+//    sort.  From the top level on the references of a level are kept GROUPED BY CELL, in cell order: a cell's
+//    references are a segment of {reference, cell} pairs, its count is the segment's length -- known when its
+//    parent is classified -- and a leaf's list is its segment.  One returning atomic per (primitive, top-level
+//    cell) pair places the pair in its cell's segment (the same atomic counts the cell's references, which the
+//    depth rule needs anyway); below the top level there are no global atomics at all: child counts and emission
+//    cursors live in LDS, per workgroup tile of references aligned to cells.  Ordered scans run over cells only.
+//    (Rounds 1-4 kept the references in emission order, drew a list slot per kept reference with a returning
+//    atomic, scattered the kept references at the end and sorted every list: build_grid 1.32 -> 1.11 ms for the
+//    1M-triangle scene, same box; profiles/NOTES.md "Round 5".)
+//  * Per level there is ONE host round trip (kept references, references and cells of the next levels) instead
+//    of four; the bounding box, the reference count, the shift and the first level's cells cost four more;
+//    concat costs one.  All temporaries of a construction come from one pool buffer (Arena).
 //  * Per-primitive bounding boxes are recomputed from the 48-byte triangle instead of being stored.
 //  * The top-level cell a reference sits in is known from its index, so the SAT filter (filter_refs,
 //    build.cu:139-157) is fused into the emission kernel.
@@ -96,34 +103,6 @@ __global__ void __launch_bounds__(kBlock) bbox_final(const float* __restrict__ p
 // over its cell range -- the wave64 counterpart of the reference's 32-lane cooperative emission (build.cu:106-135).
 constexpr int kCoopCells = 64;
 
-__global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restrict__ tris, int n, BuildK k,
-                                                         int* __restrict__ counts, int* __restrict__ refs_per_cell) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    Range r(0, 0, 0, -1, -1, -1);
-    int size = 0;
-    if (i < n) {
-        r = compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox());
-        size = max(0, r.size());
-        counts[i] = size;
-    }
-    const bool coop = size >= kCoopCells;
-    if (size > 0 && !coop)
-        for (int z = r.lz; z <= r.hz; z++)
-            for (int y = r.ly; y <= r.hy; y++)
-                for (int x = r.lx; x <= r.hx; x++)
-                    atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
-        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1, total = __shfl(size, src, 64);
-        for (int c = lane_id(); c < total; c += 64) {
-            const int x = lx + c % sx, y = ly + (c / sx) % sy, z = lz + c / (sx * sy);
-            atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
-        }
-    }
-}
 
 // compute_log_dims (build.cu:256-270) + the max reduction of build.cu:508
 __global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ refs_per_cell, int num_top, BuildK k, float snd_density,
@@ -149,56 +128,6 @@ __global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ r
     }
 }
 
-// emit_new_refs (build.cu:69-136) + filter_refs (build.cu:139-157): every (primitive, top cell) pair of the
-// primitive's cell range in x-fastest order, with -1/-1 where the triangle misses the cell.  Large ranges are spread
-// over the wavefront as in count_top_refs (slot = start + linear cell index, so the order is the serial one).
-// A cell that receives a reference and still has levels to go is marked for splitting by whoever hands it the reference
-// (compute_dims, build.cu:286-302, does that in a pass of its own over the references): entry word 1 = make_entry(1, 0), the same
-// value from every writer.
-__device__ __forceinline__ void emit_one_top_ref(const BuildK& k, const Tri& tri, int prim, int x, int y, int z, int slot,
-                                                 int* __restrict__ ref_ids, int* __restrict__ cell_ids,
-                                                 const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
-    const int inc = 1 << k.shift;
-    const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
-    const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
-    const int cell = x + k.dims.x * (y + k.dims.y * z);
-    ref_ids[slot] = hit ? prim : -1;
-    cell_ids[slot] = hit ? cell : -1;
-    if (hit && log_dims[cell] > 0) entries[cell] = 1u;
-}
-
-__global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
-                                                        int* __restrict__ ref_ids, int* __restrict__ cell_ids,
-                                                        const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    Range r(0, 0, 0, -1, -1, -1);
-    int size = 0, start = 0;
-    Tri tri;
-    if (i < n) {
-        tri = load_tri(tris, i);
-        r = compute_range(k.dims, BBox(k.bmin, k.bmax), tri.bbox());
-        size = max(0, r.size());
-        start = start_emit[i];
-    }
-    const bool coop = size >= kCoopCells;
-    if (size > 0 && !coop) {
-        int cur = start;
-        for (int z = r.lz; z <= r.hz; z++)
-            for (int y = r.ly; y <= r.hy; y++)
-                for (int x = r.lx; x <= r.hx; x++) emit_one_top_ref(k, tri, i, x, y, z, cur++, ref_ids, cell_ids, log_dims, entries);
-    }
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int prim = __shfl(i, src, 64), first = __shfl(start, src, 64), total = __shfl(size, src, 64);
-        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
-        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
-        const Tri t = load_tri(tris, prim);                     // same address in every lane: one broadcast load
-        for (int c = lane_id(); c < total; c += 64)
-            emit_one_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), first + c, ref_ids, cell_ids, log_dims, entries);
-    }
-}
 
 // emit_top_cells (build.cu:332-351)
 // + the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per level")
@@ -206,10 +135,18 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
 // be split, where classify_refs finds it in the record it loads anyway.
 // The kernel that creates a level's cells also clears their voxel-map words and reference counts (it runs before the
 // references of the level are handed out): no fill launches.
-__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k, const int* __restrict__ log_dims,
+// (The shift -- the deepest subdivision of any top-level cell, top_log_dims -- is read from device memory here and in emit_top_refs: the host learns it together
+// with the number of cells of the next level, one round trip later.)
+__device__ __forceinline__ BuildK with_device_shift(BuildK k, const int* __restrict__ shift_dev, vec3 extents) {
+    k.shift = *shift_dev;
+    k.cell_size = extents / vec3(k.dims << k.shift);
+    return k;
+}
+__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k0, const int* __restrict__ shift_dev, const int* __restrict__ log_dims,
                                                          uint32_t* __restrict__ entries, int* __restrict__ cell_counts) {
     const int id = blockIdx.x * kBlock + threadIdx.x;
     if (id >= num_top) return;
+    BuildK k = k0; k.shift = *shift_dev;
     entries[id] = 0u; cell_counts[id] = 0;
     const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
     const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
@@ -272,139 +209,6 @@ __device__ __forceinline__ int split_mask(const BuildK& k, ivec3 lo, ivec3 hi, c
     return mask;
 }
 
-constexpr int kNoRank = int(0x80000000);        // ranks[]: a reference without a cell
-
-// mark_kept_refs (build.cu:305-314) + compute_split_masks + the popcount reduction of build.cu:597, and the
-// per-cell reference count that replaces the final sort's histogram.  totals[0] += children, totals[1] += kept.
-__global__ void __launch_bounds__(kBlock) classify_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                        const float4* __restrict__ tris, const Cell* __restrict__ cells,
-                                                        const uint32_t* __restrict__ entries, BuildK k,
-                                                        unsigned char* __restrict__ masks, int* __restrict__ cell_counts, int* __restrict__ ranks,
-                                                        int* __restrict__ totals) {
-    __shared__ int lds[kWaves];
-    int children = 0, kept = 0;
-    // several rounds per workgroup: the two totals cost one atomic pair per workgroup (a same-word atomic per 256 references
-    // would run into the ~88 atomics/us ceiling of a single L2 word).  A workgroup takes a contiguous stretch of the references and the stretches
-    // go to the XCDs eighth by eighth (wave_prims.h xcd_block): the references of a cell and of its neighbours -- the same triangles -- meet in one L2.
-    const int per = ((num_refs + int(gridDim.x) - 1) / int(gridDim.x) + kBlock - 1) / kBlock * kBlock;
-    const long long first = (long long)xcd_block(blockIdx.x, gridDim.x) * per;
-    const int last = int(first + per < num_refs ? first + per : num_refs);
-    for (int i = int(first < num_refs ? first : num_refs) + threadIdx.x; i < last; i += kBlock) {
-        const int c = cell_ids[i];
-        int m = 0, r = kNoRank;
-        if (c >= 0) {
-            const uint32_t e = entries[c];
-            if ((e & 3u) == 0) {
-                kept++;
-                // the count and the reference's slot inside its cell's list in ONE atomic: random atomics run at ~26 per ns on this
-                // part whatever their scope or whether they return a value (tools/micro/atomic_scope.hip), so the scatter pass must
-                // not pay for a second one per reference
-                r = atomicAdd(cell_counts + c, 1);
-            } else {
-                const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
-                const int4 a = p[0], b = p[1];
-                m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref_ids[i]));
-                children += __popc(m);
-                // where the cell's children start and whether they split again (a.w: levels left): emit_child_refs need not look
-                // anything up
-                r = -int(((e >> 2) << 1) | uint32_t(a.w > 1)) - 1;
-            }
-        }
-        ranks[i] = r;                                  // >= 0: slot of a kept reference; < 0: not kept (scatter_kept_refs skips it unseen)
-        masks[i] = (unsigned char)m;
-    }
-    children = block_sum(children, lds);
-    kept = block_sum(kept, lds);
-    if (threadIdx.x == 0) {
-        if (children) atomicAdd(totals + 0, children);
-        if (kept) atomicAdd(totals + 1, kept);
-    }
-}
-
-// split_refs (build.cu:219-243).  Output order is irrelevant (see the header), so slots are handed out per TILE of
-// 2048 references: block-wide prefix over the per-thread child counts, one atomic per tile.  Inside a tile every wavefront owns a
-// contiguous range and fills it row by row (one reference per lane and row, up to eight children each) through a 4 KB staging
-// area in LDS, so that the children leave in full 256-byte runs: written lane by lane, each at its own offset, the same data cost
-// 3.6x its size in HBM write traffic (profiles/pmc_r2m_construction_traffic.txt) and the deepest level 142 us instead of ~60.
-constexpr int kEmitItems = 8;
-__global__ void __launch_bounds__(kBlock) emit_child_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                          const unsigned char* __restrict__ masks, const int* __restrict__ ranks,
-                                                          uint32_t* __restrict__ new_entries,
-                                                          int* __restrict__ new_ref_ids, int* __restrict__ new_cell_ids, int* __restrict__ cursor) {
-    __shared__ int lds[kWaves];
-    __shared__ int tile_base;
-    __shared__ int2 stage[kWaves][64 * 8];              // per wavefront: the children {reference, cell} of one row
-    const int tile_size = kBlock * kEmitItems;
-    int2* mine = stage[wave_id()];
-    for (int base = blockIdx.x * tile_size; base < num_refs; base += gridDim.x * tile_size) {
-        int m[kEmitItems];
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < kEmitItems; j++) {
-            const int i = base + j * kBlock + threadIdx.x;
-            m[j] = i < num_refs ? masks[i] : 0;
-            cnt += __popc(m[j]);
-        }
-        const int wave_total = wave_sum(cnt);
-        if (lane_id() == 0) lds[wave_id()] = wave_total;
-        __syncthreads();
-        int off = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; w++) { if (w < wave_id()) off += lds[w]; total += lds[w]; }
-        if (threadIdx.x == 0) tile_base = total ? atomicAdd(cursor, total) : 0;
-        __syncthreads();
-        int row_base = tile_base + off;                  // this wavefront's range, filled row after row
-#pragma unroll
-        for (int j = 0; j < kEmitItems; j++) {
-            int mm = m[j];
-            const int c = __popc(mm);
-            const int incl = wave_inclusive_scan(c);
-            const int row_total = __shfl(incl, 63, 64);
-            if (row_total == 0) continue;                 // (uniform)
-            if (mm) {
-                const int i = base + j * kBlock + threadIdx.x;
-                const int ref = ref_ids[i];
-                const int code = -ranks[i] - 1;                            // classify_refs left the children's first cell here
-                const int begin = code >> 1;
-                const bool splits_again = (code & 1) != 0;                 // the children still have a level to go
-                int at = incl - c;
-                while (mm) {
-                    const int child = __ffs(mm) - 1;
-                    mm &= mm - 1;
-                    mine[at++] = make_int2(ref, begin + child);
-                    if (splits_again) new_entries[begin + child] = 1u;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // LDS operations of a wavefront execute in order: only the
-            __builtin_amdgcn_wave_barrier();                                // compiler must not move the reads below above the writes
-            for (int q = lane_id(); q < row_total; q += 64) {
-                const int2 v = mine[q];
-                new_ref_ids[row_base + q] = v.x;
-                new_cell_ids[row_base + q] = v.y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            row_base += row_total;
-        }
-        __syncthreads();
-    }
-}
-
-// emit_new_cells (build.cu:354-383): 8 cells x 32 B = 256 contiguous bytes per split cell
-__global__ void __launch_bounds__(kBlock) emit_child_cells(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, int num_cells,
-                                                           Cell* __restrict__ new_cells, uint32_t* __restrict__ new_entries, int* __restrict__ new_cell_counts) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    const int id = t >> 3, child = t & 7;     // 8 lanes per parent: each lane stores one child
-    if (id >= num_cells) return;
-    const uint32_t e = entries[id];
-    if ((e & 3u) == 0) return;
-    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(id);
-    const int4 a = p[0], b = p[1];
-    const int inc = (b.x - a.x) >> 1;
-    const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
-    store_cell(new_cells, int(e >> 2) + child, lo, a.w - 1, lo + ivec3(inc), 0);       // (a.w: levels left, see emit_top_cells)
-    new_entries[int(e >> 2) + child] = 0u; new_cell_counts[int(e >> 2) + child] = 0;
-}
 
 // ---- concatenation ---------------------------------------------------------------------------------------
 // leaf flag + kept-reference count per cell, scanned over all levels in cell order
@@ -435,81 +239,575 @@ struct LeafOut {
     }
 };
 
-// copy_cells (build.cu:407-419) + copy_entries (:422-440) + compute_cell_ranges (:453-468)
-__global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, const int* __restrict__ cell_counts,
-                                                       const int* __restrict__ start_cell, const int* __restrict__ ref_begin, int num_cells,
-                                                       int level_off, Cell* __restrict__ out_cells, uint32_t* __restrict__ out_entries) {
+
+// ---- references grouped by cell ---------------------------------------------------------------------------------------------------------------------
+// (The level loop of rounds 1-4 handed a kept reference its list slot with one returning atomic, scattered it there at the end and left the references of a
+// level in the order the emission tiles drew.)  The references of a level are kept grouped by cell, in cell order, from the top
+// level on: a cell's references are a SEGMENT [seg_begin[c], seg_begin[c + 1]) of {reference, cell} pairs, its count is the segment's length -- known when its
+// PARENT is classified -- and a leaf's list is its segment.  Per level: classify (SAT masks + the eight child counts of every splitting cell, reduced per
+// wavefront and cell, then in LDS), ONE scan over the new cells (segment starts and child-cell bases together), emit (the children of a cell go to the segments
+// of its child cells: LDS cursors, output staged in LDS).  The deepest level needs no pass at all, the concatenation copies segments.  Workgroups take TILES of
+// references aligned to cells: tile t owns the cells whose segments start in [t * kTileRefs, (t + 1) * kTileRefs) -- tile_first[t] is the first of them, left
+// there by the scan that made the segment starts.
+#ifndef HG_TILE_REFS                       // (variant builds: tools/build_variant.sh)
+#define HG_TILE_REFS 1024
+#endif
+#ifndef HG_CHUNK_CELLS
+#define HG_CHUNK_CELLS 256
+#endif
+#ifndef HG_EMIT_CHUNK
+#define HG_EMIT_CHUNK 256
+#endif
+#ifndef HG_STAGE
+#define HG_STAGE 1024
+#endif
+constexpr int kTileRefs = HG_TILE_REFS;    // references per tile (nominal: a tile ends with the cell it ends in)
+constexpr int kChunkCells = HG_CHUNK_CELLS; // cells a workgroup of the classification holds counters for at a time
+constexpr int kEmitChunk = HG_EMIT_CHUNK;  // cells a workgroup of the emission holds cursors for at a time
+constexpr int kStage = HG_STAGE;           // output slots a workgroup stages in LDS per chunk
+
+// segment starts from per-cell reference counts; the cell a tile boundary falls into names the tile's first cell (the cell behind it)
+__device__ __forceinline__ void mark_tiles(int* __restrict__ tile_first, int i, int start, int count) {
+    for (int t = start / kTileRefs + 1; t <= (start + count) / kTileRefs; t++) tile_first[t] = i + 1;
+}
+struct SegIn {
+    const int* counts;
+    __device__ int operator()(int i) const { return counts[i]; }
+};
+struct SegOut {
+    const int* counts; int* seg_begin; int* tile_first;
+    __device__ void operator()(int i, int start) const { seg_begin[i] = start; mark_tiles(tile_first, i, start, counts[i]); }
+};
+// the new cells of a level: {references, 8 if the cell splits again} -> {segment start, first child cell}; update_entries fused as in UpdateEntriesOut
+struct ChildSegIn {
+    const int* counts; const uint32_t* entries;
+    __device__ Int2 operator()(int i) const { return Int2{counts[i], (entries[i] & 3u) ? 8 : 0}; }
+    __device__ void load4(int i, int n, Int2* v) const {
+        if (i + 4 <= n && lb_aligned16(counts + i) && lb_aligned16(entries + i)) {
+            const int4 c = *reinterpret_cast<const int4*>(counts + i);
+            const uint4 e = *reinterpret_cast<const uint4*>(entries + i);
+            v[0] = Int2{c.x, (e.x & 3u) ? 8 : 0}; v[1] = Int2{c.y, (e.y & 3u) ? 8 : 0}; v[2] = Int2{c.z, (e.z & 3u) ? 8 : 0}; v[3] = Int2{c.w, (e.w & 3u) ? 8 : 0};
+        } else {
+            for (int k = 0; k < 4; k++) v[k] = i + k < n ? (*this)(i + k) : Int2{0, 0};
+        }
+    }
+};
+struct ChildSegOut {
+    const int* counts; uint32_t* entries; int* seg_begin; int* tile_first;
+    __device__ void operator()(int i, Int2 v) const {
+        seg_begin[i] = v.a;
+        entries[i] = UpdateEntriesOut::word(entries[i], i, v.b);
+        mark_tiles(tile_first, i, v.a, counts[i]);
+    }
+    __device__ void store4(int i, int n, const Int2* v) const {
+        if (i + 4 <= n && lb_aligned16(counts + i) && lb_aligned16(entries + i) && lb_aligned16(seg_begin + i)) {
+            const int4 c = *reinterpret_cast<const int4*>(counts + i);
+            uint4* pe = reinterpret_cast<uint4*>(entries + i);
+            const uint4 e = *pe;
+            *reinterpret_cast<int4*>(seg_begin + i) = make_int4(v[0].a, v[1].a, v[2].a, v[3].a);
+            *pe = make_uint4(UpdateEntriesOut::word(e.x, i, v[0].b), UpdateEntriesOut::word(e.y, i + 1, v[1].b), UpdateEntriesOut::word(e.z, i + 2, v[2].b), UpdateEntriesOut::word(e.w, i + 3, v[3].b));
+            // (the four cells together: a tile boundary inside their references is rare -- 2048 references per tile, a handful per cell)
+            if (v[0].a / kTileRefs != (v[3].a + c.w) / kTileRefs) {
+                mark_tiles(tile_first, i, v[0].a, c.x); mark_tiles(tile_first, i + 1, v[1].a, c.y); mark_tiles(tile_first, i + 2, v[2].a, c.z); mark_tiles(tile_first, i + 3, v[3].a, c.w);
+            }
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n) (*this)(i + k, v[k]);
+        }
+    }
+};
+
+// top level, pass 1: the number of top-level cells every primitive's box covers (count_new_refs, build.cu:57-66)
+__global__ void __launch_bounds__(kBlock) top_range_sizes(const float4* __restrict__ tris, int n, BuildK k, int* __restrict__ counts) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_cells) return;
-    const uint32_t e = entries[i];
-    if ((e & 3u) == 0) {
-        const int dst = start_cell[i], cnt = cell_counts[i], rb = ref_begin[i];
-        const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
-        const int4 a = p[0], b = p[1];
-        store_cell(out_cells, dst, ivec3(a.x, a.y, a.z), cnt ? rb : 0, ivec3(b.x, b.y, b.z), cnt ? rb + cnt : 0);
-        out_entries[level_off + i] = uint32_t(dst) << 2;
-    } else {
-        out_entries[level_off + i] = (e & 3u) | (((e >> 2) + uint32_t(level_off + num_cells)) << 2);
+    if (i >= n) return;
+    counts[i] = max(0, compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox()).size());
+}
+// top level, pass 2: count_refs_per_cell (build.cu:246-253, counted BEFORE the SAT filter) with the count's return value kept per (primitive, cell) pair: the
+// pair's place inside its cell's segment.  Pairs in the order of emit_top_refs (x fastest; large ranges spread over the wavefront).
+__global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
+                                                                int* __restrict__ refs_per_cell, int* __restrict__ pair_rank) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    Range r(0, 0, 0, -1, -1, -1);
+    int size = 0, start = 0;
+    if (i < n) {
+        r = compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox());
+        size = max(0, r.size());
+        start = start_emit[i];
+    }
+    const bool coop = size >= kCoopCells;
+    if (size > 0 && !coop) {
+        int cur = start;
+        for (int z = r.lz; z <= r.hz; z++)
+            for (int y = r.ly; y <= r.hy; y++)
+                for (int x = r.lx; x <= r.hx; x++) pair_rank[cur++] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+    }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int first = __shfl(start, src, 64), total = __shfl(size, src, 64);
+        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
+        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
+        for (int c = lane_id(); c < total; c += 64) {
+            const int x = lx + c % sx, y = ly + (c / sx) % sy, z = lz + c / (sx * sy);
+            pair_rank[first + c] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+        }
+    }
+}
+// top level, pass 3: emit_new_refs + filter_refs (build.cu:69-157) into the cells' segments: a pair the SAT rejects leaves a HOLE (reference -1) in its
+// cell's segment -- the counts that sized the segments are the unfiltered ones, as the reference's depth rule wants them.  One 8-byte store per pair.
+__device__ __forceinline__ void place_top_ref(const BuildK& k, const Tri& tri, int prim, int x, int y, int z, int rank, const int* __restrict__ seg_begin,
+                                              int2* __restrict__ refs, const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
+    const int inc = 1 << k.shift;
+    const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
+    const bool hit = intersect_prim_cell(tri, cell_world_box(k, lo, lo + ivec3(inc)));
+    const int cell = x + k.dims.x * (y + k.dims.y * z);
+    refs[seg_begin[cell] + rank] = make_int2(hit ? prim : -1, cell);
+    if (hit && log_dims[cell] > 0) entries[cell] = 1u;
+}
+__global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k0, const int* __restrict__ shift_dev, vec3 extents,
+                                                                const int* __restrict__ start_emit,
+                                                                const int* __restrict__ pair_rank, const int* __restrict__ seg_begin, int2* __restrict__ refs,
+                                                                const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
+    const BuildK k = with_device_shift(k0, shift_dev, extents);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    Range r(0, 0, 0, -1, -1, -1);
+    int size = 0, start = 0;
+    Tri tri;
+    if (i < n) {
+        tri = load_tri(tris, i);
+        r = compute_range(k.dims, BBox(k.bmin, k.bmax), tri.bbox());
+        size = max(0, r.size());
+        start = start_emit[i];
+    }
+    const bool coop = size >= kCoopCells;
+    if (size > 0 && !coop) {
+        int cur = start;
+        for (int z = r.lz; z <= r.hz; z++)
+            for (int y = r.ly; y <= r.hy; y++)
+                for (int x = r.lx; x <= r.hx; x++) { place_top_ref(k, tri, i, x, y, z, pair_rank[cur], seg_begin, refs, log_dims, entries); cur++; }
+    }
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int prim = __shfl(i, src, 64), first = __shfl(start, src, 64), total = __shfl(size, src, 64);
+        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
+        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
+        const Tri t = load_tri(tris, prim);
+        for (int c = lane_id(); c < total; c += 64)
+            place_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), pair_rank[first + c], seg_begin, refs, log_dims, entries);
     }
 }
 
-// copy_refs + remap_refs + the scatter half of the sort (build.cu:634-647, :681, :691): the slot inside the cell's list is
-// the rank classify_refs drew for the reference
-__global__ void __launch_bounds__(kBlock) scatter_kept_refs(const int* __restrict__ ref_ids, const int* __restrict__ cell_ids, int num_refs,
-                                                            const int* __restrict__ ranks, const int* __restrict__ ref_begin, int* __restrict__ out_refs) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_refs) return;
-    const int r = ranks[i];
-    if (r < 0) return;                                 // split further or without a cell: classify_refs marked it
-    out_refs[ref_begin[cell_ids[i]] + r] = ref_ids[i];
+// the cells of tile t and their references
+struct TileRange { int c0, c1; };
+__device__ __forceinline__ TileRange tile_cells(const int* __restrict__ tile_first, int t, int num_tiles, int num_cells) {
+    return TileRange{ t == 0 ? 0 : tile_first[t], t + 1 >= num_tiles ? num_cells : tile_first[t + 1] };
+}
+// The lanes of a wavefront hold consecutive references, so the references of a cell are a RUN of lanes: `run` = the lanes of this lane's run from the run's
+// first lane on (for the first lane: the whole run), `first` = that lane.
+struct LaneRun { unsigned long long run; int first; bool head; };
+__device__ __forceinline__ LaneRun lane_run(int cell) {
+    const int l = lane_id();
+    const int prev = __shfl_up(cell, 1, 64);
+    LaneRun r;
+    r.head = l == 0 || prev != cell;
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long upto = heads & (~0ull >> (63 - l));                  // heads at or below this lane
+    r.first = 63 - __clzll((long long)upto);
+    const unsigned long long above = l == 63 ? 0ull : heads >> (l + 1);          // heads above this lane
+    const int next = above ? l + 1 + (__ffsll((long long)above) - 1) : 64;
+    const unsigned long long below_next = next == 64 ? ~0ull : ((1ull << next) - 1ull);
+    r.run = below_next & ~((1ull << r.first) - 1ull);
+    return r;
 }
 
-} // namespace
+#ifndef HG_CLASSIFY_WAVES
+#define HG_CLASSIFY_WAVES 8           // (64 registers, two spilled values; at 6 wavefronts per SIMD 77 registers: 1 % slower)
+#endif
+// compute_split_masks (build.cu:160-216) for the references of splitting cells + the reference count of every child cell (the popcount reduction of
+// build.cu:597 and the final sort's histogram: per wavefront and cell by ballots, then per cell in LDS -- no global atomics).  A child that receives references
+// and has levels left is marked to split again (compute_dims, build.cu:286-302).  top: segments have holes (references the SAT filter rejected), the leaves'
+// counts are taken here as well.  totals[0] += references of cells that do not split (kept).
+__global__ void __launch_bounds__(kBlock, HG_CLASSIFY_WAVES) classify_refs(const int2* __restrict__ refs, const int* __restrict__ seg_begin,
+                                                           int num_cells, int num_refs, const int* __restrict__ tile_first, int num_tiles, int top,
+                                                           const float4* __restrict__ tris, const Cell* __restrict__ cells, const uint32_t* __restrict__ entries, BuildK k,
+                                                           unsigned char* __restrict__ masks, int* __restrict__ cell_counts,
+                                                           Cell* __restrict__ new_cells, int* __restrict__ new_counts, uint32_t* __restrict__ new_entries, int* __restrict__ totals) {
+    __shared__ int hist[kChunkCells * 9];
+    __shared__ int lds[kWaves];
+    int kept = 0;
+    for (int t = xcd_block(blockIdx.x, gridDim.x); t < num_tiles; t += gridDim.x) {
+        const TileRange tr = tile_cells(tile_first, t, num_tiles, num_cells);
+        for (int cc = tr.c0; cc < tr.c1; cc += kChunkCells) {
+            const int ce = min(cc + kChunkCells, tr.c1);
+            const int r0 = seg_begin[cc], r1 = ce >= num_cells ? num_refs : seg_begin[ce];
+            if (r0 == r1) continue;                                    // (uniform: cells without references have nothing to count -- their children's counts are zero already)
+            for (int j = threadIdx.x; j < (ce - cc) * 9; j += kBlock) hist[j] = 0;
+            __syncthreads();
+            for (int base = r0 + wave_id() * 64; base < r1; base += kBlock) {      // (whole wavefronts: the ballots below)
+                const int i = base + lane_id();
+                int2 rc = make_int2(-1, 0x7fffffff);
+                if (i < r1) rc = refs[i];
+                const int ref = rc.x, c = rc.y;
+                int m = 0;
+                bool keeps = false;
+                if (ref >= 0) {
+                    const uint32_t e = entries[c];
+                    if ((e & 3u) == 0) keeps = true;
+                    else {
+                        const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
+                        const int4 a = p[0], b = p[1];
+                        m = split_mask(k, ivec3(a.x, a.y, a.z), ivec3(b.x, b.y, b.z), load_tri(tris, ref));
+                    }
+                }
+                if (i < r1) masks[i] = (unsigned char)m;
+                kept += keeps ? 1 : 0;
+                const LaneRun run = lane_run(c);
+                int* h = hist + (c - cc) * 9;
+                const unsigned long long any = __ballot(m != 0);
+                if (any) {
+#pragma unroll
+                    for (int child = 0; child < 8; child++) {
+                        const unsigned long long with = __ballot((m >> child) & 1);
+                        if (run.head && i < r1) { const int n = __popcll(with & run.run); if (n) atomicAdd(h + child, n); }
+                    }
+                }
+                if (top) {
+                    const unsigned long long with = __ballot(keeps);
+                    if (run.head && i < r1) { const int n = __popcll(with & run.run); if (n) atomicAdd(h + 8, n); }
+                }
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < (ce - cc) * 8; j += kBlock) {
+                const int c = cc + (j >> 3), child = j & 7;
+                const uint32_t e = entries[c];
+                if (e & 3u) {
+                    // emit_new_cells (build.cu:354-383) as well: eight lanes write the eight children of a cell, 256 contiguous bytes (a cell splits because it holds
+                    // references, so every splitting cell passes here); a.w: the levels the cell may still split (emit_top_cells)
+                    const int n = hist[(j >> 3) * 9 + child];
+                    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(c);
+                    const int4 a = p[0], b = p[1];
+                    const int inc = (b.x - a.x) >> 1;
+                    const ivec3 lo(a.x + (child & 1) * inc, a.y + ((child >> 1) & 1) * inc, a.z + (child >> 2) * inc);
+                    store_cell(new_cells, int(e >> 2) + child, lo, a.w - 1, lo + ivec3(inc), 0);
+                    new_counts[(e >> 2) + child] = n;
+                    new_entries[(e >> 2) + child] = (n > 0 && a.w > 1) ? 1u : 0u;
+                } else if (top && child == 0) cell_counts[c] = hist[(j >> 3) * 9 + 8];
+            }
+            __syncthreads();
+        }
+    }
+    kept = block_sum(kept, lds);
+    if (threadIdx.x == 0 && kept) atomicAdd(totals, kept);
+}
 
-namespace {
+// split_refs (build.cu:219-243) into the segments of the child cells.  The children of a tile's cells are consecutive cells, so the tile's output is one
+// contiguous run of the new array: slots from LDS cursors (one per child cell, starting at the child's segment; one returning LDS atomic per wavefront, cell and
+// child, the lanes of a run take consecutive slots), output staged in LDS and written in full lines (lane by lane at scattered offsets the same data costs
+// several times its size in HBM write traffic); what a chunk emits beyond the staging area goes out directly.
+__global__ void __launch_bounds__(kBlock) emit_child_refs(const int2* __restrict__ refs, const int* __restrict__ seg_begin,
+                                                                  int num_cells, int num_refs, const int* __restrict__ tile_first, int num_tiles,
+                                                                  const unsigned char* __restrict__ masks, const uint32_t* __restrict__ entries,
+                                                                  const int* __restrict__ new_seg_begin, int2* __restrict__ new_refs) {
+    __shared__ int cursor[kEmitChunk * 8];
+    __shared__ int2 stage[kStage];
+    __shared__ int region[2];                        // first output slot of the chunk, one past its last
+    for (int t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+        const TileRange tr = tile_cells(tile_first, t, num_tiles, num_cells);
+        for (int cc = tr.c0; cc < tr.c1; cc += kEmitChunk) {
+            const int ce = min(cc + kEmitChunk, tr.c1);
+            const int r0 = seg_begin[cc], r1 = ce >= num_cells ? num_refs : seg_begin[ce];
+            if (r0 == r1) continue;
+            if (threadIdx.x == 0) { region[0] = 0x7fffffff; region[1] = 0; }
+            __syncthreads();
+            int lo = 0x7fffffff;
+            for (int j = threadIdx.x; j < (ce - cc) * 8; j += kBlock) {
+                const uint32_t e = entries[cc + (j >> 3)];
+                const int at = (e & 3u) ? new_seg_begin[(e >> 2) + (j & 7)] : 0x7fffffff;
+                cursor[j] = at;
+                lo = min(lo, at);
+            }
+            lo = -wave_max(-lo);
+            if (lane_id() == 0 && lo != 0x7fffffff) atomicMin(&region[0], lo);
+            __syncthreads();
+            const int base = region[0];
+            int hi = 0;
+            for (int rb = r0 + wave_id() * 64; rb < r1; rb += kBlock) {             // (whole wavefronts: the ballots below)
+                const int i = rb + lane_id();
+                int m = 0;
+                int2 rc = make_int2(-1, 0x7fffffff);
+                if (i < r1) { m = masks[i]; rc = refs[i]; }
+                if (__ballot(m != 0) == 0ull) continue;
+                const int c = rc.y;
+                const int first_child = m ? int(entries[c] >> 2) : 0;
+                const LaneRun run = lane_run(c);
+                int* cur = cursor + (c - cc) * 8;
+                const unsigned long long below = (1ull << lane_id()) - 1ull;
+#pragma unroll
+                for (int child = 0; child < 8; child++) {
+                    const unsigned long long with = __ballot((m >> child) & 1);
+                    if (!with) continue;
+                    int at = 0;
+                    if (run.head && i < r1) { const int n = __popcll(with & run.run); if (n) at = atomicAdd(cur + child, n); }
+                    at = __shfl(at, run.first, 64);
+                    if ((m >> child) & 1) {
+                        const int slot = at + __popcll(with & run.run & below);
+                        hi = max(hi, slot + 1);
+                        const int2 v = make_int2(rc.x, first_child + child);
+                        if (slot - base < kStage) stage[slot - base] = v;
+                        else new_refs[slot] = v;
+                    }
+                }
+            }
+            hi = wave_max(hi);
+            if (lane_id() == 0 && hi) atomicMax(&region[1], hi);
+            __syncthreads();
+            const int staged = min(region[1] - base, kStage);
+            for (int q = threadIdx.x; q < staged; q += kBlock) new_refs[base + q] = stage[q];
+            __syncthreads();
+        }
+    }
+}
+
+// copy_cells + copy_entries + compute_cell_ranges (build.cu:407-468) + copy_refs + remap_refs + the sort (:634-647, :681, :691) of a grouped level in ONE pass: a
+// leaf's list is its segment, copied behind the lists of the leaves before it and put in ascending order by the thread that copies it (lists hold a handful
+// of references).  top: the holes of a segment (references the SAT filter rejected) are skipped.
+__global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, const int* __restrict__ cell_counts,
+                                                               const int* __restrict__ start_cell, const int* __restrict__ ref_begin, int num_cells, int level_off,
+                                                               const int2* __restrict__ refs, const int* __restrict__ seg_begin, int num_refs, int top,
+                                                               Cell* __restrict__ out_cells, uint32_t* __restrict__ out_entries, int* __restrict__ out_refs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_cells) return;
+    const uint32_t e = entries[i];
+    if (e & 3u) { out_entries[level_off + i] = (e & 3u) | (((e >> 2) + uint32_t(level_off + num_cells)) << 2); return; }
+    const int dst = start_cell[i], cnt = cell_counts[i], rb = ref_begin[i];
+    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+    const int4 a = p[0], b = p[1];
+    store_cell(out_cells, dst, ivec3(a.x, a.y, a.z), cnt ? rb : 0, ivec3(b.x, b.y, b.z), cnt ? rb + cnt : 0);
+    out_entries[level_off + i] = uint32_t(dst) << 2;
+    if (cnt == 0) return;
+    int* r = out_refs + rb;
+    const int2* src = refs + seg_begin[i];
+    int n = 0;
+    if (top) { for (int j = 0; n < cnt; j++) { const int v = src[j].x; if (v >= 0) r[n++] = v; } }
+    else for (; n < cnt; n++) r[n] = src[n].x;
+    if (cnt > 24) {                                      // (Shell passes for the rare long list, as sort_cell_refs)
+        const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
+        for (int g = 0; g < 8; g++) {
+            const int gap = gaps[g];
+            for (int x = gap; x < cnt; x++) {
+                const int v = r[x];
+                int y = x - gap;
+                while (y >= 0 && r[y] > v) { r[y + gap] = r[y]; y -= gap; }
+                r[y + gap] = v;
+            }
+        }
+    }
+    for (int x = 1; x < cnt; x++) {
+        const int v = r[x];
+        int y = x - 1;
+        while (y >= 0 && r[y] > v) { r[y + 1] = r[y]; y--; }
+        r[y + 1] = v;
+    }
+}
 
 struct PlainIn { const int* v; __device__ int operator()(int i) const { return v[i]; } };
 struct PlainOut { int* v; __device__ void operator()(int i, int s) const { v[i] = s; } };
 
-// Puts every cell's reference list in ascending order (the canonical order: primitive ids within a cell
-// are distinct).  Lists are short -- a handful of references -- so each lane sorts its own cell in place:
-// insertion sort, preceded by Shell passes for the rare long list.
-// (one launch per level over the level's own 4-byte counts and list starts: a quarter of the bytes of the finished cells)
-__global__ void __launch_bounds__(kBlock) sort_cell_refs(const int* __restrict__ cell_counts, const int* __restrict__ ref_begin, int num_cells, int* __restrict__ refs) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_cells) return;
-    const int n = cell_counts[i];                      // 0 for a cell that was split further
-    if (n < 2) return;
-    int* r = refs + ref_begin[i];
-    if (n > 24) {
-        const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
-        for (int g = 0; g < 8; g++) {
-            const int gap = gaps[g];
-            for (int a = gap; a < n; a++) {
-                const int v = r[a];
-                int b = a - gap;
-                while (b >= 0 && r[b] > v) { r[b + gap] = r[b]; b -= gap; }
-                r[b + gap] = v;
-            }
-        }
-    }
-    for (int a = 1; a < n; a++) {
-        const int v = r[a];
-        int b = a - 1;
-        while (b >= 0 && r[b] > v) { r[b + 1] = r[b]; b--; }
-        r[b + 1] = v;
-    }
-}
+using Temps = PoolTemps;
 
-struct Level {
-    int* ref_ids = nullptr; int* cell_ids = nullptr; int num_refs = 0;
+// ---- the level loop and the concatenation (host side) --------------------------------------------------------------------------------------------------
+struct GLevel {
+    int2* refs = nullptr; int num_refs = 0;     // {reference, cell}, grouped by cell, in cell order
     Cell* cells = nullptr; uint32_t* entries = nullptr; int num_cells = 0;
-    int* cell_counts = nullptr;                 // kept references per cell
-    int* ranks = nullptr;                       // per kept reference: its slot inside its cell's list
+    int* cell_counts = nullptr;                 // references per cell (leaves: the length of the list)
+    int* seg_begin = nullptr;                   // first reference of every cell
+    int* tile_first = nullptr; int num_tiles = 0;
     int* start_cell = nullptr; int* ref_begin = nullptr;
 };
 
-using Temps = PoolTemps;
+// The temporaries of the level loop come from ONE pool buffer, sized by what the last construction of this context needed (what does not fit comes from the
+// pool as before): three dozen requests of sizes that differ from level to level leave the pool's cached slots unsettled for a dozen constructions (a
+// request nothing fits re-grows the largest free slot), each paying hipFree + hipMalloc: build_grid 1.43 instead of 1.24 ms until then.
+struct Arena {
+    hagrid_ctx* ctx; Temps& tmp; char* base = nullptr; size_t size = 0, used = 0, wanted = 0;
+    Arena(hagrid_ctx* c, Temps& t) : ctx(c), tmp(t) {
+        if (c->build_arena_hint) { base = t.get<char>(c->build_arena_hint); size = base ? c->build_arena_hint : 0; }
+    }
+    ~Arena() { ctx->build_arena_hint = wanted; }
+    template <typename T> T* get(size_t n) {
+        const size_t bytes = (std::max(n, size_t(1)) * sizeof(T) + 255) & ~size_t(255);
+        wanted += bytes;
+        if (base && used + bytes <= size) { T* p = reinterpret_cast<T*>(base + used); used += bytes; return p; }
+        return tmp.get<T>(n);
+    }
+    void drop(void* p) { if (!base || p < base || p >= base + size) tmp.drop(p); }
+};
+
+int build_levels(hagrid_ctx* ctx, const float4* tris, int num_tris, hagrid_grid* grid, BuildK k, const BBox& gb, float snd_density, Temps& tmp) {
+    hipStream_t st = ctx->stream;
+    int* dsc = ctx->dscratch;
+    Arena ar(ctx, tmp);
+    const ivec3 dims = k.dims;
+    const int num_top = dims.x * dims.y * dims.z;
+
+    // ---- reference counts, per-cell depth, shift (first_build_iter, build.cu:470-512) ----
+    int* counts = ar.get<int>(size_t(num_tris));
+    int* start_emit = ar.get<int>(size_t(num_tris));
+    int* refs_per_cell = ar.get<int>(size_t(num_top));
+    int* log_dims = ar.get<int>(size_t(num_top));
+    int* const partials = nullptr;               // (the look-back scans need none)
+    if (!counts || !start_emit || !refs_per_cell || !log_dims) return HAGRID_ENOMEM;
+    HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
+    top_range_sizes<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts); HG_DBG(ctx);
+    if (!ctx_scan<int>(ctx, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0)) return HAGRID_ENOMEM;
+    int R0 = 0;
+    HG_TRY(read_back(ctx, dsc, &R0, sizeof(int)));
+    if (R0 < 0 || R0 > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many top-level references");
+    ar.drop(counts);
+    int* pair_rank = ar.get<int>(size_t(R0) + 1);
+    if (!pair_rank) return HAGRID_ENOMEM;
+    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, refs_per_cell, pair_rank); HG_DBG(ctx);
+    top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1); HG_DBG(ctx);
+
+    std::vector<GLevel> levels;
+    GLevel L;
+    L.num_refs = R0; L.num_cells = num_top;
+    L.num_tiles = grid_blocks(R0, kTileRefs);
+    L.refs = ar.get<int2>(size_t(R0) + 1);
+    L.cells = ar.get<Cell>(size_t(num_top)); L.entries = ar.get<uint32_t>(size_t(num_top) + 1);
+    L.cell_counts = ar.get<int>(size_t(num_top)); L.seg_begin = ar.get<int>(size_t(num_top) + 1);
+    L.tile_first = ar.get<int>(size_t(L.num_tiles) + 2);
+    L.start_cell = ar.get<int>(size_t(num_top)); L.ref_begin = ar.get<int>(size_t(num_top));
+    if (!L.refs || !L.cells || !L.entries || !L.cell_counts || !L.seg_begin || !L.tile_first || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
+    if (!ctx_scan<int>(ctx, SegIn{refs_per_cell}, SegOut{refs_per_cell, L.seg_begin, L.tile_first}, num_top, partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
+    hagrid_build_counts& bc = ctx->counts;
+    memset(&bc, 0, sizeof(bc));
+    bc.num_tris = num_tris; bc.top_cells = num_top; bc.top_refs = R0;
+    emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, dsc + 1, log_dims, L.entries, L.cell_counts); HG_DBG(ctx);
+    emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, dsc + 1, gb.extents(), start_emit, pair_rank, L.seg_begin, L.refs, log_dims, L.entries); HG_DBG(ctx);
+    levels.push_back(L);
+
+    // ---- subdivision, one level per iteration (build_iter, build.cu:527-619) ----
+    // tot (four words per level, zeroed by the caller): {cells of the next level, kept references of this level, {references, cells} of the level after the
+    // next: the total of the scan over the new cells}
+    {
+        if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, num_top, (int*)nullptr, (const int*)nullptr, dsc + 8)) return HAGRID_ENOMEM;
+    }
+    int num_new_cells = 0, shift = 0;
+    {   // the shift (dsc[1], top_log_dims) and the cells of the next level (dsc[8]) in one round trip
+        int h[8];
+        HG_TRY(read_back(ctx, dsc + 1, h, sizeof(h)));
+        shift = h[0]; num_new_cells = h[7];
+    }
+    if (shift >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
+    k.shift = shift;
+    k.cell_size = gb.extents() / vec3(dims << shift);
+    ar.drop(start_emit); ar.drop(pair_rank); ar.drop(refs_per_cell);
+    for (int level = 0;; level++) {
+        GLevel& P = levels.back();
+        int* tot = dsc + 8 + 4 * level;
+        if (num_new_cells < 0) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: level too large");
+        if ((int)levels.size() >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
+        const bool last = num_new_cells == 0;
+        if (last && level > 0) {
+            // no cell of this level splits: its references stay where they are, every count is known (build.cu:583-587)
+            if (level < HAGRID_MAX_LEVELS) { bc.level_refs[level] = P.num_refs; bc.level_cells[level] = P.num_cells; bc.level_kept[level] = P.num_refs; bc.num_levels = level + 1; }
+            break;
+        }
+        GLevel N;
+        N.num_cells = num_new_cells;
+        unsigned char* masks = ar.get<unsigned char>(size_t(P.num_refs) + 1);
+        if (!masks) return HAGRID_ENOMEM;
+        if (!last) {
+            N.cells = ar.get<Cell>(size_t(num_new_cells)); N.entries = ar.get<uint32_t>(size_t(num_new_cells) + 1);
+            N.cell_counts = ar.get<int>(size_t(num_new_cells)); N.seg_begin = ar.get<int>(size_t(num_new_cells) + 1);
+            N.tile_first = ar.get<int>(size_t(grid_blocks(8ll * P.num_refs, kTileRefs)) + 2);
+            N.start_cell = ar.get<int>(size_t(num_new_cells)); N.ref_begin = ar.get<int>(size_t(num_new_cells));
+            if (!N.cells || !N.entries || !N.cell_counts || !N.seg_begin || !N.tile_first || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
+        }
+        if (P.num_refs > 0) {
+            classify_refs<<<std::min(P.num_tiles, 4096), kBlock, 0, st>>>(P.refs, P.seg_begin, P.num_cells, P.num_refs, P.tile_first, P.num_tiles, level == 0 ? 1 : 0,
+                                                                             tris, P.cells, P.entries, k, masks, P.cell_counts, N.cells, N.cell_counts, N.entries, tot + 1); HG_DBG(ctx);
+        }
+        Int2* next = reinterpret_cast<Int2*>(tot + 2);
+        if (!last) {
+            if (!ctx_scan<Int2>(ctx, ChildSegIn{N.cell_counts, N.entries}, ChildSegOut{N.cell_counts, N.entries, N.seg_begin, N.tile_first}, num_new_cells, (Int2*)nullptr,
+                                (const Int2*)nullptr, next)) return HAGRID_ENOMEM;
+        }
+        int h3[3] = {0, 0, 0};                        // kept, references of the next level, cells of the level after it
+        HG_TRY(read_back(ctx, tot + 1, h3, sizeof(h3)));
+        if (level < HAGRID_MAX_LEVELS) { bc.level_refs[level] = P.num_refs; bc.level_cells[level] = P.num_cells; bc.level_kept[level] = h3[0]; bc.num_levels = level + 1; }
+        if (last) { ar.drop(masks); break; }
+        const int num_children = h3[1];
+        if (num_children < 0 || num_children > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: level too large");
+        N.num_refs = num_children; N.num_tiles = grid_blocks(num_children, kTileRefs);
+        N.refs = ar.get<int2>(size_t(num_children) + 1);
+        if (!N.refs) return HAGRID_ENOMEM;
+        if (P.num_refs > 0 && num_children > 0) {
+            emit_child_refs<<<std::min(P.num_tiles, 4096), kBlock, 0, st>>>(P.refs, P.seg_begin, P.num_cells, P.num_refs, P.tile_first, P.num_tiles,
+                                                                                   masks, P.entries, N.seg_begin, N.refs); HG_DBG(ctx);
+        }
+        ar.drop(masks);
+        num_new_cells = h3[2];
+        levels.push_back(N);
+    }
+    ar.drop(log_dims);
+
+    // ---- concat_levels (build.cu:621-716) ----
+    const int num_levels = (int)levels.size();
+    long long total_cells_ll = 0;
+    int max_cells = 0;
+    for (auto& V : levels) { total_cells_ll += V.num_cells; max_cells = std::max(max_cells, V.num_cells); }
+    if (total_cells_ll > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many voxel map entries");
+    const int total_cells = int(total_cells_ll);
+    Int2* const part2 = nullptr;                           // (the look-back scans need no partials)
+    Int2* carry = reinterpret_cast<Int2*>(dsc + 128);      // one Int2 per level, chained on the device
+    for (int l = 0; l < num_levels; l++) {
+        GLevel& V = levels[l];
+        if (!ctx_scan<Int2>(ctx, LeafIn{V.entries, V.cell_counts}, LeafOut{V.start_cell, V.ref_begin}, V.num_cells, part2,
+                            l ? carry + (l - 1) : (const Int2*)nullptr, carry + l)) return HAGRID_ENOMEM;
+    }
+    int hf[2];
+    HG_TRY(read_back(ctx, carry + (num_levels - 1), hf, sizeof(hf)));
+    const int new_total_cells = hf[0], total_refs = hf[1];
+    if (new_total_cells <= 0 || total_refs < 0) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: inconsistent totals");
+
+    Cell* out_cells = pool_alloc<Cell>(ctx, size_t(new_total_cells));
+    uint32_t* out_entries = pool_alloc<uint32_t>(ctx, size_t(total_cells));
+    int* out_refs = pool_alloc<int>(ctx, size_t(total_refs));
+    if (!out_cells || !out_entries || !out_refs) {
+        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
+        return HAGRID_ENOMEM;
+    }
+    for (int l = 0, off = 0; l < num_levels; off += levels[l].num_cells, l++) {
+        GLevel& V = levels[l];
+        concat_level<<<grid_blocks(V.num_cells, kBlock), kBlock, 0, st>>>(V.entries, V.cells, V.cell_counts, V.start_cell, V.ref_begin, V.num_cells, off,
+                                                                                  V.refs, V.seg_begin, V.num_refs, l == 0 ? 1 : 0, out_cells, out_entries, out_refs); HG_DBG(ctx);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // temporaries are released by the caller's Temps
+    if (e != hipSuccess) {
+        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
+        HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e));
+    }
+    memset(grid, 0, sizeof(*grid));
+    grid->entries = out_entries; grid->ref_ids = out_refs; grid->cells = out_cells; grid->small_cells = nullptr;
+    grid->bbox_min[0] = gb.min.x; grid->bbox_min[1] = gb.min.y; grid->bbox_min[2] = gb.min.z;
+    grid->bbox_max[0] = gb.max.x; grid->bbox_max[1] = gb.max.y; grid->bbox_max[2] = gb.max.z;
+    grid->dims[0] = dims.x; grid->dims[1] = dims.y; grid->dims[2] = dims.z;
+    grid->num_cells = new_total_cells; grid->num_entries = total_cells; grid->num_refs = total_refs;
+    bc.build_cells = new_total_cells; bc.build_entries = total_cells; bc.build_refs = total_refs;
+    grid->shift = shift;                         // the cell-coordinate shift (DESIGN.md D3)
+    grid->num_offsets = shift + 1;
+    for (int i = 0, off = 0; i <= shift; i++) {  // build.cu:711-715, padded when the deepest level is empty
+        if (i < num_levels) off += levels[i].num_cells;
+        grid->offsets[i] = off;
+    }
+    return HAGRID_OK;
+}
 
 } // namespace
 
@@ -547,135 +845,5 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     BuildK k;
     k.dims = dims; k.shift = 0; k.bmin = gb.min; k.bmax = gb.max; k.cell_size = vec3(0.0f);
 
-    // ---- reference counts, per-cell depth, shift (first_build_iter, build.cu:470-512) ----
-    int* counts = tmp.get<int>(size_t(num_tris));
-    int* start_emit = tmp.get<int>(size_t(num_tris));
-    int* refs_per_cell = tmp.get<int>(size_t(num_top));
-    int* log_dims = tmp.get<int>(size_t(num_top));
-    int* partials = tmp.get<int>(2 * size_t(scan_num_tiles(std::max(num_tris, num_top)) + 1));
-    if (!counts || !start_emit || !refs_per_cell || !log_dims || !partials) return HAGRID_ENOMEM;
-    HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
-    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, refs_per_cell); HG_DBG(ctx);
-    if (!ctx_scan<int>(ctx, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0)) return HAGRID_ENOMEM;
-    top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1); HG_DBG(ctx);
-    int h2[2];
-    HG_TRY(read_back(ctx, dsc, h2, sizeof(h2)));
-    const int R0 = h2[0], shift = h2[1];
-    if (R0 < 0 || R0 > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many top-level references");
-    if (shift >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
-    k.shift = shift;
-    k.cell_size = gb.extents() / vec3(dims << shift);
-    tmp.drop(counts); tmp.drop(refs_per_cell);
-    hagrid_build_counts& bc = ctx->counts;
-    memset(&bc, 0, sizeof(bc));
-    bc.num_tris = num_tris; bc.top_cells = num_top; bc.top_refs = R0;
-
-    std::vector<Level> levels;
-    {
-        Level L;
-        L.num_refs = R0; L.num_cells = num_top;
-        L.ref_ids = tmp.get<int>(size_t(R0)); L.cell_ids = tmp.get<int>(size_t(R0));
-        L.cells = tmp.get<Cell>(size_t(num_top)); L.entries = tmp.get<uint32_t>(size_t(num_top) + 1);
-        L.cell_counts = tmp.get<int>(size_t(num_top)); L.ranks = tmp.get<int>(size_t(R0));
-        L.start_cell = tmp.get<int>(size_t(num_top)); L.ref_begin = tmp.get<int>(size_t(num_top));
-        if (!L.ref_ids || !L.cell_ids || !L.cells || !L.entries || !L.cell_counts || !L.ranks || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
-        emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, log_dims, L.entries, L.cell_counts); HG_DBG(ctx);
-        emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, L.ref_ids, L.cell_ids, log_dims, L.entries); HG_DBG(ctx);
-        levels.push_back(L);
-    }
-    tmp.drop(start_emit);
-
-    // ---- subdivision, one level per iteration (build_iter, build.cu:527-619) ----
-    for (int level = 0;; level++) {
-        Level& L = levels.back();
-        int* tot = dsc + 8 + 4 * level;              // {new cells, children, kept}; zeroed above
-        int* part = tmp.get<int>(size_t(scan_num_tiles(L.num_cells)) + 1);
-        unsigned char* masks = tmp.get<unsigned char>(size_t(L.num_refs) + 1);
-        if (!part || !masks) return HAGRID_ENOMEM;
-        if (!ctx_scan<int>(ctx, ChildCountIn{L.entries}, UpdateEntriesOut{L.entries}, L.num_cells, part, (const int*)nullptr, tot + 0)) return HAGRID_ENOMEM;
-        if (L.num_refs > 0)
-            classify_refs<<<std::min(grid_blocks(L.num_refs, kBlock), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, tris, L.cells, L.entries, k,
-                                                                               masks, L.cell_counts, L.ranks, tot + 1); HG_DBG(ctx);
-        int h3[3];
-        HG_TRY(read_back(ctx, tot, h3, sizeof(h3)));
-        const int num_new_cells = h3[0], num_children = h3[1];
-        if (level < HAGRID_MAX_LEVELS) { bc.level_refs[level] = L.num_refs; bc.level_cells[level] = L.num_cells; bc.level_kept[level] = h3[2]; bc.num_levels = level + 1; }
-        tmp.drop(part);
-        if (num_new_cells == 0) { tmp.drop(masks); break; }              // build.cu:583-587
-        if (num_new_cells < 0 || num_children < 0 || num_children > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: level too large");
-        if ((int)levels.size() >= 24) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many levels");
-
-        Level N;
-        N.num_refs = num_children; N.num_cells = num_new_cells;
-        N.ref_ids = tmp.get<int>(size_t(num_children)); N.cell_ids = tmp.get<int>(size_t(num_children));
-        N.cells = tmp.get<Cell>(size_t(num_new_cells)); N.entries = tmp.get<uint32_t>(size_t(num_new_cells) + 1);
-        N.cell_counts = tmp.get<int>(size_t(num_new_cells)); N.ranks = tmp.get<int>(size_t(num_children));
-        N.start_cell = tmp.get<int>(size_t(num_new_cells)); N.ref_begin = tmp.get<int>(size_t(num_new_cells));
-        if (!N.ref_ids || !N.cell_ids || !N.cells || !N.entries || !N.cell_counts || !N.ranks || !N.start_cell || !N.ref_begin) return HAGRID_ENOMEM;
-        int* cursor = tot + 3;                                              // zeroed above
-        emit_child_cells<<<grid_blocks((long long)L.num_cells * 8, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.num_cells, N.cells, N.entries, N.cell_counts); HG_DBG(ctx);
-        emit_child_refs<<<std::min(grid_blocks(L.num_refs, kBlock * kEmitItems), 4096), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, masks, L.ranks,
-                                                                             N.entries, N.ref_ids, N.cell_ids, cursor); HG_DBG(ctx);
-        tmp.drop(masks);
-        levels.push_back(N);
-    }
-    tmp.drop(log_dims);
-
-    // ---- concat_levels (build.cu:621-716) ----
-    const int num_levels = (int)levels.size();
-    long long total_cells_ll = 0;
-    int max_cells = 0;
-    for (auto& L : levels) { total_cells_ll += L.num_cells; max_cells = std::max(max_cells, L.num_cells); }
-    if (total_cells_ll > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many voxel map entries");
-    const int total_cells = int(total_cells_ll);
-    Int2* part2 = tmp.get<Int2>(size_t(scan_num_tiles(max_cells)) + 1);
-    Int2* carry = reinterpret_cast<Int2*>(dsc + 128);      // one Int2 per level, chained on the device
-    if (!part2) return HAGRID_ENOMEM;
-    for (int l = 0; l < num_levels; l++) {
-        Level& L = levels[l];
-        if (!ctx_scan<Int2>(ctx, LeafIn{L.entries, L.cell_counts}, LeafOut{L.start_cell, L.ref_begin}, L.num_cells, part2,
-                            l ? carry + (l - 1) : (const Int2*)nullptr, carry + l)) return HAGRID_ENOMEM;
-    }
-    int hf[2];
-    HG_TRY(read_back(ctx, carry + (num_levels - 1), hf, sizeof(hf)));
-    const int new_total_cells = hf[0], total_refs = hf[1];
-    if (new_total_cells <= 0 || total_refs < 0) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: inconsistent totals");
-
-    Cell* out_cells = pool_alloc<Cell>(ctx, size_t(new_total_cells));
-    uint32_t* out_entries = pool_alloc<uint32_t>(ctx, size_t(total_cells));
-    int* out_refs = pool_alloc<int>(ctx, size_t(total_refs));
-    if (!out_cells || !out_entries || !out_refs) {
-        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
-        return HAGRID_ENOMEM;
-    }
-    for (int l = 0, off = 0; l < num_levels; off += levels[l].num_cells, l++) {
-        Level& L = levels[l];
-        concat_level<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.entries, L.cells, L.cell_counts, L.start_cell, L.ref_begin,
-                                                                          L.num_cells, off, out_cells, out_entries); HG_DBG(ctx);
-        if (L.num_refs > 0)
-            scatter_kept_refs<<<grid_blocks(L.num_refs, kBlock), kBlock, 0, st>>>(L.ref_ids, L.cell_ids, L.num_refs, L.ranks, L.ref_begin, out_refs); HG_DBG(ctx);
-        if (L.num_refs > 0)
-            sort_cell_refs<<<grid_blocks(L.num_cells, kBlock), kBlock, 0, st>>>(L.cell_counts, L.ref_begin, L.num_cells, out_refs); HG_DBG(ctx);
-    }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);      // temporaries are released below
-    if (e != hipSuccess) {
-        hagrid_mem_free(ctx, out_cells); hagrid_mem_free(ctx, out_entries); hagrid_mem_free(ctx, out_refs);
-        HG_FAIL(ctx, HAGRID_EHIP, hipGetErrorString(e));
-    }
-
-    memset(grid, 0, sizeof(*grid));
-    grid->entries = out_entries; grid->ref_ids = out_refs; grid->cells = out_cells; grid->small_cells = nullptr;
-    grid->bbox_min[0] = gb.min.x; grid->bbox_min[1] = gb.min.y; grid->bbox_min[2] = gb.min.z;
-    grid->bbox_max[0] = gb.max.x; grid->bbox_max[1] = gb.max.y; grid->bbox_max[2] = gb.max.z;
-    grid->dims[0] = dims.x; grid->dims[1] = dims.y; grid->dims[2] = dims.z;
-    grid->num_cells = new_total_cells; grid->num_entries = total_cells; grid->num_refs = total_refs;
-    bc.build_cells = new_total_cells; bc.build_entries = total_cells; bc.build_refs = total_refs;
-    grid->shift = shift;                         // the cell-coordinate shift (DESIGN.md D3)
-    grid->num_offsets = shift + 1;
-    for (int i = 0, off = 0; i <= shift; i++) {  // build.cu:711-715, padded when the deepest level is empty
-        if (i < num_levels) off += levels[i].num_cells;
-        grid->offsets[i] = off;
-    }
-    return HAGRID_OK;
+    return build_levels(ctx, tris, num_tris, grid, k, gb, snd_density, tmp);
 }
