@@ -19,5 +19,7 @@ timeout 900 python bench.py --gpus 1 --steps 10 --warmup 2 --config 3 > $OUT/ben
 timeout 900 python bench.py --gpus 1 --steps 10 --warmup 2 --config 3 --snd-density 5.0 --top-density 0.12 --no-cpu-baseline --inflight 0 > $OUT/bench_soup_sd5_4096.json 2> $OUT/bench_soup_sd5_4096.err; cut -c1-160 $OUT/bench_soup_sd5_4096.json
 ITERS=5 PYTHONPATH=$PWD tools/gpu_prof_cmd.sh ${TAG}_buildprof python $PWD/tools/dev_build_time.py > $OUT/build_prof.txt 2>&1; head -30 $OUT/build_prof.txt | cut -c1-170
 timeout 300 python tools/dev_build_time.py 2>&1 | tail -1 > $OUT/build_time.txt; cut -c1-300 $OUT/build_time.txt
+TRIS=8000000 ITERS=3 timeout 600 python tools/dev_build_time.py 2>&1 | tail -1 > $OUT/build_time_8M.txt; cut -c1-300 $OUT/build_time_8M.txt
+bash tools/gpu_build_traffic.sh ${TAG}_buildtraffic > /dev/null 2>&1; cp gpurun_out/${TAG}_buildtraffic/construction_traffic.txt $OUT/ 2>/dev/null; tail -3 $OUT/construction_traffic.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 du -sh $OUT
