@@ -129,28 +129,11 @@ __global__ void __launch_bounds__(kBlock) top_log_dims(const int* __restrict__ r
 }
 
 
-// emit_top_cells (build.cu:332-351)
-// + the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per level")
-// While a level is under construction the `begin` word of its cells is free: it carries the number of levels the cell may still
-// be split, where classify_refs finds it in the record it loads anyway.
-// The kernel that creates a level's cells also clears their voxel-map words and reference counts (it runs before the
-// references of the level are handed out): no fill launches.
-// (The shift -- the deepest subdivision of any top-level cell, top_log_dims -- is read from device memory here and in emit_top_refs: the host learns it together
-// with the number of cells of the next level, one round trip later.)
+// the grid constants of the top-level emission, with the shift read on the device (SegOut below)
 __device__ __forceinline__ BuildK with_device_shift(BuildK k, const int* __restrict__ shift_dev, vec3 extents) {
     k.shift = *shift_dev;
     k.cell_size = extents / vec3(k.dims << k.shift);
     return k;
-}
-__global__ void __launch_bounds__(kBlock) emit_top_cells(Cell* __restrict__ cells, int num_top, BuildK k0, const int* __restrict__ shift_dev, const int* __restrict__ log_dims,
-                                                         uint32_t* __restrict__ entries, int* __restrict__ cell_counts) {
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= num_top) return;
-    BuildK k = k0; k.shift = *shift_dev;
-    entries[id] = 0u; cell_counts[id] = 0;
-    const int x = id % k.dims.x, y = (id / k.dims.x) % k.dims.y, z = id / (k.dims.x * k.dims.y);
-    const ivec3 lo(x << k.shift, y << k.shift, z << k.shift);
-    store_cell(cells, id, lo, log_dims[id], lo + ivec3(1 << k.shift), 0);
 }
 
 // ---- one subdivision level -----------------------------------------------------------------------------
@@ -274,9 +257,22 @@ struct SegIn {
     const int* counts;
     __device__ int operator()(int i) const { return counts[i]; }
 };
+// ... and emit_top_cells (build.cu:332-351) with the levels the cell may still be split (log_dims, build.cu:256-270; update_log_dims :273-278 becomes "one less per
+// level"): while a level is under construction the `begin` word of its cells is free and carries that number, where classify_refs finds it in the record it loads
+// anyway.  The top-level cells' voxel-map words and reference counts are cleared here as well (before the references of the level are handed out): no fill launches.
+// The shift -- the deepest subdivision of any top-level cell, top_log_dims -- is read from device memory here and in emit_top_refs: the host learns it together
+// with the number of cells of the next level, one round trip later.
 struct SegOut {
     const int* counts; int* seg_begin; int* tile_first;
-    __device__ void operator()(int i, int start) const { seg_begin[i] = start; mark_tiles(tile_first, i, start, counts[i]); }
+    Cell* cells; uint32_t* entries; int* cell_counts; const int* log_dims; const int* shift_dev; ivec3 dims;
+    __device__ void operator()(int i, int start) const {
+        seg_begin[i] = start; mark_tiles(tile_first, i, start, counts[i]);
+        const int shift = *shift_dev;
+        entries[i] = 0u; cell_counts[i] = 0;
+        const int x = i % dims.x, y = (i / dims.x) % dims.y, z = i / (dims.x * dims.y);
+        const ivec3 lo(x << shift, y << shift, z << shift);
+        store_cell(cells, i, lo, log_dims[i], lo + ivec3(1 << shift), 0);
+    }
 };
 // the new cells of a level: {references, 8 if the cell splits again} -> {segment start, first child cell}; update_entries fused as in UpdateEntriesOut
 struct ChildSegIn {
@@ -590,6 +586,21 @@ __global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restric
     if (cnt == 0) return;
     int* r = out_refs + rb;
     const int2* src = refs + seg_begin[i];
+    if (!top && cnt <= 4) {                             // the common list: four loads, a sorting network in registers, no list read back from memory
+        const int big = 0x7fffffff;
+        int v0 = src[0].x, v1 = cnt > 1 ? src[1].x : big, v2 = cnt > 2 ? src[2].x : big, v3 = cnt > 3 ? src[3].x : big;
+        int t;
+        if (v0 > v1) { t = v0; v0 = v1; v1 = t; }
+        if (v2 > v3) { t = v2; v2 = v3; v3 = t; }
+        if (v0 > v2) { t = v0; v0 = v2; v2 = t; }
+        if (v1 > v3) { t = v1; v1 = v3; v3 = t; }
+        if (v1 > v2) { t = v1; v1 = v2; v2 = t; }
+        r[0] = v0;
+        if (cnt > 1) r[1] = v1;
+        if (cnt > 2) r[2] = v2;
+        if (cnt > 3) r[3] = v3;
+        return;
+    }
     int n = 0;
     if (top) { for (int j = 0; n < cnt; j++) { const int v = src[j].x; if (v >= 0) r[n++] = v; } }
     else for (; n < cnt; n++) r[n] = src[n].x;
@@ -682,11 +693,11 @@ int build_levels(hagrid_ctx* ctx, const float4* tris, int num_tris, hagrid_grid*
     L.tile_first = ar.get<int>(size_t(L.num_tiles) + 2);
     L.start_cell = ar.get<int>(size_t(num_top)); L.ref_begin = ar.get<int>(size_t(num_top));
     if (!L.refs || !L.cells || !L.entries || !L.cell_counts || !L.seg_begin || !L.tile_first || !L.start_cell || !L.ref_begin) return HAGRID_ENOMEM;
-    if (!ctx_scan<int>(ctx, SegIn{refs_per_cell}, SegOut{refs_per_cell, L.seg_begin, L.tile_first}, num_top, partials, (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
+    if (!ctx_scan<int>(ctx, SegIn{refs_per_cell}, SegOut{refs_per_cell, L.seg_begin, L.tile_first, L.cells, L.entries, L.cell_counts, log_dims, dsc + 1, dims}, num_top, partials,
+                       (const int*)nullptr, (int*)nullptr)) return HAGRID_ENOMEM;
     hagrid_build_counts& bc = ctx->counts;
     memset(&bc, 0, sizeof(bc));
     bc.num_tris = num_tris; bc.top_cells = num_top; bc.top_refs = R0;
-    emit_top_cells<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(L.cells, num_top, k, dsc + 1, log_dims, L.entries, L.cell_counts); HG_DBG(ctx);
     emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, dsc + 1, gb.extents(), start_emit, pair_rank, L.seg_begin, L.refs, log_dims, L.entries); HG_DBG(ctx);
     levels.push_back(L);
 

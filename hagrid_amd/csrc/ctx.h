@@ -133,6 +133,8 @@ struct hagrid_ctx {
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
 
     hagrid_impl::TravImageCache image;
+    int readback_epoch = 0;               // read_back (ctx.hip): the epoch the publishing wavefront leaves behind the words in the mailbox (word 310)
+    int opt_fast_readback = 1;            // scalar read-backs through a publishing wavefront and a spinning host instead of hipMemcpyAsync + hipStreamSynchronize
     size_t build_arena_hint = 0;          // bytes of temporaries the last build_grid of this context asked for (build.hip: one pool buffer for all of them)
     hagrid_build_counts counts = {};      // sizes of the last construction (hagrid_get_build_counts)
 

@@ -63,7 +63,10 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "traverse.row_cache" 1 (default) = a row length found for a ray buffer is kept for the next 15 calls, 0 = looked for at every call
  *   "traverse.lds_pad"   bytes of dynamic LDS per workgroup of the tail kernel (limits the resident wavefronts: profiles/dev_r3_quad_tail.txt)
  *   "merge.narrow_cells" 1 (default) = 16-byte working cell records between the merge passes when the virtual resolution is below 65536
- *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss (the three-kernel form exists in hagrid_kat_scan only) */
+ *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss (the three-kernel form exists in hagrid_kat_scan only)
+ *   "traverse.image_vtop" 1 (default) = the general layout of the image has a virtual top level one level below the voxel map's (eight records per top-level cell,
+ *                        where look-ups that left their block start again), 0 = look-ups start at the map's top level
+ *   "ctx.fast_readback"  1 (default) = scalar read-backs through a publishing wavefront and a spinning host, 0 = hipMemcpyAsync + hipStreamSynchronize */
 int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 
 #ifdef __cplusplus

@@ -92,3 +92,14 @@ def test_header_is_plain_c():
         undefined = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout
         used = sorted(set(re.findall(r"\b(hagrid_[a-z0-9_]+)", undefined)))
         assert len(used) >= 20 and set(used) <= set(declared_symbols())
+
+
+def test_product_library_kernel_count(built):
+    """Variant sprawl stays pruned: at most 120 kernels in the product library's code objects (tools/count_kernels.py reads the .kd symbols of every
+    gfx950 code object in the library's fat binary), none of them a three-kernel scan form (those live in the test library)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_kernels.py"), "-v"], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"(\d+) kernels in", out)
+    assert m and 40 <= int(m.group(1)) <= 120, out[-300:]
+    assert "scan_spine" not in out.replace("scan_spine<int>(int*, int, int const*, int*)", "", 1), "the three-kernel scan belongs to the test library (compress.hip uses its halves once)"
