@@ -94,6 +94,7 @@ struct hagrid_ctx {
     int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // traversal image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); an image beyond it is not built
+    int opt_quad_head = 20;     // tail kernel: the tiles of a learned order that cost at least this many TENTHS of the median working tile -- if they are more than a twelfth of the tiles -- start with four lanes per ray, first (0: never)
     int opt_image_vtop = 1;     // traversal image, general layout: records of a virtual top level one level below the map's (0: look-ups start at the map's top level, rounds 1-5a)
     int opt_image_uniform = 1;  // traversal image: use the table-free uniform layout when it is not much bigger than the table layout (2: whatever it costs; 0: never)
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
@@ -105,7 +106,7 @@ struct hagrid_ctx {
         const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
-        int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32; bool lpt_valid = false;
+        int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32, lpt_rot = 0 /* positions the stored order is rotated by: its last lpt_rot tiles are the longest */; bool rot_adopted = false /* the first suggestion of a sort was taken up by a sort of its own */; bool lpt_valid = false;
         // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
         // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[304 + i],

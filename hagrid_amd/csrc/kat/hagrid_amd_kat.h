@@ -66,6 +66,8 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "scan.lookback"      construction scans: 1 (default) = single-pass decoupled look-back, 2 = the same helping at the first miss (the three-kernel form exists in hagrid_kat_scan only)
  *   "traverse.image_vtop" 1 (default) = the general layout of the image has a virtual top level one level below the voxel map's (eight records per top-level cell,
  *                        where look-ups that left their block start again), 0 = look-ups start at the map's top level
+ *   "traverse.quad_head" 20 (default): in a learned tile order of a launch of one to five rounds the tiles that cost at least 2.0 times the median working tile -- if they
+ *                        are more than a twelfth of the tiles -- start with four lanes per ray and are dispatched first; tenths of the median; 0 = never
  *   "ctx.fast_readback"  1 (default) = scalar read-backs through a publishing wavefront and a spinning host, 0 = hipMemcpyAsync + hipStreamSynchronize */
 int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 

@@ -276,7 +276,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
     if (!ctx || !key) return HAGRID_EINVAL;
     struct { const char* name; int* dst; int lo, hi; } table[] = {
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
-        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2}, {"traverse.image_vtop", &ctx->opt_image_vtop, 0, 1}, {"ctx.fast_readback", &ctx->opt_fast_readback, 0, 1},
+        {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2}, {"traverse.image_vtop", &ctx->opt_image_vtop, 0, 1}, {"traverse.quad_head", &ctx->opt_quad_head, 0, 1000}, {"ctx.fast_readback", &ctx->opt_fast_readback, 0, 1},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
         {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},

@@ -282,8 +282,14 @@ __global__ void __launch_bounds__(kBlock) ray_bin_scatter(const unsigned short* 
 // 16 384 tiles, every gather of a cost a dependent load: 3 % of the launches it was meant to speed up.)
 constexpr int kOrderBlock = 1024, kOrderBins = 4096;
 // The sort also leaves behind WHAT the order was learned on: a copy of the sample ray order_still_fits (trav_common.h) compares the buffer with.
-__global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int n,
+// rot: the order is stored rotated by this many positions -- its LAST rot positions hold the longest tiles, which the tail kernel dispatches first, four lanes per
+// ray (trav_kernels.h, a.quad_head).
+// suggest (pinned host word, polled): how many tiles cost at least head_tenths / 10 times the MEDIAN working tile, if they are more than a twelfth of the working
+// tiles -- the share the next sort is rotated by (the host rounds and caps it): a launch whose tiles cost about the same has none, a scene with a few dense
+// objects a tenth of its tiles.
+__global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict__ cost, int* __restrict__ order, int n, int rot, int head_tenths, int* suggest,
                                                                  const float4* __restrict__ rays, int num_rays, float4* __restrict__ samples) {
+    __shared__ int median_cost;
     __shared__ int bins[kOrderBins];
     __shared__ int wave_total[kOrderBlock / 64];
     const int t = threadIdx.x;
@@ -312,20 +318,37 @@ __global__ void __launch_bounds__(kOrderBlock) tile_order_kernel(int* __restrict
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < (t >> 6); w++) run += wave_total[w];
-    for (int k = 0; k < 4; k++) { bins[4 * t + k] = run; run += c[k]; }
+    if (t == 0) median_cost = 0;
+    int start[4];
+    for (int k = 0; k < 4; k++) { start[k] = run; bins[4 * t + k] = run; run += c[k]; }
+    __syncthreads();
+    // the median over the tiles that do any work (cost >= 3: the tiles of an image's empty margin would pull it to nothing); bins[b] = tiles of a cost above kOrderBins - 1 - b
+    const int live = bins[kOrderBins - 3];
+    for (int k = 0; k < 4; k++)
+        if (c[k] > 0 && start[k] <= live / 2 && live / 2 < start[k] + c[k]) median_cost = kOrderBins - 1 - (4 * t + k);
+    __syncthreads();
+    if (t == 0 && suggest) {
+        int sg = 0;
+        if (head_tenths > 0 && live > 0) {
+            const int thr = min(kOrderBins - 1, max(3, (median_cost * head_tenths + 9) / 10));        // cost >= thr  <=>  bin <= kOrderBins - 1 - thr
+            sg = bins[kOrderBins - thr];
+            if (sg * 12 < live) sg = 0;             // a thin tail (a twelfth of the working tiles or less): the launch is not as long as a few dense places
+        }
+        *suggest = sg;
+    }
     __syncthreads();
     if (keep) {
 #pragma unroll
         for (int r = 0; r < kKeep; r++) {
             if (r * kOrderBlock >= n) break;
             const int i = r * kOrderBlock + t;
-            if (mine[r] >= 0) { order[atomicAdd(&bins[mine[r]], 1)] = i; cost[i] = 0; }
+            if (mine[r] >= 0) { const int p = atomicAdd(&bins[mine[r]], 1); order[p >= rot ? p - rot : p + (n - rot)] = i; cost[i] = 0; }
             __syncthreads();                                   // (sweep after sweep: equal costs stay in tile order across sweeps)
         }
     } else {
         for (int i0 = 0; i0 < n; i0 += kOrderBlock) {
             const int i = i0 + t;
-            if (i < n) { order[atomicAdd(&bins[bin_of(cost[i])], 1)] = i; cost[i] = 0; }
+            if (i < n) { const int p = atomicAdd(&bins[bin_of(cost[i])], 1); order[p >= rot ? p - rot : p + (n - rot)] = i; cost[i] = 0; }
             __syncthreads();
         }
     }
@@ -364,9 +387,11 @@ bool hagrid_trav::tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, i
     h.lpt_cap = cap; h.lpt_valid = false;
     return true;
 }
-void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a) {
+void hagrid_trav::launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a, int rot, int* suggest) {
     int* cost = h.lpt_buf, *order = cost + h.lpt_cap;
-    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles, a.rays, a.num_rays, tile_order_samples(h)); HG_DBG(ctx);
+    rot = std::max(0, std::min(rot, tiles));
+    tile_order_kernel<<<1, kOrderBlock, 0, ctx->stream>>>(cost, order, tiles, rot, ctx->opt_quad_head, suggest, a.rays, a.num_rays, tile_order_samples(h)); HG_DBG(ctx);
+    h.lpt_rot = rot;
     h.lpt_epoch++;
 }
 

@@ -52,6 +52,7 @@ struct TraverseArgs {
     int mailbox;                  // host side only: the instantiation with a mailbox of the last four triangles per ray
     int refill;                   // tail kernel (REFILL instantiations): tiles per wavefront whose lanes take new rays as they finish (0: off)
     int tri64;                    // host side only: `tris` is the copy padded to 64 bytes per triangle (instantiations with TRI64)
+    int quad_head;                // tail kernel: this many tiles at the HEAD of a learned tile order start with four lanes per ray (four blocks each, the first of the grid); 0: none
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     unsigned mode;                // v2 and the image kernel: HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS of this call (read at run time)
     int id_is_steps;              // statistics kernel: Hit.id receives the step count, as the reference's kernel writes it (traverse.cu:93)
@@ -312,7 +313,7 @@ void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* ro
 // launches since the last call left, costs cleared
 constexpr int kMaxOrderTiles = 1 << 18;          // launches of more tiles keep the default order whatever the options say (the sort is one workgroup)
 bool tile_order_buffers(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles);
-void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a);
+void launch_tile_order(hagrid_ctx* ctx, hagrid_ctx::RayHints& h, int tiles, const TraverseArgs& a, int rot, int* suggest);
 inline float4* tile_order_samples(const hagrid_ctx::RayHints& h) { return reinterpret_cast<float4*>(h.lpt_buf + 2 * size_t(h.lpt_cap)); }
 
 // Does the tile order still describe the rays in the buffer?  One sample ray (three eighths into the buffer) is compared BIT FOR BIT with the copy the sort

@@ -297,17 +297,20 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     // The last tiles in dispatch order are traversed with four lanes per ray from their first cell on (phase 2 below): a tile is then
     // four blocks of 16 rays (its 4 x 4 pixel quadrants).  They are the wavefronts that start when the machine begins to drain, where
     // wavefront slots are free and what counts is how long the longest ray of a wavefront takes.
-    const bool quad_start = int(blockIdx.x) >= a.quad_first_block;
+    // With a.quad_head > 0 those blocks are dispatched FIRST (the grid rotated by 4 * quad_head blocks) and the tile order is rotated the same way (its last quad_head
+    // positions hold the longest tiles, ray_order.hip): the tiles the launch is as long as start at once and take half as many iterations per ray.
+    const int bid = a.quad_head ? (int(blockIdx.x) < 4 * a.quad_head ? int(blockIdx.x) + (int(gridDim.x) - 4 * a.quad_head) : int(blockIdx.x) - 4 * a.quad_head) : int(blockIdx.x);
+    const bool quad_start = bid >= a.quad_first_block;
     const int group = lane >> 2, sub = lane & 3;
     int b, lane_in_tile = lane;
     if (quad_start) {
-        const int q = int(blockIdx.x) - a.quad_first_block, nq = int(gridDim.x) - a.quad_first_block;
+        const int q = bid - a.quad_first_block, nq = int(gridDim.x) - a.quad_first_block;
         const int lq = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(q, nq, a.xcd_chunk_log2 + 2) : xcd_split(q, nq);
         b = a.quad_first_block + (lq >> 2);
         lane_in_tile = ((((lq >> 1) & 1) << 2) + (group >> 2)) * 8 + ((lq & 1) << 2) + (group & 3);
     } else {
         const int nb = min(int(gridDim.x), a.quad_first_block);
-        b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(blockIdx.x, nb, a.xcd_chunk_log2) : xcd_split(blockIdx.x, nb);
+        b = (w && a.xcd_chunk_log2 >= 0) ? xcd_chunked(bid, nb, a.xcd_chunk_log2) : xcd_split(bid, nb);
     }
     // Which tile: position b of the dispatch order, or -- when the previous launch over this ray buffer left its costs -- the tile that
     // order names (longest first, traverse.hip "tile order").  The wavefront leaves its own cost (iterations = cells of its longest ray) behind.

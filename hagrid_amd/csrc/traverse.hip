@@ -135,7 +135,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0; a.gen_shift = g->shift; a.gen_x = g->dims[0]; a.gen_xy = 0; a.gen_base = 0u;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.quad_head = 0; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -204,9 +204,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
-            N.lpt_epoch++; __atomic_store_n(ctx->mailbox + 304 + lru, -1, __ATOMIC_RELAXED);
+            N.lpt_epoch++; __atomic_store_n(ctx->mailbox + 304 + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + 312 + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
             // row length counts as seen (the kernel reads the one found for THIS buffer either way), its tile order is the first order (below).
             const hagrid_ctx::RayHints* donor = nullptr;
@@ -335,7 +335,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // 0.192 against 0.184 ms per frame over its first 32 frames.)  A buffer refilled every 8th launch keeps its orders: they last six launches.
                     const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
-                    H.lpt_valid = false; H.lpt_age = 0;
+                    H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
@@ -354,7 +354,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                         // (with the donor's sample rays: the order is followed only if THIS buffer's rays are near them)
                         // (the stand-in's refresh count goes on: buffers that come and go -- a new allocation per frame -- still re-sort every 32nd launch,
                         // from the costs of that one launch: every wavefront of a launch leaves its cost)
-                        H.lpt_valid = true; H.lpt_period = 32; H.lpt_age = donor->lpt_age;
+                        H.lpt_valid = true; H.lpt_period = 32; H.lpt_age = donor->lpt_age; H.lpt_rot = donor->lpt_rot;
                         H.lpt_epoch++;                 // an order of its own epoch: no report written so far can name it
                     }
                 }
@@ -392,7 +392,25 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // per ray (256^2 ... 960 x 540: -8 ... -23 % against the shares above in the default order), none of a larger one
             if (a.tile_order && !shared) quad_pct = r100 <= 100 ? 100 : 0;
         }
-        if (quad_pct > 0 && ctx->opt_tail && !flags && narrow) {
+        // "traverse.quad_head": in a learned order of a launch of MORE than one round the tiles that cost several times the median tile -- the chains the launch is as
+        // long as, where a scene has a few dense objects -- start with four lanes per ray, and first.  The sort counts them (a pinned word the host polls), the NEXT sort
+        // stores the order rotated by that many positions (its last lpt_rot positions are the longest tiles) and the kernel dispatches the blocks of those positions
+        // first (a.quad_head).  The share follows the suggestion at the periodic sorts; the first suggestion gets a sort of its own.
+        int want_rot = 0;
+        int* suggest = ctx->mailbox + 312 + hint_slot;
+        const bool head_ok = ctx->opt_quad_head > 0 && ctx->opt_quad_tail < 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tail && !flags && narrow && refill_k <= 1 &&
+                             !(ctx->image.alive && ctx->image.alive.use_count() > 1);
+        if (head_ok) {
+            const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
+            const int s = std::min(std::max(__atomic_load_n(suggest, __ATOMIC_RELAXED), 0), tiles / 8);
+            const int full = std::min(blocks, (blocks - s + chunk / 2) / chunk * chunk);            // (whole XCD chunks of ordinary blocks)
+            want_rot = blocks - full;
+        }
+        if (a.tile_order && H.lpt_rot > 0 && head_ok) {
+            a.quad_first_block = tiles - H.lpt_rot; a.quad_head = H.lpt_rot; blocks = tiles + 3 * H.lpt_rot;
+        } else if (a.tile_order && H.lpt_rot > 0) {
+            a.tile_order = nullptr; a.order_samples = nullptr; learn_order = true;              // (rotated for a launch this one is not: default order, sorted again behind it)
+        } else if (quad_pct > 0 && ctx->opt_tail && !flags && narrow) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
@@ -418,7 +436,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (learn_order) { launch_tile_order(ctx, H, tiles, a); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
+        if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
+        if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
     } else {

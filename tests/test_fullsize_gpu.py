@@ -342,6 +342,22 @@ def test_clustered_scene_structure_and_hits_match_oracle():
                 else: mem.set_option(k, v)
             assert same_hits(traverse(mem, grid, d_tris, rays), oh), opts
             mem.set_ray_binning(0); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_slim", 1)
+        # ONE 1024 x 1024 buffer traversed 120 times: the tile order is learned, and -- the blobs' tiles cost several times the median tile -- the longest tiles of the
+        # order start with four lanes per ray, first ("traverse.quad_head": the share a sort suggests is taken up by a later sort, trav_kernels.h a.quad_head).  Every
+        # checked launch gives the oracle's hits; with a lower threshold (more tiles at the head) and without the feature as well.
+        prim = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024); n = prim.shape[0]
+        ohp, _ = G.traverse(tris, prim, nthreads=8)
+        d_rays = mem.upload(prim); d_hits = mem.alloc(16 * n)
+        for head in (20, 12, 0):
+            mem.set_option("traverse.quad_head", head)
+            for launch in range(1, 121):
+                if launch in (1, 2, 3, 34, 35, 67, 68, 100, 120): mem.zero(d_hits, 16 * n)
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+                if launch in (1, 2, 3, 34, 35, 67, 68, 100, 120):
+                    mem.synchronize()
+                    assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), ohp), (head, launch)
+        mem.set_option("traverse.quad_head", 20)
+        mem.free(d_rays); mem.free(d_hits)
         grid.free()
     finally:
         mem.close()

@@ -16,7 +16,7 @@ for kv in filter(None, os.environ.get("OPTS", "").split(",")):
     k, v = kv.split("="); mem.set_option(k, int(v))
 td, sd = (0.15, 3.0) if "config3" in batch else (0.12, 2.4)
 td, sd = float(os.environ.get("TD", td)), float(os.environ.get("SD", sd))          # (other grids of the same scene: TD=0.15 SD=3.0 primary 1024^2 ...)
-tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
+tris = scene.make_clustered() if os.environ.get("SCENE") == "clustered" else scene.make_soup(1_000_000); d_tris = mem.upload(tris)          # (SCENE=clustered: the non-uniform scene of bench.py --config clustered)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
 api.setup_traversal(grid)
 print(json.dumps({"grid": grid.summary(), "image": mem.image_format(grid)}), flush=True)
@@ -25,6 +25,7 @@ gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bb
         "primary 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
+        "aimed 1M": lambda: scene.make_rays_aimed(grid.bbox_min, grid.bbox_max, 1 << 20, 5),
         "incoherent 1M": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4)}
 import re
 m = re.match(r"primary (\d+)x(\d+)$", batch)
