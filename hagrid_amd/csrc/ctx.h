@@ -106,7 +106,11 @@ struct hagrid_ctx {
         const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
-        int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32, lpt_rot = 0 /* positions the stored order is rotated by: its last lpt_rot tiles are the longest */; bool rot_adopted = false /* the first suggestion of a sort was taken up by a sort of its own */; bool lpt_valid = false;
+        int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32, lpt_rot = 0 /* positions the stored order is rotated by: its last lpt_rot tiles are the longest */; bool rot_adopted = false /* the first suggestion of a sort was taken up by a sort of its own */;
+        // the head share measures itself: launches in the learned order are timed (an event pair around the kernel, polled by later calls) without it and with it --
+        // three samples each, the smaller ones compared -- and a share that does not pay is dropped for as long as the order lives
+        hipEvent_t trial_evt[2] = {nullptr, nullptr}; bool trial_pending = false, trial_with_head = false, head_disabled = false;
+        float t_base = 0.0f, t_head = 0.0f; int n_base = 0, n_head = 0, trial_opt = -1 /* the value of traverse.quad_head the trial belongs to */; bool lpt_valid = false;
         // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
         // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[304 + i],

@@ -11,6 +11,8 @@
 // format); how rays meet lanes: trav_common.h (tile packets), ray_order.hip (row-length detection, ray binning).  DESIGN.md 4.2.
 #include "trav_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace hagrid;
@@ -204,7 +206,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = 0.0f; N.n_base = N.n_head = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + 304 + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + 312 + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -335,7 +337,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // 0.192 against 0.184 ms per frame over its first 32 frames.)  A buffer refilled every 8th launch keeps its orders: they last six launches.
                     const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
-                    H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false;
+                    H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
@@ -400,13 +402,30 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         int* suggest = ctx->mailbox + 312 + hint_slot;
         const bool head_ok = ctx->opt_quad_head > 0 && ctx->opt_quad_tail < 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tail && !flags && narrow && refill_k <= 1 &&
                              !(ctx->image.alive && ctx->image.alive.use_count() > 1);
-        if (head_ok) {
+        // The share measures itself (the rule above is fitted on two scene families; on a soup with a density gradient it takes tiles whose lists are short and loses
+        // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
+        // until the order is learned again from nothing.
+        if (H.trial_opt != ctx->opt_quad_head) {            // (the test library changed the threshold: the trial starts again)
+            H.trial_opt = ctx->opt_quad_head; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
+        }
+        if (H.trial_pending && hipEventQuery(H.trial_evt[1]) == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, H.trial_evt[0], H.trial_evt[1]) == hipSuccess && ms > 0.0f) {
+                if (H.trial_with_head) { H.t_head = H.n_head ? std::min(H.t_head, ms) : ms; H.n_head++; }
+                else { H.t_base = H.n_base ? std::min(H.t_base, ms) : ms; H.n_base++; }
+            }
+            H.trial_pending = false;
+            if (H.n_head >= 3 && H.n_base >= 3 && !H.head_disabled && H.t_head > 0.97f * H.t_base) H.head_disabled = true;
+        } else if (H.trial_pending) (void)hipGetLastError();          // not ready yet: not an error
+        if (head_ok && H.n_base >= 3 && !H.head_disabled) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int s = std::min(std::max(__atomic_load_n(suggest, __ATOMIC_RELAXED), 0), tiles / 8);
             const int full = std::min(blocks, (blocks - s + chunk / 2) / chunk * chunk);            // (whole XCD chunks of ordinary blocks)
-            want_rot = blocks - full;
+            // a share once taken up stays: the costs the head's tiles leave while they run with four lanes per ray are lower, a sort over those would suggest none
+            // (and the share would come and go every other refresh)
+            want_rot = H.lpt_rot > 0 ? H.lpt_rot : blocks - full;
         }
-        if (a.tile_order && H.lpt_rot > 0 && head_ok) {
+        if (a.tile_order && H.lpt_rot > 0 && head_ok && !H.head_disabled) {
             a.quad_first_block = tiles - H.lpt_rot; a.quad_head = H.lpt_rot; blocks = tiles + 3 * H.lpt_rot;
         } else if (a.tile_order && H.lpt_rot > 0) {
             a.tile_order = nullptr; a.order_samples = nullptr; learn_order = true;              // (rotated for a launch this one is not: default order, sorted again behind it)
@@ -434,9 +453,20 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (refill_k > 1) {      // ("traverse.refill" above)
             a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
+        // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
+        const bool timed = head_ok && a.tile_order && !learn_order && !H.trial_pending && !H.head_disabled && H.lpt_age >= 2 &&
+                           (a.quad_head ? H.n_head < 3 : H.n_base < 3) && ctx->opt_quad_head > 0;
+        if (timed) {
+            for (auto& e : H.trial_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
+            HG_HIP(ctx, hipEventRecord(H.trial_evt[0], ctx->stream));
+        }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
+        if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
+        if (learn_order && getenv("HAGRID_TRACE_HEAD"))
+            fprintf(stderr, "[head] call %llu: sort rot %d (was %d) suggestion %d quad_head %d base %.4f x%d head %.4f x%d disabled %d\n", ctx->hint_clock, want_rot, H.lpt_rot,
+                    __atomic_load_n(suggest, __ATOMIC_RELAXED), a.quad_head, H.t_base, H.n_base, H.t_head, H.n_head, int(H.head_disabled));
         if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
