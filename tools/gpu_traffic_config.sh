@@ -12,8 +12,8 @@ python -c "import __graft_entry__ as g; g.build()" || exit 1
 BENCH="python $ROOT/bench.py --gpus 1 --steps 5 --warmup 2 --build-iter 1 --no-cpu-baseline --inflight 0 --no-order-compare --config $C $*"
 echo "$BENCH" > $OUT/command.txt
 # the un-profiled line first (its kernel_ms is what the counters are divided by when the stats pass is missing)
-timeout 900 $BENCH > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/stats -o trace -- $BENCH > /dev/null 2> $ROOT/$OUT/stats.err)
+timeout -k 5 ${PASS_LIMIT:-900} $BENCH > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
+(cd /tmp && timeout -k 5 ${PASS_LIMIT:-900} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/stats -o trace -- $BENCH > /dev/null 2> $ROOT/$OUT/stats.err)
 # ESSENTIAL=1 leaves out the three passes the bench line does not read (SALU / LDS counts, TA busy, TCP stalls): configuration 5 takes 2.6 minutes per pass
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
@@ -25,7 +25,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum"; do
   i=$((i+1))
   if [ -n "$ESSENTIAL" ] && { [ $i = 5 ] || [ $i = 7 ] || [ $i = 8 ]; }; then continue; fi
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$OUT/p$i -o pmc -- $BENCH > /dev/null 2> $ROOT/$OUT/p$i.err)
+  # (pass 7, the TA set, is refused by the counter hardware of these boxes -- "exceeds the capabilities of the hardware to collect" -- and the aborted process then sat out its
+  # whole time limit, a quarter of an hour per configuration, unnoticed for most of round 5: skipped; the bench line does not read it)
+  if [ $i = 7 ]; then continue; fi
+  (cd /tmp && timeout -k 5 ${PASS_LIMIT:-900} rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$OUT/p$i -o pmc -- $BENCH > /dev/null 2> $ROOT/$OUT/p$i.err)
 done
 python tools/summarize_counters.py $OUT $C > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
