@@ -94,6 +94,23 @@ def make_clustered(num_sparse: int = 100000, clusters: int = 6, per_cluster: int
     return np.ascontiguousarray(np.concatenate(parts), np.float32)
 
 
+def make_gradient(num_tris: int = 1_000_000, seed: int | None = None) -> np.ndarray:
+    """A soup whose density rises towards one corner: positions squared, edges scaled with the local stretch.  Long tiles of many cells with short lists -- the
+    scene family on which counting iterations mispredicts what four lanes per ray buy (profiles/NOTES.md "Round 5")."""
+    base = make_soup(num_tris, seed=seed)
+    v0 = base[:, 0:3].astype(np.float64); e1 = -base[:, 4:7].astype(np.float64); e2 = base[:, 8:11].astype(np.float64)      # v1 = v0 - e1, v2 = v0 + e2 (prims.h)
+    k = np.maximum(2.0 * v0, 0.05); v0 = v0 ** 2
+    return tris_from_vertices(v0.astype(np.float32), (v0 + e1 * k).astype(np.float32), (v0 + e2 * k).astype(np.float32))
+
+
+def make_shell(num_tris: int = 1_000_000, seed: int | None = None) -> np.ndarray:
+    """A surface: the soup's triangles moved onto a sphere of radius 0.4, nothing inside or around it."""
+    base = make_soup(num_tris, seed=seed)
+    v0 = base[:, 0:3].astype(np.float64); e1 = -base[:, 4:7].astype(np.float64); e2 = base[:, 8:11].astype(np.float64)
+    d = v0 - 0.5; d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6); v0 = 0.5 + 0.4 * d
+    return tris_from_vertices(v0.astype(np.float32), (v0 + e1).astype(np.float32), (v0 + e2).astype(np.float32))
+
+
 def make_rays_aimed(bbox_min, bbox_max, num_rays: int, seed: int, first: int = 0) -> np.ndarray:
     """Incoherent origins (make_rays_incoherent) with directions towards the blobs of make_clustered, with some spread: ray i aims at blob i % 6.  The rays
     that end inside the dense parts of a very non-uniform scene (bench.py --config clustered --rays aimed; tests/test_fullsize_gpu.py)."""

@@ -603,6 +603,36 @@ def test_general_layout_virtual_top_level_on_and_off(mem):
         mem.set_option("traverse.image_vtop", 1); mem.set_option("traverse.image_general", 1); mem.set_option("traverse.tail", 1)
 
 
+@pytest.mark.parametrize("family", ["gradient", "shell"])
+def test_head_share_trial_never_changes_hits(mem, family):
+    """The tile order's head share ("traverse.quad_head") on scene families its counting rule was not fitted on: a soup with a density gradient (the share is
+    suggested, measured and dropped: the order is stored rotated, then un-rotated again) and a sphere shell.  140 launches over one buffer of a launch of more than one
+    round: every checked launch -- before the share, with it, after a drop -- gives the oracle's hits; with a lower threshold (more tiles at the head) as well."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_gradient(150000, seed=3) if family == "gradient" else scene.make_shell(150000, seed=4)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    rays = scene.make_rays_primary(np.asarray(G.bbox_min), np.asarray(G.bbox_max), 1024, 640).astype(np.float32); n = rays.shape[0]
+    want, _ = G.traverse(tris, rays, nthreads=8)
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    try:
+        for head in (20, 11):
+            mem.set_option("traverse.quad_head", head)
+            for launch in range(1, 141):
+                check = launch in (1, 2, 3, 30, 60, 61, 62, 90, 100, 101, 120, 140)
+                if check: mem.zero(d_hits, 16 * n)
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+                if check:
+                    mem.synchronize()
+                    got = mem.download(d_hits, api.HIT_DTYPE, n)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (family, head, launch)
+    finally:
+        mem.set_option("traverse.quad_head", 20)
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
 def test_image_lifetime(mem):
     """The image belongs to the grid of the last setup_traversal call and never outlives its source arrays."""
     from oracle import oracle as O

@@ -20,14 +20,9 @@ def other_scene(name):
     """scene families beside the uniform soup and the six blobs (what do rules fitted on those two do elsewhere?)"""
     if name == "clustered": return scene.make_clustered()
     if name == "clustered2": return scene.make_clustered(400000, 2, 300000)               # two large blobs in a denser soup
-    base = scene.make_soup(1_000_000)
-    v0 = base[:, 0:3].astype(np.float64); e1 = -base[:, 4:7].astype(np.float64); e2 = base[:, 8:11].astype(np.float64)      # v1 = v0 - e1', v2 = v0 + e2' (prims.h)
-    if name == "gradient":                                                                # density rising towards one corner: positions squared, edges scaled with them
-        k = np.maximum(2.0 * v0, 0.05); v0 = v0 ** 2; e1 *= k; e2 *= k
-    elif name == "shell":                                                                 # a surface: triangles on a sphere, nothing inside or around it
-        d = v0 - 0.5; d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6); v0 = 0.5 + 0.4 * d
-    else: raise SystemExit("unknown SCENE " + name)
-    return scene.tris_from_vertices(v0.astype(np.float32), (v0 + e1).astype(np.float32), (v0 + e2).astype(np.float32))
+    if name == "gradient": return scene.make_gradient()
+    if name == "shell": return scene.make_shell()
+    raise SystemExit("unknown SCENE " + name)
 tris = other_scene(os.environ["SCENE"]) if os.environ.get("SCENE") else scene.make_soup(1_000_000); d_tris = mem.upload(tris)          # (SCENE=clustered: the non-uniform scene of bench.py --config clustered)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
 api.setup_traversal(grid)
