@@ -193,6 +193,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+            # started bare (`python bench.py --gpus N`, the shape of the driver's N = 1 command): become the launch line DESIGN.md section 7
+            # names -- one rank per GPU under torch.distributed.run -- instead of giving up; rank 0's JSON line is this process's stdout.
+            port = os.environ.get("MASTER_PORT") or str(29600 + os.getpid() % 2000)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+            log(f"[bench] --gpus {args.gpus} without a launcher: re-executing under torch.distributed.run (port {port})")
+            sys.stdout.flush(); sys.stderr.flush()
+            os.execv(sys.executable, cmd)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")

@@ -69,3 +69,15 @@ def test_clustered_configuration_is_named():
     from hagrid_amd import scene
     r = scene.make_rays_aimed([0, 0, 0], [1, 1, 1], 12, 5)
     assert r.shape == (12, 8) and (scene.make_rays_aimed([0, 0, 0], [1, 1, 1], 6, 5, first=6) == r[6:]).all()
+
+
+def test_bench_started_bare_with_several_gpus_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run.  Here there is no
+    GPU, so the two ranks it starts stop at "needs a GPU" -- what is checked is that it is THEY who stop, not the bare process at the WORLD_SIZE test."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert "re-executing under torch.distributed.run" in r.stderr
+    assert "launch with torch.distributed.run" not in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") >= 2 or "local_rank: 1" in r.stderr

@@ -38,6 +38,22 @@ def test_bench_two_ranks_share_one_gpu():
     assert 0.3 < out["hit_fraction"] <= 1.0
 
 
+def test_bench_started_bare_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the shape of the driver's N = 1 command) re-executes itself under
+    torch.distributed.run instead of exiting: one JSON line from rank 0, two ranks in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR")}
+    env["MASTER_PORT"] = str(free_port())
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "100000", "--width", "256",
+           "--height", "256", "--backend", "gloo", "--device", "0", "--build-iter", "1", "--no-cpu-baseline"]
+    r = _subproc.run(cmd, timeout=300, cwd=ROOT, env=env)
+    assert not r.timed_out, r.diagnosis
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rays_total"] == 2 * 256 * 256
+
+
 @pytest.mark.parametrize("config,extra", [(4, ["--total-rays", "300001"]), (3, ["--width", "512", "--height", "256"]),
                                           (5, ["--width", "256", "--height", "256"])])
 def test_bench_strong_scaling_two_ranks(config, extra):

@@ -18,11 +18,14 @@ run c4_rccl_1  1 --force-dist --config 4 --total-rays 4194304
 run c5_rccl_1  1 --force-dist --config 5 --tris 1000000 --width 2048 --height 2048
 run c2_gloo_2  2 --backend gloo --device 0
 run c4_gloo_2  2 --backend gloo --device 0 --config 4 --total-rays 4194304
+# started bare, the shape of the driver's N = 1 command: bench.py launches its own ranks
+env -u RANK -u LOCAL_RANK -u WORLD_SIZE -u LOCAL_WORLD_SIZE timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --inflight 0 --build-iter 2 \
+    --backend gloo --device 0 > $OUT/c2_bare_2.json 2> $OUT/c2_bare_2.err; echo "c2_bare_2 rc=$?"
 python - "$OUT" <<'PY'
 import json, sys, os
 out = sys.argv[1]
 ok = True
-for name, world, strong in (("c2_rccl_1", 1, False), ("c4_rccl_1", 1, True), ("c5_rccl_1", 1, True), ("c2_gloo_2", 2, False), ("c4_gloo_2", 2, True)):
+for name, world, strong in (("c2_rccl_1", 1, False), ("c4_rccl_1", 1, True), ("c5_rccl_1", 1, True), ("c2_gloo_2", 2, False), ("c4_gloo_2", 2, True), ("c2_bare_2", 2, False)):
     try:
         lines = [l for l in open(os.path.join(out, name + ".json")) if l.startswith("{")]
         assert len(lines) == 1, f"{len(lines)} JSON lines (rank 0 prints exactly one)"
