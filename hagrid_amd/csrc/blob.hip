@@ -99,7 +99,7 @@ __global__ void validate_arrays(const uint32_t* entries, int num_entries, const 
 }
 
 int validate_unpacked(hagrid_ctx* ctx, const hagrid_grid& g, int num_tris) {
-    int* flag = ctx->dscratch + 250;
+    int* flag = ctx->dscratch + kScrBlobFlag;
     HG_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     const long long most = std::max<long long>(std::max(g.num_entries, g.num_cells), g.num_refs);
     const int blocks = int(std::min<long long>((most + 255) / 256, 4096));

@@ -643,11 +643,19 @@ struct GLevel {
 // pool as before): three dozen requests of sizes that differ from level to level leave the pool's cached slots unsettled for a dozen constructions (a
 // request nothing fits re-grows the largest free slot), each paying hipFree + hipMalloc: build_grid 1.43 instead of 1.24 ms until then.
 struct Arena {
-    hagrid_ctx* ctx; Temps& tmp; char* base = nullptr; size_t size = 0, used = 0, wanted = 0;
-    Arena(hagrid_ctx* c, Temps& t) : ctx(c), tmp(t) {
-        if (c->build_arena_hint) { base = t.get<char>(c->build_arena_hint); size = base ? c->build_arena_hint : 0; }
+    hagrid_ctx* ctx; Temps& tmp; char* base = nullptr; size_t size = 0, used = 0, wanted = 0; int num_tris;
+    Arena(hagrid_ctx* c, Temps& t, int n_tris) : ctx(c), tmp(t), num_tris(n_tris) {
+        // the hint belongs to a scene of build_arena_tris primitives: a much smaller scene takes its share of it (a small construction after a large one must not
+        // allocate the large one's buffer); the buffer is OPTIONAL -- without it every request goes to the pool, and a failed hipMalloc must leave no error behind
+        size_t want = c->build_arena_hint;
+        if (want && c->build_arena_tris > 0 && 2ll * n_tris < c->build_arena_tris)
+            want = size_t(double(want) * 1.25 * double(std::max(n_tris, 1)) / double(c->build_arena_tris)) + 4096;
+        if (want) {
+            base = pool_try_alloc<char>(c, want);
+            if (base) { t.ptrs.push_back(base); size = want; }
+        }
     }
-    ~Arena() { ctx->build_arena_hint = wanted; }
+    ~Arena() { ctx->build_arena_hint = wanted; ctx->build_arena_tris = num_tris; }
     template <typename T> T* get(size_t n) {
         const size_t bytes = (std::max(n, size_t(1)) * sizeof(T) + 255) & ~size_t(255);
         wanted += bytes;
@@ -660,7 +668,7 @@ struct Arena {
 int build_levels(hagrid_ctx* ctx, const float4* tris, int num_tris, hagrid_grid* grid, BuildK k, const BBox& gb, float snd_density, Temps& tmp) {
     hipStream_t st = ctx->stream;
     int* dsc = ctx->dscratch;
-    Arena ar(ctx, tmp);
+    Arena ar(ctx, tmp, num_tris);
     const ivec3 dims = k.dims;
     const int num_top = dims.x * dims.y * dims.z;
 

@@ -51,6 +51,24 @@ struct TravImageCache {
 
 } // namespace hagrid_impl
 
+// Words of the context's pinned mailbox and of its device scratch that have a fixed owner (the first 256 mailbox words are the read-back area of the
+// construction passes; every other use of dscratch is a pass-local counter named where it is used).
+namespace hagrid_impl {
+enum MailboxWord : int {
+    kMbxRowLen = 300,          // + hint slot (4): row length found for a ray buffer (traverse.hip; copied behind the launch, polled)
+    kMbxOrderStale = 304,      // + hint slot (4): epoch of a tile order whose buffer holds other rays now (written by the kernel's first wavefront, polled)
+    kMbxReadBackEpoch = 310,   // ctx.hip read_back: the epoch the publishing wavefront stores behind the words
+    kMbxHeadSuggest = 312,     // + hint slot (4): tiles the last sort suggests for the four-lanes-per-ray head (tile_order_kernel, polled)
+    kMbxPriorStats = 316,      // + 4: the grid prior's statistics (trav_prior.hip)
+};
+enum ScratchWord : int {
+    kScrRowLenBinned = 232,    // ray_order.hip: row length / flag of the binning pass
+    kScrRowLen = 236,          // + hint slot (4): row length of a ray buffer (detect_ray_rows writes, the kernels read)
+    kScrMaxRef = 240,          // trav_image.hip: largest reference id
+    kScrBlobFlag = 250,        // blob.hip: validation flag
+};
+} // namespace hagrid_impl
+
 struct hagrid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -65,7 +83,7 @@ struct hagrid_ctx {
     // profile()
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
-    // pinned mailbox for scalar read-backs (build passes) -- 256 ints, + words 256.. for values the host only polls (words 300 .. 303: row lengths, 304 .. 307: epochs of tile orders that no longer fit their buffer)
+    // pinned mailbox for scalar read-backs (build passes) -- 256 ints, + words 256.. for values the host only polls (named in MailboxWord above)
     int* mailbox = nullptr;
     // device scratch words (counters, scan totals) -- 256 ints, zeroed by the passes that use them
     int* dscratch = nullptr;
@@ -100,7 +118,7 @@ struct hagrid_ctx {
     int opt_row_cache = 1;      // tile packets: the row length found for a ray buffer is reused by the next 15 calls with the same buffer and count
     // What the context remembers about a ray buffer it has traversed (traverse.hip): the row length found for it and the order of its tiles.  A few
     // buffers are remembered at once (a renderer that alternates between two or three ray buffers keeps the hints of each); the least recently used
-    // slot is taken over by a new buffer.  Slot i owns the device word dscratch[236 + i] and the pinned word mailbox[300 + i].
+    // slot is taken over by a new buffer.  Slot i owns the device word dscratch[kScrRowLen + i] and the pinned words mailbox[kMbxRowLen + i], [kMbxOrderStale + i], [kMbxHeadSuggest + i].
     struct RayHints {
         const void* key_rays = nullptr; int key_n = 0;       // the buffer the slot belongs to
         const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false;   // rowlen_known: the row length as the host has seen it (-1: not yet)
@@ -113,7 +131,7 @@ struct hagrid_ctx {
         float t_base = 0.0f, t_head = 0.0f; int n_base = 0, n_head = 0, trial_opt = -1 /* the value of traverse.quad_head the trial belongs to */; bool lpt_valid = false;
         // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
         // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
-        // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[304 + i],
+        // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[kMbxOrderStale + i],
         // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
         int lpt_epoch = 1 /* never 0: the pinned report word starts as 0 and is reset to -1 */, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
         unsigned long long used = 0;                    // clock of the last call that used the slot
@@ -132,7 +150,7 @@ struct hagrid_ctx {
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
     int opt_image_slim = 1;     // traversal image: 1: reference ids packed in 20 bits where every id fits, else 26; 2: always 26 bits (tests)
-    int opt_image_general = 1;  // traversal image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: 32-byte records there (tests); 2: for every grid (tests)
+    int opt_image_general = 1;  // traversal image: the general layout of slim records (a record per voxel-map entry) for grids deeper than three levels and for cells the block layouts' bound bytes cannot hold; 0: no general layout -- such grids are traversed in the construction format (tests); 2: for every grid (tests)
     int opt_image = 2;          // 0: none; 1 / 2: setup_traversal builds the traversal image (trav_image.hip; the two values are one since round 5) and traverse_grid uses it
 
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
@@ -140,6 +158,7 @@ struct hagrid_ctx {
     hagrid_impl::TravImageCache image;
     int readback_epoch = 0;               // read_back (ctx.hip): the epoch the publishing wavefront leaves behind the words in the mailbox (word 310)
     int opt_fast_readback = 1;            // scalar read-backs through a publishing wavefront and a spinning host instead of hipMemcpyAsync + hipStreamSynchronize
+    int build_arena_tris = 0;             // ... and the primitives of that construction
     size_t build_arena_hint = 0;          // bytes of temporaries the last build_grid of this context asked for (build.hip: one pool buffer for all of them)
     hagrid_build_counts counts = {};      // sizes of the last construction (hagrid_get_build_counts)
 

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) publish_words(const int* __restrict__ src
 
 int hagrid_impl::read_back(hagrid_ctx* ctx, const void* dptr, void* hptr, size_t bytes) {
     if (ctx->opt_fast_readback && bytes > 0 && bytes <= 256 * sizeof(int) && (bytes & 3u) == 0 && (reinterpret_cast<uintptr_t>(dptr) & 3u) == 0) {
-        int* flag = ctx->mailbox + 310;
+        int* flag = ctx->mailbox + kMbxReadBackEpoch;
         const int epoch = ++ctx->readback_epoch;
         publish_words<<<1, 256, 0, ctx->stream>>>(static_cast<const int*>(dptr), int(bytes / 4), ctx->mailbox, flag, epoch);
         HG_HIP(ctx, hipGetLastError());

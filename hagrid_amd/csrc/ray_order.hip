@@ -409,8 +409,8 @@ int bin_rays_bits(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp
     if (ctx->ray_binning == 2) {
         // automatic: everything is decided on the device, nobody waits.  row length (image-ordered batches are left to the
         // tile packets) -> keys + coherence estimate -> scan -> decision -> scatter; the traversal kernel reads the decision.
-        int* row_len = ctx->dscratch + 232;
-        int* flag = ctx->dscratch + 233;
+        int* row_len = ctx->dscratch + kScrRowLenBinned;
+        int* flag = ctx->dscratch + kScrRowLenBinned + 1;
         if (!ctx->bin_diff) {
             HG_HIP(ctx, hipMalloc((void**)&ctx->bin_diff, 64 * sizeof(int)));
             HG_HIP(ctx, hipMemsetAsync(ctx->bin_diff, 0, 64 * sizeof(int), ctx->stream));

@@ -132,6 +132,11 @@ __device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uin
         rl |= (unsigned long long)((uint32_t(dl) & 255u) | (uint32_t(dh) & 255u) << 8) << (16 * ax);
     }
     if (n >= (1 << 20)) bad |= 2;
+    // an id that the field cannot tell from its markers -- in ANY list form: the kernels end a list by index at id == NONE as well -- : the whole image needs
+    // the wider field (lists by index and lists of wide cells were not looked at)
+    bool wide_ids = false;
+    for (int i = 0; i < n; i++) wide_ids = wide_ids || uint32_t(k.refs[begin + i]) >= NONE - 3u;
+    if (wide_ids) atomicAdd(status + 1, 1);
     if (!fits) {
         // the cell's wide record: the first entry that names the cell draws its index; the record holds the CELL until image_general_patch
         // replaces it by that index (the winner's store may not be visible to the other entries of the cell during this launch)
@@ -140,9 +145,6 @@ __device__ __forceinline__ bool general_record(const ImgK& k, const int IDB, uin
         put_bits(rl, rh, 80, 20, uint32_t(n));
         put_bits(rl, rh, 48 + (NI - 1) * IDB, IDB, NONE - 3u);
     } else {
-        bool wide_ids = false;               // an id that the field cannot tell from its markers: the whole image needs the wider field
-        for (int i = 0; i < n && i < NI; i++) wide_ids = wide_ids || uint32_t(k.refs[begin + i]) >= NONE - 3u;
-        if (n <= NI && wide_ids) atomicAdd(status + 1, 1);
         if (n <= NI && !wide_ids) {
             for (int i = 0; i < n; i++) put_bits(rl, rh, 48 + i * IDB, IDB, uint32_t(k.refs[begin + i]));
         } else {
@@ -247,9 +249,13 @@ int build_general(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     if (k.num_entries <= 0 || k.num_entries >= (1 << 28) || k.shift > 15) return 1;
     // the virtual top level (image_general_vtop): where the map has a level below its top level and the record index stays within the kernels' 24-bit products
     const int top_z = k.num_top / std::max(k.top_x * k.top_y, 1);
-    const bool vtop = ctx->opt_image_vtop && k.shift >= 1 && 4ll * k.top_x * k.top_y < (1 << 23) && 2ll * top_z < (1 << 23) && (long long)k.num_entries + 8ll * k.num_top < (1ll << 28);
+    // the same size limit as the block layouts (build_blocks): "traverse.image_max_mb", else 8x the arrays the image replaces and at least 1 GB; a virtual top
+    // level that does not fit it is left out before the image is
+    const long long limit = ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes);
+    bool vtop = ctx->opt_image_vtop && k.shift >= 1 && 4ll * k.top_x * k.top_y < (1 << 23) && 2ll * top_z < (1 << 23) && (long long)k.num_entries + 8ll * k.num_top < (1ll << 28);
+    if (vtop && ((long long)k.num_entries + 8ll * k.num_top) * 16 > limit) vtop = false;
     const size_t records = size_t(k.num_entries) + (vtop ? 8u * size_t(k.num_top) : 0u);
-    if (ctx->opt_image_max_mb > 0 && records * 16u > (size_t(ctx->opt_image_max_mb) << 20)) return 1;      // ("traverse.image_max_mb")
+    if ((long long)records * 16 > limit) return 1;
     const size_t cap = size_t(std::max(k.num_top, k.num_entries / 8)) + 1;
     uint4* recs = static_cast<uint4*>(hagrid_mem_alloc(ctx, records * 16u));
     GenItem* items[2] = {pool_alloc<GenItem>(ctx, cap), pool_alloc<GenItem>(ctx, cap)};
@@ -552,10 +558,14 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
     img.dims[0] = g->dims[0]; img.dims[1] = g->dims[1]; img.dims[2] = g->dims[2];
     if (img.valid) img.alive = std::make_shared<std::atomic<bool>>(true);
     if (img.valid && g->num_refs > 0) {
-        int* word = ctx->dscratch + 240;
+        int* word = ctx->dscratch + kScrMaxRef;
         HG_HIP(ctx, hipMemsetAsync(word, 0xff, sizeof(int), ctx->stream));
         max_ref_kernel<<<std::min(grid_blocks(g->num_refs, kBlock), 2048), kBlock, 0, ctx->stream>>>(static_cast<const int*>(g->ref_ids), g->num_refs, word); HG_DBG(ctx);
-        HG_TRY(read_back(ctx, word, &img.max_ref, sizeof(int)));
+        const int rb = read_back(ctx, word, &img.max_ref, sizeof(int));
+        if (rb != HAGRID_OK) {                     // img is not the context's yet: its buffers go back here
+            hagrid_mem_free(ctx, img.blocks); hagrid_mem_free(ctx, img.table);
+            return rb;
+        }
     }
     ctx->image = img;
     return HAGRID_OK;
@@ -591,7 +601,7 @@ extern "C" int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* g
     if (!ctx || !grid) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
     const TravImageCache& img = ctx->image;
-    if (format4) { format4[0] = img.general ? 2 : 1; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = img.slim ? 16 : 32; }
+    if (format4) { format4[0] = img.general ? 2 : 1; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = 16; }
     if (image_bytes) *image_bytes = (int64_t)img.block_bytes + (int64_t)img.table_bytes;
     return HAGRID_OK;
 }

@@ -208,7 +208,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
             N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = 0.0f; N.n_base = N.n_head = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
-            N.lpt_epoch++; __atomic_store_n(ctx->mailbox + 304 + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + 312 + lru, 0, __ATOMIC_RELAXED);
+            N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
             // row length counts as seen (the kernel reads the one found for THIS buffer either way), its tile order is the first order (below).
             const hagrid_ctx::RayHints* donor = nullptr;
@@ -224,7 +224,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     // batch; without one the latency-oriented v2 walks the construction format (trav_plain.hip).
     // hagrid_set_option("traverse.variant", 1|2|4) forces the reference-shaped kernel, v2 or the image kernel (tests, experiments).
     const bool have_image = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
-    if (ctx->image.detached && have_image && ((ctx->opt_variant && ctx->opt_variant != 4) || false))
+    if (ctx->image.detached && have_image && ctx->opt_variant && ctx->opt_variant != 4)
         HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal, only the traversal-image kernel can serve it");
     if (ctx->opt_variant == 4 && !have_image) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: no traversal image for this grid (hagrid_setup_traversal)");
     int variant = ctx->opt_variant ? ctx->opt_variant : (have_image ? 4 : 2);
@@ -258,10 +258,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // polls) and never keeps "not image-ordered" once it has seen it, so a buffer that alternates between unordered rays and an
             // image looks every time.  A buffer refilled with rows of another length runs on the stale length for at most 15 calls --
             // slower, never wrong.
-            int* row_len = ctx->dscratch + 236 + hint_slot;
+            int* row_len = ctx->dscratch + kScrRowLen + hint_slot;
             const bool same = ctx->opt_row_cache && H.rowlen_rays == rays && H.rowlen_n == num_rays;
             if (same && H.rowlen_pending) {
-                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[300 + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rows_from_origins = (word & kRowsFromOrigins) != 0; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
+                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[kMbxRowLen + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rows_from_origins = (word & kRowsFromOrigins) != 0; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
             if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
@@ -326,7 +326,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
             if (H.cooldown > 0) H.cooldown--;              // orders did not last on this buffer (a camera that moves fast): not learned for a while
             else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
-                int* report = ctx->mailbox + 304 + hint_slot;
+                int* report = ctx->mailbox + kMbxOrderStale + hint_slot;
                 if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && __atomic_load_n(report, __ATOMIC_ACQUIRE) == H.lpt_epoch) {
                     // A launch since the last sort found other rays in the buffer than the order was learned on (its first wavefront reported it): learn
                     // again, from costs of the new rays only.  An order costs about a third of a launch to get (the launch that follows the stale one, the cost
@@ -399,7 +399,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // stores the order rotated by that many positions (its last lpt_rot positions are the longest tiles) and the kernel dispatches the blocks of those positions
         // first (a.quad_head).  The share follows the suggestion at the periodic sorts; the first suggestion gets a sort of its own.
         int want_rot = 0;
-        int* suggest = ctx->mailbox + 312 + hint_slot;
+        int* suggest = ctx->mailbox + kMbxHeadSuggest + hint_slot;
         const bool head_ok = ctx->opt_quad_head > 0 && ctx->opt_quad_tail < 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tail && !flags && narrow && refill_k <= 1 &&
                              !(ctx->image.alive && ctx->image.alive.use_count() > 1);
         // The share measures itself (the rule above is fitted on two scene families; on a soup with a density gradient it takes tiles whose lists are short and loses
@@ -464,9 +464,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
+#ifdef HAGRID_DEBUG_TRACE                      // (development builds only: the decisions of the head share, tools/build_variant.sh -DHAGRID_DEBUG_TRACE)
         if (learn_order && getenv("HAGRID_TRACE_HEAD"))
             fprintf(stderr, "[head] call %llu: sort rot %d (was %d) suggestion %d quad_head %d base %.4f x%d head %.4f x%d disabled %d\n", ctx->hint_clock, want_rot, H.lpt_rot,
                     __atomic_load_n(suggest, __ATOMIC_RELAXED), a.quad_head, H.t_base, H.n_base, H.t_head, H.n_head, int(H.head_disabled));
+#endif
         if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
@@ -483,7 +485,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     HG_HIP(ctx, hipGetLastError());
     if (publish_row_len) {                         // behind the traversal launch: nobody waits for it
         if (!H.rowlen_evt) HG_HIP(ctx, hipEventCreateWithFlags(&H.rowlen_evt, hipEventDisableTiming));
-        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox + 300 + hint_slot, ctx->dscratch + 236 + hint_slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HG_HIP(ctx, hipMemcpyAsync(ctx->mailbox + kMbxRowLen + hint_slot, ctx->dscratch + kScrRowLen + hint_slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HG_HIP(ctx, hipEventRecord(H.rowlen_evt, ctx->stream));
         H.rowlen_pending = true;
     }

@@ -380,6 +380,10 @@ __global__ void __launch_bounds__(kBlock) scan_lookback(In in, Out out, int n, i
                 // no output stored yet".  The publishes are agent-scope atomic stores of this lane; the outputs are plain stores of every thread behind the
                 // barrier below.  Waiting here until the atomics are acknowledged puts them in front of every output at the memory side.  (An agent-scope
                 // release fence in front of the outputs says the same formally and writes the L2 back per tile: +0.6 ms per construction, measured.)
+                // This is a gfx9 argument (stores and atomics are both counted by vmcnt there; gfx10+ count stores in vscnt): the library is built for gfx950 only.
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "scan_lookback: the in-place ordering relies on gfx9's vmcnt counting stores; use a release fence on this target"
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 tile_prefix = excl;
                 if (total_out && tile == tiles - 1) *total_out = excl + agg;

@@ -80,15 +80,7 @@ unsigned p_entry(unsigned a, unsigned b) { return as<unsigned>(make_entry(a, b))
                 assert L.p_lookup(p(ent), int(kat[f"lk_{tag}_shift"]), p(td), p(vox[i:i + 1])) == kat[f"lk_{tag}_out"][i]
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
-def test_reference_main_cpp_parses_against_our_headers():
-    """API-compat: the reference's own front-end, syntax-checked against include/hagrid/*.h (load_obj.h included: main.cpp
-    defines its own static load_model, which must not collide with ours).  Its SDL2 include is
-    satisfied by a declarations-only stand-in created in a temp dir (this checks OUR headers, it builds nothing)."""
-    ref = "/root/reference/src"
-    with tempfile.TemporaryDirectory() as d:
-        os.makedirs(os.path.join(d, "SDL2")); os.makedirs(os.path.join(d, "src"))
-        open(os.path.join(d, "SDL2", "SDL.h"), "w").write('''#include <cstdint>
+_SDL_DECLS = '''#include <cstdint>
 struct SDL_Surface { int w, h, pitch; void* pixels; }; struct SDL_Window;
 struct SDL_Keysym { int sym; }; struct SDL_KeyboardEvent { SDL_Keysym keysym; }; struct SDL_MouseMotionEvent { int xrel, yrel; }; struct SDL_MouseButtonEvent { int button; };
 union SDL_Event { int type; SDL_KeyboardEvent key; SDL_MouseMotionEvent motion; SDL_MouseButtonEvent button; };
@@ -97,15 +89,54 @@ enum { SDL_INIT_VIDEO=1, SDL_WINDOWPOS_UNDEFINED=0, SDL_QUIT=1, SDL_KEYDOWN, SDL
 int SDL_Init(int); SDL_Window* SDL_CreateWindow(const char*,int,int,int,int,int); SDL_Surface* SDL_GetWindowSurface(SDL_Window*);
 int SDL_PollEvent(SDL_Event*); void SDL_SetWindowTitle(SDL_Window*, const char*); int SDL_LockSurface(SDL_Surface*); void SDL_UnlockSurface(SDL_Surface*);
 int SDL_UpdateWindowSurface(SDL_Window*); void SDL_DestroyWindow(SDL_Window*); void SDL_Quit(); int SDL_SetRelativeMouseMode(int); void SDL_FlushEvents(int,int); int SDL_GetTicks();
-''')
-        # main.cpp uses quote-includes ("build.h"): put OUR headers next to a symlink of main.cpp so they win
+'''
+# the same functions with empty bodies: the object the viewer's calls resolve against at link time (nothing is run)
+_SDL_STUBS = '''#include <SDL2/SDL.h>
+int SDL_Init(int) { return -1; } SDL_Window* SDL_CreateWindow(const char*,int,int,int,int,int) { return nullptr; } SDL_Surface* SDL_GetWindowSurface(SDL_Window*) { return nullptr; }
+int SDL_PollEvent(SDL_Event*) { return 0; } void SDL_SetWindowTitle(SDL_Window*, const char*) {} int SDL_LockSurface(SDL_Surface*) { return 0; } void SDL_UnlockSurface(SDL_Surface*) {}
+int SDL_UpdateWindowSurface(SDL_Window*) { return 0; } void SDL_DestroyWindow(SDL_Window*) {} void SDL_Quit() {} int SDL_SetRelativeMouseMode(int) { return 0; } void SDL_FlushEvents(int,int) {} int SDL_GetTicks() { return 0; }
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_reference_main_cpp_compiles_and_links_against_the_library():
+    """The drop-in claim at LINK level (VERDICT r5 item 8): the reference's own front-end, main.cpp, compiled from where it lies against include/hagrid/*.h (which
+    win over the reference's headers of the same names: main.cpp uses quote includes and sits next to symlinks of ours) and LINKED with libhagrid_amd.so.  Every
+    hagrid:: function main.cpp:12-15 pulls in -- build_grid, merge_grid, flatten_grid, expand_grid, compress_grid, setup_traversal, traverse_grid, profile, the
+    MemManager members, load_obj / load_mtl -- must resolve: to the header-level shims and through them to the C ABI of the library.  SDL2 (absent here) is a
+    declarations-only header plus an object of empty functions made in a temp dir; nothing is run, nothing from the reference is copied or kept.
+    (The reference's load_obj.cpp is not part of the link: include/hagrid/load_obj.h is header-only and defines the same functions.)"""
+    import shutil
+    if not os.path.exists(os.path.join(ROOT, "hagrid_amd", "libhagrid_amd.so")):
+        pytest.skip("libhagrid_amd.so not built")
+    ref = "/root/reference/src"
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "SDL2")); os.makedirs(os.path.join(d, "src"))
+        open(os.path.join(d, "SDL2", "SDL.h"), "w").write(_SDL_DECLS)
+        open(os.path.join(d, "sdl_stubs.cpp"), "w").write(_SDL_STUBS)
         os.symlink(os.path.join(ref, "main.cpp"), os.path.join(d, "src", "main.cpp"))
         for h in os.listdir(os.path.join(INC, "hagrid")):
             os.symlink(os.path.join(INC, "hagrid", h), os.path.join(d, "src", h))
         os.symlink(os.path.join(INC, "hagrid_amd.h"), os.path.join(d, "hagrid_amd.h"))
-        r = subprocess.run(["g++", "-std=c++11", "-DHOST=", "-DDEVICE=", "-I", d, "-fsyntax-only", "main.cpp"],
-                           cwd=os.path.join(d, "src"), capture_output=True, text=True)
+        cxx = ["g++", "-std=c++11", "-O1", "-DHOST=", "-DDEVICE=", "-I", d]
+        r = subprocess.run(cxx + ["-c", "main.cpp", "-o", os.path.join(d, "main.o")], cwd=os.path.join(d, "src"), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
+        r = subprocess.run(cxx + ["-c", os.path.join(d, "sdl_stubs.cpp"), "-o", os.path.join(d, "sdl_stubs.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        # what main.o still needs from outside: every hagrid_* symbol must be one the library exports
+        need = subprocess.run(["nm", "-u", "-C", os.path.join(d, "main.o")], capture_output=True, text=True, check=True).stdout
+        have = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "hagrid_amd", "libhagrid_amd.so")], capture_output=True, text=True, check=True).stdout
+        exported = {l.split()[-1] for l in have.splitlines() if l.strip()}
+        wanted = {l.split()[-1] for l in need.splitlines() if "hagrid" in l}
+        assert wanted and all(w.startswith("hagrid_") for w in wanted), f"main.o wants C++-mangled hagrid symbols no shim defines: {sorted(wanted)}"
+        assert wanted <= exported, f"not exported by libhagrid_amd.so: {sorted(wanted - exported)}"
+        for must in ("hagrid_build_grid", "hagrid_merge_grid", "hagrid_flatten_grid", "hagrid_expand_grid", "hagrid_compress_grid", "hagrid_setup_traversal", "hagrid_traverse_grid"):
+            assert must in wanted, must
+        # and the link itself: the library's own dependency on the HIP runtime is left open (it binds to whichever libamdhip64 the process holds, hagrid_amd/build.py)
+        r = subprocess.run(["g++", os.path.join(d, "main.o"), os.path.join(d, "sdl_stubs.o"), "-o", os.path.join(d, "hagrid_ref_frontend"), "-L", os.path.join(ROOT, "hagrid_amd"),
+                            "-lhagrid_amd", "-Wl,--allow-shlib-undefined", "-lpthread"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert os.path.getsize(os.path.join(d, "hagrid_ref_frontend")) > 0
 
 
 @pytest.mark.gpu

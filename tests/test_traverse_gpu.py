@@ -556,6 +556,53 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
     grid.free(); mem.free(d_tris)
 
 
+def test_marker_ids_in_long_lists_widen_the_id_field(mem):
+    """an id that a 20-bit field cannot tell from its markers (2^20 - 4 ... 2^20 - 1; the kernels also end a list BY INDEX at id 2^20 - 1) must
+    widen the whole image to 26-bit fields wherever it occurs -- also when it occurs only in lists of more than four ids, which the general layout did not
+    look at.  A grid whose four largest ids live only in a stack of twelve triangles (the LAST one nearest to the rays): general and table layout."""
+    from oracle import oracle as O
+    n = 3000
+    base = scene.make_soup(n - 12, seed=41).copy()
+    one = base[7:8].copy()
+    one[0, 0:3] = np.float32(0.5)                                   # v0 in the middle of the scene; e1, e2, n as drawn
+    stack = np.repeat(one, 12, axis=0)
+    nrm = stack[0, [3, 7, 11]] / np.linalg.norm(stack[0, [3, 7, 11]])                      # (Tri: v0, nx | e1, ny | e2, nz)
+    for i in range(12): stack[i, 0:3] += (np.float32(2e-5 * i) * nrm).astype(np.float32)   # id i of the stack lies 2e-5 i along the normal
+    small = np.ascontiguousarray(np.concatenate([base, stack]).astype(np.float32))
+    off = (1 << 20) - n                                              # ids off ... 2^20 - 1
+    tris = np.zeros((off + n, small.shape[1]), np.float32); tris[off:] = small
+    for params, general in ((dict(top_density=0.15, snd_density=3.0), 1), ({}, 2)):
+        G = O.Grid.full(small, **params)
+        refs = G.ref_ids; refs += off
+        cells = G.cells
+        lens = (cells["end"] - cells["begin"]).astype(np.int64)
+        long_ids = np.concatenate([refs[b:e] for b, e, l in zip(cells["begin"], cells["end"], lens) if l > 4] or [np.zeros(0, np.int32)])
+        short_ids = np.concatenate([refs[b:e] for b, e, l in zip(cells["begin"], cells["end"], lens) if 0 < l <= 4] or [np.zeros(0, np.int32)])
+        assert long_ids.max() == (1 << 20) - 1 and short_ids.max() < (1 << 20) - 4, "the scene no longer isolates the case: marker ids only in lists by index"
+        d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+        # rays along the stack's normal from both sides (the nearest of the twelve is the last or the first id), plus a general batch
+        c = (small[-1, 0:3] + 0.25 * (-small[-1, 4:7] + small[-1, 8:11])).astype(np.float32)       # a point inside the triangle (v0 + (e2 - e1) / 4)
+        rng = np.random.default_rng(5)
+        k = 4096
+        org = np.concatenate([c + 0.3 * nrm + 1e-3 * rng.standard_normal((k, 3)), c - 0.3 * nrm + 1e-3 * rng.standard_normal((k, 3))]).astype(np.float32)
+        dirs = np.concatenate([np.tile(-nrm, (k, 1)), np.tile(nrm, (k, 1))]).astype(np.float32)
+        aimed = np.zeros((2 * k, 8), np.float32); aimed[:, 0:3] = org; aimed[:, 3] = 0.0; aimed[:, 4:7] = dirs; aimed[:, 7] = np.float32(3.4e38)
+        rays = np.ascontiguousarray(np.concatenate([aimed, scene.make_rays_incoherent(G.bbox_min - 0.1, G.bbox_max + 0.1, 20000, 7)]).astype(np.float32))
+        want, _ = G.traverse(tris, rays, nthreads=8)
+        assert (want["id"] == (1 << 20) - 1).any() and (want["id"] >= off).sum() > 1000
+        try:
+            mem.set_option("traverse.image_general", general)
+            for tail in (1, 0):
+                mem.set_option("traverse.tail", tail)
+                got = gpu_traverse(mem, grid, d_tris, rays)
+                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (general, tail)
+            info = mem.image_format(grid)
+            assert info["general"] == (general == 2) and info["slim_id_bits"] == 26, info
+        finally:
+            mem.set_option("traverse.image_general", 1); mem.set_option("traverse.tail", 1)
+        grid.free(); mem.free(d_tris)
+
+
 def test_general_layout_virtual_top_level_on_and_off(mem):
     """The general layout's virtual top level ("traverse.image_vtop", trav_image.hip image_general_vtop: eight records per top-level cell, where look-ups that left
     their block start again) only shortens the walk: with it and without it every kernel gives the oracle's hits, and every voxel resolves to its cell."""
