@@ -134,6 +134,10 @@ struct hagrid_ctx {
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[kMbxOrderStale + i],
         // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
         int lpt_epoch = 1 /* never 0: the pinned report word starts as 0 and is reset to -1 */, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
+        // the share trial of launches in the default order (traverse.hip "traverse.share_trial"): [0] the rule's share of tiles with four lanes per ray, [1] a half
+        hipEvent_t share_evt[2] = {nullptr, nullptr}; bool share_pending = false; int share_pending_cand = 0, share_n[2] = {0, 0}, share_choice = -1 /* -1: being measured */,
+            share_last = -1 /* the answer before this trial */, share_launches = 0; float share_t[2] = {0.0f, 0.0f}; unsigned share_serial = 0 /* ctx->image_serial the answer belongs to */;
+        bool moving = false; int moving_since = 0, still = 0, last_report = -1;       // MOVING mode (traverse.hip): the rays change from launch to launch -- sorted behind every launch; epoch at which the mode began, launches without a report, the report word as last seen
         unsigned long long used = 0;                    // clock of the last call that used the slot
     };
     static constexpr int kRayHints = 4;
@@ -146,6 +150,8 @@ struct hagrid_ctx {
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
     int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
     int opt_tile_order_rounds_incoherent = 1000;   // ... and up to this many for rays in image order without coherent directions (rows found from the origins alone)
+    int opt_share_trial = 1;            // launches in the default order: the share of tiles that start with four lanes per ray measures itself (the rule's share against a half); 0: the rule
+    int opt_order_moving = 0;           // ... rays that change from launch to launch (a moving camera): 1 = the order is sorted again behind every launch from the costs of that launch (pays below ~2 pixels of drift per frame only: NOTES round 6); 0 = no order for a while
     int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch
@@ -156,6 +162,7 @@ struct hagrid_ctx {
     int opt_id_is_steps = 0;    // hagrid_traverse_grid writes the reference kernel's step count into Hit.id (traverse.cu:93) instead of the primitive id
 
     hagrid_impl::TravImageCache image;
+    unsigned image_serial = 0;           // counts the traversal images this context has built (what is measured per launch shape belongs to one of them)
     int readback_epoch = 0;               // read_back (ctx.hip): the epoch the publishing wavefront leaves behind the words in the mailbox (word 310)
     int opt_fast_readback = 1;            // scalar read-backs through a publishing wavefront and a spinning host instead of hipMemcpyAsync + hipStreamSynchronize
     int build_arena_tris = 0;             // ... and the primitives of that construction

@@ -71,6 +71,11 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "ctx.fast_readback"  1 (default) = scalar read-backs through a publishing wavefront and a spinning host, 0 = hipMemcpyAsync + hipStreamSynchronize */
 int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 
+/* What the context remembers about the ray buffer `rays` (traverse.hip, RayHints): out12 = { slot or -1, order valid, moving mode, positions the order is rotated by (the
+ * four-lanes-per-ray head), head share dropped by its trial, timed samples without / with the head, the share trial's choice (-1 measuring, 0 rule, 1 half), its samples (rule + 100 x half), cooldown, epoch, launches since the choice };
+ * ms4 = the head trial's best launch times without / with the head, the share trial's with the rule's share / with a half.  Dev tools and tests only: nothing in the product reads it. */
+int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t* out12, float* ms4);
+
 #ifdef __cplusplus
 }
 #endif

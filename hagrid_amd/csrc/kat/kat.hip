@@ -282,7 +282,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 1, 2},
-        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.tri_pad", &ctx->opt_tri_pad, -1, 1}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
+        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.order_moving", &ctx->opt_order_moving, 0, 1}, {"traverse.share_trial", &ctx->opt_share_trial, 0, 1}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.tri_pad", &ctx->opt_tri_pad, -1, 1}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
         {"merge.inplace", &ctx->opt_merge_inplace, 0, 1},           {"merge.inplace_iters", &ctx->opt_merge_inplace_iters, 0, 1 << 20}, {"merge.inplace_room", &ctx->opt_merge_inplace_room, 0, 0x7fffffff}, {"merge.inplace_div", &ctx->opt_merge_inplace_div, 0, 1 << 20},
         {"expand.voxel_map", &ctx->opt_expand_voxel_map, 0, 1},      {"traverse.refill", &ctx->opt_refill, -1, 64},
     };
@@ -293,4 +293,19 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
             return HAGRID_OK;
         }
     return hagrid_set_option(ctx, key, value);              // the product's own options
+}
+
+extern "C" int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t* out12, float* ms2 /* 4 floats */) {
+    if (!ctx || !out12) return HAGRID_EINVAL;
+    for (int i = 0; i < 12; i++) out12[i] = 0;
+    out12[0] = -1;
+    for (int i = 0; i < hagrid_ctx::kRayHints; i++) {
+        const hagrid_ctx::RayHints& h = ctx->hints[i];
+        if (h.key_rays != rays) continue;
+        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice, h.share_n[0] + 100 * h.share_n[1], h.cooldown, h.lpt_epoch, h.share_launches};
+        for (int k = 0; k < 12; k++) out12[k] = v[k];
+        if (ms2) { ms2[0] = h.t_base; ms2[1] = h.t_head; ms2[2] = h.share_t[0]; ms2[3] = h.share_t[1]; }
+        return HAGRID_OK;
+    }
+    return HAGRID_OK;
 }

@@ -568,6 +568,7 @@ int hagrid_impl::trav_image_build(hagrid_ctx* ctx, const hagrid_grid* g) {
         }
     }
     ctx->image = img;
+    ctx->image_serial++;
     return HAGRID_OK;
 }
 

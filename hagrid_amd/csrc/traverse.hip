@@ -206,7 +206,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = 0.0f; N.n_base = N.n_head = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = 0.0f; N.n_base = N.n_head = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -215,7 +215,9 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
             N.rows_from_origins = false;
+            N.share_choice = -1; N.share_last = -1; N.share_n[0] = N.share_n[1] = 0; N.share_pending = false; N.share_launches = 0; N.share_serial = ctx->image_serial;
             if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
+            if (donor && donor->share_serial == ctx->image_serial) { N.share_choice = donor->share_choice; N.share_last = donor->share_choice >= 0 ? donor->share_choice : donor->share_last; N.share_launches = donor->share_launches; }
         }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
     }
@@ -327,19 +329,30 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             if (H.cooldown > 0) H.cooldown--;              // orders did not last on this buffer (a camera that moves fast): not learned for a while
             else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
                 int* report = ctx->mailbox + kMbxOrderStale + hint_slot;
-                if (H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles && __atomic_load_n(report, __ATOMIC_ACQUIRE) == H.lpt_epoch) {
-                    // A launch since the last sort found other rays in the buffer than the order was learned on (its first wavefront reported it): learn
-                    // again, from costs of the new rays only.  An order costs about a third of a launch to get (the launch that follows the stale one, the cost
-                    // bookkeeping of the launch that learns, two sorts) and returns about a sixth per launch it is followed: one that was stale within four launches
-                    // of the last time that happened was not worth it -- the rays change every launch (a moving camera) -- and the buffer gets no order for 64
-                    // launches, for twice as many every time that happens again before an order has lasted through a refresh (up to 1024).  (Round 4 gave up after
-                    // three such orders in a row that lasted fewer than eight launches: a camera at the viewer's speed then paid for nine launches of learning,
-                    // 0.192 against 0.184 ms per frame over its first 32 frames.)  A buffer refilled every 8th launch keeps its orders: they last six launches.
+                // What the launches since the last look reported (their first wavefront compares the sample ray the order was sorted with against the buffer, bit for bit,
+                // and leaves the order's epoch when the buffer holds other rays).  A static order: a report that names it.  A buffer in MOVING mode (below) is sorted
+                // behind every launch, so the report of launch N names the epoch of the sort behind launch N - 1: any new report since the mode began counts.
+                const int rep = __atomic_load_n(report, __ATOMIC_ACQUIRE);
+                const bool new_report = rep != H.last_report && rep > 0;
+                H.last_report = rep;
+                const bool same_buffer = H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles;
+                if (same_buffer && H.moving) {
+                    // the rays change from launch to launch (a camera that moves: the reference's viewer, main.cpp:591-601).  The costs of frame N are the best there is
+                    // for frame N + 1 -- its longest rays have drifted by a pixel, not by a tile -- so the order is sorted again behind EVERY launch and followed by the
+                    // next one whatever the sample says; the reports only tell when the rays have stopped changing (none for four launches: a static order again).
+                    if (new_report && rep > H.moving_since && rep <= H.lpt_epoch) H.still = 0;
+                    else if (++H.still >= 4) { H.moving = false; H.lpt_age = 0; H.lpt_period = 32; }
+                } else if (same_buffer && new_report && rep == H.lpt_epoch) {
+                    // A launch since the last sort found other rays in the buffer than the order was learned on: learn again, from costs of the new rays only (the
+                    // cost words hold the maximum over the launches since the last sort).  Rays that changed once (a buffer refilled now and then) get a static order
+                    // again; rays that change again within four launches of the last time are a camera that moves: MOVING mode ("traverse.order_moving" = 0: round 5's
+                    // answer -- no order for 64 launches, for twice as many every time that happens again, up to 1024).
                     const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
                     H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
-                    if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
+                    if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
+                    else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
                 if (H.cooldown > 0) { /* this launch and the next ones: default order, no costs */ }
                 else {
@@ -364,7 +377,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 if (H.lpt_valid) { a.tile_order = H.lpt_buf + H.lpt_cap; a.order_samples = ctx->opt_order_gate ? tile_order_samples(H) : nullptr; a.order_report = report; a.order_epoch = H.lpt_epoch; }
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
-                learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
+                learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period || H.moving;
                 if (H.lpt_valid && learn_order && H.lpt_period >= 32) H.cooldown_len = 64;       // an order that lasted through a refresh period
                 }
             }
@@ -385,6 +398,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                                          : ctx->opt_mailbox;
         if (a.mailbox) a.tail_dual = 0;
         int quad_pct = ctx->opt_quad_tail;
+        int share_cand = 0; bool share_timed = false;             // the share trial of launches in the default order (below)
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
             const bool shared = ctx->image.alive && ctx->image.alive.use_count() > 1;
@@ -393,6 +407,33 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // in a learned tile order the tiles with the longest rays come first: all tiles of a launch of up to one round start with four lanes
             // per ray (256^2 ... 960 x 540: -8 ... -23 % against the shares above in the default order), none of a larger one
             if (a.tile_order && !shared) quad_pct = r100 <= 100 ? 100 : 0;
+            // "traverse.share_trial" (round 6): in the DEFAULT order -- the first launches over a buffer, every launch of a camera that moves -- the share measures itself.
+            // The rule above was fitted on the uniform soup; a scene with a few dense objects wants HALF of its tiles with four lanes per ray at sizes where the soup wants
+            // a quarter or none (six blobs in a sparse soup, back to back: 1024^2 0.259 -> 0.180 ms, 1280 x 720 0.183 -> 0.141, 1920 x 1080 0.277 -> 0.211; a sphere shell
+            // 1024^2 0.178 -> 0.165; the soup 0.165 -> 0.193, a density gradient 0.177 -> 0.195: gpurun_out/r6c), and nothing the host knows about a grid tells the two
+            // apart -- an event pair around the kernel does (polled by later calls, nobody waits): three samples with the rule's share and three with a half, taken in
+            // turn (a camera that moves changes the image from sample to sample: in turn, the drift cancels), the smaller of each compared; the half is kept if it is 3 %
+            // faster, until the next trial 512 launches later.  What is measured depends on the scene and the launch shape, not on the rays: a buffer of the same shape
+            // the context knows starts with that buffer's answer.  Launches of 0.65 to 10 rounds (below, the rule already takes half or all; beyond, four lanes per ray
+            // lose everywhere measured).
+            const bool trial_ok = ctx->opt_share_trial && !a.tile_order && !perm && !shared && ctx->opt_tail && !flags && narrow && refill_k <= 1 && a.row_len && r100 > 65 && r100 <= 1000;
+            if (trial_ok) {
+                if (H.share_serial != ctx->image_serial) { H.share_serial = ctx->image_serial; H.share_choice = -1; H.share_n[0] = H.share_n[1] = 0; H.share_pending = false; }   // (another grid)
+                if (H.share_pending && hipEventQuery(H.share_evt[1]) == hipSuccess) {
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, H.share_evt[0], H.share_evt[1]) == hipSuccess && ms > 0.0f) {
+                        const int c = H.share_pending_cand;
+                        H.share_t[c] = H.share_n[c] ? std::min(H.share_t[c], ms) : ms; H.share_n[c]++;
+                    }
+                    H.share_pending = false;
+                    if (H.share_choice < 0 && H.share_n[0] >= 3 && H.share_n[1] >= 3) { H.share_choice = H.share_t[1] < 0.97f * H.share_t[0] ? 1 : 0; H.share_last = H.share_choice; H.share_launches = 0; }
+                } else if (H.share_pending) (void)hipGetLastError();          // not ready yet: not an error
+                if (H.share_choice >= 0 && ++H.share_launches >= 512) { H.share_choice = -1; H.share_n[0] = H.share_n[1] = 0; }      // (the scene in view may have changed: measured again)
+                if (H.share_choice >= 0) share_cand = H.share_choice;
+                else if (!H.share_pending) { share_cand = H.share_n[1] < H.share_n[0] ? 1 : 0; share_timed = true; }
+                else share_cand = H.share_last >= 0 ? H.share_last : 0;        // (a sample is still in flight: the last answer, else the rule)
+                if (share_cand == 1) quad_pct = 50;
+            }
         }
         // "traverse.quad_head": in a learned order of a launch of MORE than one round the tiles that cost several times the median tile -- the chains the launch is as
         // long as, where a scene has a few dense objects -- start with four lanes per ray, and first.  The sort counts them (a pinned word the host polls), the NEXT sort
@@ -454,22 +495,27 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
         // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
-        const bool timed = head_ok && a.tile_order && !learn_order && !H.trial_pending && !H.head_disabled && H.lpt_age >= 2 &&
+        const bool timed = head_ok && a.tile_order && (!learn_order || H.moving) && !H.trial_pending && !H.head_disabled && (H.lpt_age >= 2 || H.moving) &&
                            (a.quad_head ? H.n_head < 3 : H.n_base < 3) && ctx->opt_quad_head > 0;
         if (timed) {
             for (auto& e : H.trial_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
             HG_HIP(ctx, hipEventRecord(H.trial_evt[0], ctx->stream));
         }
+        if (share_timed) {
+            for (auto& e : H.share_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
+            HG_HIP(ctx, hipEventRecord(H.share_evt[0], ctx->stream));
+        }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; }
+        if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[1], ctx->stream)); H.share_pending = true; H.share_pending_cand = share_cand; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
 #ifdef HAGRID_DEBUG_TRACE                      // (development builds only: the decisions of the head share, tools/build_variant.sh -DHAGRID_DEBUG_TRACE)
         if (learn_order && getenv("HAGRID_TRACE_HEAD"))
             fprintf(stderr, "[head] call %llu: sort rot %d (was %d) suggestion %d quad_head %d base %.4f x%d head %.4f x%d disabled %d\n", ctx->hint_clock, want_rot, H.lpt_rot,
                     __atomic_load_n(suggest, __ATOMIC_RELAXED), a.quad_head, H.t_base, H.n_base, H.t_head, H.n_head, int(H.head_disabled));
 #endif
-        if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
+        if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = (H.lpt_valid && !H.moving) ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
     } else {

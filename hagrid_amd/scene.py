@@ -111,6 +111,116 @@ def make_shell(num_tris: int = 1_000_000, seed: int | None = None) -> np.ndarray
     return tris_from_vertices(v0.astype(np.float32), (v0 + e1).astype(np.float32), (v0 + e2).astype(np.float32))
 
 
+def _sincos_turns(turns: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """sin and cos of 2 pi * turns in float64 from + and x only (octant reduction, Taylor series): any machine produces identical bits (no libm)."""
+    t = np.asarray(turns, np.float64); t = t - np.floor(t)
+    q = np.floor(t * 8.0 + 0.5)                       # nearest multiple of an eighth turn
+    x = (t - q / 8.0) * 6.283185307179586             # |x| <= pi / 8
+    x2 = x * x
+    s = x * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800 + x2 * (1.0 / 6227020800)))))))
+    c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600 + x2 * (-1.0 / 87178291200)))))))
+    r = 0.7071067811865476
+    sq = np.array([0.0, r, 1.0, r, 0.0, -r, -1.0, -r])[q.astype(np.int64) % 8]; cq = np.array([1.0, r, 0.0, -r, -1.0, -r, 0.0, r])[q.astype(np.int64) % 8]
+    return sq * c + cq * s, cq * c - sq * s
+
+
+def _grid_faces(nu: int, nv: int, wrap_u: bool, wrap_v: bool, base: int) -> np.ndarray:
+    """two triangles per quad of an nu x nv vertex lattice (vertex (i, j) = base + i * nv + j), wrapping where asked: shared vertices, no duplicates"""
+    iu = np.arange(nu if wrap_u else nu - 1); jv = np.arange(nv if wrap_v else nv - 1)
+    i, j = np.meshgrid(iu, jv, indexing="ij"); i = i.ravel(); j = j.ravel()
+    i1 = (i + 1) % nu; j1 = (j + 1) % nv
+    a = base + i * nv + j; b = base + i1 * nv + j; c = base + i1 * nv + j1; d = base + i * nv + j1
+    return np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.int32)
+
+
+def make_stadium_mesh(detail: float = 1.0) -> tuple[np.ndarray, np.ndarray]:
+    """"Teapot in a stadium" (the reference README's own motivation, README.md:5-12) as an INDEXED mesh: finely tessellated connected surfaces -- tori and
+    spheres with shared vertices, a grain of dust among them -- inside a hall of ten huge triangles, with terraces of long thin ones and pillars of slivers as
+    high as the hall.  With detail = 1: ~0.96M triangles whose edges span four orders of magnitude (1.0 ... 1e-4).  Returns (vertices float32 [nv, 3], faces
+    int32 [nf, 3], zero-based); write_obj() / tris_from_mesh() take it from there.  `detail` scales the tessellation (tests use small ones)."""
+    V = []; F = []; nvert = 0
+
+    def add(verts, faces):
+        nonlocal nvert
+        V.append(np.asarray(verts, np.float64)); F.append(np.asarray(faces, np.int32)); nvert += len(verts)
+
+    # the hall: floor, ceiling, two side walls, back wall of the unit cube (open towards the camera at -z): 8 shared corners, 10 triangles of edge 1
+    corners = [[x, y, z] for z in (0.0, 1.0) for y in (0.0, 1.0) for x in (0.0, 1.0)]
+    quads = [(0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5), (4, 5, 7, 6)]
+    add(corners, [[nvert + q[0], nvert + q[1], nvert + q[2]] for q in quads] + [[nvert + q[0], nvert + q[2], nvert + q[3]] for q in quads])
+    # terraces along the back wall: a staircase profile swept across x (treads and risers 0.9 long, 0.03 deep)
+    steps = 12
+    prof = [(0.0 + 0.03 * ((k + 1) // 2), 0.97 - 0.03 * (k // 2)) for k in range(2 * steps + 1)]          # (y, z) of the profile's corners
+    tv = [[x, y, z] for (y, z) in prof for x in (0.05, 0.95)]
+    add(tv, _grid_faces(len(prof), 2, False, False, nvert))
+    # pillars: coarse cylinders from floor to ceiling, 16 segments: slivers 1.0 high and 0.004 wide
+    for k in range(8):
+        cx, cz = (0.12 if k % 2 == 0 else 0.88), 0.15 + 0.2 * (k // 2)
+        sn, cs = _sincos_turns(np.arange(16) / 16.0)
+        ring = [[cx + 0.01 * c, y, cz + 0.01 * s_] for c, s_ in zip(cs, sn) for y in (0.0, 1.0)]
+        add(ring, _grid_faces(16, 2, True, False, nvert))
+
+    def torus(centre, R, r, nu, nv, tilt):
+        u = np.arange(nu) / nu; v = np.arange(nv) / nv
+        su, cu = _sincos_turns(u); sv, cv = _sincos_turns(v); st, ct = _sincos_turns(np.array([tilt]))
+        x = (R + r * cv[None, :]) * cu[:, None]; z = (R + r * cv[None, :]) * su[:, None]; y = np.broadcast_to(r * sv[None, :], x.shape)
+        y2 = y * ct[0] - z * st[0]; z2 = y * st[0] + z * ct[0]                                   # tilted about the x axis
+        add(np.stack([x + centre[0], y2 + centre[1], z2 + centre[2]], -1).reshape(-1, 3), _grid_faces(nu, nv, True, True, nvert))
+
+    def sphere(centre, r, nu, nv):
+        # nu meridians x (nv - 1) rings between two pole vertices (fans at the poles: no degenerate triangles)
+        u = np.arange(nu) / nu; lat = np.arange(1, nv) / (2.0 * nv)                              # turns from the north pole, (0, 1/2)
+        su, cu = _sincos_turns(u); sl, cl = _sincos_turns(lat)
+        x = r * sl[None, :] * cu[:, None]; z = r * sl[None, :] * su[:, None]; y = np.broadcast_to(r * cl[None, :], x.shape)
+        base = nvert
+        body = np.stack([x + centre[0], y + centre[1], z + centre[2]], -1).reshape(-1, 3)
+        faces = _grid_faces(nu, nv - 1, True, False, base)
+        north, south = base + nu * (nv - 1), base + nu * (nv - 1) + 1
+        i = np.arange(nu); i1 = (i + 1) % nu
+        fans = np.concatenate([np.stack([np.full(nu, north), base + i1 * (nv - 1), base + i * (nv - 1)], 1),
+                               np.stack([np.full(nu, south), base + i * (nv - 1) + nv - 2, base + i1 * (nv - 1) + nv - 2], 1)]).astype(np.int32)
+        add(np.concatenate([body, [[centre[0], centre[1] + r, centre[2]], [centre[0], centre[1] - r, centre[2]]]]), np.concatenate([faces, fans]))
+
+    d = lambda n: max(8, int(round(n * detail)))
+    for k, (c, tilt) in enumerate([((0.30, 0.12, 0.35), 0.0), ((0.68, 0.15, 0.40), 0.07), ((0.45, 0.30, 0.62), 0.19), ((0.60, 0.10, 0.25), 0.31)]):
+        torus(c, 0.08, 0.03, d(400), d(200), tilt)                                               # 4 x 160k triangles, edge ~1.3e-3
+    for c in ((0.40, 0.06, 0.20), (0.75, 0.30, 0.65), (0.22, 0.25, 0.55)):
+        sphere(c, 0.05, d(300), d(150))                                                          # 3 x 90k, edge ~1e-3
+    sphere((0.50, 0.02, 0.30), 0.004, d(200), d(100))                                            # a grain of dust: 40k triangles, edge ~1e-4
+    for c in ((0.2, 0.8, 0.5), (0.5, 0.85, 0.7), (0.8, 0.8, 0.45)):
+        sphere(c, 0.1, 16, 8)                                                                    # lamps: coarse, edge ~0.04
+    return np.concatenate(V).astype(np.float32), np.concatenate(F).astype(np.int32)
+
+
+def tris_from_mesh(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """the triangles of an indexed mesh as main.cpp:259-267 packs them (v0, e1 = v0 - v1, e2 = v2 - v0, n)"""
+    return np.ascontiguousarray(tris_from_vertices(verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]))
+
+
+def make_stadium(detail: float = 1.0) -> np.ndarray:
+    """the triangles of make_stadium_mesh(), in face order"""
+    return tris_from_mesh(*make_stadium_mesh(detail))
+
+
+def write_obj(path: str, verts: np.ndarray, faces: np.ndarray, mixed_forms: bool = True) -> None:
+    """An indexed mesh as a Wavefront OBJ file the reference's loader reads (load_obj.cpp:78-239): vertices with nine significant digits (a float32 survives the
+    round trip), one-based faces; with mixed_forms every third face is written as v/vt/vn and every third with negative indices."""
+    nv = verts.shape[0]
+    with open(path, "w") as f:
+        f.write("# hagrid_amd.scene.write_obj\nvt 0 0\nvn 0 0 1\n")
+        f.write("".join("v %.9g %.9g %.9g\n" % (float(x), float(y), float(z)) for x, y, z in verts.astype(np.float64)))
+        a = faces.astype(np.int64) + 1
+        lines = []
+        for k in range(0, a.shape[0], 1 << 16):
+            blk = a[k:k + (1 << 16)]
+            for i, (p, q, r) in enumerate(blk, start=k):
+                m = i % 3 if mixed_forms else 0
+                if m == 0: lines.append("f %d %d %d\n" % (p, q, r))
+                elif m == 1: lines.append("f %d/1/1 %d/1/1 %d/1/1\n" % (p, q, r))
+                else: lines.append("f %d %d %d\n" % (p - nv - 1, q - nv - 1, r - nv - 1))
+            f.write("".join(lines)); lines = []
+
+
 def make_rays_aimed(bbox_min, bbox_max, num_rays: int, seed: int, first: int = 0) -> np.ndarray:
     """Incoherent origins (make_rays_incoherent) with directions towards the blobs of make_clustered, with some spread: ray i aims at blob i % 6.  The rays
     that end inside the dense parts of a very non-uniform scene (bench.py --config clustered --rays aimed; tests/test_fullsize_gpu.py)."""

@@ -6,7 +6,11 @@ order at its defaults and in the default order (traverse.tile_order = 0), frames
 viewer's speed (the give-up period of orders that do not last doubles: what a camera that keeps moving pays in the long run); then a buffer REFILLED
 with another image every 8th frame.
 
-usage: python tools/dev_moving_camera.py [--width 1024] [--frames 48] [--speeds 0,0.1,0.25,0.5,1,2] [--long 400]"""
+Round 6: `--scene soup|clustered|gradient|shell|stadium`, and a third policy next to "order" (the defaults: rays that keep changing are sorted again behind every
+launch, MOVING mode) and "default_order": "order_r5" = traverse.order_moving 0, round 5's answer (no order for a while).  Every loop also returns a checksum of
+the last frame's hits: the policies must agree.
+
+usage: python tools/dev_moving_camera.py [--scene soup] [--width 1024] [--frames 48] [--speeds 0,0.1,0.25,0.5,1,2] [--long 400]"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +20,10 @@ arg = lambda name, default: (sys.argv[sys.argv.index(name) + 1] if name in sys.a
 W = int(arg("--width", "1024")); frames = int(arg("--frames", "48")); long_frames = int(arg("--long", "0"))
 speeds = [float(v) for v in arg("--speeds", "0,0.1,0.25,0.5,1,2").split(",")]
 mem = api.MemManager(keep=True)
-tris = scene.make_soup(1_000_000); d_tris = mem.upload(tris)
+SCENE = arg("--scene", "soup")
+tris = {"soup": lambda: scene.make_soup(1_000_000), "clustered": scene.make_clustered, "gradient": scene.make_gradient, "shell": scene.make_shell,
+        "stadium": getattr(scene, "make_stadium", None)}[SCENE]()
+d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, tris.shape[0]); api.setup_traversal(grid)
 n = W * W
 d_rays = mem.alloc(32 * n); d_hits = mem.alloc(16 * n)
@@ -35,7 +42,15 @@ def loop(speed, refill_every=0):
             rays = np.ascontiguousarray(rays.reshape(W, W, 8)[::-1].reshape(n, 8))          # another image: flipped top to bottom
         mem.copy_h2d(d_rays, rays)
         ms.append(api.profile(lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n), mem))
+    global last_sum
+    h = mem.download(d_hits, api.HIT_DTYPE, n)
+    last_sum = int(h["id"].astype(np.int64).sum()) ^ int(h["t"].view(np.uint32).astype(np.int64).sum())
     return ms
+
+
+POLICIES = [("order", {"traverse.tile_order": -1, "traverse.order_moving": 1}), ("order_r5", {"traverse.tile_order": -1, "traverse.order_moving": 0}),
+            ("default_order", {"traverse.tile_order": 0})]
+last_sum = 0
 
 
 def settle():
@@ -46,15 +61,18 @@ def settle():
 
 for speed in speeds:
     row = {"speed": speed, "turn_rad_per_frame": 0.005 * speed, "strafe_diag_per_frame": 0.005 * speed}
-    for label, opts in [("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})]:
+    sums = set()
+    for label, opts in POLICIES:
         for k, v in opts.items(): mem.set_option(k, v)
         settle()
         ms = loop(speed)
         row[label] = {"mean_ms": round(float(np.mean(ms[8:])), 4), "first8": round(float(np.mean(ms[:8])), 4)}
+        sums.add(last_sum)
+    row["hits_agree"] = len(sums) == 1
     print(json.dumps(row), flush=True)
 if long_frames:
     row = {"viewer speed, frames": long_frames}
-    for label, opts in [("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})]:
+    for label, opts in POLICIES:
         for k, v in opts.items(): mem.set_option(k, v)
         settle()
         frames, keep = long_frames, frames
@@ -63,7 +81,7 @@ if long_frames:
         row[label] = {"mean_ms": round(float(np.mean(ms)), 4), "frames 1-16": round(float(np.mean(ms[:16])), 4), "frames 17-80": round(float(np.mean(ms[16:80])), 4),
                       "after 80": round(float(np.mean(ms[80:])), 4) if len(ms) > 80 else None}
     print(json.dumps(row), flush=True)
-for label, opts in (("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})):
+for label, opts in POLICIES:
     for k, v in opts.items(): mem.set_option(k, v)
     settle()
     ms = loop(0.0, refill_every=8)

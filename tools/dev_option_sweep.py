@@ -22,6 +22,7 @@ def other_scene(name):
     if name == "clustered2": return scene.make_clustered(400000, 2, 300000)               # two large blobs in a denser soup
     if name == "gradient": return scene.make_gradient()
     if name == "shell": return scene.make_shell()
+    if name == "stadium": return scene.make_stadium()
     raise SystemExit("unknown SCENE " + name)
 tris = other_scene(os.environ["SCENE"]) if os.environ.get("SCENE") else scene.make_soup(1_000_000); d_tris = mem.upload(tris)          # (SCENE=clustered: the non-uniform scene of bench.py --config clustered)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
