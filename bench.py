@@ -114,8 +114,13 @@ CONFIGS = {
     # sparse soup, grid shift 6 -- `--config clustered`; `--rays aimed`: 1M incoherent rays aimed at the blobs
     6: dict(baseline="(extension, not in BASELINE.json) clustered 1M-triangle scene (scene.make_clustered: six dense blobs in a sparse soup, six-level voxel map), 1M primary rays",
             tris=1_000_000, scene="clustered", rays="primary", width=1024, height=1024, scaling="weak", params={}),
+    # a MESH-shaped scene through the front-end's own triangle packing: scene.make_stadium -- tori and spheres with shared vertices and a grain of
+    # dust inside a hall of ten huge triangles, edges over four orders of magnitude ("teapot in a stadium", the reference README's motivation) -- `--config stadium`
+    7: dict(baseline="(extension, not in BASELINE.json) stadium: a 0.95M-triangle indexed mesh (scene.make_stadium: finely tessellated tori / spheres / a grain of dust inside a hall "
+                     "of ten huge triangles, edges 1.4 ... 1.3e-4; six-level voxel map, lists of up to hundreds of references), 1M primary rays",
+            tris=948_786, scene="stadium", rays="primary", width=1024, height=1024, scaling="weak", params={}),
 }
-CONFIG_NAMES = {"clustered": 6}
+CONFIG_NAMES = {"clustered": 6, "stadium": 7}
 
 
 def log(*a):
@@ -142,7 +147,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=lambda v: CONFIG_NAMES.get(v) or int(v), default=2, choices=sorted(CONFIGS),
-                    help="BASELINE.md configuration (config C = BASELINE.json configs[C - 1]); `clustered` (= 6): the non-uniform scene, an extension")
+                    help="BASELINE.md configuration (config C = BASELINE.json configs[C - 1]); extensions: `clustered` (= 6), the non-uniform soup; `stadium` (= 7), a mesh-shaped scene")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak for config 2, strong (one batch sharded over the ranks) for 3-5")
     ap.add_argument("--tris", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -236,9 +241,9 @@ def main():
     d_tris = 0
     t_bcast = 0.0
     tris_host = None
-    clustered = cfg.get("scene") == "clustered"
+    clustered = cfg.get("scene") == "clustered"; stadium = cfg.get("scene") == "stadium"
     if rank == 0 or ray_kind == "bounce":
-        tris_host = scene.make_clustered() if clustered else scene.make_soup(n_tris)             # bounce rays need the hit triangles' normals on every rank
+        tris_host = scene.make_clustered() if clustered else (scene.make_stadium() if stadium else scene.make_soup(n_tris))    # bounce rays need the hit triangles' normals on every rank
         n_tris = tris_host.shape[0]
     if rank == 0:
         d_tris = mem.upload(tris_host)
@@ -370,6 +375,12 @@ def main():
             mem.set_option("traverse.tile_order", 0)
             for _ in range(max(args.warmup, 1)):
                 api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
+            # (settled like the timed region: launches in this order for --settle-ms first, synchronised now and then as a renderer's frames are -- the share of tiles that
+            # start with four lanes per ray measures itself over the first launches in this order, and the host only learns a sample's time once it looks again)
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+                for _ in range(10): api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays)
+                mem.synchronize()
             ms0 = api.profile(lambda: [api.traverse_grid(grid, d_tris, d_rays, d_hits, n_rays) for _ in range(args.steps)], mem) / args.steps
             hits0 = mem.download(d_hits, api.HIT_DTYPE, n_head)
             tile_order = {"ms_per_step_default_order": round(ms0, 5),
@@ -379,7 +390,9 @@ def main():
                           (hits0["t"].view(np.uint32) == hits["t"].view(np.uint32)).all()),
                           "how": "`value` is the steady state of a renderer's loop: tiles dispatched longest first, by the costs the previous launches over the same ray "
                                  "buffer left (learned in the warm-up steps, refreshed every 32nd launch); ms_per_step_default_order = the "
-                                 "same K steps with traverse.tile_order = 0, i.e. what the first launch over a new buffer costs.  Hits do not depend on the order"}
+                                 "same K steps with traverse.tile_order = 0: launches in the default order, as the first launches over a new buffer and every launch of a camera that moves run "
+                                 "(in that order the share of tiles that start with four lanes per ray measures itself over the first launches: the rule's share against a half; "
+                                 "the very first launch runs with the rule's).  Hits do not depend on the order"}
             # A frame loop with a MOVING camera (the reference's viewer, main.cpp:597-603: new rays into the same buffer every frame): per frame the
             # view turns by 0.005 rad and the eye moves sideways by 0.005 scene diagonals -- one mouse pixel and one key event of that viewer --
             # and a quarter of that; the host synchronises per frame.  The order is followed only while the buffer's rays are near the ones it was
@@ -410,7 +423,8 @@ def main():
                     "viewer_speed": pair(1.0), "quarter_speed": pair(0.25), "frozen": pair(0.0), "refilled_every_8th_frame": pair(0.0, refill=8),
                     "how": "mean traversal ms (HIP events) of frames 9-32 of a loop that writes each frame's rays into the one ray buffer and synchronises per frame, two loops per "
                            "policy in turn; viewer speed = 0.005 rad turn + 0.005 scene diagonals sideways per frame (main.cpp:579-586: one mouse pixel, one key event).  An order that is "
-                           "stale again within four launches is given up at once (64 launches without, doubling): a moving camera runs in the default order"}
+                           "stale again within four launches is given up at once (64 launches without, doubling): a moving camera runs in the default order, with the share of "
+                           "tiles that start with four lanes per ray chosen by measurement (traverse.hip, share trial); the default_order loops run the same trial"}
                 mem.copy_h2d(d_rays, scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, eye_dist=args.eye_dist))      # the batch of the line again
         except Exception as e:                                       # (an option the library does not know: older build)
             log(f"[bench] tile order block skipped: {e}")
@@ -509,7 +523,7 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[{args.config - 1}]: " if args.config <= 5 else "") + f"{cfg['baseline']} -- {'clustered' if clustered else 'soup'}-{n_tris} triangles, "
+            "config": {"workload": (f"BASELINE.json configs[{args.config - 1}]: " if args.config <= 5 else "") + f"{cfg['baseline']} -- {'clustered' if clustered else ('stadium' if stadium else 'soup')}-{n_tris} triangles, "
                                    + (f"{ray_kind} rays, {total} in the batch" + (f" ({width}x{height})" if ray_kind not in ("incoherent", "aimed") else ""))
                                    + (f", rays [{first}, {first + n_rays}) = the share of rank {shard[0]} of {shard[1]}, on ONE GPU" if shard else f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),

@@ -235,6 +235,14 @@ class Grid:
         return d
 
     @staticmethod
+    def load(mem: MemManager, path: str) -> tuple["Grid", int, int]:
+        """A grid file written by hagrid_grid_save (hagrid_cli --save-grid): (grid, device pointer of its triangles, their number)."""
+        g = Grid(); g.mem = mem
+        tris = C.c_void_p(); n = C.c_int32()
+        _check(mem, mem._L.hagrid_grid_load(mem._ctx, path.encode(), C.byref(g.pod), C.byref(tris), C.byref(n)), "grid_load")
+        return g, tris.value, n.value
+
+    @staticmethod
     def upload(mem: MemManager, entries, ref_ids, cells, small_cells, bbox_min, bbox_max, dims, shift, offsets) -> "Grid":
         """Assemble a device grid from host arrays (fixtures, the broadcast blob of dist.py)."""
         g = Grid(); g.mem = mem

@@ -128,14 +128,15 @@ struct hagrid_ctx {
         // the head share measures itself: launches in the learned order are timed (an event pair around the kernel, polled by later calls) without it and with it --
         // three samples each, the smaller ones compared -- and a share that does not pay is dropped for as long as the order lives
         hipEvent_t trial_evt[2] = {nullptr, nullptr}; bool trial_pending = false, trial_with_head = false, head_disabled = false;
-        float t_base = 0.0f, t_head = 0.0f; int n_base = 0, n_head = 0, trial_opt = -1 /* the value of traverse.quad_head the trial belongs to */; bool lpt_valid = false;
+        float t_base = 0.0f, t_head = 0.0f; int n_base = 0, n_head = 0, trial_opt = -1 /* the value of traverse.quad_head the trial belongs to */; unsigned head_serial = 0 /* ... and the traversal image (ctx->image_serial) */; bool lpt_valid = false;
         // The order is only as good as the rays it was learned on: the sort leaves a copy of one sample ray of the buffer behind the order
         // (lpt_buf + 2 * lpt_cap: 2 float4), the first wavefront of every launch compares them with the buffer's rays ON THE DEVICE, bit for bit, and when the
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[kMbxOrderStale + i],
         // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
         int lpt_epoch = 1 /* never 0: the pinned report word starts as 0 and is reset to -1 */, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
         // the share trial of launches in the default order (traverse.hip "traverse.share_trial"): [0] the rule's share of tiles with four lanes per ray, [1] a half
-        hipEvent_t share_evt[2] = {nullptr, nullptr}; bool share_pending = false; int share_pending_cand = 0, share_n[2] = {0, 0}, share_choice = -1 /* -1: being measured */,
+        // (sample k = candidate k & 1, each with its own event pair: all six may be in flight at once)
+        hipEvent_t share_evt[6][2] = {}; int share_issued = 0, share_done = 0, share_choice = -1 /* -1: being measured */,
             share_last = -1 /* the answer before this trial */, share_launches = 0; float share_t[2] = {0.0f, 0.0f}; unsigned share_serial = 0 /* ctx->image_serial the answer belongs to */;
         bool moving = false; int moving_since = 0, still = 0, last_report = -1;       // MOVING mode (traverse.hip): the rays change from launch to launch -- sorted behind every launch; epoch at which the mode began, launches without a report, the report word as last seen
         unsigned long long used = 0;                    // clock of the last call that used the slot

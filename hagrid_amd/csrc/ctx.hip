@@ -48,7 +48,7 @@ extern "C" void hagrid_ctx_destroy(hagrid_ctx* ctx) {
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
-    for (auto& h : ctx->hints) { if (h.rowlen_evt) (void)hipEventDestroy(h.rowlen_evt); if (h.lpt_buf) (void)hipFree(h.lpt_buf); for (auto& e : h.trial_evt) if (e) (void)hipEventDestroy(e); for (auto& e : h.share_evt) if (e) (void)hipEventDestroy(e); }
+    for (auto& h : ctx->hints) { if (h.rowlen_evt) (void)hipEventDestroy(h.rowlen_evt); if (h.lpt_buf) (void)hipFree(h.lpt_buf); for (auto& e : h.trial_evt) if (e) (void)hipEventDestroy(e); for (auto& pr : h.share_evt) for (auto& e : pr) if (e) (void)hipEventDestroy(e); }
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->bin_diff) (void)hipFree(ctx->bin_diff);

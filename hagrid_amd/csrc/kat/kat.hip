@@ -302,7 +302,7 @@ extern "C" int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t
     for (int i = 0; i < hagrid_ctx::kRayHints; i++) {
         const hagrid_ctx::RayHints& h = ctx->hints[i];
         if (h.key_rays != rays) continue;
-        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice, h.share_n[0] + 100 * h.share_n[1], h.cooldown, h.lpt_epoch, h.share_launches};
+        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice, h.share_done + 100 * h.share_issued, h.cooldown, h.lpt_epoch, h.share_launches};
         for (int k = 0; k < 12; k++) out12[k] = v[k];
         if (ms2) { ms2[0] = h.t_base; ms2[1] = h.t_head; ms2[2] = h.share_t[0]; ms2[3] = h.share_t[1]; }
         return HAGRID_OK;

@@ -256,8 +256,8 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // UNIFORM = false: the table layout of slim records (grids of at most three levels whose top-level cells differ in depth): the block of a
 // top-level cell is found through its table entry, kept while the ray stays inside the cell; bounds count from that cell's origin.
 // DUAL: phase 1 tests the ids of an inline list two per round trip (see test_list)
-// COST: the wavefront counts its iterations and leaves them at its tile (the tile order of traverse.hip); the table layout pays for that bookkeeping with
-// a dozen spilled registers around its loops, so launches of it that keep no costs run the instantiation without
+// COST: the wavefront counts its iterations and leaves them at its tile (the tile order of traverse.hip); the table layout runs that bookkeeping at seven resident
+// wavefronts per SIMD (HG_TABLE_WAVES below: at eight it spills a dozen registers around its loops), so launches of it that keep no costs run the instantiation without
 // TRI64: the triangles are read from a copy padded to 64 bytes each (traverse.hip, "traverse.tri_pad"): a triangle is then ONE 64-byte sector of L2 / HBM
 // (the caller's 48-byte records straddle two sectors every second time) -- a third fewer requests to L2 per triangle test
 // MAILBOX: every ray remembers the last four triangles it was tested against (a FIFO of ids per lane in LDS: the kernel has no registers for it) and skips
@@ -267,11 +267,19 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // accepted: it either writes the same id and t again or is rejected -- so the hits stay bit-identical.  What it saves is the three lane accesses of the
 // triangle in the vector L1 and its L2 / HBM sector: the resources the incoherent and the beyond-cache batches are bound by (profiles/r4a).  It costs an LDS
 // round trip in front of every triangle round.
+#ifndef HG_TABLE_WAVES
+// resident wavefronts per SIMD of the table-layout instantiations WITH cost bookkeeping (launches that learn or follow a tile order: a few rounds, latency-bound).  At
+// eight they keep 64 registers and spill 9 - 11 values AROUND their loops (none inside: the compiler's listing, tools/kernel_resources.py); at seven (70 registers) none.
+// Same box, round 6 (gpurun_out/r6g): config 3's grid 1024^2 in a learned order 0.1618 -> 0.1582 ms (-2.2 %), with wide records 0.166 -> 0.164.  The instantiations
+// WITHOUT costs (launches beyond 25 rounds: throughput-bound) stay at eight: the soup at --snd-density 5, 4096^2, 1.327 -> 1.372 ms (+3.4 %) at seven, although the
+// wide-record one reloads a spilled value once per iteration of its four-lanes-per-ray phase.
+#define HG_TABLE_WAVES 7
+#endif
 #ifndef HG_GENERAL_WAVES
 #define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
 #endif
 template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false, bool WIDE = GENERAL>
-__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : 8)) traverse_kernel_tail(const TraverseArgs a) {
+__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : ((!UNIFORM && COST) ? HG_TABLE_WAVES : 8))) traverse_kernel_tail(const TraverseArgs a) {
     // WIDE: the image holds wide records (always possible in the general layout; a table-layout image without any runs the instantiation without the checks)
     static_assert(!WIDE || !UNIFORM, "the uniform layout has no wide records");
     static_assert(!GENERAL || !UNIFORM, "a layout is uniform, table (blocks per top-level cell) or general (a record per voxel-map entry)");

@@ -215,7 +215,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
             N.rows_from_origins = false;
-            N.share_choice = -1; N.share_last = -1; N.share_n[0] = N.share_n[1] = 0; N.share_pending = false; N.share_launches = 0; N.share_serial = ctx->image_serial;
+            N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial;
             if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
             if (donor && donor->share_serial == ctx->image_serial) { N.share_choice = donor->share_choice; N.share_last = donor->share_choice >= 0 ? donor->share_choice : donor->share_last; N.share_launches = donor->share_launches; }
         }
@@ -349,7 +349,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // answer -- no order for 64 launches, for twice as many every time that happens again, up to 1024).
                     const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
-                    H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
+                    // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
+                    // not about these rays: a concluded trial stands, the next order is stored with the same share at its head; an unfinished one starts again)
+                    H.lpt_valid = false; H.lpt_age = 0;
+                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
                     else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
@@ -418,20 +421,21 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // lose everywhere measured).
             const bool trial_ok = ctx->opt_share_trial && !a.tile_order && !perm && !shared && ctx->opt_tail && !flags && narrow && refill_k <= 1 && a.row_len && r100 > 65 && r100 <= 1000;
             if (trial_ok) {
-                if (H.share_serial != ctx->image_serial) { H.share_serial = ctx->image_serial; H.share_choice = -1; H.share_n[0] = H.share_n[1] = 0; H.share_pending = false; }   // (another grid)
-                if (H.share_pending && hipEventQuery(H.share_evt[1]) == hipSuccess) {
+                if (H.share_serial != ctx->image_serial) { H.share_serial = ctx->image_serial; H.share_choice = -1; H.share_issued = H.share_done = 0; }   // (another grid)
+                // six samples, each with an event pair of its own: a caller that never synchronises (a burst of launches) has all of them in flight at once
+                while (H.share_done < H.share_issued) {
+                    const int k = H.share_done;
+                    if (hipEventQuery(H.share_evt[k][1]) != hipSuccess) { (void)hipGetLastError(); break; }          // not ready yet: not an error (samples finish in stream order)
                     float ms = 0.0f;
-                    if (hipEventElapsedTime(&ms, H.share_evt[0], H.share_evt[1]) == hipSuccess && ms > 0.0f) {
-                        const int c = H.share_pending_cand;
-                        H.share_t[c] = H.share_n[c] ? std::min(H.share_t[c], ms) : ms; H.share_n[c]++;
-                    }
-                    H.share_pending = false;
-                    if (H.share_choice < 0 && H.share_n[0] >= 3 && H.share_n[1] >= 3) { H.share_choice = H.share_t[1] < 0.97f * H.share_t[0] ? 1 : 0; H.share_last = H.share_choice; H.share_launches = 0; }
-                } else if (H.share_pending) (void)hipGetLastError();          // not ready yet: not an error
-                if (H.share_choice >= 0 && ++H.share_launches >= 512) { H.share_choice = -1; H.share_n[0] = H.share_n[1] = 0; }      // (the scene in view may have changed: measured again)
+                    if (hipEventElapsedTime(&ms, H.share_evt[k][0], H.share_evt[k][1]) != hipSuccess || !(ms > 0.0f)) ms = 1.0e30f;
+                    H.share_t[k & 1] = k < 2 ? ms : std::min(H.share_t[k & 1], ms);
+                    H.share_done++;
+                }
+                if (H.share_choice < 0 && H.share_done >= 6) { H.share_choice = H.share_t[1] < 0.97f * H.share_t[0] ? 1 : 0; H.share_last = H.share_choice; H.share_launches = 0; }
+                if (H.share_choice >= 0 && ++H.share_launches >= 512) { H.share_choice = -1; H.share_issued = H.share_done = 0; }      // (the scene in view may have changed: measured again)
                 if (H.share_choice >= 0) share_cand = H.share_choice;
-                else if (!H.share_pending) { share_cand = H.share_n[1] < H.share_n[0] ? 1 : 0; share_timed = true; }
-                else share_cand = H.share_last >= 0 ? H.share_last : 0;        // (a sample is still in flight: the last answer, else the rule)
+                else if (H.share_issued < 6) { share_cand = H.share_issued & 1; share_timed = true; }
+                else share_cand = H.share_last >= 0 ? H.share_last : 0;        // (the samples are still in flight: the last answer, else the rule)
                 if (share_cand == 1) quad_pct = 50;
             }
         }
@@ -446,8 +450,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // The share measures itself (the rule above is fitted on two scene families; on a soup with a density gradient it takes tiles whose lists are short and loses
         // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
         // until the order is learned again from nothing.
-        if (H.trial_opt != ctx->opt_quad_head) {            // (the test library changed the threshold: the trial starts again)
-            H.trial_opt = ctx->opt_quad_head; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
+        if (H.trial_opt != ctx->opt_quad_head || H.head_serial != ctx->image_serial) {            // (the test library changed the threshold, or another grid: the trial starts again)
+            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
         }
         if (H.trial_pending && hipEventQuery(H.trial_evt[1]) == hipSuccess) {
             float ms = 0.0f;
@@ -502,13 +506,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             HG_HIP(ctx, hipEventRecord(H.trial_evt[0], ctx->stream));
         }
         if (share_timed) {
-            for (auto& e : H.share_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
-            HG_HIP(ctx, hipEventRecord(H.share_evt[0], ctx->stream));
+            for (auto& e : H.share_evt[H.share_issued]) if (!e) HG_HIP(ctx, hipEventCreate(&e));
+            HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][0], ctx->stream));
         }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; }
-        if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[1], ctx->stream)); H.share_pending = true; H.share_pending_cand = share_cand; }
+        if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][1], ctx->stream)); H.share_issued++; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
 #ifdef HAGRID_DEBUG_TRACE                      // (development builds only: the decisions of the head share, tools/build_variant.sh -DHAGRID_DEBUG_TRACE)
         if (learn_order && getenv("HAGRID_TRACE_HEAD"))

@@ -357,7 +357,94 @@ def test_clustered_scene_structure_and_hits_match_oracle():
                     mem.synchronize()
                     assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), ohp), (head, launch)
         mem.set_option("traverse.quad_head", 20)
+        # A camera that MOVES (the reference's viewer writes new rays every frame, main.cpp:591-601): eight frames at the viewer's speed into the same buffer, behind the
+        # launches above (a learned order that goes stale, the pause from learning, the share trial of launches in the default order -- half of the tiles with four
+        # lanes per ray, measured against the rule's share): every frame gives the oracle's hits.
+        moving_camera_frames(mem, grid, d_tris, G, tris, d_rays, d_hits, 1024, 1024)
         mem.free(d_rays); mem.free(d_hits)
         grid.free()
+    finally:
+        mem.close()
+
+
+def moving_camera_frames(mem, grid, d_tris, G, tris, d_rays, d_hits, width, height, frames=8, extra_launches=3):
+    """`frames` frames of a camera that turns and strafes at the reference viewer's speed, written into ONE ray buffer; every frame is traversed a few times (the
+    policy's trials take their samples over launches) and its hits compared with the oracle's."""
+    from hagrid_amd import api
+    n = width * height
+    for f in range(frames):
+        r = scene.make_rays_primary(grid.bbox_min, grid.bbox_max, width, height, yaw=0.005 * (f + 1), strafe=0.005 * (f + 1))
+        want, _ = G.traverse(tris, r, nthreads=8)
+        mem.copy_h2d(d_rays, r)
+        for k in range(extra_launches):
+            mem.zero(d_hits, 16 * n)
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            mem.synchronize()
+            assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), want), (f, k, mem.order_state(d_rays))
+
+
+def test_stadium_mesh_through_the_front_door(tmp_path):
+    """A mesh-shaped scene (scene.make_stadium_mesh: tori and spheres with shared vertices, a grain of dust, inside a hall of ten huge triangles -- edges over four
+    orders of magnitude, "teapot in a stadium", the reference README's motivation) through the FRONT DOOR: written as OBJ, read by hagrid_cli with
+    include/hagrid/load_obj.h (main.cpp:246-275, load_obj.cpp:78-239), built, traced from a .rays file, saved with --save-grid.  The CLI's triangle, cell and
+    reference counts and its intersection count are the oracle's; the grid file it wrote holds the oracle's arrays and the mesh's Tri records bit for bit; the
+    Python API builds the same arrays; primary, incoherent and dust-aimed rays give the oracle's hits on the image and on the construction format; eight frames
+    of a moving camera as well."""
+    import os, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _subproc
+    from test_cpp_api import _build_cli
+    from hagrid_amd import api
+    from oracle import oracle as O
+    V, F = scene.make_stadium_mesh()
+    tris = scene.tris_from_mesh(V, F)
+    G = O.Grid.full(tris)
+    assert G.shift >= 5 and int((G.cells["end"] - G.cells["begin"]).max()) > 100        # a deep grid with long lists (the dust)
+    mem = api.MemManager(keep=True)
+    try:
+        d_tris = mem.upload(tris)
+        grid = api.build_all(mem, d_tris, tris.shape[0])
+        d = grid.download()
+        assert grid.summary() == G.summary()
+        assert (d["entries"] == G.entries).all() and (d["ref_ids"] == G.ref_ids).all() and d["cells"].tobytes() == G.cells.tobytes()
+        lo, hi = grid.bbox_min, grid.bbox_max
+        dust = scene.make_rays_incoherent(lo, hi, 1 << 16, 21).copy()
+        dust[:, 4:7] = np.float32([0.50, 0.02, 0.30]) - dust[:, 0:3] + np.float32(0.004) * dust[:, 4:7]       # towards the grain of dust (lists of hundreds of ids)
+        rays = np.ascontiguousarray(np.concatenate([scene.make_rays_primary(lo, hi, 1024, 512), scene.make_rays_incoherent(lo, hi, 1 << 18, 11), dust]).astype(np.float32))
+        rays[:, 3] = 0.0; rays[:, 7] = scene.FLT_MAX
+        want, _ = G.traverse(tris, rays, nthreads=8)
+        assert (want["id"] >= 0).mean() > 0.5                                # (a 2:1 image from outside sees past the hall; from inside only the open front lets a ray out)
+        n_dust = tris.shape[0] - 3 * (2 * 16 * 6 + 2 * 16)                   # (the three coarse lamps are the last objects, the dust is just before them)
+        assert ((want["id"] < n_dust) & (want["id"] >= n_dust - 39000)).sum() > 100, "no ray ends on the grain of dust"
+        for image in (2, 0):
+            mem.set_option("traverse.image", image)
+            assert same_hits(traverse(mem, grid, d_tris, rays), want), f"traverse.image={image}"
+        mem.set_option("traverse.image", 2); api.setup_traversal(grid)
+        assert mem.image_format(grid)["general"]
+        # the front door
+        obj = str(tmp_path / "stadium.obj"); rfile = str(tmp_path / "stadium.rays"); gfile = str(tmp_path / "stadium.grid")
+        scene.write_obj(obj, V, F)
+        np.ascontiguousarray(rays[:, [0, 1, 2, 4, 5, 6]]).tofile(rfile)
+        exe = _build_cli(str(tmp_path))
+        r = _subproc.check([exe, obj, "-r", rfile, "-n", "3", "-w", "1", "-k", "-nb", "2", "--save-grid", gfile], timeout=300)
+        assert f"{tris.shape[0]} triangle(s)" in r.stdout and f"{G.num_cells} cells, {G.num_refs} references)" in r.stdout, r.stdout
+        assert f"{int((want['id'] >= 0).sum())} intersection(s)." in r.stdout, r.stdout
+        g2, d_tris2, n2 = api.Grid.load(mem, gfile)
+        assert n2 == tris.shape[0] and mem.download(d_tris2, np.float32, 12 * n2).tobytes() == tris.tobytes()
+        d2 = g2.download()
+        assert g2.summary() == G.summary() and (d2["entries"] == G.entries).all() and (d2["ref_ids"] == G.ref_ids).all() and d2["cells"].tobytes() == G.cells.tobytes()
+        g2.free(); mem.free(d_tris2)
+        # a loop over one buffer, then a camera that moves
+        prim = scene.make_rays_primary(lo, hi, 1024, 1024); n = prim.shape[0]
+        wp, _ = G.traverse(tris, prim, nthreads=8)
+        d_rays = mem.upload(prim); d_hits = mem.alloc(16 * n)
+        for launch in range(1, 80):
+            if launch in (1, 2, 3, 34, 35, 79): mem.zero(d_hits, 16 * n)
+            api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+            if launch in (1, 2, 3, 34, 35, 79):
+                mem.synchronize()
+                assert same_hits(mem.download(d_hits, api.HIT_DTYPE, n), wp), launch
+        moving_camera_frames(mem, grid, d_tris, G, tris, d_rays, d_hits, 1024, 1024)
+        mem.free(d_rays); mem.free(d_hits); grid.free()
     finally:
         mem.close()

@@ -66,3 +66,47 @@ def test_clustered_scene_is_pinned_and_well_formed():
     assert (n[:, 0] == t[:, 3]).all() and (n[:, 1] == t[:, 7]).all() and (n[:, 2] == t[:, 11]).all()
     blob = t[2000:3000, 0:3]
     assert (blob >= np.float32([0.15, 0.30, 0.20])).all() and (blob <= np.float32([0.19, 0.34, 0.24]) + 1e-6).all()
+
+
+def test_stadium_mesh_is_pinned_connected_and_spans_orders_of_magnitude():
+    """scene.make_stadium_mesh: an indexed mesh (shared vertices: every edge of a torus or a sphere belongs to exactly two faces), no degenerate triangle, edges from
+    the hall's 1.0 down to the grain of dust; the same bits everywhere (no libm in it)."""
+    import hashlib
+    V, F = scene.make_stadium_mesh(0.1)
+    assert V.dtype == np.float32 and F.dtype == np.int32 and F.min() == 0 and F.max() == V.shape[0] - 1
+    assert hashlib.sha256(V.tobytes() + F.tobytes()).hexdigest()[:16] == "7b9b521d0f9a1490"
+    t = scene.tris_from_mesh(V, F)
+    e1 = t[:, 4:7].astype(np.float64); e2 = t[:, 8:11].astype(np.float64)
+    assert (np.linalg.norm(np.cross(e1, e2), axis=1) > 0).all()
+    longest = np.maximum(np.linalg.norm(e1, axis=1), np.maximum(np.linalg.norm(e2, axis=1), np.linalg.norm(e1 + e2, axis=1)))
+    assert longest.max() > 1.0 and longest.min() < 2e-3
+    # closed surfaces: the faces of the LAST object (a coarse sphere: 16 x 8) form a closed 2-manifold, every undirected edge twice, once in each direction
+    nf = 2 * 16 * 6 + 2 * 16
+    f = F[-nf:].astype(np.int64)
+    edges = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = edges[:, 0] * (1 << 32) + edges[:, 1]; rev = edges[:, 1] * (1 << 32) + edges[:, 0]
+    assert len(np.unique(key)) == len(key) and set(key.tolist()) == set(rev.tolist())
+    # the full-size scene: about a million triangles, four orders of magnitude
+    V, F = scene.make_stadium_mesh()
+    assert 900_000 < F.shape[0] < 1_000_000 and V.shape[0] < 0.51 * F.shape[0] + 1000
+    a = V[F[:, 0]].astype(np.float64); b = V[F[:, 1]].astype(np.float64)
+    assert np.linalg.norm(a - b, axis=1).min() < 2e-4
+
+
+def test_stadium_obj_round_trip_through_the_loader():
+    """write_obj -> include/hagrid/load_obj.h (the front door of hagrid_cli; fan of main.cpp:246-275) gives back the very Tri records of tris_from_mesh: nine
+    significant digits carry a float32, negative and v/vt/vn index forms resolve to the same vertices."""
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    V, F = scene.make_stadium_mesh(0.06)
+    want = scene.tris_from_mesh(V, F)
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "obj_dump")
+        subprocess.run(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DHOST=", "-DDEVICE=", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "cpp", "obj_dump.cpp"), "-o", exe], check=True)
+        obj = os.path.join(d, "stadium.obj")
+        scene.write_obj(obj, V, F)
+        r = subprocess.run([exe, obj], capture_output=True, check=True)
+        head, _, body = r.stdout.partition(b"\n")
+        assert int(head) == want.shape[0]
+        assert body == want.tobytes()

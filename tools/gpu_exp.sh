@@ -1,14 +1,11 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job; outputs quoted in profiles/NOTES.md).  Job 4: the share trial -- frame loops at the viewer's speed and back-to-back
-# launches in the default order on four scene families; tests that touch the policy.
+# One-off experiment script of round 6 (rewritten per job).  Job 7: stadium test again; table-layout instantiations at seven resident wavefronts without spills (B) against
+# eight with their spills around the loops (A), same box.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r6d; mkdir -p $OUT
+OUT=gpurun_out/r6g; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" || exit 1
-timeout 400 python -m pytest tests/test_traverse_gpu.py -m gpu -q -x -k "tile_order or head_share or lifetime or tile_packets" 2>&1 | tail -3 | cut -c1-250
-for sc in clustered soup gradient shell stadium; do
-  timeout 300 python tools/dev_frame_policies.py --scene $sc --speed 1.0 2>&1 | grep -v amdgpu | tee $OUT/policies_$sc.txt | cut -c1-600
-done
-for sc in clustered "" shell stadium; do
-  echo "== back to back, default order, scene ${sc:-soup}"
-  SCENE=$sc OPTS=traverse.tile_order=0 timeout 200 python tools/dev_option_sweep.py traverse.share_trial 0,1 --batch "primary 1024^2" --reps 2 --launches 100 2>&1 | grep ms_median | cut -c1-200 | tee -a $OUT/share_trial_${sc:-soup}.txt
-done
+timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -k "stadium" 2>&1 | tail -5 | cut -c1-300
+echo "== config 3's grid, 1024^2 (learned order: cost bookkeeping)"; TD=0.15 SD=3.0 tools/dev_ab.sh "primary 1024^2" 2>&1 | grep -v amdgpu | cut -c1-200 | tee $OUT/ab_table_cost.txt
+echo "== config 3's grid, 4096^2 (no costs: not affected -- control)"; tools/dev_ab.sh "config3 4096^2" 2>&1 | grep -v amdgpu | cut -c1-200 | tee $OUT/ab_table_plain.txt
+echo "== soup at snd-density 5, 4096^2 (wide records)"; TD=0.12 SD=5.0 tools/dev_ab.sh "primary 4096^2" 2>&1 | grep -v amdgpu | cut -c1-200 | tee $OUT/ab_table_wide.txt
+echo "== soup at snd-density 5, 1024^2 (wide records + costs)"; TD=0.12 SD=5.0 tools/dev_ab.sh "primary 1024^2" 2>&1 | grep -v amdgpu | cut -c1-200 | tee $OUT/ab_table_wide_cost.txt
