@@ -313,15 +313,61 @@ struct ChildSegOut {
 };
 
 // top level, pass 1: the number of top-level cells every primitive's box covers (count_new_refs, build.cu:57-66)
-__global__ void __launch_bounds__(kBlock) top_range_sizes(const float4* __restrict__ tris, int n, BuildK k, int* __restrict__ counts) {
+// Primitives whose box covers kCoopCells top-level cells or more -- the walls of a hall, a ground plane: a few triangles with thousands of cells each -- are LISTED
+// and get workgroups of their own behind the others' in count_top_refs and emit_top_refs (a workgroup per primitive, a thread per cell): as guests of the wavefront their index falls into,
+// ten such triangles were one wavefront's 360 dependent rounds of returning atomics / of SAT tests -- count_top_refs 311 us and emit_top_refs 561 us on the stadium
+// scene against 127 / 73 us on the soup (round 6, gpurun_out/r6i, r6j).
+__global__ void __launch_bounds__(kBlock) top_range_sizes(const float4* __restrict__ tris, int n, BuildK k, int* __restrict__ counts, int* __restrict__ big_list, int* __restrict__ big_count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    counts[i] = max(0, compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox()).size());
+    int size = 0;
+    if (i < n) { size = max(0, compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, i).bbox()).size()); counts[i] = size; }
+    const bool big = size >= kCoopCells;
+    const int at = wave_append(big ? 1 : 0, big_count);
+    if (big) big_list[at] = i;
 }
+// A returning atomic increment whose lanes may name the SAME counter.  A mesh puts thousands of consecutive primitives into one top-level cell (a finely
+// tessellated object smaller than a cell: 40 000 triangles of the stadium's grain of dust, 150 000 of a blob of the clustered scene in eight cells), and atomics on
+// one address are served one after the other by its L2 channel, ~15 ns each across the XCDs: count_top_refs 128 us on the uniform soup, 1028 us on the clustered
+// scene, 865 us on the stadium (round 6, gpurun_out/r6i).  So the wavefront looks at the counter of its first active lane: when other lanes name it too, the
+// lanes are served group by group -- one atomic per distinct counter, its return value shared out by lane position -- for up to sixteen groups; lanes left
+// over, and wavefronts whose first counter is named once (the soup: 64 lanes, 64 cells), take the plain atomic.
+__device__ __forceinline__ int wave_shared_increment(int* __restrict__ counters, int index, bool active) {
+    int rank = 0;
+    unsigned long long todo = __ballot(active);
+    const unsigned long long below = (1ull << lane_id()) - 1ull;
+    for (int round = 0; todo && round < 16; round++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __shfl(index, leader, 64);
+        const unsigned long long same = __ballot(active && index == c) & todo;
+        if (round == 0 && (same & (same - 1)) == 0ull) break;           // named once: no crowd here
+        int base = 0;
+        if (lane_id() == leader) base = atomicAdd(counters + c, __popcll(same));
+        base = __shfl(base, leader, 64);
+        if ((same >> lane_id()) & 1ull) rank = base + __popcll(same & below);
+        todo &= ~same;
+    }
+    if ((todo >> lane_id()) & 1ull) rank = atomicAdd(counters + index, 1);
+    return rank;
+}
+
 // top level, pass 2: count_refs_per_cell (build.cu:246-253, counted BEFORE the SAT filter) with the count's return value kept per (primitive, cell) pair: the
 // pair's place inside its cell's segment.  Pairs in the order of emit_top_refs (x fastest; large ranges spread over the wavefront).
 __global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restrict__ tris, int n, BuildK k, const int* __restrict__ start_emit,
-                                                                int* __restrict__ refs_per_cell, int* __restrict__ pair_rank) {
+                                                                int* __restrict__ refs_per_cell, int* __restrict__ pair_rank,
+                                                                const int* __restrict__ big_list, const int* __restrict__ big_count, int first_big_block) {
+    if (int(blockIdx.x) >= first_big_block) {      // the blocks behind the primitives' own: a workgroup per large primitive, its cells over the threads (every cell once: plain atomics)
+        const int nb = *big_count;
+        for (int b = int(blockIdx.x) - first_big_block; b < nb; b += int(gridDim.x) - first_big_block) {
+            const int prim = big_list[b];
+            const Range r = compute_range(k.dims, BBox(k.bmin, k.bmax), load_tri(tris, prim).bbox());
+            const int total = r.size(), first = start_emit[prim], sx = r.hx - r.lx + 1, sy = r.hy - r.ly + 1;
+            for (int c = threadIdx.x; c < total; c += kBlock) {
+                const int x = r.lx + c % sx, y = r.ly + (c / sx) % sy, z = r.lz + c / (sx * sy);
+                pair_rank[first + c] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+            }
+        }
+        return;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     Range r(0, 0, 0, -1, -1, -1);
     int size = 0, start = 0;
@@ -331,22 +377,29 @@ __global__ void __launch_bounds__(kBlock) count_top_refs(const float4* __restric
         start = start_emit[i];
     }
     const bool coop = size >= kCoopCells;
-    if (size > 0 && !coop) {
-        int cur = start;
-        for (int z = r.lz; z <= r.hz; z++)
-            for (int y = r.ly; y <= r.hy; y++)
-                for (int x = r.lx; x <= r.hx; x++) pair_rank[cur++] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
-    }
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int first = __shfl(start, src, 64), total = __shfl(size, src, 64);
-        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
-        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
-        for (int c = lane_id(); c < total; c += 64) {
-            const int x = lx + c % sx, y = ly + (c / sx) % sy, z = lz + c / (sx * sy);
-            pair_rank[first + c] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+    {   // the lanes walk their (small) ranges in step: pair j of every lane in round j, lanes that name the same cell served together
+        const bool mine = size > 0 && !coop;
+        // a crowd? the first cell of the wavefront's first primitive, named by another lane's first cell as well (consecutive primitives of a mesh lie next to each
+        // other; those of a soup do not, and walk their ranges on their own with plain atomics -- the lock step costs them a fifth: 128 -> 158 us, gpurun_out/r6k)
+        const int c0 = mine ? r.lx + k.dims.x * (r.ly + k.dims.y * r.lz) : -1 - lane_id();
+        const unsigned long long any = __ballot(mine);
+        const bool crowd = any != 0ull && __popcll(__ballot(c0 == __shfl(c0, __ffsll((long long)any) - 1, 64))) >= 2;
+        if (!crowd) {
+            if (mine) {
+                int cur = start;
+                for (int z = r.lz; z <= r.hz; z++)
+                    for (int y = r.ly; y <= r.hy; y++)
+                        for (int x = r.lx; x <= r.hx; x++) pair_rank[cur++] = atomicAdd(refs_per_cell + (x + k.dims.x * (y + k.dims.y * z)), 1);
+            }
+        } else {
+            const int rounds = wave_max(mine ? size : 0);
+            int x = r.lx, y = r.ly, z = r.lz;                      // (x fastest, as emit_top_refs walks the range)
+            for (int j = 0; j < rounds; j++) {
+                const bool act = mine && j < size;
+                const int rank = wave_shared_increment(refs_per_cell, act ? x + k.dims.x * (y + k.dims.y * z) : 0, act);
+                if (act) pair_rank[start + j] = rank;
+                if (++x > r.hx) { x = r.lx; if (++y > r.hy) { y = r.ly; z++; } }
+            }
         }
     }
 }
@@ -364,8 +417,21 @@ __device__ __forceinline__ void place_top_ref(const BuildK& k, const Tri& tri, i
 __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict__ tris, int n, BuildK k0, const int* __restrict__ shift_dev, vec3 extents,
                                                                 const int* __restrict__ start_emit,
                                                                 const int* __restrict__ pair_rank, const int* __restrict__ seg_begin, int2* __restrict__ refs,
-                                                                const int* __restrict__ log_dims, uint32_t* __restrict__ entries) {
+                                                                const int* __restrict__ log_dims, uint32_t* __restrict__ entries,
+                                                                const int* __restrict__ big_list, const int* __restrict__ big_count, int first_big_block) {
     const BuildK k = with_device_shift(k0, shift_dev, extents);
+    if (int(blockIdx.x) >= first_big_block) {      // a workgroup per large primitive (count_top_refs)
+        const int nb = *big_count;
+        for (int b = int(blockIdx.x) - first_big_block; b < nb; b += int(gridDim.x) - first_big_block) {
+            const int prim = big_list[b];
+            const Tri t = load_tri(tris, prim);
+            const Range r = compute_range(k.dims, BBox(k.bmin, k.bmax), t.bbox());
+            const int total = r.size(), first = start_emit[prim], sx = r.hx - r.lx + 1, sy = r.hy - r.ly + 1;
+            for (int c = threadIdx.x; c < total; c += kBlock)
+                place_top_ref(k, t, prim, r.lx + c % sx, r.ly + (c / sx) % sy, r.lz + c / (sx * sy), pair_rank[first + c], seg_begin, refs, log_dims, entries);
+        }
+        return;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     Range r(0, 0, 0, -1, -1, -1);
     int size = 0, start = 0;
@@ -382,17 +448,6 @@ __global__ void __launch_bounds__(kBlock) emit_top_refs(const float4* __restrict
         for (int z = r.lz; z <= r.hz; z++)
             for (int y = r.ly; y <= r.hy; y++)
                 for (int x = r.lx; x <= r.hx; x++) { place_top_ref(k, tri, i, x, y, z, pair_rank[cur], seg_begin, refs, log_dims, entries); cur++; }
-    }
-    unsigned long long todo = __ballot(coop);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int prim = __shfl(i, src, 64), first = __shfl(start, src, 64), total = __shfl(size, src, 64);
-        const int lx = __shfl(r.lx, src, 64), ly = __shfl(r.ly, src, 64), lz = __shfl(r.lz, src, 64);
-        const int sx = __shfl(r.hx, src, 64) - lx + 1, sy = __shfl(r.hy, src, 64) - ly + 1;
-        const Tri t = load_tri(tris, prim);
-        for (int c = lane_id(); c < total; c += 64)
-            place_top_ref(k, t, prim, lx + c % sx, ly + (c / sx) % sy, lz + c / (sx * sy), pair_rank[first + c], seg_begin, refs, log_dims, entries);
     }
 }
 
@@ -570,57 +625,102 @@ __global__ void __launch_bounds__(kBlock) emit_child_refs(const int2* __restrict
 // copy_cells + copy_entries + compute_cell_ranges (build.cu:407-468) + copy_refs + remap_refs + the sort (:634-647, :681, :691) of a grouped level in ONE pass: a
 // leaf's list is its segment, copied behind the lists of the leaves before it and put in ascending order by the thread that copies it (lists hold a handful
 // of references).  top: the holes of a segment (references the SAT filter rejected) are skipped.
+constexpr int kCoopListMin = 9, kCoopListMax = 1024;        // lists of this many references are put in order by a wavefront (concat_level), longer ones by one thread
 __global__ void __launch_bounds__(kBlock) concat_level(const uint32_t* __restrict__ entries, const Cell* __restrict__ cells, const int* __restrict__ cell_counts,
                                                                const int* __restrict__ start_cell, const int* __restrict__ ref_begin, int num_cells, int level_off,
                                                                const int2* __restrict__ refs, const int* __restrict__ seg_begin, int num_refs, int top,
                                                                Cell* __restrict__ out_cells, uint32_t* __restrict__ out_entries, int* __restrict__ out_refs) {
+    // Lists of more than eight references (a mesh: the stadium's deepest level averages six per cell, its grain of dust hundreds) are left to the WAVEFRONTS of the
+    // workgroup, one list at a time: a thread that sorts 20 references in global memory by insertion while its neighbours sort two keeps its whole wavefront waiting
+    // (concat_level 1.29 ms for the stadium's last level, 0.05 ms for the soup's: round 6, gpurun_out/r6i).
+    __shared__ int long_cells[kBlock];
+    __shared__ int num_long;
+    __shared__ int stage[kWaves][kCoopListMax];
+    if (threadIdx.x == 0) num_long = 0;
+    __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_cells) return;
-    const uint32_t e = entries[i];
-    if (e & 3u) { out_entries[level_off + i] = (e & 3u) | (((e >> 2) + uint32_t(level_off + num_cells)) << 2); return; }
-    const int dst = start_cell[i], cnt = cell_counts[i], rb = ref_begin[i];
-    const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
-    const int4 a = p[0], b = p[1];
-    store_cell(out_cells, dst, ivec3(a.x, a.y, a.z), cnt ? rb : 0, ivec3(b.x, b.y, b.z), cnt ? rb + cnt : 0);
-    out_entries[level_off + i] = uint32_t(dst) << 2;
-    if (cnt == 0) return;
-    int* r = out_refs + rb;
-    const int2* src = refs + seg_begin[i];
-    if (!top && cnt <= 4) {                             // the common list: four loads, a sorting network in registers, no list read back from memory
-        const int big = 0x7fffffff;
-        int v0 = src[0].x, v1 = cnt > 1 ? src[1].x : big, v2 = cnt > 2 ? src[2].x : big, v3 = cnt > 3 ? src[3].x : big;
-        int t;
-        if (v0 > v1) { t = v0; v0 = v1; v1 = t; }
-        if (v2 > v3) { t = v2; v2 = v3; v3 = t; }
-        if (v0 > v2) { t = v0; v0 = v2; v2 = t; }
-        if (v1 > v3) { t = v1; v1 = v3; v3 = t; }
-        if (v1 > v2) { t = v1; v1 = v2; v2 = t; }
-        r[0] = v0;
-        if (cnt > 1) r[1] = v1;
-        if (cnt > 2) r[2] = v2;
-        if (cnt > 3) r[3] = v3;
-        return;
-    }
-    int n = 0;
-    if (top) { for (int j = 0; n < cnt; j++) { const int v = src[j].x; if (v >= 0) r[n++] = v; } }
-    else for (; n < cnt; n++) r[n] = src[n].x;
-    if (cnt > 24) {                                      // (Shell passes for the rare long list, as sort_cell_refs)
-        const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
-        for (int g = 0; g < 8; g++) {
-            const int gap = gaps[g];
-            for (int x = gap; x < cnt; x++) {
-                const int v = r[x];
-                int y = x - gap;
-                while (y >= 0 && r[y] > v) { r[y + gap] = r[y]; y -= gap; }
-                r[y + gap] = v;
+    if (i < num_cells) {
+        const uint32_t e = entries[i];
+        if (e & 3u) out_entries[level_off + i] = (e & 3u) | (((e >> 2) + uint32_t(level_off + num_cells)) << 2);
+        else {
+            const int dst = start_cell[i], cnt = cell_counts[i], rb = ref_begin[i];
+            const int4* p = reinterpret_cast<const int4*>(cells) + 2 * size_t(i);
+            const int4 a = p[0], b = p[1];
+            store_cell(out_cells, dst, ivec3(a.x, a.y, a.z), cnt ? rb : 0, ivec3(b.x, b.y, b.z), cnt ? rb + cnt : 0);
+            out_entries[level_off + i] = uint32_t(dst) << 2;
+            int* r = out_refs + rb;
+            const int2* src = refs + seg_begin[i];
+            if (cnt == 0) { }
+            else if (!top && cnt <= 4) {                        // the common list: four loads, a sorting network in registers, no list read back from memory
+                const int big = 0x7fffffff;
+                int v0 = src[0].x, v1 = cnt > 1 ? src[1].x : big, v2 = cnt > 2 ? src[2].x : big, v3 = cnt > 3 ? src[3].x : big;
+                int t;
+                if (v0 > v1) { t = v0; v0 = v1; v1 = t; }
+                if (v2 > v3) { t = v2; v2 = v3; v3 = t; }
+                if (v0 > v2) { t = v0; v0 = v2; v2 = t; }
+                if (v1 > v3) { t = v1; v1 = v3; v3 = t; }
+                if (v1 > v2) { t = v1; v1 = v2; v2 = t; }
+                r[0] = v0;
+                if (cnt > 1) r[1] = v1;
+                if (cnt > 2) r[2] = v2;
+                if (cnt > 3) r[3] = v3;
+            } else if (cnt >= kCoopListMin && cnt <= kCoopListMax) {
+                long_cells[atomicAdd(&num_long, 1)] = i;
+            } else {
+                int n = 0;
+                if (top) { for (int j = 0; n < cnt; j++) { const int v = src[j].x; if (v >= 0) r[n++] = v; } }
+                else for (; n < cnt; n++) r[n] = src[n].x;
+                if (cnt > 24) {                                  // (Shell passes for the rare list beyond what a wavefront stages)
+                    const int gaps[8] = { 1750, 701, 301, 132, 57, 23, 10, 4 };
+                    for (int g = 0; g < 8; g++) {
+                        const int gap = gaps[g];
+                        for (int x = gap; x < cnt; x++) {
+                            const int v = r[x];
+                            int y = x - gap;
+                            while (y >= 0 && r[y] > v) { r[y + gap] = r[y]; y -= gap; }
+                            r[y + gap] = v;
+                        }
+                    }
+                }
+                for (int x = 1; x < cnt; x++) {
+                    const int v = r[x];
+                    int y = x - 1;
+                    while (y >= 0 && r[y] > v) { r[y + 1] = r[y]; y--; }
+                    r[y + 1] = v;
+                }
             }
         }
     }
-    for (int x = 1; x < cnt; x++) {
-        const int v = r[x];
-        int y = x - 1;
-        while (y >= 0 && r[y] > v) { r[y + 1] = r[y]; y--; }
-        r[y + 1] = v;
+    __syncthreads();
+    // one list per wavefront: staged in LDS (top level: without the holes the SAT filter left), every reference placed by its RANK -- the ids of a list are distinct
+    // (a primitive is referenced once per cell), so the rank is the number of smaller ids
+    const int nl = num_long, lane = lane_id();
+    int* buf = stage[wave_id()];
+    for (int q = wave_id(); q < nl; q += kWaves) {
+        const int c = long_cells[q];
+        const int cnt = cell_counts[c];
+        int* r = out_refs + ref_begin[c];
+        const int2* src = refs + seg_begin[c];
+        if (top) {
+            int found = 0;
+            for (int base = 0; found < cnt; base += 64) {       // (the segment holds cnt references that passed: the loop ends)
+                const int v = seg_begin[c] + base + lane < num_refs ? src[base + lane].x : -1;
+                const unsigned long long ok = __ballot(v >= 0);
+                const int at = found + __popcll(ok & ((1ull << lane) - 1ull));
+                if (v >= 0 && at < cnt) buf[at] = v;
+                found += __popcll(ok);
+            }
+        } else {
+            for (int x = lane; x < cnt; x += 64) buf[x] = src[x].x;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int x = lane; x < cnt; x += 64) {
+            const int v = buf[x];
+            int rank = 0;
+            for (int y = 0; y < cnt; y++) rank += buf[y] < v ? 1 : 0;
+            r[rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -680,15 +780,22 @@ int build_levels(hagrid_ctx* ctx, const float4* tris, int num_tris, hagrid_grid*
     int* const partials = nullptr;               // (the look-back scans need none)
     if (!counts || !start_emit || !refs_per_cell || !log_dims) return HAGRID_ENOMEM;
     HG_HIP(ctx, hipMemsetAsync(refs_per_cell, 0, size_t(num_top) * sizeof(int), st));
-    top_range_sizes<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts); HG_DBG(ctx);
+    int* big_list = ar.get<int>(size_t(num_tris));               // primitives of kCoopCells cells and more (top_range_sizes); their number in dsc[2]
+    if (!big_list) return HAGRID_ENOMEM;
+    top_range_sizes<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, counts, big_list, dsc + 2); HG_DBG(ctx);
     if (!ctx_scan<int>(ctx, PlainIn{counts}, PlainOut{start_emit}, num_tris, partials, (const int*)nullptr, dsc + 0)) return HAGRID_ENOMEM;
-    int R0 = 0;
-    HG_TRY(read_back(ctx, dsc, &R0, sizeof(int)));
+    int R0 = 0, num_big = 0;
+    {
+        int h[3];
+        HG_TRY(read_back(ctx, dsc, h, sizeof(h)));
+        R0 = h[0]; num_big = h[2];
+    }
     if (R0 < 0 || R0 > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: too many top-level references");
     ar.drop(counts);
     int* pair_rank = ar.get<int>(size_t(R0) + 1);
     if (!pair_rank) return HAGRID_ENOMEM;
-    count_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, start_emit, refs_per_cell, pair_rank); HG_DBG(ctx);
+    const int prim_blocks = grid_blocks(num_tris, kBlock), big_blocks = std::min(num_big, 2048);      // (the large primitives' workgroups ride behind the others' in the same launches)
+    count_top_refs<<<prim_blocks + big_blocks, kBlock, 0, st>>>(tris, num_tris, k, start_emit, refs_per_cell, pair_rank, big_list, dsc + 2, prim_blocks); HG_DBG(ctx);
     top_log_dims<<<grid_blocks(num_top, kBlock), kBlock, 0, st>>>(refs_per_cell, num_top, k, snd_density, log_dims, dsc + 1); HG_DBG(ctx);
 
     std::vector<GLevel> levels;
@@ -706,7 +813,7 @@ int build_levels(hagrid_ctx* ctx, const float4* tris, int num_tris, hagrid_grid*
     hagrid_build_counts& bc = ctx->counts;
     memset(&bc, 0, sizeof(bc));
     bc.num_tris = num_tris; bc.top_cells = num_top; bc.top_refs = R0;
-    emit_top_refs<<<grid_blocks(num_tris, kBlock), kBlock, 0, st>>>(tris, num_tris, k, dsc + 1, gb.extents(), start_emit, pair_rank, L.seg_begin, L.refs, log_dims, L.entries); HG_DBG(ctx);
+    emit_top_refs<<<prim_blocks + big_blocks, kBlock, 0, st>>>(tris, num_tris, k, dsc + 1, gb.extents(), start_emit, pair_rank, L.seg_begin, L.refs, log_dims, L.entries, big_list, dsc + 2, prim_blocks); HG_DBG(ctx);
     levels.push_back(L);
 
     // ---- subdivision, one level per iteration (build_iter, build.cu:527-619) ----
@@ -859,7 +966,6 @@ extern "C" int hagrid_build_grid(hagrid_ctx* ctx, const void* tris_v, int num_tr
     gb.max += ext * 0.001f;
     const long long num_top_ll = (long long)dims.x * dims.y * dims.z;
     if (num_top_ll > 0x3fffffff) HG_FAIL(ctx, HAGRID_ERANGE, "build_grid: top-level grid too large");
-    const int num_top = int(num_top_ll);
 
     BuildK k;
     k.dims = dims; k.shift = 0; k.bmin = gb.min; k.bmax = gb.max; k.cell_size = vec3(0.0f);

@@ -8,7 +8,8 @@ n = int(os.environ.get("TRIS", 1_000_000)); iters = int(os.environ.get("ITERS", 
 mem = api.MemManager(keep=True)
 for kv in filter(None, os.environ.get("OPTS", "").split(",")):
     k, v = kv.split("="); mem.set_option(k, int(v))
-tris = scene.make_soup(n); d_tris = mem.upload(tris)
+SCENE = os.environ.get("SCENE", "")          # "" = soup-N, or clustered | gradient | shell | stadium
+tris = scene.make_soup(n) if not SCENE else getattr(scene, "make_" + SCENE)(); n = tris.shape[0]; d_tris = mem.upload(tris)
 grid = api.build_all(mem, d_tris, n)
 t = []
 stages = {"build": [], "merge": [], "flatten": [], "expand": []}
