@@ -474,6 +474,48 @@ def main():
             log(f"[bench] pipelined block skipped: {e}")
             mem.use_stream(None)
 
+    # ---- the launch's critical path, measured (outside the timed region; never `value`) --------------------------------------------------------
+    # A launch of a few rounds of resident wavefronts cannot end before its longest dependent chain does -- the 8 x 8 tile whose longest ray crosses the most cells,
+    # gather after gather.  That chain is timed ALONE: the 64 rays of each of the eight tiles with the longest ray (step counts of the statistics pass) traversed as
+    # a launch of their own on an otherwise empty GPU, as one wavefront (one ray per lane, four once 16 are left: how the tile runs inside the full launch) and as
+    # four wavefronts with four lanes per ray from the start; an empty launch (64 rays that miss the grid) gives the launch overhead to subtract.
+    critical_path = None
+    if ray_kind == "primary" and n_rays == width * height and n_rays <= (1 << 22) and world == 1 and not bin_rays and args.image and not args.no_order_compare:
+        try:
+            d_steps = mem.alloc(4 * n_rays)
+            api.traverse_grid_stats(grid, d_tris, d_rays, d_hits, n_rays, d_steps)
+            steps = mem.download(d_steps, np.int32, n_rays).reshape(height // 8, 8, width // 8, 8)
+            mem.free(d_steps)
+            tile_max = steps.max(axis=(1, 3))
+            worst = np.argsort(-tile_max.ravel())[:8]
+            rays_all = mem.download(d_rays, np.float32, 8 * n_rays).reshape(height, width, 8)
+            d_r64 = mem.alloc(32 * 64); d_h64 = mem.alloc(16 * 64)
+            def alone(rays64, quad):
+                mem.set_option("traverse.quad_tail", quad); mem.set_option("traverse.tile_order", 0)
+                mem.copy_h2d(d_r64, np.ascontiguousarray(rays64.reshape(64, 8)))
+                for _ in range(3): api.traverse_grid(grid, d_tris, d_r64, d_h64, 64)
+                return min(api.profile(lambda: api.traverse_grid(grid, d_tris, d_r64, d_h64, 64), mem) for _ in range(7))
+            miss = np.zeros((64, 8), np.float32); miss[:, 0:3] = grid.bbox_max + 10.0; miss[:, 4:7] = 1.0; miss[:, 7] = 1.0
+            overhead = alone(miss, 0)
+            one, four, nsteps = [], [], []
+            for t in worst:
+                ty, tx = divmod(int(t), width // 8)
+                r64 = rays_all[8 * ty:8 * ty + 8, 8 * tx:8 * tx + 8]
+                one.append(alone(r64, 0)); four.append(alone(r64, 100)); nsteps.append(int(tile_max.ravel()[t]))
+            mem.free(d_r64); mem.free(d_h64)
+            cp1 = max(one) - overhead; cp4 = max(four) - overhead
+            critical_path = {"critical_path_ms": round(cp1, 5), "critical_path_ms_four_lanes_per_ray": round(cp4, 5), "launch_overhead_ms": round(overhead, 5),
+                             "steps_of_the_longest_rays": nsteps, "tile_alone_ms": [round(x, 5) for x in one], "tile_alone_ms_four_lanes_per_ray": [round(x, 5) for x in four],
+                             "how": "the 64 rays of each of the eight 8x8 tiles with the longest ray (cells + triangle tests of the statistics pass) traversed as a launch of their own "
+                                    "(HIP events, best of 7, minus an empty 64-ray launch): the time of the launch's longest dependent chain with the machine to itself.  The "
+                                    "full launch cannot be shorter; ms_per_step / critical_path_ms says how much of it is that chain"}
+        except Exception as e:
+            log(f"[bench] critical path block skipped: {e}")
+        finally:
+            for k in ("traverse.quad_tail", "traverse.tile_order"):
+                try: mem.set_option(k, -1)
+                except Exception: pass
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_rays / (ms_per_step * 1e3)                   # Mrays/s, whole job
@@ -577,10 +619,27 @@ def main():
                                           "how": "counters per launch from separate rocprofv3 --pmc passes on these kernel sources (traffic_source), divided by this run's kernel time; "
                                                  "`resource` = the most used throughput resource; `limiter` = memory_latency when the wavefronts wait for memory >= 60 % of their time and no "
                                                  "throughput fraction reaches 0.95 (dependent gathers at the occupancy the kernel has: fewer fetches do not make such a launch faster)"}
+            if counters.get("TCP_TCC_READ_REQ_LATENCY_sum") and counters.get("TCP_TCC_READ_REQ_sum"):
+                # Little's law on the vector L1s' requests to L2: requests in flight = sum of their latencies / kernel time; against the rays that can have one in flight
+                lat_cycles = counters["TCP_TCC_READ_REQ_LATENCY_sum"] / counters["TCP_TCC_READ_REQ_sum"]
+                in_flight = counters["TCP_TCC_READ_REQ_LATENCY_sum"] / (kernel_ms * 1e-3 * SHADER_CLOCK_HZ)
+                out["roofline"]["binding"]["littles_law"] = {
+                    "l1_miss_latency_cycles": round(lat_cycles, 1), "l1_miss_latency_ns": round(lat_cycles / SHADER_CLOCK_HZ * 1e9, 1), "requests_in_flight": round(in_flight, 1),
+                    "requests_in_flight_per_cu": round(in_flight / NUM_CUS, 2),
+                    "request_rate_from_latency": round(in_flight / (lat_cycles / SHADER_CLOCK_HZ) / 1e9, 2), "request_rate_measured": round(counters["TCP_TCC_READ_REQ_sum"] / (kernel_ms * 1e-3) / 1e9, 2),
+                    "unit": "G requests/s", "what": "vector-L1 misses: average latency (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ) and the number in flight (sum of latencies / kernel time); "
+                            "rate = in flight / latency by construction -- a launch whose rays each wait for ONE dependent gather at a time raises it only with more rays in flight "
+                            "(resident wavefronts x live lanes) or a shorter latency, not with fewer bytes"}
+            if critical_path:
+                critical_path["ms_per_step_over_critical_path"] = round(ms_per_step / critical_path["critical_path_ms"], 3) if critical_path["critical_path_ms"] > 0 else None
+                out["roofline"]["binding"]["critical_path"] = critical_path
             out["roofline"]["bound"] = top if top in ("hbm_bytes",) else (f"{top} (not hbm bytes: see binding)" if limiter == top else
                                                                          f"memory latency of dependent gathers (wavefronts wait {waiting:.2f} of their time; most used resource: {top} {top_frac:.2f}; see binding)")
         else:
             out["roofline"]["binding"] = {"resource": None, "why": traffic_source or "no counter file for this configuration and batch (tools/gpu_traffic_config.sh)"}
+            if critical_path:
+                critical_path["ms_per_step_over_critical_path"] = round(ms_per_step / critical_path["critical_path_ms"], 3) if critical_path["critical_path_ms"] > 0 else None
+                out["roofline"]["binding"]["critical_path"] = critical_path
         # ---- CPU baseline + parity check: the oracle on the SAME grid, rank 0, N = 1 only ---------------------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O

@@ -92,12 +92,17 @@ class MemManager:
         else:
             _check(self, self._K.hagrid_kat_set_option(self._ctx, key.encode(), int(value)), f"kat_set_option({key})")
 
+    def forget_hints(self):
+        """dev tools: the context forgets every ray buffer it has traversed (csrc/kat/hagrid_amd_kat.h: hagrid_kat_forget_hints)"""
+        _check(self, self._K.hagrid_kat_forget_hints(self._ctx), "forget_hints")
+
     def order_state(self, d_rays) -> dict:
         """dev tools / tests: what the context remembers about a ray buffer's tile order (csrc/kat/hagrid_amd_kat.h: hagrid_kat_order_state)"""
         out = (C.c_int32 * 12)(); ms = (C.c_float * 4)()
         _check(self, self._K.hagrid_kat_order_state(self._ctx, C.c_void_p(d_rays), out, ms), "order_state")
-        keys = ("slot", "valid", "moving", "head_tiles", "head_dropped", "n_base", "n_head", "share_choice", "share_samples", "cooldown", "epoch", "share_launches")
-        d = dict(zip(keys, list(out))); d["ms_base"] = round(ms[0], 4); d["ms_head"] = round(ms[1], 4); d["ms_share_rule"] = round(ms[2], 4); d["ms_share_half"] = round(ms[3], 4)
+        keys = ("slot", "valid", "moving", "head_tiles", "head_dropped", "n_base", "n_head", "share_choice", "share_samples", "n_all", "head_suggested", "share_launches")
+        d = dict(zip(keys, list(out))); d["ms_base"] = round(ms[0], 4); d["ms_head"] = round(ms[1], 4); d["ms_all"] = round(ms[2], 4); d["ms_share_best"] = round(ms[3], 4)
+        d["order_loses"] = d["share_samples"] >= 10000; d["share_samples"] %= 10000; d["cooldown"] = d["n_all"] // 100; d["learned_all"] = (d["n_all"] // 10) % 10 == 1; d["n_all"] %= 10
         return d
 
     def device_info(self) -> dict:

@@ -74,6 +74,9 @@ int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 /* What the context remembers about the ray buffer `rays` (traverse.hip, RayHints): out12 = { slot or -1, order valid, moving mode, positions the order is rotated by (the
  * four-lanes-per-ray head), head share dropped by its trial, timed samples without / with the head, the share trial's choice (-1 measuring, 0 rule, 1 half), its samples (rule + 100 x half), cooldown, epoch, launches since the choice };
  * ms4 = the head trial's best launch times without / with the head, the share trial's with the rule's share / with a half.  Dev tools and tests only: nothing in the product reads it. */
+/* Makes the context forget every ray buffer it has traversed (row lengths, tile orders, the trials' answers): the next call over any buffer starts from nothing.
+ * Sweep tools call it between settings, so that what was measured under one setting does not decide under the next. */
+int hagrid_kat_forget_hints(hagrid_ctx* ctx);
 int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t* out12, float* ms4);
 
 #ifdef __cplusplus

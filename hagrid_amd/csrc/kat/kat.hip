@@ -302,10 +302,16 @@ extern "C" int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t
     for (int i = 0; i < hagrid_ctx::kRayHints; i++) {
         const hagrid_ctx::RayHints& h = ctx->hints[i];
         if (h.key_rays != rays) continue;
-        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice, h.share_done + 100 * h.share_issued, h.cooldown, h.lpt_epoch, h.share_launches};
+        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice >= 0 ? h.share_cands[h.share_choice] : -1, h.share_done + 100 * h.share_issued + 10000 * int(h.order_loses), h.n_all + 10 * int(h.learned_all) + 100 * h.cooldown, __atomic_load_n(ctx->mailbox + kMbxHeadSuggest + i, __ATOMIC_RELAXED), h.share_launches};
         for (int k = 0; k < 12; k++) out12[k] = v[k];
-        if (ms2) { ms2[0] = h.t_base; ms2[1] = h.t_head; ms2[2] = h.share_t[0]; ms2[3] = h.share_t[1]; }
+        if (ms2) { ms2[0] = h.t_base; ms2[1] = h.t_head; ms2[2] = h.t_all; ms2[3] = h.share_choice >= 0 ? h.share_t[h.share_choice] : 0.0f; }
         return HAGRID_OK;
     }
+    return HAGRID_OK;
+}
+
+extern "C" int hagrid_kat_forget_hints(hagrid_ctx* ctx) {
+    if (!ctx) return HAGRID_EINVAL;
+    for (auto& h : ctx->hints) { h.key_rays = nullptr; h.key_n = 0; h.used = 0; h.lpt_rays = nullptr; h.lpt_valid = false; h.rowlen_rays = nullptr; h.rowlen_seen = 0; h.share_ncand = 0; h.share_choice = -1; }
     return HAGRID_OK;
 }

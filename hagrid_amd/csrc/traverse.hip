@@ -206,7 +206,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = 0.0f; N.n_base = N.n_head = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = 0; N.learned_all = false; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -215,13 +215,20 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
             N.rows_from_origins = false;
-            N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial;
+            N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial; N.share_ncand = 0; N.order_loses = false; N.learned_once = false;
             if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
-            if (donor && donor->share_serial == ctx->image_serial) { N.share_choice = donor->share_choice; N.share_last = donor->share_choice >= 0 ? donor->share_choice : donor->share_last; N.share_launches = donor->share_launches; }
+            if (donor && donor->share_serial == ctx->image_serial && donor->share_ncand > 0) {       // (the donor's answer, its candidates and times with it: same launch shape)
+                N.share_ncand = donor->share_ncand; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
+                N.share_choice = donor->share_choice; N.share_last = donor->share_last; N.share_launches = donor->share_launches; N.order_loses = donor->order_loses;
+                if (N.share_choice < 0) N.share_ncand = 0;          // (a donor still measuring: measured here from nothing, with its last answer meanwhile)
+            }
         }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
     }
     hagrid_ctx::RayHints& H = ctx->hints[hint_slot];
+    if (H.order_serial != ctx->image_serial) {        // another traversal image since the slot's tile order was learned (another grid, another scene): learned from nothing
+        H.order_serial = ctx->image_serial; H.lpt_rays = nullptr; H.lpt_valid = false; H.moving = false; H.cooldown = 0; H.cooldown_len = 64;
+    }
     // Kernel choice.  With a traversal image (hagrid_setup_traversal built one for this very grid) its kernel is used for every
     // batch; without one the latency-oriented v2 walks the construction format (trav_plain.hip).
     // hagrid_set_option("traverse.variant", 1|2|4) forces the reference-shaped kernel, v2 or the image kernel (tests, experiments).
@@ -312,6 +319,66 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         const int tiles = blocks;
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
+        // ---- "traverse.share_trial" (round 6): what a launch in the DEFAULT order does with its tiles is measured, and so is whether a learned order beats it ----------
+        // The share of tiles that start with four lanes per ray (the last in dispatch order) follows a rule fitted on the uniform soup (below: all tiles up to 0.4 rounds
+        // ... none beyond 3.2, none for binned batches).  Scenes with a few expensive regions want HALF of their tiles at every size up to ten rounds (six blobs in a sparse
+        // soup, back to back: 1024^2 0.259 -> 0.180 ms, 1280 x 720 0.183 -> 0.141 and 0.125 with all of them, 1920 x 1080 0.277 -> 0.211; the stadium mesh 0.300 -> 0.186;
+        // a sphere shell 0.177 -> 0.165), the soup and a density gradient do not (+17 %, +10 %), bounce rays want none where the rule says a quarter (+12 ... +14 %), a
+        // binned incoherent batch of two rounds wants all where the rule says none (+21 % on the soup) -- and nothing the host knows about a grid tells them apart
+        // (gpurun_out/r6c, r6e, r6m: tools/dev_policy_regret.py).  An event pair around the kernel does: the first launches over a buffer run in the default order with the
+        // candidates in turn -- the rule's share, a half, none, all (up to five rounds) -- three samples each, every sample with an event pair of its own (polled by later
+        // calls, nobody waits; a caller that never synchronises has all of them in flight at once); the smallest time wins, the rule's share unless another is 3 % faster.
+        // The answer is about the scene and the launch shape, not about the rays: it survives a camera that moves, a new buffer of the same shape starts with it, it is
+        // measured again every 1024 launches.  A LEARNED tile order (below) is then held against it: an order whose steady launches (three timed ones, with the head share
+        // if that was adopted) are not 3 % faster than the best default-order launch is not followed (clustered 1280 x 720: learned 0.181 ms, default order with all tiles
+        // four lanes per ray 0.125; stadium 1920 x 1080 0.366 against 0.186; bounce rays over the soup at 2048^2 1.17 against 0.85 -- round 5's rule ordered all three).
+        bool default_sample = false; int share_pct = -1;
+        {
+            const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
+            const bool rows = a.row_len_hint > 0 || a.row_len != nullptr;
+            const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && refill_k <= 1 && (perm || rows) && tiles >= 64 && rounds100 <= 1000;
+            if (elig) {
+                const int rule = (perm != nullptr) ? 0 : (rounds100 <= 40 ? 100 : (rounds100 <= 65 ? 50 : (rounds100 <= 110 ? 37 : (rounds100 <= 320 ? 25 : 0))));
+                int cands[4], nc = 0;
+                cands[nc++] = rule;
+                if (rule != 50) cands[nc++] = 50;
+                if (rule != 0) cands[nc++] = 0;
+                if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
+                if (H.share_serial != ctx->image_serial || H.share_ncand != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
+                    H.share_serial = ctx->image_serial; H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
+                    H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.learned_once = false;
+                }
+                while (H.share_done < H.share_issued) {
+                    const int k = H.share_done;
+                    if (hipEventQuery(H.share_evt[k][1]) != hipSuccess) { (void)hipGetLastError(); break; }          // not ready yet: not an error (samples finish in stream order)
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, H.share_evt[k][0], H.share_evt[k][1]) != hipSuccess || !(ms > 0.0f)) ms = 1.0e30f;
+                    H.share_t[k % nc] = k < nc ? ms : std::min(H.share_t[k % nc], ms);
+                    H.share_done++;
+                }
+                if (H.share_choice < 0 && H.share_done >= 3 * nc) {
+                    int best = 0;
+                    for (int i = 1; i < nc; i++) if (H.share_t[i] < 0.97f * H.share_t[0] && H.share_t[i] < H.share_t[best]) best = i;
+                    H.share_choice = best; H.share_last = H.share_cands[best]; H.share_launches = 0;
+                    // the learned order starts from nothing behind the samples (their costs come from launches in which a share of the tiles ran with four lanes per
+                    // ray and counted differently: a sort over those suggests no head share where a clean one suggests a seventh of the tiles): sorted behind the next
+                    // launch and behind the one after it, then timed -- without its head share and with it -- and held against the winner of the samples
+                    // (the FIRST trial of a launch shape; a later one -- every 1024 launches -- only samples the default order again and holds the order's known times
+                    // against the new winner: learning again would mean dozens of launches in the order alone, which on the stadium mesh is twice as slow as what
+                    // the trials then settle on)
+                    if (!H.learned_once) {
+                        H.learned_once = true;
+                        H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.lpt_rot = 0;
+                    }
+                }
+                if (H.share_choice >= 0 && ++H.share_launches >= 1024) {         // (the scene in view may have changed: measured again, and the learned order held against it again)
+                    H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false;
+                }
+                if (H.share_choice >= 0) share_pct = H.share_cands[H.share_choice];
+                else if (H.share_issued < 3 * nc) { share_pct = H.share_cands[H.share_issued % nc]; default_sample = true; }
+                else share_pct = H.share_last >= 0 ? H.share_last : rule;        // (the samples are still in flight: the last answer, else the rule)
+            }
+        }
         {
             const bool tail_kernel = ctx->opt_tail && !flags && narrow;
             // by default for launches of up to 25 rounds (2048^2, eight rounds: -8 %; 2560^2: -4.9 %, 3072^2, 18 rounds: -1.3 %, 4096^2, 32 rounds: +-0 -- the tiles
@@ -352,7 +419,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
                     // not about these rays: a concluded trial stands, the next order is stored with the same share at its head; an unfinished one starts again)
                     H.lpt_valid = false; H.lpt_age = 0;
-                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0; }
+                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
                     else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
@@ -385,6 +452,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 }
             }
         }
+        const bool order_lost = H.order_loses && share_pct >= 0 && ctx->opt_tile_order < 0;           // ("traverse.tile_order" = 1 of the test library: followed whatever it costs)
+        if (default_sample && H.lpt_valid && H.learned_once) a.tile_cost = nullptr;          // (samples of a later trial leave no costs: shares of their tiles run with four lanes per ray and count differently)
+        if (a.tile_order && (default_sample || order_lost)) { a.tile_order = nullptr; a.order_samples = nullptr; }     // (costs are still kept: the order is there when wanted)
+        if (order_lost) learn_order = false;
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
         // LDS, trav_kernels.h test_list).  -1 (default): for rays in tile-packet order (1024^2: -2.6 %, 640 x 480: -4.4 %, 2048^2 and
         // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly
@@ -401,7 +472,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                                          : ctx->opt_mailbox;
         if (a.mailbox) a.tail_dual = 0;
         int quad_pct = ctx->opt_quad_tail;
-        int share_cand = 0; bool share_timed = false;             // the share trial of launches in the default order (below)
+        const bool share_timed = default_sample;
         if (quad_pct < 0) {
             const long long slots = (long long)ctx->num_cus * 32;
             const bool shared = ctx->image.alive && ctx->image.alive.use_count() > 1;
@@ -410,34 +481,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // in a learned tile order the tiles with the longest rays come first: all tiles of a launch of up to one round start with four lanes
             // per ray (256^2 ... 960 x 540: -8 ... -23 % against the shares above in the default order), none of a larger one
             if (a.tile_order && !shared) quad_pct = r100 <= 100 ? 100 : 0;
-            // "traverse.share_trial" (round 6): in the DEFAULT order -- the first launches over a buffer, every launch of a camera that moves -- the share measures itself.
-            // The rule above was fitted on the uniform soup; a scene with a few dense objects wants HALF of its tiles with four lanes per ray at sizes where the soup wants
-            // a quarter or none (six blobs in a sparse soup, back to back: 1024^2 0.259 -> 0.180 ms, 1280 x 720 0.183 -> 0.141, 1920 x 1080 0.277 -> 0.211; a sphere shell
-            // 1024^2 0.178 -> 0.165; the soup 0.165 -> 0.193, a density gradient 0.177 -> 0.195: gpurun_out/r6c), and nothing the host knows about a grid tells the two
-            // apart -- an event pair around the kernel does (polled by later calls, nobody waits): three samples with the rule's share and three with a half, taken in
-            // turn (a camera that moves changes the image from sample to sample: in turn, the drift cancels), the smaller of each compared; the half is kept if it is 3 %
-            // faster, until the next trial 512 launches later.  What is measured depends on the scene and the launch shape, not on the rays: a buffer of the same shape
-            // the context knows starts with that buffer's answer.  Launches of 0.65 to 10 rounds (below, the rule already takes half or all; beyond, four lanes per ray
-            // lose everywhere measured).
-            const bool trial_ok = ctx->opt_share_trial && !a.tile_order && !perm && !shared && ctx->opt_tail && !flags && narrow && refill_k <= 1 && a.row_len && r100 > 65 && r100 <= 1000;
-            if (trial_ok) {
-                if (H.share_serial != ctx->image_serial) { H.share_serial = ctx->image_serial; H.share_choice = -1; H.share_issued = H.share_done = 0; }   // (another grid)
-                // six samples, each with an event pair of its own: a caller that never synchronises (a burst of launches) has all of them in flight at once
-                while (H.share_done < H.share_issued) {
-                    const int k = H.share_done;
-                    if (hipEventQuery(H.share_evt[k][1]) != hipSuccess) { (void)hipGetLastError(); break; }          // not ready yet: not an error (samples finish in stream order)
-                    float ms = 0.0f;
-                    if (hipEventElapsedTime(&ms, H.share_evt[k][0], H.share_evt[k][1]) != hipSuccess || !(ms > 0.0f)) ms = 1.0e30f;
-                    H.share_t[k & 1] = k < 2 ? ms : std::min(H.share_t[k & 1], ms);
-                    H.share_done++;
-                }
-                if (H.share_choice < 0 && H.share_done >= 6) { H.share_choice = H.share_t[1] < 0.97f * H.share_t[0] ? 1 : 0; H.share_last = H.share_choice; H.share_launches = 0; }
-                if (H.share_choice >= 0 && ++H.share_launches >= 512) { H.share_choice = -1; H.share_issued = H.share_done = 0; }      // (the scene in view may have changed: measured again)
-                if (H.share_choice >= 0) share_cand = H.share_choice;
-                else if (H.share_issued < 6) { share_cand = H.share_issued & 1; share_timed = true; }
-                else share_cand = H.share_last >= 0 ? H.share_last : 0;        // (the samples are still in flight: the last answer, else the rule)
-                if (share_cand == 1) quad_pct = 50;
-            }
+            else if (share_pct >= 0) quad_pct = share_pct;               // the default order: the share the trial above chose (or is sampling)
         }
         // "traverse.quad_head": in a learned order of a launch of MORE than one round the tiles that cost several times the median tile -- the chains the launch is as
         // long as, where a scene has a few dense objects -- start with four lanes per ray, and first.  The sort counts them (a pinned word the host polls), the NEXT sort
@@ -451,18 +495,43 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
         // until the order is learned again from nothing.
         if (H.trial_opt != ctx->opt_quad_head || H.head_serial != ctx->image_serial) {            // (the test library changed the threshold, or another grid: the trial starts again)
-            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = 0.0f; H.n_base = H.n_head = 0;
+            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false;
         }
         if (H.trial_pending && hipEventQuery(H.trial_evt[1]) == hipSuccess) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, H.trial_evt[0], H.trial_evt[1]) == hipSuccess && ms > 0.0f) {
-                if (H.trial_with_head) { H.t_head = H.n_head ? std::min(H.t_head, ms) : ms; H.n_head++; }
+                if (H.trial_kind == 1) { H.t_head = H.n_head ? std::min(H.t_head, ms) : ms; H.n_head++; }
+                else if (H.trial_kind == 2) { H.t_all = H.n_all ? std::min(H.t_all, ms) : ms; H.n_all++; if (H.n_all >= 3) H.learned_all = H.t_all < 0.97f * H.t_base; }
                 else { H.t_base = H.n_base ? std::min(H.t_base, ms) : ms; H.n_base++; }
             }
             H.trial_pending = false;
-            if (H.n_head >= 3 && H.n_base >= 3 && !H.head_disabled && H.t_head > 0.97f * H.t_base) H.head_disabled = true;
+            // (the head share has to beat the order alone AND the order with all tiles four lanes per ray, where that was taken up)
+            if (H.n_head >= 3 && H.n_base >= 3 && !H.head_disabled && H.t_head > 0.97f * ((H.n_all >= 3 && H.learned_all) ? std::min(H.t_base, H.t_all) : H.t_base)) H.head_disabled = true;
         } else if (H.trial_pending) (void)hipGetLastError();          // not ready yet: not an error
-        if (head_ok && H.n_base >= 3 && !H.head_disabled) {
+        // the learned order against the best default-order launch (the share trial's): both known -> an order that is not 3 % faster is not followed
+        // A third candidate in the learned order where the head share is not in play (not suggested, or dropped): ALL tiles with four lanes per ray, for launches of one
+        // to five rounds (clustered 1280 x 720: learned order 0.181 ms, default order with all tiles 0.139, learned order with all tiles 0.124; stadium 1920 x 1080 0.376 /
+        // 0.203 / 0.188: gpurun_out/r6n, r6o) -- three timed launches, kept if 3 % faster than the order alone.
+        // (sampled BEFORE the head share is taken up -- the order is stored rotated for that -- and the head share then has to beat it)
+        const bool head_wanted = head_ok && !H.head_disabled && (H.lpt_rot > 0 || __atomic_load_n(suggest, __ATOMIC_RELAXED) > 0);
+        const bool all_ok = share_pct >= 0 && rounds100 > 100 && rounds100 <= 500 && !perm;
+        bool all_sample = false;
+        if (a.tile_order && all_ok && H.lpt_rot == 0 && H.n_base >= 3 && quad_pct == 0) {
+            all_sample = H.n_all < 3 && !learn_order && !H.trial_pending && H.lpt_age >= 2;
+            if (all_sample || (H.n_all >= 3 && H.learned_all)) quad_pct = 100;
+            // (the samples leave no costs: tiles that run with four lanes per ray count differently -- a sort over a window that holds such a launch found no head share
+            // where the order's own launches suggest a twelfth of the tiles, gpurun_out/r6q)
+            if (all_sample) a.tile_cost = nullptr;
+        }
+        if (share_pct >= 0 && H.share_choice >= 0 && !H.order_loses && H.n_base >= 3) {
+            if ((!head_wanted || H.n_head >= 3) && (!all_ok || H.n_all >= 3)) {
+                float learned = H.t_base;
+                if (H.n_head >= 3 && !H.head_disabled) learned = std::min(learned, H.t_head);
+                if (H.n_all >= 3 && H.learned_all) learned = std::min(learned, H.t_all);
+                if (learned > 0.97f * H.share_t[H.share_choice]) H.order_loses = true;
+            }
+        }
+        if (head_ok && H.n_base >= 3 && !H.head_disabled && (!all_ok || H.n_all >= 3)) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int s = std::min(std::max(__atomic_load_n(suggest, __ATOMIC_RELAXED), 0), tiles / 8);
             const int full = std::min(blocks, (blocks - s + chunk / 2) / chunk * chunk);            // (whole XCD chunks of ordinary blocks)
@@ -499,8 +568,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
         // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
-        const bool timed = head_ok && a.tile_order && (!learn_order || H.moving) && !H.trial_pending && !H.head_disabled && (H.lpt_age >= 2 || H.moving) &&
-                           (a.quad_head ? H.n_head < 3 : H.n_base < 3) && ctx->opt_quad_head > 0;
+        const bool timed = a.tile_order && (!learn_order || H.moving) && !H.trial_pending && (H.lpt_age >= 2 || H.moving) &&
+                           (a.quad_head ? (head_ok && !H.head_disabled && H.n_head < 3 && ctx->opt_quad_head > 0) : (all_sample || H.n_base < 3));
         if (timed) {
             for (auto& e : H.trial_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
             HG_HIP(ctx, hipEventRecord(H.trial_evt[0], ctx->stream));
@@ -511,7 +580,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; }
+        if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; H.trial_kind = a.quad_head > 0 ? 1 : (all_sample ? 2 : 0); }
         if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][1], ctx->stream)); H.share_issued++; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
 #ifdef HAGRID_DEBUG_TRACE                      // (development builds only: the decisions of the head share, tools/build_variant.sh -DHAGRID_DEBUG_TRACE)

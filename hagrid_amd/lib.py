@@ -132,6 +132,7 @@ KAT_SIGNATURES = {
     "hagrid_kat_scan": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "hagrid_kat_set_option": (_i32, [_vp, C.c_char_p, _i32]),
     "hagrid_kat_order_state": (_i32, [_vp, _vp, _vp, _vp]),
+    "hagrid_kat_forget_hints": (_i32, [_vp]),
     "hagrid_kat_detect_ray_rows": (_i32, [_vp, _vp, _i32, C.c_float, _vp]),
     "hagrid_kat_image_records": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "hagrid_kat_tile_slots": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp]),

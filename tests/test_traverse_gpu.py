@@ -680,6 +680,62 @@ def test_head_share_trial_never_changes_hits(mem, family):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
+def test_share_trial_and_the_order_held_against_it_never_change_hits(mem):
+    """Round 6: launches in the default tile order measure the share of tiles that start with four lanes per ray (candidates: the rule's share, a half, none, all --
+    every sample with its own event pair), and a learned order is then held against the winner (traverse.hip "traverse.share_trial").  Every launch of the sequence --
+    the samples in the default order, the order learned behind them, its own trial, the choice, a re-trial -- gives the oracle's hits, on an image-ordered batch, on
+    bounce-like rays (image order without coherent directions) and on a binned incoherent batch; the trial reaches a choice (synchronising callers: after a few dozen
+    launches), a buffer of the same shape inherits it, and with the option off the state stays untouched."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_clustered(30000, 3, 40000)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+    prim = scene.make_rays_primary(lo, hi, 1024, 640).astype(np.float32)
+    inc = scene.make_rays_incoherent(lo, hi, prim.shape[0], 31).astype(np.float32)
+    bounce = prim.copy(); bounce[:, 4:7] = inc[:, 4:7]                     # origins in image order, directions anywhere: rows found from the origins alone (or none: both fine)
+    api.setup_traversal(grid)
+    try:
+        for name, rays, binning in (("primary", prim, 0), ("bounce-like", bounce, 0), ("incoherent binned", inc, 1)):
+            n = rays.shape[0]
+            want, _ = G.traverse(tris, rays, nthreads=8)
+            d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+            mem.set_ray_binning(binning)
+            for launch in range(1, 91):
+                mem.zero(d_hits, 16 * n)
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+                mem.synchronize()
+                if launch <= 30 or launch % 6 == 0:
+                    got = mem.download(d_hits, api.HIT_DTYPE, n)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), (name, launch, mem.order_state(d_rays))
+            st = mem.order_state(d_rays)
+            assert st["slot"] >= 0 and st["share_choice"] in (0, 25, 37, 50, 100), (name, st)          # a choice was made (a percentage of the tiles)
+            if name == "primary":
+                # another buffer of the same shape starts with the answer
+                d_rays2 = mem.upload(rays)
+                api.traverse_grid(grid, d_tris, d_rays2, d_hits, n); mem.synchronize()
+                st2 = mem.order_state(d_rays2)
+                assert st2["share_choice"] == st["share_choice"], (st, st2)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all()
+                mem.free(d_rays2)
+            mem.set_ray_binning(0)
+            mem.free(d_rays); mem.free(d_hits)
+        # off: no samples are taken
+        mem.set_option("traverse.share_trial", 0)
+        n = prim.shape[0]; d_rays = mem.upload(prim[::-1].copy()); d_hits = mem.alloc(16 * n)
+        api.traverse_grid(grid, d_tris, d_rays, d_hits, n); mem.synchronize()
+        before = mem.order_state(d_rays)["share_samples"]                      # (a recycled address finds the slot of the buffer that lived there)
+        for _ in range(20): api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
+        mem.synchronize()
+        assert mem.order_state(d_rays)["share_samples"] == before
+        mem.free(d_rays); mem.free(d_hits)
+    finally:
+        mem.set_option("traverse.share_trial", 1); mem.set_ray_binning(0)
+    grid.free(); mem.free(d_tris)
+
+
 def test_image_lifetime(mem):
     """The image belongs to the grid of the last setup_traversal call and never outlives its source arrays."""
     from oracle import oracle as O

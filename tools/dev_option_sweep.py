@@ -44,6 +44,7 @@ go = lambda: api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
 for rep in range(reps):
     for v in values:
         mem.set_option(key, v)
+        mem.forget_hints()
         t0 = time.time()
         while time.time() - t0 < 0.15:
             for _ in range(20): go()
