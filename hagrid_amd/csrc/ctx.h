@@ -138,7 +138,7 @@ struct hagrid_ctx {
         // (sample k = candidate k % share_ncand, each with its own event pair: all may be in flight at once)
         hipEvent_t share_evt[12][2] = {}; int share_issued = 0, share_done = 0, share_choice = -1 /* index into share_cands; -1: being measured */, share_ncand = 0, share_cands[4] = {0, 0, 0, 0} /* per cent */,
             share_last = -1 /* the share (per cent) the last trial chose */, share_launches = 0; float share_t[4] = {0.0f, 0.0f, 0.0f, 0.0f}; unsigned share_serial = 0 /* ctx->image_serial the answer belongs to */;
-        int trial_kind = 0 /* the timed launch in flight: 0 the order alone, 1 with the head share, 2 with ALL tiles four lanes per ray */, n_all = 0; float t_all = 0.0f; bool learned_all = false;
+        int trial_kind = 0 /* the timed launch in flight: 0 the order alone, 1 with the head share, 2 with ALL tiles four lanes per ray */, n_all = 0, all_stage = 0 /* 0 not tried, 1 - 2 learning its own order, 3 timed, 4 decided */; float t_all = 0.0f; bool learned_all = false;
         bool learned_once = false;          // the first share trial of this launch shape has been decided and the order learned behind it
         unsigned order_serial = 0;          // ctx->image_serial the learned tile order belongs to
         bool order_loses = false;           // the learned order's steady launches were not 3 % faster than the best default-order launch: not followed until the next trial

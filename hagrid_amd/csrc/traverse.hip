@@ -206,7 +206,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = 0; N.learned_all = false; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = 0; N.learned_all = false; N.all_stage = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -368,7 +368,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // the trials then settle on)
                     if (!H.learned_once) {
                         H.learned_once = true;
-                        H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.lpt_rot = 0;
+                        H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0; H.lpt_rot = 0;
                     }
                 }
                 if (H.share_choice >= 0 && ++H.share_launches >= 1024) {         // (the scene in view may have changed: measured again, and the learned order held against it again)
@@ -419,7 +419,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
                     // not about these rays: a concluded trial stands, the next order is stored with the same share at its head; an unfinished one starts again)
                     H.lpt_valid = false; H.lpt_age = 0;
-                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; }
+                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
                     else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
@@ -495,43 +495,47 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
         // until the order is learned again from nothing.
         if (H.trial_opt != ctx->opt_quad_head || H.head_serial != ctx->image_serial) {            // (the test library changed the threshold, or another grid: the trial starts again)
-            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false;
+            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0;
         }
         if (H.trial_pending && hipEventQuery(H.trial_evt[1]) == hipSuccess) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, H.trial_evt[0], H.trial_evt[1]) == hipSuccess && ms > 0.0f) {
                 if (H.trial_kind == 1) { H.t_head = H.n_head ? std::min(H.t_head, ms) : ms; H.n_head++; }
-                else if (H.trial_kind == 2) { H.t_all = H.n_all ? std::min(H.t_all, ms) : ms; H.n_all++; if (H.n_all >= 3) H.learned_all = H.t_all < 0.97f * H.t_base; }
+                else if (H.trial_kind == 2) { H.t_all = H.n_all ? std::min(H.t_all, ms) : ms; H.n_all++; }
                 else { H.t_base = H.n_base ? std::min(H.t_base, ms) : ms; H.n_base++; }
             }
             H.trial_pending = false;
-            // (the head share has to beat the order alone AND the order with all tiles four lanes per ray, where that was taken up)
-            if (H.n_head >= 3 && H.n_base >= 3 && !H.head_disabled && H.t_head > 0.97f * ((H.n_all >= 3 && H.learned_all) ? std::min(H.t_base, H.t_all) : H.t_base)) H.head_disabled = true;
+            if (H.n_head >= 3 && H.n_base >= 3 && !H.head_disabled && H.t_head > 0.97f * H.t_base) H.head_disabled = true;
         } else if (H.trial_pending) (void)hipGetLastError();          // not ready yet: not an error
-        // the learned order against the best default-order launch (the share trial's): both known -> an order that is not 3 % faster is not followed
-        // A third candidate in the learned order where the head share is not in play (not suggested, or dropped): ALL tiles with four lanes per ray, for launches of one
-        // to five rounds (clustered 1280 x 720: learned order 0.181 ms, default order with all tiles 0.139, learned order with all tiles 0.124; stadium 1920 x 1080 0.376 /
-        // 0.203 / 0.188: gpurun_out/r6n, r6o) -- three timed launches, kept if 3 % faster than the order alone.
-        // (sampled BEFORE the head share is taken up -- the order is stored rotated for that -- and the head share then has to beat it)
+        // A third candidate of the learned order, for launches of one to five rounds in which the head share is not in play (not suggested, or measured and dropped): ALL
+        // tiles with four lanes per ray, in an order learned from launches that run that way -- an order learned from one-ray-per-lane costs serves it badly (clustered
+        // 1280 x 720: the order alone 0.189 ms, all tiles in that order 0.170, in an order of their own 0.124, the best default-order launch 0.142; stadium 1920 x 1080
+        // 0.376 / 0.248 / 0.188 / 0.204: gpurun_out/r6s, r6t).  Stages: 1, 2 = a launch that way with a sort behind it each (the second sort sees only such costs),
+        // 3 = three timed launches; kept if 3 % faster than the order alone, else the order is learned again from one-ray-per-lane launches.
         const bool head_wanted = head_ok && !H.head_disabled && (H.lpt_rot > 0 || __atomic_load_n(suggest, __ATOMIC_RELAXED) > 0);
-        const bool all_ok = share_pct >= 0 && rounds100 > 100 && rounds100 <= 500 && !perm;
+        const bool head_done = !head_wanted || H.n_head >= 3;
+        const bool all_ok = share_pct >= 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tile_order < 0;
         bool all_sample = false;
-        if (a.tile_order && all_ok && H.lpt_rot == 0 && H.n_base >= 3 && quad_pct == 0) {
-            all_sample = H.n_all < 3 && !learn_order && !H.trial_pending && H.lpt_age >= 2;
-            if (all_sample || (H.n_all >= 3 && H.learned_all)) quad_pct = 100;
-            // (the samples leave no costs: tiles that run with four lanes per ray count differently -- a sort over a window that holds such a launch found no head share
-            // where the order's own launches suggest a twelfth of the tiles, gpurun_out/r6q)
-            if (all_sample) a.tile_cost = nullptr;
+        if (a.tile_order && all_ok && H.lpt_rot == 0 && H.n_base >= 3 && quad_pct == 0 && (H.all_stage > 0 || (head_done && !(H.n_head >= 3 && !H.head_disabled)))) {
+            if (H.all_stage == 0 && !learn_order && !H.trial_pending) H.all_stage = 1;
+            if (H.all_stage == 1 || H.all_stage == 2) { quad_pct = 100; learn_order = true; H.all_stage++; }                 // (the sort below: behind this launch)
+            else if (H.all_stage == 3) {
+                quad_pct = 100;
+                if (H.n_all >= 3) {
+                    H.learned_all = H.t_all < 0.97f * H.t_base; H.all_stage = 4;
+                    if (!H.learned_all) { H.lpt_valid = false; quad_pct = 0; a.tile_order = nullptr; a.order_samples = nullptr; learn_order = true; }      // back: learned again from one-ray-per-lane launches
+                } else all_sample = !learn_order && !H.trial_pending && H.lpt_age >= 2;
+            } else if (H.learned_all) quad_pct = 100;
         }
-        if (share_pct >= 0 && H.share_choice >= 0 && !H.order_loses && H.n_base >= 3) {
-            if ((!head_wanted || H.n_head >= 3) && (!all_ok || H.n_all >= 3)) {
-                float learned = H.t_base;
-                if (H.n_head >= 3 && !H.head_disabled) learned = std::min(learned, H.t_head);
-                if (H.n_all >= 3 && H.learned_all) learned = std::min(learned, H.t_all);
-                if (learned > 0.97f * H.share_t[H.share_choice]) H.order_loses = true;
-            }
+        const bool all_done = !all_ok || H.all_stage >= 4 || (H.n_head >= 3 && !H.head_disabled);
+        // the learned order against the best default-order launch (the share trial's): all known -> an order that is not 3 % faster is not followed
+        if (share_pct >= 0 && H.share_choice >= 0 && !H.order_loses && H.n_base >= 3 && head_done && all_done) {
+            float learned = H.t_base;
+            if (H.n_head >= 3 && !H.head_disabled) learned = std::min(learned, H.t_head);
+            if (H.all_stage >= 4 && H.learned_all) learned = std::min(learned, H.t_all);
+            if (learned > 0.97f * H.share_t[H.share_choice]) H.order_loses = true;
         }
-        if (head_ok && H.n_base >= 3 && !H.head_disabled && (!all_ok || H.n_all >= 3)) {
+        if (head_ok && H.n_base >= 3 && !H.head_disabled && H.all_stage == 0) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int s = std::min(std::max(__atomic_load_n(suggest, __ATOMIC_RELAXED), 0), tiles / 8);
             const int full = std::min(blocks, (blocks - s + chunk / 2) / chunk * chunk);            // (whole XCD chunks of ordinary blocks)
