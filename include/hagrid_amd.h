@@ -256,8 +256,11 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  *   their primary hits), > 0 = w given by the caller, -1 = off.  It only steers the lane <-> ray assignment: hits never depend on it;
  * "traverse.tile_order": -1 (default) / 1 = launches over a ray buffer the context has traversed before dispatch their 8 x 8 tiles longest
  *   first, by the costs the previous launches left (the order is dropped on the device when the buffer holds other rays than the ones it was
- *   learned on); 0 = every launch in the default order, no state kept between calls -- like the row length it only steers which wavefront
- *   takes which rays, hits never depend on it;
+ *   learned on; with -1 it is also held against the default order by measurement -- event pairs around launches, polled, nobody waits -- and not
+ *   followed where it loses); 0 = every launch in the default order -- like the row length it only steers which wavefront takes which rays,
+ *   hits never depend on it.  In either order the context MEASURES, over the first dozen launches of a launch shape and again every 1024
+ *   launches, which share of the tiles starts with four lanes per ray (a scheduling choice: same hits); what it finds belongs to the scene and
+ *   the shape of the launch, not to the rays, so a camera that moves keeps it;
  * "traverse.id_is_steps": 1 = hagrid_traverse_grid stores the traversal step count in Hit.id, exactly what the reference's kernel leaves
  *   there (traverse.cu:80,93) for its viewer's heat-map display (main.cpp:100-107); 0 (default) = the primitive id or -1 that ray.h:22
  *   documents; t is the same either way;

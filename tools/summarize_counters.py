@@ -70,7 +70,7 @@ res["source_hash"] = _build.source_hash()
 res["commit"] = os.environ.get("HAGRID_COMMIT", "unknown")
 res["source"] = ("separate rocprofv3 --pmc passes (one counter set each, with --kernel-trace only) of `" + open(os.path.join(out, "command.txt")).read().strip().replace(os.getcwd() + "/", "")
                  + "` (tools/gpu_traffic_config.sh); FETCH x2 per the gfx950 note of MI355X_MICROARCH.md; per launch of the timed traversal kernel; NOT measured in the bench run itself")
-json.dump(res, open(os.path.join(out, f"traffic_config{config}.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, f"traffic_config{config}{os.environ.get('TRAFFIC_SUFFIX', '')}.json"), "w"), indent=1)      # (TRAFFIC_SUFFIX=_aimed: a batch of another ray kind)
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for name, calls, avg, tot in table[:12]:
     print(f"{name:90s} calls {calls:5d} avg_us {avg / 1e3:10.2f} total_ms {tot / 1e6:9.3f}")
