@@ -312,6 +312,6 @@ extern "C" int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t
 
 extern "C" int hagrid_kat_forget_hints(hagrid_ctx* ctx) {
     if (!ctx) return HAGRID_EINVAL;
-    for (auto& h : ctx->hints) { h.key_rays = nullptr; h.key_n = 0; h.used = 0; h.lpt_rays = nullptr; h.lpt_valid = false; h.rowlen_rays = nullptr; h.rowlen_seen = 0; h.share_ncand = 0; h.share_choice = -1; }
+    for (auto& h : ctx->hints) { h.key_rays = nullptr; h.key_n = 0; h.used = 0; h.lpt_rays = nullptr; h.lpt_valid = false; h.rowlen_rays = nullptr; h.rowlen_seen = 0; h.share_ncand = 0; h.share_shape_nc = 0; h.share_choice = -1; }
     return HAGRID_OK;
 }

@@ -215,12 +215,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
             N.rows_from_origins = false;
-            N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial; N.share_ncand = 0; N.order_loses = false; N.learned_once = false;
+            N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial; N.share_ncand = 0; N.share_shape_nc = 0; N.order_loses = false; N.learned_once = false;
             if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
             if (donor && donor->share_serial == ctx->image_serial && donor->share_ncand > 0) {       // (the donor's answer, its candidates and times with it: same launch shape)
-                N.share_ncand = donor->share_ncand; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
+                N.share_ncand = donor->share_ncand; N.share_shape_nc = donor->share_shape_nc; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
                 N.share_choice = donor->share_choice; N.share_last = donor->share_last; N.share_launches = donor->share_launches; N.order_loses = donor->order_loses;
-                if (N.share_choice < 0) N.share_ncand = 0;          // (a donor still measuring: measured here from nothing, with its last answer meanwhile)
+                if (N.share_choice < 0) N.share_ncand = N.share_shape_nc = 0;          // (a donor still measuring: measured here from nothing, with its last answer meanwhile)
             }
         }
         ctx->hints[hint_slot].used = ++ctx->hint_clock;
@@ -339,15 +339,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && refill_k <= 1 && (perm || rows) && tiles >= 64 && rounds100 <= 1000;
             if (elig) {
                 const int rule = (perm != nullptr) ? 0 : (rounds100 <= 40 ? 100 : (rounds100 <= 65 ? 50 : (rounds100 <= 110 ? 37 : (rounds100 <= 320 ? 25 : 0))));
-                int cands[4], nc = 0;
+                int cands[4]; int nc = 0;
                 cands[nc++] = rule;
                 if (rule != 50) cands[nc++] = 50;
                 if (rule != 0) cands[nc++] = 0;
                 if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
-                if (H.share_serial != ctx->image_serial || H.share_ncand != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
-                    H.share_serial = ctx->image_serial; H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
+                if (H.share_serial != ctx->image_serial || H.share_shape_nc != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
+                    H.share_serial = ctx->image_serial; H.share_shape_nc = H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
                     H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.learned_once = false;
                 }
+                nc = H.share_ncand;                           // (a later trial samples fewer candidates: below)
                 while (H.share_done < H.share_issued) {
                     const int k = H.share_done;
                     if (hipEventQuery(H.share_evt[k][1]) != hipSuccess) { (void)hipGetLastError(); break; }          // not ready yet: not an error (samples finish in stream order)
@@ -372,6 +373,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     }
                 }
                 if (H.share_choice >= 0 && ++H.share_launches >= 1024) {         // (the scene in view may have changed: measured again, and the learned order held against it again)
+                    // ... the candidates that came within 15 % of the winner only (the rule's share always): on the soup all tiles with four lanes per ray cost a launch
+                    // twice its time -- a dozen such frames every 1024 are a hiccup a viewer sees
+                    int keep = 1;
+                    const float bar = 1.15f * H.share_t[H.share_choice];
+                    for (int i = 1; i < nc; i++) if (H.share_t[i] <= bar) { H.share_cands[keep] = H.share_cands[i]; keep++; }
+                    H.share_ncand = nc = keep;
                     H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false;
                 }
                 if (H.share_choice >= 0) share_pct = H.share_cands[H.share_choice];
