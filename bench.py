@@ -532,7 +532,7 @@ def main():
         # (a batch of another ray kind than the configuration's own -- `--config clustered --rays aimed` -- has a counter file of its own)
         tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}{'' if ray_kind == cfg['rays'] else '_' + ray_kind}.json")
         counters = None
-        std_shape = (args.image == 2 and n_tris == cfg["tris"] and ray_kind == cfg["rays"] and (ray_kind == "incoherent" or (width, height) == (cfg.get("width"), cfg.get("height")))
+        std_shape = (args.image == 2 and n_tris == cfg["tris"] and (ray_kind in ("incoherent", "aimed") or (width, height) == (cfg.get("width"), cfg.get("height")))
                      and (top_density, snd_density, expansion, bool(compress)) == (cfg["params"].get("top_density", 0.12), cfg["params"].get("snd_density", 2.4), cfg["params"].get("expansion", 3), bool(cfg["params"].get("compress", False)))
                      and not args.opts)
         if os.path.exists(tpath) and world == 1 and std_shape:

@@ -336,14 +336,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         {
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
             const bool rows = a.row_len_hint > 0 || a.row_len != nullptr;
-            const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && refill_k <= 1 && (perm || rows) && tiles >= 64 && rounds100 <= 1000;
+            const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && refill_k <= 1 && (perm || rows) && tiles >= 64 && tiles <= kMaxOrderTiles;
             if (elig) {
                 const int rule = (perm != nullptr) ? 0 : (rounds100 <= 40 ? 100 : (rounds100 <= 65 ? 50 : (rounds100 <= 110 ? 37 : (rounds100 <= 320 ? 25 : 0))));
                 int cands[4]; int nc = 0;
                 cands[nc++] = rule;
-                if (rule != 50) cands[nc++] = 50;
-                if (rule != 0) cands[nc++] = 0;
-                if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
+                if (rounds100 <= 1000) {                     // (beyond ten rounds four lanes per ray lose everywhere measured: the rule's share -- none -- is sampled alone, for the order's comparison)
+                    if (rule != 50) cands[nc++] = 50;
+                    if (rule != 0) cands[nc++] = 0;
+                    if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
+                }
                 if (H.share_serial != ctx->image_serial || H.share_shape_nc != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
                     H.share_serial = ctx->image_serial; H.share_shape_nc = H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
                     H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.learned_once = false;
@@ -395,7 +397,10 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // order takes those away: up to 10 rounds only (round 5, 8M triangles: 8 rounds -3 %, 4 and 2 rounds +-0, 16 rounds +5 % slower -- the per-GPU share
             // of configuration 5, which round 4's rule ordered; primary rays at the same time: 4.5 / 8 / 12.5 / 18 rounds -14 / -11 / -6.5 / -5.3 %).
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
-            const int limit = H.rows_from_origins ? std::min(ctx->opt_tile_order_rounds, ctx->opt_tile_order_rounds_incoherent) : ctx->opt_tile_order_rounds;
+            // (with the share trial the order is held against the default order by measurement -- below -- and may be TRIED on launches of any size the sort covers: the
+            // limits fitted in rounds 3 - 5 -- 25 rounds, 10 for rays without coherent directions -- stand where nothing is measured: "traverse.share_trial" = 0)
+            const bool measured = share_pct >= 0;
+            const int limit = measured ? (1 << 20) : (H.rows_from_origins ? std::min(ctx->opt_tile_order_rounds, ctx->opt_tile_order_rounds_incoherent) : ctx->opt_tile_order_rounds);
             const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? ((rounds100 <= limit && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
@@ -461,8 +466,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         const bool order_lost = H.order_loses && share_pct >= 0 && ctx->opt_tile_order < 0;           // ("traverse.tile_order" = 1 of the test library: followed whatever it costs)
         if (default_sample && H.lpt_valid && H.learned_once) a.tile_cost = nullptr;          // (samples of a later trial leave no costs: shares of their tiles run with four lanes per ray and count differently)
-        if (a.tile_order && (default_sample || order_lost)) { a.tile_order = nullptr; a.order_samples = nullptr; }     // (costs are still kept: the order is there when wanted)
-        if (order_lost) learn_order = false;
+        if (a.tile_order && (default_sample || order_lost)) { a.tile_order = nullptr; a.order_samples = nullptr; }     // (the samples still keep costs: the order is there when wanted)
+        if (order_lost) { learn_order = false; a.tile_cost = nullptr; }          // (an order that lost is neither followed nor refreshed: launches without the cost bookkeeping)
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
         // LDS, trav_kernels.h test_list).  -1 (default): for rays in tile-packet order (1024^2: -2.6 %, 640 x 480: -4.4 %, 2048^2 and
         // beyond -0.2 ... -0.4 %), not for binned batches (+2.2 %: their wavefronts hold few rays per cell, the second request is mostly

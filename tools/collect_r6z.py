@@ -21,8 +21,9 @@ for c in (2, 3, 4, 5, 6, 7):
     cp(os.path.join(d, "summary.txt"), os.path.join(D, f"summary_config{c}.txt"))
     cp(os.path.join(d, "stats", "trace_kernel_stats.csv"), os.path.join(D, f"kernel_stats_config{c}.csv"))
 cp(os.path.join(S, "construction_traffic.txt"), os.path.join(ROOT, "profiles", "pmc_r6z_construction_traffic.txt"))
-if cp(os.path.join(S, "config6", "traffic_config6_aimed.json"), os.path.join(D, "traffic_config6_aimed.json")):
-    shutil.copyfile(os.path.join(S, "config6", "traffic_config6_aimed.json"), os.path.join(ROOT, "profiles", "traffic_config6_aimed.json"))
+if cp(os.path.join(S, "config6_aimed", "traffic_config6_aimed.json"), os.path.join(D, "traffic_config6_aimed.json")):
+    shutil.copyfile(os.path.join(S, "config6_aimed", "traffic_config6_aimed.json"), os.path.join(ROOT, "profiles", "traffic_config6_aimed.json"))
+    cp(os.path.join(S, "config6_aimed", "summary.txt"), os.path.join(D, "summary_config6_aimed.txt")); cp(os.path.join(S, "config6_aimed", "stats", "trace_kernel_stats.csv"), os.path.join(D, "kernel_stats_config6_aimed.csv"))
 def line(name):
     p = os.path.join(D, name)
     if not os.path.exists(p): return None

@@ -9,7 +9,7 @@ timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | cut -c1-300 | 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | cut -c1-200
 export ESSENTIAL=1 PASS_LIMIT=120
 tools/gpu_traffic_config.sh $TAG 2 > $OUT/traffic2.log 2>&1; cp $OUT/config2/traffic_config2.json profiles/ 2>/dev/null
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench.json
+( time timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench_time.txt; cut -c1-200 $OUT/bench.json; grep real $OUT/bench_time.txt
 tools/gpu_traffic_config.sh $TAG 6 > $OUT/traffic6.log 2>&1; cp $OUT/config6/traffic_config6.json profiles/ 2>/dev/null
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 --config clustered --no-cpu-baseline > $OUT/bench_clustered.json 2> $OUT/bench_clustered.err; cut -c1-200 $OUT/bench_clustered.json
 tools/gpu_traffic_config.sh $TAG 7 > $OUT/traffic7.log 2>&1; cp $OUT/config7/traffic_config7.json profiles/ 2>/dev/null

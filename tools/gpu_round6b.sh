@@ -10,7 +10,7 @@ tools/gpu_traffic_config.sh $TAG 4 --shard 3/8 > $OUT/traffic4.log 2>&1; cp $OUT
 timeout 300 python bench.py --gpus 1 --steps 10 --warmup 2 --config 4 --shard 3/8 --no-cpu-baseline > $OUT/bench_config4_shard.json 2> $OUT/bench_config4_shard.err; cut -c1-160 $OUT/bench_config4_shard.json
 PASS_LIMIT=200 tools/gpu_traffic_config.sh $TAG 5 --shard 3/8 > $OUT/traffic5.log 2>&1; cp $OUT/config5/traffic_config5.json profiles/ 2>/dev/null
 timeout 300 python bench.py --gpus 1 --steps 10 --warmup 2 --config 5 --shard 3/8 --no-cpu-baseline > $OUT/bench_config5_shard.json 2> $OUT/bench_config5_shard.err; cut -c1-160 $OUT/bench_config5_shard.json
-TRAFFIC_SUFFIX=_aimed tools/gpu_traffic_config.sh $TAG 6 --rays aimed > $OUT/traffic6_aimed.log 2>&1; cp $OUT/config6/traffic_config6_aimed.json profiles/ 2>/dev/null
+TRAFFIC_SUFFIX=_aimed tools/gpu_traffic_config.sh $TAG 6 --rays aimed > $OUT/traffic6_aimed.log 2>&1; cp $OUT/config6_aimed/traffic_config6_aimed.json profiles/ 2>/dev/null
 B="python bench.py --gpus 1 --no-cpu-baseline --inflight 0"
 timeout 100 $B --steps 20 --warmup 3 --config clustered --rays aimed > $OUT/bench_clustered_aimed.json 2> $OUT/bench_clustered_aimed.err; cut -c1-160 $OUT/bench_clustered_aimed.json
 timeout 100 $B --steps 20 --warmup 3 --config clustered --rays aimed --bin-rays 0 > $OUT/bench_clustered_aimed_unbinned.json 2> $OUT/bench_clustered_aimed_unbinned.err; cut -c1-160 $OUT/bench_clustered_aimed_unbinned.json

@@ -5,7 +5,7 @@
 # usage: tools/gpu_traffic_config.sh TAG CONFIG [bench.py arguments, e.g. --shard 3/8]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=$1; C=$2; shift; shift
-OUT=gpurun_out/$TAG/config$C; mkdir -p $OUT
+OUT=gpurun_out/$TAG/config$C$TRAFFIC_SUFFIX; mkdir -p $OUT        # (TRAFFIC_SUFFIX=_aimed: a batch of another ray kind keeps its own directory and file)
 export TMPDIR=/tmp
 ROOT=$PWD
 python -c "import __graft_entry__ as g; g.build()" || exit 1
