@@ -1,15 +1,11 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job).  Job 25: evidence repair -- the clustered scene's counters again (its directory was overwritten by the aimed batch's),
-# the aimed batch's counters in a directory of their own and its bench lines with them.
+# One-off experiment script of round 6 (rewritten per job).  Job 26: the order tried beyond 25 rounds where it is measured: regret cells at 4096^2, the large configurations.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=r6z; OUT=gpurun_out/$TAG; mkdir -p $OUT
+OUT=gpurun_out/r6v; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" || exit 1
-python -c "from hagrid_amd import build as b; print('kernel sources', b.source_hash())"
-export ESSENTIAL=1 PASS_LIMIT=120
-rm -rf $OUT/config6
-tools/gpu_traffic_config.sh $TAG 6 > $OUT/traffic6.log 2>&1; cp $OUT/config6/traffic_config6.json profiles/ 2>/dev/null
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 --config clustered --no-cpu-baseline > $OUT/bench_clustered.json 2> $OUT/bench_clustered.err; cut -c1-200 $OUT/bench_clustered.json
-TRAFFIC_SUFFIX=_aimed tools/gpu_traffic_config.sh $TAG 6 --rays aimed > $OUT/traffic6_aimed.log 2>&1; cp $OUT/config6_aimed/traffic_config6_aimed.json profiles/ 2>/dev/null
-B="python bench.py --gpus 1 --no-cpu-baseline --inflight 0"
-timeout 100 $B --steps 20 --warmup 3 --config clustered --rays aimed > $OUT/bench_clustered_aimed.json 2> $OUT/bench_clustered_aimed.err; cut -c1-160 $OUT/bench_clustered_aimed.json
-find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+timeout 900 python -m pytest tests/test_traverse_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x -k "tile_order or head_share or share_trial or config3 or config2_loop" 2>&1 | tail -3 | cut -c1-300
+timeout 1500 python tools/dev_policy_regret.py --sizes 4096x4096,2048x2048 --kinds primary,bounce > $OUT/policy_regret.txt 2> $OUT/policy_regret.err; sed -n '/| scene | batch/,$p' $OUT/policy_regret.txt | grep "^|" | cut -c1-200
+B="python bench.py --gpus 1 --no-cpu-baseline --inflight 0 --no-order-compare"
+timeout 200 $B --steps 10 --warmup 2 --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.err; cut -c1-160 $OUT/bench_config3.json
+timeout 200 $B --steps 10 --warmup 2 --config 5 --shard 3/8 > $OUT/bench_config5_shard.json 2> $OUT/bench_config5_shard.err; cut -c1-160 $OUT/bench_config5_shard.json
+timeout 200 $B --steps 10 --warmup 2 --config 4 --shard 3/8 > $OUT/bench_config4_shard.json 2> $OUT/bench_config4_shard.err; cut -c1-160 $OUT/bench_config4_shard.json
