@@ -141,6 +141,7 @@ struct hagrid_ctx {
         int trial_kind = 0 /* the timed launch in flight: 0 the order alone, 1 with the head share, 2 with ALL tiles four lanes per ray */, n_all = 0, all_stage = 0 /* 0 not tried, 1 - 2 learning its own order, 3 timed, 4 decided */; float t_all = 0.0f; bool learned_all = false;
         bool learned_once = false;          // the first share trial of this launch shape has been decided and the order learned behind it
         unsigned order_serial = 0;          // ctx->image_serial the learned tile order belongs to
+        bool cmp_pending = false, cmp_done = false; int n_conf = 0; float t_conf = 0.0f;     // the order against the default order: three default-order launches timed next to the order's own samples
         bool order_loses = false;           // the learned order's steady launches were not 3 % faster than the best default-order launch: not followed until the next trial
         bool moving = false; int moving_since = 0, still = 0, last_report = -1;       // MOVING mode (traverse.hip): the rays change from launch to launch -- sorted behind every launch; epoch at which the mode began, launches without a report, the report word as last seen
         unsigned long long used = 0;                    // clock of the last call that used the slot

@@ -206,7 +206,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = 0; N.learned_all = false; N.all_stage = 0; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = N.n_conf = 0; N.learned_all = false; N.all_stage = 0; N.cmp_pending = N.cmp_done = false; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -371,7 +371,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // the trials then settle on)
                     if (!H.learned_once) {
                         H.learned_once = true;
-                        H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0; H.lpt_rot = 0;
+                        H.lpt_valid = false; H.lpt_age = 0; H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false; H.lpt_rot = 0;
                     }
                 }
                 if (H.share_choice >= 0 && ++H.share_launches >= 1024) {         // (the scene in view may have changed: measured again, and the learned order held against it again)
@@ -381,7 +381,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     const float bar = 1.15f * H.share_t[H.share_choice];
                     for (int i = 1; i < nc; i++) if (H.share_t[i] <= bar) { H.share_cands[keep] = H.share_cands[i]; keep++; }
                     H.share_ncand = nc = keep;
-                    H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false;
+                    H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.cmp_done = false; H.cmp_pending = false; H.n_conf = 0;
                 }
                 if (H.share_choice >= 0) share_pct = H.share_cands[H.share_choice];
                 else if (H.share_issued < 3 * nc) { share_pct = H.share_cands[H.share_issued % nc]; default_sample = true; }
@@ -431,7 +431,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
                     // not about these rays: a concluded trial stands, the next order is stored with the same share at its head; an unfinished one starts again)
                     H.lpt_valid = false; H.lpt_age = 0;
-                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0; }
+                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
                     else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
@@ -465,8 +465,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             }
         }
         const bool order_lost = H.order_loses && share_pct >= 0 && ctx->opt_tile_order < 0;           // ("traverse.tile_order" = 1 of the test library: followed whatever it costs)
-        if (default_sample && H.lpt_valid && H.learned_once) a.tile_cost = nullptr;          // (samples of a later trial leave no costs: shares of their tiles run with four lanes per ray and count differently)
-        if (a.tile_order && (default_sample || order_lost)) { a.tile_order = nullptr; a.order_samples = nullptr; }     // (the samples still keep costs: the order is there when wanted)
+        // (the samples keep no costs: shares of their tiles run with four lanes per ray and count differently, the order is learned from nothing behind them anyway -- and on
+        // the table and general layouts cost bookkeeping is another instantiation, a few per cent slower on launches of many rounds: the default order has to be timed as it
+        // would run for good, without it.  Configuration 3 at 4096^2: 13.3 Grays/s so, 12.4 when an order that only beat cost-keeping samples was followed, gpurun_out/r6z2)
+        if (default_sample) a.tile_cost = nullptr;
+        // Before an order is accepted or dropped for good the default order is timed ONCE MORE, next to the order's own samples: the first samples of a launch shape are the
+        // first launches of a process as often as not (clocks still rising, first touches: 1.31 ms where the steady default order takes 1.13 at 4096^2 on the soup) and an
+        // order measured half a second later would beat them whatever it is worth (configuration 3 at 4096^2: 12.3 instead of 13.3 Grays/s, gpurun_out/r6w).
+        const bool conf_sample = a.tile_order && H.cmp_pending && H.n_conf < 3 && !H.trial_pending && !learn_order && !default_sample;
+        if (conf_sample) a.tile_cost = nullptr;
+        if (a.tile_order && (default_sample || order_lost || conf_sample)) { a.tile_order = nullptr; a.order_samples = nullptr; }
         if (order_lost) { learn_order = false; a.tile_cost = nullptr; }          // (an order that lost is neither followed nor refreshed: launches without the cost bookkeeping)
         // "traverse.tail_dual": phase 1 of the tail kernel tests two ids of an inline list per round trip (the second triangle comes through
         // LDS, trav_kernels.h test_list).  -1 (default): for rays in tile-packet order (1024^2: -2.6 %, 640 x 480: -4.4 %, 2048^2 and
@@ -507,13 +515,14 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
         // until the order is learned again from nothing.
         if (H.trial_opt != ctx->opt_quad_head || H.head_serial != ctx->image_serial) {            // (the test library changed the threshold, or another grid: the trial starts again)
-            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = 0; H.learned_all = false; H.all_stage = 0;
+            H.trial_opt = ctx->opt_quad_head; H.head_serial = ctx->image_serial; H.head_disabled = false; H.rot_adopted = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false;
         }
         if (H.trial_pending && hipEventQuery(H.trial_evt[1]) == hipSuccess) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, H.trial_evt[0], H.trial_evt[1]) == hipSuccess && ms > 0.0f) {
                 if (H.trial_kind == 1) { H.t_head = H.n_head ? std::min(H.t_head, ms) : ms; H.n_head++; }
                 else if (H.trial_kind == 2) { H.t_all = H.n_all ? std::min(H.t_all, ms) : ms; H.n_all++; }
+                else if (H.trial_kind == 3) { H.t_conf = H.n_conf ? std::min(H.t_conf, ms) : ms; H.n_conf++; }
                 else { H.t_base = H.n_base ? std::min(H.t_base, ms) : ms; H.n_base++; }
             }
             H.trial_pending = false;
@@ -541,11 +550,15 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         const bool all_done = !all_ok || H.all_stage >= 4 || (H.n_head >= 3 && !H.head_disabled);
         // the learned order against the best default-order launch (the share trial's): all known -> an order that is not 3 % faster is not followed
-        if (share_pct >= 0 && H.share_choice >= 0 && !H.order_loses && H.n_base >= 3 && head_done && all_done) {
-            float learned = H.t_base;
-            if (H.n_head >= 3 && !H.head_disabled) learned = std::min(learned, H.t_head);
-            if (H.all_stage >= 4 && H.learned_all) learned = std::min(learned, H.t_all);
-            if (learned > 0.97f * H.share_t[H.share_choice]) H.order_loses = true;
+        if (share_pct >= 0 && H.share_choice >= 0 && !H.order_loses && !H.cmp_done && H.n_base >= 3 && head_done && all_done) {
+            if (H.n_conf < 3) H.cmp_pending = true;              // (three launches in the default order, timed now: above)
+            else {
+                float learned = H.t_base;
+                if (H.n_head >= 3 && !H.head_disabled) learned = std::min(learned, H.t_head);
+                if (H.all_stage >= 4 && H.learned_all) learned = std::min(learned, H.t_all);
+                if (learned > 0.97f * std::min(H.share_t[H.share_choice], H.t_conf)) H.order_loses = true;
+                H.cmp_pending = false; H.cmp_done = true;
+            }
         }
         if (head_ok && H.n_base >= 3 && !H.head_disabled && H.all_stage == 0) {
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
@@ -584,8 +597,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
         // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
-        const bool timed = a.tile_order && (!learn_order || H.moving) && !H.trial_pending && (H.lpt_age >= 2 || H.moving) &&
-                           (a.quad_head ? (head_ok && !H.head_disabled && H.n_head < 3 && ctx->opt_quad_head > 0) : (all_sample || H.n_base < 3));
+        const bool timed = conf_sample || (a.tile_order && (!learn_order || H.moving) && !H.trial_pending && (H.lpt_age >= 2 || H.moving) &&
+                                           (a.quad_head ? (head_ok && !H.head_disabled && H.n_head < 3 && ctx->opt_quad_head > 0) : (all_sample || H.n_base < 3)));
         if (timed) {
             for (auto& e : H.trial_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
             HG_HIP(ctx, hipEventRecord(H.trial_evt[0], ctx->stream));
@@ -596,7 +609,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         }
         if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
-        if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; H.trial_kind = a.quad_head > 0 ? 1 : (all_sample ? 2 : 0); }
+        if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; H.trial_kind = conf_sample ? 3 : (a.quad_head > 0 ? 1 : (all_sample ? 2 : 0)); }
         if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][1], ctx->stream)); H.share_issued++; }
         if (a.tile_order && H.lpt_valid && !H.rot_adopted && want_rot != H.lpt_rot) { learn_order = true; H.rot_adopted = true; }
 #ifdef HAGRID_DEBUG_TRACE                      // (development builds only: the decisions of the head share, tools/build_variant.sh -DHAGRID_DEBUG_TRACE)
