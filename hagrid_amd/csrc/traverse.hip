@@ -346,6 +346,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     if (rule != 0) cands[nc++] = 0;
                     if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
                 }
+                // ... and, where the bands rule of make_args takes four rows of super-tiles (launches of eight rounds and more; fitted on configuration 5's bounce rays in round
+                // 4), ONE row with the rule's share (bit 8 of a candidate): the stadium at 2048^2 0.386 -> 0.361 ms, bounce rays there 0.911 -> 0.878 (the last two cells of
+                // tools/dev_policy_regret.py above 3 %).  The band decides which tile a block index means, so it is chosen here, before an order is learned, and then holds for
+                // the order as well.
+                if (!perm && ctx->opt_band_rows <= 0 && a.band_rows > 1 && nc < 4) cands[nc++] = rule | 256;
                 if (H.share_serial != ctx->image_serial || H.share_shape_nc != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
                     H.share_serial = ctx->image_serial; H.share_shape_nc = H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
                     H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.learned_once = false;
@@ -386,6 +391,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 if (H.share_choice >= 0) share_pct = H.share_cands[H.share_choice];
                 else if (H.share_issued < 3 * nc) { share_pct = H.share_cands[H.share_issued % nc]; default_sample = true; }
                 else share_pct = H.share_last >= 0 ? H.share_last : rule;        // (the samples are still in flight: the last answer, else the rule)
+                if (share_pct & 256) { a.band_rows = 1; share_pct &= 255; }      // (one row of super-tiles per band: in the learned order as well)
             }
         }
         {
@@ -431,7 +437,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
                     // not about these rays: a concluded trial stands, the next order is stored with the same share at its head; an unfinished one starts again)
                     H.lpt_valid = false; H.lpt_age = 0;
-                    if (!(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false; }
+                    if (!H.cmp_done && !(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
                     if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
                     else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
