@@ -736,6 +736,59 @@ def test_share_trial_and_the_order_held_against_it_never_change_hits(mem):
     grid.free(); mem.free(d_tris)
 
 
+def test_policy_state_machine_under_a_random_sequence_of_launches(mem):
+    """The measured dispatch policy (share trial, order or no order, head share, all tiles, re-trials, hint slots taken over by other buffers, another traversal image
+    under the same buffers) is a state machine per ray buffer; whatever state a sequence of calls leaves it in, a launch gives the oracle's hits.  300 launches over SIX
+    ray buffers (the context remembers four) of five shapes and three ray kinds, in random order, with refills (another frame into the same buffer), ray binning switched
+    on and off, occasional synchronisation, and the grid rebuilt with other parameters half-way (same scene: same hits)."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    rng = np.random.default_rng(77)
+    tris = scene.make_clustered(20000, 3, 30000)
+    G = O.Grid.full(tris)
+    d_tris = mem.upload(tris)
+    grid = api.build_all(mem, d_tris, tris.shape[0]); api.setup_traversal(grid)
+    lo, hi = np.asarray(G.bbox_min), np.asarray(G.bbox_max)
+    shapes = [(512, 512), (1024, 256), (640, 480), (200, 77), (768, 768)]
+    def frame(shape, kind, f):
+        w, h = shape
+        prim = scene.make_rays_primary(lo, hi, w, h, yaw=0.01 * f, strafe=0.01 * f).astype(np.float32)
+        if kind == "primary": return prim
+        inc = scene.make_rays_incoherent(lo, hi, prim.shape[0], 100 + f).astype(np.float32)
+        if kind == "incoherent": return inc
+        b = prim.copy(); b[:, 4:7] = inc[:, 4:7]; return b                                  # bounce-like: origins in image order, directions anywhere
+    want_cache = {}
+    def want(shape, kind, f):
+        key = (shape, kind, f)
+        if key not in want_cache:
+            want_cache[key] = G.traverse(tris, np.ascontiguousarray(frame(shape, kind, f)), nthreads=8)[0]
+        return want_cache[key]
+    bufs = []
+    for i in range(6):
+        shape = shapes[i % len(shapes)]; kind = ("primary", "incoherent", "bounce")[i % 3]
+        n = shape[0] * shape[1]
+        bufs.append(dict(shape=shape, kind=kind, f=0, n=n, d_rays=mem.upload(np.ascontiguousarray(frame(shape, kind, 0))), d_hits=mem.alloc(16 * n)))
+    try:
+        for launch in range(300):
+            b = bufs[int(rng.integers(len(bufs))) if launch % 5 else int(rng.integers(2))]        # (two buffers get most of the launches: their trials conclude)
+            r = rng.random()
+            if r < 0.08:                                             # another frame into the same buffer
+                b["f"] = int(rng.integers(4)); mem.copy_h2d(b["d_rays"], np.ascontiguousarray(frame(b["shape"], b["kind"], b["f"])))
+            if launch == 150:                                        # another grid (and traversal image) of the same scene under the same buffers
+                grid.free(); grid = api.build_all(mem, d_tris, tris.shape[0], top_density=0.2, snd_density=3.0); api.setup_traversal(grid)
+            mem.set_ray_binning(1 if (b["kind"] == "incoherent" and rng.random() < 0.7) else 0)
+            mem.zero(b["d_hits"], 16 * b["n"])
+            api.traverse_grid(grid, d_tris, b["d_rays"], b["d_hits"], b["n"])
+            if rng.random() < 0.5: mem.synchronize()
+            got = mem.download(b["d_hits"], api.HIT_DTYPE, b["n"])
+            w = want(b["shape"], b["kind"], b["f"])
+            assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (launch, b["shape"], b["kind"], b["f"], mem.order_state(b["d_rays"]))
+    finally:
+        mem.set_ray_binning(0)
+        for b in bufs: mem.free(b["d_rays"]); mem.free(b["d_hits"])
+    grid.free(); mem.free(d_tris)
+
+
 def test_image_lifetime(mem):
     """The image belongs to the grid of the last setup_traversal call and never outlives its source arrays."""
     from oracle import oracle as O
