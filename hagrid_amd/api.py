@@ -100,7 +100,7 @@ class MemManager:
         """dev tools / tests: what the context remembers about a ray buffer's tile order (csrc/kat/hagrid_amd_kat.h: hagrid_kat_order_state)"""
         out = (C.c_int32 * 12)(); ms = (C.c_float * 4)()
         _check(self, self._K.hagrid_kat_order_state(self._ctx, C.c_void_p(d_rays), out, ms), "order_state")
-        keys = ("slot", "valid", "moving", "head_tiles", "head_dropped", "n_base", "n_head", "share_choice", "share_samples", "n_all", "head_suggested", "share_launches")
+        keys = ("slot", "valid", "cooling", "head_tiles", "head_dropped", "n_base", "n_head", "share_choice", "share_samples", "n_all", "head_suggested", "share_launches")
         d = dict(zip(keys, list(out))); d["ms_base"] = round(ms[0], 4); d["ms_head"] = round(ms[1], 4); d["ms_all"] = round(ms[2], 4); d["ms_share_best"] = round(ms[3], 4)
         d["order_loses"] = d["share_samples"] >= 10000; d["share_samples"] %= 10000; d["cooldown"] = d["n_all"] // 100; d["learned_all"] = (d["n_all"] // 10) % 10 == 1; d["n_all"] %= 10
         return d

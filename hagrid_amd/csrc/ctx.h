@@ -121,7 +121,7 @@ struct hagrid_ctx {
     // slot is taken over by a new buffer.  Slot i owns the device word dscratch[kScrRowLen + i] and the pinned words mailbox[kMbxRowLen + i], [kMbxOrderStale + i], [kMbxHeadSuggest + i].
     struct RayHints {
         const void* key_rays = nullptr; int key_n = 0;       // the buffer the slot belongs to
-        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false;   // rowlen_known: the row length as the host has seen it (-1: not yet)
+        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
         int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32, lpt_rot = 0 /* positions the stored order is rotated by: its last lpt_rot tiles are the longest */; bool rot_adopted = false /* the first suggestion of a sort was taken up by a sort of its own */;
@@ -143,21 +143,17 @@ struct hagrid_ctx {
         unsigned order_serial = 0;          // ctx->image_serial the learned tile order belongs to
         bool cmp_pending = false, cmp_done = false; int n_conf = 0; float t_conf = 0.0f;     // the order against the default order: three default-order launches timed next to the order's own samples
         bool order_loses = false;           // the learned order's steady launches were not 3 % faster than the best default-order launch: not followed until the next trial
-        bool moving = false; int moving_since = 0, still = 0, last_report = -1;       // MOVING mode (traverse.hip): the rays change from launch to launch -- sorted behind every launch; epoch at which the mode began, launches without a report, the report word as last seen
+        int last_report = -1;               // the report word (mailbox[kMbxOrderStale + slot]) as last seen
         unsigned long long used = 0;                    // clock of the last call that used the slot
     };
     static constexpr int kRayHints = 4;
     RayHints hints[kRayHints];
     unsigned long long hint_clock = 0;
     int opt_mailbox = -1;       // tail kernel: per ray a mailbox of the last four triangles it was tested against (LDS); -1: chosen per launch
-    int opt_tri_pad = -1;       // tail kernel: triangles read from a copy padded to 64 bytes each (one L2 / HBM sector per triangle instead of 1.5), made at every call; -1: chosen per launch
     int opt_tail = 1;           // table-free slim image, nearest hit: the kernel with the tail mode (four lanes per ray once a wavefront holds at most 16 live rays)
     int opt_lds_pad = 0;         // experiments: dynamic LDS bytes per block of the tail kernel
     int opt_tail_dual = -1;      // tail kernel, phase 1: two ids of an inline list per round trip (trav_kernels.h, test_list); -1: chosen per launch
-    int opt_tile_order_rounds = 2500;   // ... up to this many rounds of resident wavefronts, in per cent
-    int opt_tile_order_rounds_incoherent = 1000;   // ... and up to this many for rays in image order without coherent directions (rows found from the origins alone)
     int opt_share_trial = 1;            // launches in the default order: the share of tiles that start with four lanes per ray measures itself (the rule's share against a half); 0: the rule
-    int opt_order_moving = 0;           // ... rays that change from launch to launch (a moving camera): 1 = the order is sorted again behind every launch from the costs of that launch (pays below ~2 pixels of drift per frame only: NOTES round 6); 0 = no order for a while
     int opt_order_gate = 1;             // ... and only while the buffer holds the rays it was learned on (0: the order is followed unseen -- A/B runs)
     int opt_tile_order = -1;     // tail kernel: tiles dispatched longest first, by the costs the previous launches over the same ray buffer left; -1: chosen per launch
     int opt_quad_tail = -1;      // per cent of the tiles (the last in dispatch order) that start with four lanes per ray; -1: chosen per launch

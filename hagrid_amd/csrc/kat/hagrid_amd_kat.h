@@ -57,7 +57,6 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "traverse.tail"      1 (default) = slim-record images are traversed by the kernel with the tail mode, 0 = one ray per lane throughout
  *   "traverse.quad_tail" per cent of the tiles, the last in dispatch order, that start with four lanes per ray; -1 (default) = by launch size
  *   "traverse.tail_dual" 1 = phase 1 of the tail kernel tests two ids of an inline list per round trip; -1 (default) = 1 unless the batch is binned
- *   "traverse.tile_order_rounds"  the tile order is used for launches of up to this many per cent of a round of resident wavefronts (2500)
  *   "traverse.super_tile", "traverse.xcd_chunk"   tile packets: log2 of the tiles per super-tile edge (3); the XCDs take chunks of 2^k wavefronts in
  *                        turn (k >= 0), one eighth of the range each (-1), by launch size (-2, default)
  *   "traverse.row_cache" 1 (default) = a row length found for a ray buffer is kept for the next 15 calls, 0 = looked for at every call
@@ -71,7 +70,7 @@ int hagrid_kat_image_records(hagrid_ctx* ctx, const hagrid_grid* grid, const int
  *   "ctx.fast_readback"  1 (default) = scalar read-backs through a publishing wavefront and a spinning host, 0 = hipMemcpyAsync + hipStreamSynchronize */
 int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value);
 
-/* What the context remembers about the ray buffer `rays` (traverse.hip, RayHints): out12 = { slot or -1, order valid, moving mode, positions the order is rotated by (the
+/* What the context remembers about the ray buffer `rays` (traverse.hip, RayHints): out12 = { slot or -1, order valid, no order for a while (rays that keep changing), positions the order is rotated by (the
  * four-lanes-per-ray head), head share dropped by its trial, timed samples without / with the head, the share trial's choice (-1 measuring, 0 rule, 1 half), its samples (rule + 100 x half), cooldown, epoch, launches since the choice };
  * ms4 = the head trial's best launch times without / with the head, the share trial's with the rule's share / with a half.  Dev tools and tests only: nothing in the product reads it. */
 /* Makes the context forget every ray buffer it has traversed (row lengths, tile orders, the trials' answers): the next call over any buffer starts from nothing.

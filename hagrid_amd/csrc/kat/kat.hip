@@ -278,11 +278,11 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
         {"traverse.variant", &ctx->opt_variant, 0, 4},              {"traverse.narrow", &ctx->opt_narrow, 0, 1},
         {"traverse.image_uniform", &ctx->opt_image_uniform, 0, 2},  {"traverse.image_slim", &ctx->opt_image_slim, 1, 2}, {"traverse.image_general", &ctx->opt_image_general, 0, 2}, {"traverse.image_vtop", &ctx->opt_image_vtop, 0, 1}, {"traverse.quad_head", &ctx->opt_quad_head, 0, 1000}, {"ctx.fast_readback", &ctx->opt_fast_readback, 0, 1},
         {"traverse.tail", &ctx->opt_tail, 0, 1},                    {"traverse.quad_tail", &ctx->opt_quad_tail, -1, 100},
-        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},         {"traverse.tile_order_rounds", &ctx->opt_tile_order_rounds, 0, 1 << 20}, {"traverse.tile_order_rounds_incoherent", &ctx->opt_tile_order_rounds_incoherent, 0, 1 << 20},
+        {"traverse.tail_dual", &ctx->opt_tail_dual, -1, 1},        
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 1, 2},
-        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.order_moving", &ctx->opt_order_moving, 0, 1}, {"traverse.share_trial", &ctx->opt_share_trial, 0, 1}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.tri_pad", &ctx->opt_tri_pad, -1, 1}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
+        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.share_trial", &ctx->opt_share_trial, 0, 1}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
         {"merge.inplace", &ctx->opt_merge_inplace, 0, 1},           {"merge.inplace_iters", &ctx->opt_merge_inplace_iters, 0, 1 << 20}, {"merge.inplace_room", &ctx->opt_merge_inplace_room, 0, 0x7fffffff}, {"merge.inplace_div", &ctx->opt_merge_inplace_div, 0, 1 << 20},
         {"expand.voxel_map", &ctx->opt_expand_voxel_map, 0, 1},      {"traverse.refill", &ctx->opt_refill, -1, 64},
     };
@@ -302,7 +302,7 @@ extern "C" int hagrid_kat_order_state(hagrid_ctx* ctx, const void* rays, int32_t
     for (int i = 0; i < hagrid_ctx::kRayHints; i++) {
         const hagrid_ctx::RayHints& h = ctx->hints[i];
         if (h.key_rays != rays) continue;
-        const int v[12] = {i, h.lpt_valid, h.moving, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice >= 0 ? h.share_cands[h.share_choice] : -1, h.share_done + 100 * h.share_issued + 10000 * int(h.order_loses), h.n_all + 10 * int(h.learned_all) + 100 * h.cooldown, __atomic_load_n(ctx->mailbox + kMbxHeadSuggest + i, __ATOMIC_RELAXED), h.share_launches};
+        const int v[12] = {i, h.lpt_valid, h.cooldown > 0, h.lpt_rot, h.head_disabled, h.n_base, h.n_head, h.share_choice >= 0 ? h.share_cands[h.share_choice] : -1, h.share_done + 100 * h.share_issued + 10000 * int(h.order_loses), h.n_all + 10 * int(h.learned_all) + 100 * h.cooldown, __atomic_load_n(ctx->mailbox + kMbxHeadSuggest + i, __ATOMIC_RELAXED), h.share_launches};
         for (int k = 0; k < 12; k++) out12[k] = v[k];
         if (ms2) { ms2[0] = h.t_base; ms2[1] = h.t_head; ms2[2] = h.t_all; ms2[3] = h.share_choice >= 0 ? h.share_t[h.share_choice] : 0.0f; }
         return HAGRID_OK;

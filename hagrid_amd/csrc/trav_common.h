@@ -51,7 +51,6 @@ struct TraverseArgs {
     int tail_dual;                // host side only: which instantiation of the tail kernel is launched
     int mailbox;                  // host side only: the instantiation with a mailbox of the last four triangles per ray
     int refill;                   // tail kernel (REFILL instantiations): tiles per wavefront whose lanes take new rays as they finish (0: off)
-    int tri64;                    // host side only: `tris` is the copy padded to 64 bytes per triangle (instantiations with TRI64)
     int quad_head;                // tail kernel: this many tiles at the HEAD of a learned tile order start with four lanes per ray (four blocks each, the first of the grid); 0: none
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     unsigned mode;                // v2 and the image kernel: HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS of this call (read at run time)
@@ -229,11 +228,10 @@ __device__ __forceinline__ T gather32(const void* base, uint32_t byte_offset) {
 #ifndef HG_SOLO
 #define HG_SOLO 1
 #endif
-template <int STRIDE = 48>
 __device__ __forceinline__ Tri load_tri_scalar(const float4* tris, int ref) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef const f4 __attribute__((address_space(4)))* const_f4;
-    const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * unsigned(STRIDE));
+    const_f4 p = (const_f4)(reinterpret_cast<uintptr_t>(tris) + size_t(uint32_t(__builtin_amdgcn_readfirstlane(ref))) * 48u);
     const f4 p0 = p[0], p1 = p[1], p2 = p[2];
     return Tri(vec3(p0.x, p0.y, p0.z), p0.w, vec3(p1.x, p1.y, p1.z), p1.w, vec3(p2.x, p2.y, p2.z), p2.w);
 }

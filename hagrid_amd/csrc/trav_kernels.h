@@ -258,8 +258,6 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 // DUAL: phase 1 tests the ids of an inline list two per round trip (see test_list)
 // COST: the wavefront counts its iterations and leaves them at its tile (the tile order of traverse.hip); the table layout runs that bookkeeping at seven resident
 // wavefronts per SIMD (HG_TABLE_WAVES below: at eight it spills a dozen registers around its loops), so launches of it that keep no costs run the instantiation without
-// TRI64: the triangles are read from a copy padded to 64 bytes each (traverse.hip, "traverse.tri_pad"): a triangle is then ONE 64-byte sector of L2 / HBM
-// (the caller's 48-byte records straddle two sectors every second time) -- a third fewer requests to L2 per triangle test
 // MAILBOX: every ray remembers the last four triangles it was tested against (a FIFO of ids per lane in LDS: the kernel has no registers for it) and skips
 // a test it has made before.  A triangle is referenced by the several cells it overlaps and a ray that passes it crosses several of them: on the oracle's
 // traces a quarter of the tests of a ray repeat one of its last four (15 % one of its last two), primary and incoherent batches alike.  A repeated test
@@ -278,7 +276,7 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 #ifndef HG_GENERAL_WAVES
 #define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
 #endif
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool TRI64 = false, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false, bool WIDE = GENERAL>
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false, bool WIDE = GENERAL>
 __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : ((!UNIFORM && COST) ? HG_TABLE_WAVES : 8))) traverse_kernel_tail(const TraverseArgs a) {
     // WIDE: the image holds wide records (always possible in the general layout; a table-layout image without any runs the instantiation without the checks)
     static_assert(!WIDE || !UNIFORM, "the uniform layout has no wide records");
@@ -394,11 +392,8 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     };
     auto tri_ptr = [&](int ref) -> const float4* {
         uint32_t r3, o;
-        if (TRI64) asm("v_lshlrev_b32 %0, 6, %1" : "=v"(o) : "v"(ref));
-        else {
-            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
-            asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
-        }
+        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r3) : "v"(ref));
+        asm("v_lshlrev_b32 %0, 4, %1" : "=v"(o) : "v"(r3));
         return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.tris) + o);
     };
     auto tri_vec = [&](int ref) -> Tri {
@@ -408,7 +403,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     };
     auto tri_for = [&](int ref) -> Tri {                   // every live lane the same triangle: through the scalar cache
         const int f = __builtin_amdgcn_readfirstlane(ref);
-        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar<TRI64 ? 64 : 48>(a.tris, f);
+        if (HG_SOLO && __ballot(ref != f) == 0ull) return load_tri_scalar(a.tris, f);
         return tri_vec(ref);
     };
     auto field = [&](const uint4& rec, int pos, int n) -> uint32_t {

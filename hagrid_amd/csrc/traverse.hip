@@ -21,39 +21,31 @@ using namespace hagrid_trav;
 
 namespace {
 
-// The caller's triangles, 48 bytes each, copied to 64-byte slots (the fourth 16 bytes of a slot are never read): one thread per 16-byte piece.
-__global__ void __launch_bounds__(256) pad_triangles(const float4* __restrict__ tris, int num_pieces, float4* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= num_pieces) return;
-    const int t = int(uint32_t(i) / 3u);
-    out[i + t] = tris[i];                            // piece p of triangle t: 4 t + p = i + t
-}
-
 // the kernels of the traversal image: the tail kernel for the nearest hit, the image kernel for any-hit / barycentrics (and with "traverse.tail" = 0)
 template <bool UVS>
 bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
     if (!narrow || (slim != 20 && slim != 26)) return false;          // (32-bit offsets: the caller sends larger grids to the construction-format kernels)
     if (tail && a.mode == 0u && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL; always with the mailbox, never on padded triangles)
-        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        else            traverse_kernel_tail<26, false, true, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        else            traverse_kernel_tail<26, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         return true;
     }
     if (tail && a.mode == 0u && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
+        if (a.tile_cost) {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
+    }
+    else if (tail && a.mode == 0u && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         } else {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        }
-    }
-    else if (tail && a.mode == 0u && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
-        if (a.tile_cost) {
-            if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, false, false, true, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        } else {
-            if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
     else if (tail && a.mode == 0u && slim && !uniform) {
@@ -67,10 +59,6 @@ bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool
         }
     }
     else if (tail && a.mode == 0u && uniform && slim && a.mailbox) {          // (one id per round trip: the mailbox sits in front of every round; the caller's triangles)
-        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        else            traverse_kernel_tail<26, false, true, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-    }
-    else if (tail && a.mode == 0u && uniform && slim && a.tri64) {            // (padded triangles are for binned batches: one id per round trip)
         if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
         else            traverse_kernel_tail<26, false, true, false, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
     }
@@ -137,7 +125,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0; a.gen_shift = g->shift; a.gen_x = g->dims[0]; a.gen_xy = 0; a.gen_base = 0u;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.quad_head = 0; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.tri64 = 0; a.mailbox = 0; a.refill = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.quad_head = 0; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.mailbox = 0; a.refill = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -206,7 +194,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             hagrid_ctx::RayHints& N = ctx->hints[lru];
             N.key_rays = rays; N.key_n = num_rays;
             N.rowlen_rays = nullptr; N.rowlen_n = 0; N.rowlen_age = 0; N.rowlen_known = -1; N.rowlen_seen = 0;      // (a read-back still under way is overtaken by the next look)
-            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = N.n_conf = 0; N.learned_all = false; N.all_stage = 0; N.cmp_pending = N.cmp_done = false; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.moving = false; N.still = 0; N.last_report = -1;
+            N.lpt_rays = nullptr; N.lpt_valid = false; N.lpt_rot = 0; N.rot_adopted = false; N.head_disabled = false; N.t_base = N.t_head = N.t_all = 0.0f; N.n_base = N.n_head = N.n_all = N.n_conf = 0; N.learned_all = false; N.all_stage = 0; N.cmp_pending = N.cmp_done = false; N.trial_pending = false; N.relearn_streak = 0; N.cooldown = 0; N.cooldown_len = 64; N.last_report = -1;
             // (the slot's epochs go on counting -- a launch over the forgotten buffer may still report one -- and the report word says "nothing": epochs are >= 1)
             N.lpt_epoch++; __atomic_store_n(ctx->mailbox + kMbxOrderStale + lru, -1, __ATOMIC_RELAXED); __atomic_store_n(ctx->mailbox + kMbxHeadSuggest + lru, 0, __ATOMIC_RELAXED);
             // A buffer of the same shape the context knows (a renderer's next frame in a new allocation) stands in until this one's own answers are there: its
@@ -214,9 +202,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const hagrid_ctx::RayHints* donor = nullptr;
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
-            N.rows_from_origins = false;
             N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial; N.share_ncand = 0; N.share_shape_nc = 0; N.order_loses = false; N.learned_once = false;
-            if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
+            if (donor) N.rowlen_seen = donor->rowlen_seen;
             if (donor && donor->share_serial == ctx->image_serial && donor->share_ncand > 0) {       // (the donor's answer, its candidates and times with it: same launch shape)
                 N.share_ncand = donor->share_ncand; N.share_shape_nc = donor->share_shape_nc; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
                 N.share_choice = donor->share_choice; N.share_last = donor->share_last; N.share_launches = donor->share_launches; N.order_loses = donor->order_loses;
@@ -227,7 +214,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     }
     hagrid_ctx::RayHints& H = ctx->hints[hint_slot];
     if (H.order_serial != ctx->image_serial) {        // another traversal image since the slot's tile order was learned (another grid, another scene): learned from nothing
-        H.order_serial = ctx->image_serial; H.lpt_rays = nullptr; H.lpt_valid = false; H.moving = false; H.cooldown = 0; H.cooldown_len = 64;
+        H.order_serial = ctx->image_serial; H.lpt_rays = nullptr; H.lpt_valid = false; H.cooldown = 0; H.cooldown_len = 64;
     }
     // Kernel choice.  With a traversal image (hagrid_setup_traversal built one for this very grid) its kernel is used for every
     // batch; without one the latency-oriented v2 walks the construction format (trav_plain.hip).
@@ -270,7 +257,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             int* row_len = ctx->dscratch + kScrRowLen + hint_slot;
             const bool same = ctx->opt_row_cache && H.rowlen_rays == rays && H.rowlen_n == num_rays;
             if (same && H.rowlen_pending) {
-                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[kMbxRowLen + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rows_from_origins = (word & kRowsFromOrigins) != 0; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
+                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[kMbxRowLen + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
             if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
@@ -398,16 +385,12 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool tail_kernel = ctx->opt_tail && !flags && narrow;
             // by default for launches of up to 25 rounds (2048^2, eight rounds: -8 %; 2560^2: -4.9 %, 3072^2, 18 rounds: -1.3 %, 4096^2, 32 rounds: +-0 -- the tiles
             // of a class of equal cost are scattered over the image, and a throughput-bound launch pays for that in its caches) and not while the image is shared
-            // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch).  Rays in image order WITHOUT coherent
-            // directions (the row length came from neighbouring origins: bounce rays) have nothing but their neighbours in the image to share lines with, and an
-            // order takes those away: up to 10 rounds only (round 5, 8M triangles: 8 rounds -3 %, 4 and 2 rounds +-0, 16 rounds +5 % slower -- the per-GPU share
-            // of configuration 5, which round 4's rule ordered; primary rays at the same time: 4.5 / 8 / 12.5 / 18 rounds -14 / -11 / -6.5 / -5.3 %).
+            // between contexts (batches in flight fill each other's drain: two in flight 0.118 -> 0.119 ms per batch).
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
-            // (with the share trial the order is held against the default order by measurement -- below -- and may be TRIED on launches of any size the sort covers: the
-            // limits fitted in rounds 3 - 5 -- 25 rounds, 10 for rays without coherent directions -- stand where nothing is measured: "traverse.share_trial" = 0)
+            // (with the share trial the order is held against the default order by measurement -- below -- and may be TRIED on launches of any size the sort covers; the
+            // limit fitted in rounds 3 - 5 -- 25 rounds -- stands where nothing is measured: "traverse.share_trial" = 0 of the test library)
             const bool measured = share_pct >= 0;
-            const int limit = measured ? (1 << 20) : (H.rows_from_origins ? std::min(ctx->opt_tile_order_rounds, ctx->opt_tile_order_rounds_incoherent) : ctx->opt_tile_order_rounds);
-            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? ((rounds100 <= limit && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
+            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? (((measured || rounds100 <= 2500) && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
@@ -415,23 +398,17 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             else if (want && tail_kernel && !perm && rows_known && tiles >= 64 && tiles <= kMaxOrderTiles && tile_order_buffers(ctx, H, tiles)) {
                 int* report = ctx->mailbox + kMbxOrderStale + hint_slot;
                 // What the launches since the last look reported (their first wavefront compares the sample ray the order was sorted with against the buffer, bit for bit,
-                // and leaves the order's epoch when the buffer holds other rays).  A static order: a report that names it.  A buffer in MOVING mode (below) is sorted
-                // behind every launch, so the report of launch N names the epoch of the sort behind launch N - 1: any new report since the mode began counts.
+                // and leaves the order's epoch when the buffer holds other rays): a report that names the current order.
                 const int rep = __atomic_load_n(report, __ATOMIC_ACQUIRE);
                 const bool new_report = rep != H.last_report && rep > 0;
                 H.last_report = rep;
                 const bool same_buffer = H.lpt_valid && H.lpt_rays == rays && H.lpt_n == num_rays && H.lpt_blocks == tiles;
-                if (same_buffer && H.moving) {
-                    // the rays change from launch to launch (a camera that moves: the reference's viewer, main.cpp:591-601).  The costs of frame N are the best there is
-                    // for frame N + 1 -- its longest rays have drifted by a pixel, not by a tile -- so the order is sorted again behind EVERY launch and followed by the
-                    // next one whatever the sample says; the reports only tell when the rays have stopped changing (none for four launches: a static order again).
-                    if (new_report && rep > H.moving_since && rep <= H.lpt_epoch) H.still = 0;
-                    else if (++H.still >= 4) { H.moving = false; H.lpt_age = 0; H.lpt_period = 32; }
-                } else if (same_buffer && new_report && rep == H.lpt_epoch) {
+                if (same_buffer && new_report && rep == H.lpt_epoch) {
                     // A launch since the last sort found other rays in the buffer than the order was learned on: learn again, from costs of the new rays only (the
-                    // cost words hold the maximum over the launches since the last sort).  Rays that changed once (a buffer refilled now and then) get a static order
-                    // again; rays that change again within four launches of the last time are a camera that moves: MOVING mode ("traverse.order_moving" = 0: round 5's
-                    // answer -- no order for 64 launches, for twice as many every time that happens again, up to 1024).
+                    // cost words hold the maximum over the launches since the last sort).  Rays that changed once (a buffer refilled now and then) get an order again; rays
+                    // that change again within four launches of the last time are a camera that moves: no order for 64 launches, for twice as many every time that happens
+                    // again, up to 1024 -- the default order with its measured share is what serves them (sorting again behind every launch from the previous frame's costs
+                    // was built and measured: it loses 10 - 19 % at the reference viewer's speed, tools/proto/order_moving.patch).
                     const bool short_lived = ctx->hint_clock - H.relearn_clock < 4;
                     H.relearn_clock = ctx->hint_clock;
                     // (what the head share's trial found -- four lanes per ray for the longest tiles pay on this scene at this launch shape, or do not -- is about the scene,
@@ -439,8 +416,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                     H.lpt_valid = false; H.lpt_age = 0;
                     if (!H.cmp_done && !(H.n_base >= 3 && (H.n_head >= 3 || H.head_disabled))) { H.rot_adopted = false; H.head_disabled = false; H.t_base = H.t_head = H.t_all = 0.0f; H.n_base = H.n_head = H.n_all = H.n_conf = 0; H.learned_all = false; H.all_stage = 0; H.cmp_pending = H.cmp_done = false; }
                     (void)hipMemsetAsync(H.lpt_buf, 0, size_t(tiles) * sizeof(int), ctx->stream);
-                    if (short_lived && ctx->opt_order_moving) { H.moving = true; H.moving_since = H.lpt_epoch; H.still = 0; }
-                    else if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
+                    if (short_lived) { H.cooldown = H.cooldown_len; H.cooldown_len = std::min(2 * H.cooldown_len, 1024); }
                 }
                 if (H.cooldown > 0) { /* this launch and the next ones: default order, no costs */ }
                 else {
@@ -465,7 +441,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
                 if (H.lpt_valid) { a.tile_order = H.lpt_buf + H.lpt_cap; a.order_samples = ctx->opt_order_gate ? tile_order_samples(H) : nullptr; a.order_report = report; a.order_epoch = H.lpt_epoch; }
                 // (sorted behind the launch that learns, behind the next one -- the first costs come from a launch in which a share of the tiles
                 // started with four lanes per ray and counted differently -- and behind every 32nd after that)
-                learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period || H.moving;
+                learn_order = !H.lpt_valid || ++H.lpt_age >= H.lpt_period;
                 if (H.lpt_valid && learn_order && H.lpt_period >= 32) H.cooldown_len = 64;       // an order that lasted through a refresh period
                 }
             }
@@ -583,27 +559,11 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
         }
-        // "traverse.tri_pad": the tail kernel (table-free slim image) reads the triangles from a copy padded to 64 bytes each, made by THIS call (the
-        // caller's array may change between calls, so nothing is kept): a 48-byte triangle straddles two 64-byte sectors every second time, which costs
-        // a binned incoherent batch a quarter more requests from the vector L1s to L2 than it needs (profiles/r4a).  Measured (NOTES "Round 4"): +2.4 % on
-        // the 16M-ray share of configuration 4, nothing on image-ordered batches, -13 % where the copy (112 bytes per triangle) is not small against the
-        // launch.  -1 (default): for binned batches of at least four rays per triangle the grid refers to.
-        if (ctx->opt_tail && !flags && ctx->image.uniform && narrow && ctx->image.max_ref >= 0 && ctx->image.max_ref < (1 << 25)) {
-            const long long n_tris = (long long)ctx->image.max_ref + 1;
-            const bool want = ctx->opt_tri_pad < 0 ? (perm != nullptr && (long long)num_rays >= 4 * n_tris) : ctx->opt_tri_pad != 0;
-            if (want && refill_k <= 1 && !a.mailbox) {          // (the refill and mailbox instantiations read the caller's triangles: their defaults never meet a binned batch of four rays per triangle)
-                float4* padded = tmp.get<float4>(size_t(n_tris) * 4);
-                if (padded) {
-                    pad_triangles<<<grid_blocks(3 * n_tris, 256), 256, 0, ctx->stream>>>(a.tris, int(3 * n_tris), padded); HG_DBG(ctx);
-                    a.tris = padded; a.tri64 = 1; a.tail_dual = 0;          // (one instantiation on padded triangles: one id per round trip, the default of a binned batch)
-                }
-            }
-        }
         if (refill_k > 1) {      // ("traverse.refill" above)
             a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
         // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
-        const bool timed = conf_sample || (a.tile_order && (!learn_order || H.moving) && !H.trial_pending && (H.lpt_age >= 2 || H.moving) &&
+        const bool timed = conf_sample || (a.tile_order && !learn_order && !H.trial_pending && H.lpt_age >= 2 &&
                                            (a.quad_head ? (head_ok && !H.head_disabled && H.n_head < 3 && ctx->opt_quad_head > 0) : (all_sample || H.n_base < 3)));
         if (timed) {
             for (auto& e : H.trial_evt) if (!e) HG_HIP(ctx, hipEventCreate(&e));
@@ -623,7 +583,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             fprintf(stderr, "[head] call %llu: sort rot %d (was %d) suggestion %d quad_head %d base %.4f x%d head %.4f x%d disabled %d\n", ctx->hint_clock, want_rot, H.lpt_rot,
                     __atomic_load_n(suggest, __ATOMIC_RELAXED), a.quad_head, H.t_base, H.n_base, H.t_head, H.n_head, int(H.head_disabled));
 #endif
-        if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = (H.lpt_valid && !H.moving) ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
+        if (learn_order) { launch_tile_order(ctx, H, tiles, a, want_rot, suggest); H.lpt_period = H.lpt_valid ? 32 : 1; H.lpt_valid = true; H.lpt_age = 0; }
     } else if (variant == 1) {
         launch_plain(ctx->stream, num_rays, grid->small_cells != nullptr, a);
     } else {

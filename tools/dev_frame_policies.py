@@ -9,13 +9,13 @@ from hagrid_amd import api, scene
 
 arg = lambda name, default: (sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default)
 W = int(arg("--width", "1024")); H = int(arg("--height", str(W))); frames = int(arg("--frames", "40")); speed = float(arg("--speed", "1.0")); SCENE = arg("--scene", "clustered")
-DEFAULT_SETS = ("policy:;no_share_trial:traverse.share_trial=0;moving_mode:traverse.order_moving=1;default_order:traverse.tile_order=0;"
+DEFAULT_SETS = ("policy:;no_share_trial:traverse.share_trial=0;default_order:traverse.tile_order=0;"
                 "default_order_no_trial:traverse.tile_order=0,traverse.share_trial=0;default_order_quad50:traverse.tile_order=0,traverse.quad_tail=50")
 sets = []
 for item in arg("--sets", DEFAULT_SETS).split(";"):
     name, _, kv = item.partition(":")
     sets.append((name, {k: int(v) for k, v in (p.split("=") for p in kv.split(",") if p)}))
-RESET = {"traverse.tile_order": -1, "traverse.order_moving": 0, "traverse.quad_head": 20, "traverse.quad_tail": -1, "traverse.share_trial": 1}
+RESET = {"traverse.tile_order": -1, "traverse.quad_head": 20, "traverse.quad_tail": -1, "traverse.share_trial": 1}
 mem = api.MemManager(keep=True)
 tris = {"soup": lambda: scene.make_soup(1_000_000), "clustered": scene.make_clustered, "gradient": scene.make_gradient, "shell": scene.make_shell,
         "stadium": getattr(scene, "make_stadium", None)}[SCENE]()

@@ -33,9 +33,9 @@ for r in range(rounds):
     n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     out = {}
-    for name, opts in (("tail", {"traverse.image": 2, "traverse.tail": 1}), ("tail quad 0", {"traverse.quad_tail": 0}), ("tail one id per round", {"traverse.tail_dual": 0}), ("tail two ids per round", {"traverse.tail_dual": 1}), ("tail mailbox", {"traverse.mailbox": 1}), ("tail mailbox padded", {"traverse.mailbox": 1, "traverse.tri_pad": 1}), ("tail padded", {"traverse.tri_pad": 1}), ("tail, no tile order", {"traverse.tile_order": 0}), ("tail quad 40", {"traverse.quad_tail": 40}), ("tail quad 100", {"traverse.quad_tail": 100}), ("img", {"traverse.image": 2, "traverse.tail": 0}),
+    for name, opts in (("tail", {"traverse.image": 2, "traverse.tail": 1}), ("tail quad 0", {"traverse.quad_tail": 0}), ("tail one id per round", {"traverse.tail_dual": 0}), ("tail two ids per round", {"traverse.tail_dual": 1}), ("tail mailbox", {"traverse.mailbox": 1}), ("tail, no tile order", {"traverse.tile_order": 0}), ("tail quad 40", {"traverse.quad_tail": 40}), ("tail quad 100", {"traverse.quad_tail": 100}), ("img", {"traverse.image": 2, "traverse.tail": 0}),
                        ("wide ids", {"traverse.image_slim": 2}), ("general layout", {"traverse.image_general": 2}), ("v2", {"traverse.image": 0})):
-        for k, v in {"traverse.image": 2, "traverse.tail": 1, "traverse.image_slim": 1, "traverse.image_general": 1, "traverse.quad_tail": -1, "traverse.tail_dual": -1, "traverse.tile_order": -1, "traverse.mailbox": -1, "traverse.tri_pad": -1, **opts}.items(): mem.set_option(k, v)
+        for k, v in {"traverse.image": 2, "traverse.tail": 1, "traverse.image_slim": 1, "traverse.image_general": 1, "traverse.quad_tail": -1, "traverse.tail_dual": -1, "traverse.tile_order": -1, "traverse.mailbox": -1, **opts}.items(): mem.set_option(k, v)
         for binning in (0, 1):
             mem.set_ray_binning(binning)
             api.setup_traversal(grid)

@@ -6,9 +6,9 @@ order at its defaults and in the default order (traverse.tile_order = 0), frames
 viewer's speed (the give-up period of orders that do not last doubles: what a camera that keeps moving pays in the long run); then a buffer REFILLED
 with another image every 8th frame.
 
-Round 6: `--scene soup|clustered|gradient|shell|stadium`, and a third policy next to "order" (the defaults: rays that keep changing are sorted again behind every
-launch, MOVING mode) and "default_order": "order_r5" = traverse.order_moving 0, round 5's answer (no order for a while).  Every loop also returns a checksum of
-the last frame's hits: the policies must agree.
+Round 6: `--scene soup|clustered|gradient|shell|stadium`; policies "order" (the defaults: rays that keep changing get no order for a while and run in the default
+order with its measured share) and "default_order" (traverse.tile_order = 0).  Every loop also returns a checksum of the last frame's hits: the policies must agree.
+(A third policy -- the order sorted again behind every launch from the previous frame's costs -- was measured here and removed: tools/proto/README.md.)
 
 usage: python tools/dev_moving_camera.py [--scene soup] [--width 1024] [--frames 48] [--speeds 0,0.1,0.25,0.5,1,2] [--long 400]"""
 import json, os, sys
@@ -48,8 +48,7 @@ def loop(speed, refill_every=0):
     return ms
 
 
-POLICIES = [("order", {"traverse.tile_order": -1, "traverse.order_moving": 1}), ("order_r5", {"traverse.tile_order": -1, "traverse.order_moving": 0}),
-            ("default_order", {"traverse.tile_order": 0})]
+POLICIES = [("order", {"traverse.tile_order": -1}), ("default_order", {"traverse.tile_order": 0})]
 last_sum = 0
 
 

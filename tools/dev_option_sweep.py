@@ -23,6 +23,7 @@ def other_scene(name):
     if name == "gradient": return scene.make_gradient()
     if name == "shell": return scene.make_shell()
     if name == "stadium": return scene.make_stadium()
+    if name == "soup8m": return scene.make_soup(8_000_000)                               # the scene of configurations 4 and 5
     raise SystemExit("unknown SCENE " + name)
 tris = other_scene(os.environ["SCENE"]) if os.environ.get("SCENE") else scene.make_soup(1_000_000); d_tris = mem.upload(tris)          # (SCENE=clustered: the non-uniform scene of bench.py --config clustered)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
@@ -33,6 +34,7 @@ gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bb
         "primary 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
+        "incoherent 16M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 24, scene.RAY_SEED_BASE + 4),       # the per-GPU share of configuration 4
         "aimed 1M": lambda: scene.make_rays_aimed(grid.bbox_min, grid.bbox_max, 1 << 20, 5),
         "incoherent 1M": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4)}
 import re

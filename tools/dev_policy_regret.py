@@ -16,9 +16,9 @@ scenes = arg("--scenes", "soup,clustered,gradient,shell,stadium").split(",")
 sizes = [tuple(int(v) for v in s.split("x")) for s in arg("--sizes", "640x480,1280x720,1024x1024,1920x1080,4096x4096").split(",")]
 kinds = arg("--kinds", "primary,bounce,incoherent,aimed").split(",")
 FORCED = [("traverse.tile_order", (0, 1)), ("traverse.quad_tail", (0, 25, 50, 100)), ("traverse.quad_head", (0,)), ("traverse.share_trial", (0,)), ("traverse.refill", (0, 2)),
-          ("traverse.mailbox", (0, 1)), ("traverse.tri_pad", (0, 1)), ("traverse.tail_dual", (0, 1)), ("traverse.band_rows", (1, 4))]
+          ("traverse.mailbox", (0, 1)), ("traverse.tail_dual", (0, 1)), ("traverse.band_rows", (1, 4))]
 DEFAULTS = {"traverse.tile_order": -1, "traverse.quad_tail": -1, "traverse.quad_head": 20, "traverse.share_trial": 1, "traverse.refill": -1, "traverse.mailbox": -1,
-            "traverse.tri_pad": -1, "traverse.tail_dual": -1, "traverse.band_rows": 0}
+            "traverse.tail_dual": -1, "traverse.band_rows": 0}
 mem = api.MemManager(keep=True)
 rows = []
 

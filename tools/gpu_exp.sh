@@ -1,10 +1,7 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job).  Job 41: "traverse.step_cap" with more room in the queue
-OUT=gpurun_out/r6cap; mkdir -p $OUT
-for sc in clustered stadium; do
-  for room in 25 50 100; do
-    o="traverse.tile_order=0,traverse.share_trial=0,traverse.quad_tail=0,traverse.cap_room=$room"
-    echo "== scene '${sc:-soup}' opts $o"
-    SCENE=$sc OPTS=$o timeout 300 python tools/dev_option_sweep.py traverse.step_cap 0,32,48,64,96,128 --batch "primary 1024^2" --reps 1 --launches 100 2>&1 | grep "ms_median\|rror" | cut -c1-120
-  done
-done 2>&1 | tee $OUT/sweep_room.txt
+# One-off experiment script of round 6 (rewritten per job).  Job 45: after the pruning (padded triangles, MOVING mode, the unmeasured limits): the GPU tests that touch it and the affected bench lines
+OUT=gpurun_out/r6prune; mkdir -p $OUT
+timeout 1500 python -m pytest tests/test_traverse_gpu.py tests/test_abi.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench.json
+timeout 300 python bench.py --gpus 1 --steps 10 --warmup 2 --config 4 --shard 3/8 --no-cpu-baseline > $OUT/bench_config4_shard.json 2> $OUT/bench_config4_shard.err; cut -c1-200 $OUT/bench_config4_shard.json
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 --config clustered --no-cpu-baseline > $OUT/bench_clustered.json 2> $OUT/bench_clustered.err; cut -c1-200 $OUT/bench_clustered.json
