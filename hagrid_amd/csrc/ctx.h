@@ -103,7 +103,6 @@ struct hagrid_ctx {
     int opt_merge_inplace_div = 0;     // the mode is entered once an iteration merges less than 1 / this of its cells (0: the default, 2); tests enter earlier or later
     int opt_merge_inplace_room = 0;    // tests: the in-place mode may use the reference buffer up to this index only (0: all of it) -- the overflow path
     int opt_merge_narrow = 1;    // merge_grid: 16-byte working cell records between the passes (0: the 32-byte record throughout)
-    int opt_refill = -1;        // tail kernel: tiles per wavefront whose lanes take new rays as they finish; -1 = two where the mailbox rule applies to an image-ordered batch, 0 / 1 = off
     int opt_expand_voxel_map = 1;     // expand_grid: the voxel map resolved into one word per voxel for the passes' look-ups (expand.hip); 0: the chain through the levels
     int opt_expand_subset_only = 1;   // expand_grid: 1 = the reference's compiled setting, 0 = precise (compute_overlap)
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller

@@ -50,7 +50,6 @@ struct TraverseArgs {
     int lds_pad;                  // host only: dynamic LDS bytes per block of the tail kernel (experiments: fewer resident wavefronts)
     int tail_dual;                // host side only: which instantiation of the tail kernel is launched
     int mailbox;                  // host side only: the instantiation with a mailbox of the last four triangles per ray
-    int refill;                   // tail kernel (REFILL instantiations): tiles per wavefront whose lanes take new rays as they finish (0: off)
     int quad_head;                // tail kernel: this many tiles at the HEAD of a learned tile order start with four lanes per ray (four blocks each, the first of the grid); 0: none
     int quad_first_block;         // tail kernel: blocks from this index on start with four lanes per ray (16 rays each, four blocks per tile); INT_MAX: none
     unsigned mode;                // v2 and the image kernel: HAGRID_TRAVERSE_ANY_HIT | HAGRID_TRAVERSE_UVS of this call (read at run time)

@@ -276,14 +276,12 @@ constexpr int kTailRays = 16;        // live rays at which a wavefront compacts 
 #ifndef HG_GENERAL_WAVES
 #define HG_GENERAL_WAVES 7          // resident wavefronts per SIMD of the general-layout instantiations (8: a dozen spilled registers around the loops)
 #endif
-template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool MAILBOX = false, bool REFILL = false, bool GENERAL = false, bool WIDE = GENERAL>
-__global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GENERAL_WAVES : ((!UNIFORM && COST) ? HG_TABLE_WAVES : 8))) traverse_kernel_tail(const TraverseArgs a) {
+template <int SLIM, bool TIMES = false, bool UNIFORM = true, bool DUAL = false, bool COST = UNIFORM, bool MAILBOX = false, bool GENERAL = false, bool WIDE = GENERAL>
+__global__ void __launch_bounds__(64, MAILBOX ? 7 : (GENERAL ? HG_GENERAL_WAVES : ((!UNIFORM && COST) ? HG_TABLE_WAVES : 8))) traverse_kernel_tail(const TraverseArgs a) {
     // WIDE: the image holds wide records (always possible in the general layout; a table-layout image without any runs the instantiation without the checks)
     static_assert(!WIDE || !UNIFORM, "the uniform layout has no wide records");
     static_assert(!GENERAL || !UNIFORM, "a layout is uniform, table (blocks per top-level cell) or general (a record per voxel-map entry)");
     constexpr bool TABLE = !UNIFORM && !GENERAL;
-    static_assert(!REFILL || (UNIFORM && !DUAL && !TIMES), "refill: for the table-free layout, one id per round trip");
-    __shared__ float4 ray_lds[REFILL ? 128 : 1];          // REFILL: the next 64 rays of the wavefront's pool, requested ahead (LDS-DMA)
     constexpr int NONE = (1 << SLIM) - 1, NI = 80 / SLIM, LAST = 48 + (NI - 1) * SLIM;
     static_assert(!(MAILBOX && DUAL), "the mailbox is built into the one-id-per-round loops");
     __shared__ int lanes_of[64];
@@ -322,22 +320,15 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     // order names (longest first, traverse.hip "tile order").  The wavefront leaves its own cost (iterations = cells of its longest ray) behind.
     int iters = 0;                                        // iterations this wavefront ran, those of phase 1 counted twice: its cost
     int slot;
-    int pool_next = 0, pool_end = 0;                      // REFILL: positions (tile * 64 + lane) of this wavefront's pool that no lane has taken yet
     {
         int tile = b;
-        if (REFILL) {
-            const int total_tiles = (a.num_rays + 63) >> 6;
-            tile = b * a.refill;
-            pool_end = min(tile + a.refill, total_tiles) << 6;
-            pool_next = (tile << 6) + 64;
-        }
         if (COST && w && a.tile_order) {
             tile = a.tile_order[b];
             // (an order learned on other rays than the buffer holds now -- refilled, another buffer at a recycled address, the camera moved -- is
             // reported by the first wavefront of the launch and not used again: a stale order is slower than none)
             if (a.order_samples && blockIdx.x == 0) order_check(a, lane);
         }
-        slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : (REFILL ? tile : b) * 64 + lane_in_tile;
+        slot = w ? tile_packet_slot(a, w, tile, lane_in_tile) : b * 64 + lane_in_tile;
         // (a block that starts with four lanes per ray has no one-ray-per-lane phase to count twice: the first dozen of its iterations are doubled
         // instead -- about what that phase lasts)
         if (COST && lane == 0) { cost_at = (a.tile_cost && w) ? a.tile_cost + tile : nullptr; cost_bonus = quad_start ? 12 : 0; }      // (in LDS: the kernel has no register to spare for the whole traversal)
@@ -563,77 +554,7 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
     // ---- phase 1: one ray per lane, while the wavefront holds more than kTailRays live rays -------------------------------
     {
         vec3 inv_dir(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-        // REFILL: the wavefront owns a POOL of a.refill tiles.  A lane whose ray is done hands its hit in and takes the next position of the
-        // pool -- when at least kRefillMin lanes are idle -- so that the lock-step iterations of this phase run with 48 - 64 rays instead of with whatever
-        // the longest ray of one tile leaves (tests/analysis/lockstep_model.py: 70 % of a wavefront's iterations have at most 16 rays alive).  The next 64
-        // rays of the pool are requested one refill ahead straight into LDS (no registers), a new ray's first record is requested at the refill and the
-        // ray JOINS one iteration later: the wavefront never waits for a refill's own round trips.  Same rays, same arithmetic per ray: same hits.
-        #ifndef HG_REFILL_MIN
-#define HG_REFILL_MIN 16
-#endif
-        constexpr int kRefillMin = HG_REFILL_MIN;
-        __shared__ int rid_lds[REFILL ? 64 : 1];
-        bool joining = false;
-        auto request_rays = [&](int first_pos) {
-            typedef __attribute__((address_space(1))) const void* gptr_t;
-            typedef __attribute__((address_space(3))) void* lptr_t;
-            typedef __attribute__((address_space(3))) float4 lds_f4;
-            const int p = first_pos + lane;
-            int rid = -1;
-            if (p < pool_end) {
-                const int s = w ? tile_packet_slot(a, w, p >> 6, p & 63) : p;
-                if (s < a.num_rays) rid = perm ? perm[s] : s;
-            }
-            rid_lds[lane] = rid;
-            if (rid >= 0) {
-                const float4* src = a.rays + 2 * size_t(rid);
-                lds_f4* const slots = (lds_f4*)ray_lds;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(slots), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(slots + 63), 16, 16, 0);
-            }
-        };
-        int win = pool_next;                                  // the 64 positions from `win` on are (being) copied to LDS; refills take them in order
-        if (REFILL && pool_next < pool_end) request_rays(win);
-        while (__popcll(live) > kTailRays || (REFILL && pool_next < pool_end)) {
-            if (REFILL && pool_next < pool_end && __popcll(live) <= 64 - kRefillMin) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the rays requested ahead have landed
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long idle = ~live;
-                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-                const int at = pool_next - win;                                   // first window slot not taken yet
-                if (!alive) {
-                    if (pending) { nt_store4(a.hits + id, __int_as_float(hit_id), hit_t, 0.0f, 0.0f); pending = false; }
-                    const int rid = (at + rank < 64 && pool_next + rank < pool_end) ? rid_lds[at + rank] : -1;
-                    if (rid >= 0) {
-                        const float4 n0 = ray_lds[at + rank], n1 = ray_lds[64 + at + rank];
-                        id = rid; pending = true;
-                        org = vec3(n0.x, n0.y, n0.z); dir = vec3(n1.x, n1.y, n1.z); tmin = n0.w;
-                        hit_t = n1.w; hit_id = -1;
-                        inv_dir = vec3(safe_rcp(dir.x), safe_rcp(dir.y), safe_rcp(dir.z));
-                        const vec3 ta = (gmin - org) * inv_dir, tb = (gmax - org) * inv_dir;
-                        const vec3 t0 = min(ta, tb), t1 = max(ta, tb);
-                        const float tstart = detail::fmax2(detail::fmax2(t0.x, detail::fmax2(t0.y, t0.z)), tmin);
-                        const float tend = detail::fmin2(detail::fmin2(t1.x, detail::fmin2(t1.y, t1.z)), n1.w);
-                        if (!(tstart > tend)) {
-                            const vec3 fv = (tstart * dir + org - gmin) * ginv;
-                            vx = min(max(int(fv.x), 0), a.dims_x - 1);
-                            vy = min(max(int(fv.y), 0), a.dims_y - 1);
-                            vz = min(max(int(fv.z), 0), a.dims_z - 1);
-                            ca = load_record(vx, vy, vz);
-                            joining = true;
-                        }
-                        if (MAILBOX) mailbox[lane] = make_int4(-1, -1, -1, -1);
-                    }
-                }
-                pool_next += min(__popcll(idle), 64 - at);
-                // the window is copied again from the first position not taken once it cannot serve another refill (a pool of two tiles never gets here:
-                // its second tile is the one window)
-                if (pool_next < pool_end && win + 64 < pool_end && win + 64 - pool_next < kRefillMin) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the slots are read before the request overwrites them
-                    __builtin_amdgcn_wave_barrier();
-                    win = pool_next; request_rays(win);
-                }
-            }
+        while (__popcll(live) > kTailRays) {
             if (alive) {
                 const uint4 na = cell_step(ca, inv_dir);
                 test_list(ca);
@@ -641,7 +562,6 @@ __global__ void __launch_bounds__(64, (MAILBOX || REFILL) ? 7 : (GENERAL ? HG_GE
                 ca = na;
                 if (GENERAL && alive) gw.descend(a, ca, vx, vy, vz);          // general layout: a link leads on to the child block (its first gather was in flight during the tests)
             }
-            if (REFILL && joining) { alive = true; joining = false; }
             live = __ballot(alive);
             if (COST) iters += 2;              // (an iteration of this phase runs its lists' rounds one after the other: it weighs about two of the other phase's)
         }

@@ -25,27 +25,22 @@ namespace {
 template <bool UVS>
 bool launch_img_mode(hipStream_t st, int blocks, bool narrow, bool uniform, bool general, int slim, bool tail, const TraverseArgs& a) {
     if (!narrow || (slim != 20 && slim != 26)) return false;          // (32-bit offsets: the caller sends larger grids to the construction-format kernels)
-    if (tail && a.mode == 0u && uniform && slim && a.refill) {          // lanes take new rays as they finish (trav_kernels.h REFILL; always with the mailbox, never on padded triangles)
-        if (slim == 20) traverse_kernel_tail<20, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        else            traverse_kernel_tail<26, false, true, false, true, true, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        return true;
-    }
     if (tail && a.mode == 0u && slim && general) {          // a record per voxel-map entry: grids deeper than three levels, cells too long for the block layouts' bound bytes
+        if (a.tile_cost) {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, true, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        } else {
+            if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+            else            traverse_kernel_tail<26, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
+        }
+    }
+    else if (tail && a.mode == 0u && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
         if (a.tile_cost) {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, true, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         } else {
             if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
             else            traverse_kernel_tail<26, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        }
-    }
-    else if (tail && a.mode == 0u && slim && !uniform && a.img_wide) {          // table layout whose image holds wide records (cells its bound bytes cannot say)
-        if (a.tile_cost) {
-            if (slim == 20) traverse_kernel_tail<20, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, false, false, true, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-        } else {
-            if (slim == 20) traverse_kernel_tail<20, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
-            else            traverse_kernel_tail<26, false, false, false, false, false, false, false, true><<<blocks, 64, a.lds_pad, st>>>(a);
         }
     }
     else if (tail && a.mode == 0u && slim && !uniform) {
@@ -125,7 +120,7 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     // launch (two rounds) in the DEFAULT tile order 0.164 -> 0.180 ms with four: its second round then starts in a corner of the image.
     a.band_rows = ctx->opt_band_rows > 0 ? ctx->opt_band_rows : (grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 ? 4 : 1);
     a.img_table = nullptr; a.img_blocks = nullptr; a.img_wide = 0; a.gen_shift = g->shift; a.gen_x = g->dims[0]; a.gen_xy = 0; a.gen_base = 0u;
-    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.quad_head = 0; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.mailbox = 0; a.refill = 0;
+    a.bin_working_set = 0; a.num_rays = num_rays; a.shift = g->shift; a.id_is_steps = 0; a.mode = 0u; a.quad_first_block = 0x7fffffff; a.quad_head = 0; a.lds_pad = ctx->opt_lds_pad; a.tail_dual = 0; a.mailbox = 0;
     a.dims_x = dims.x; a.dims_y = dims.y; a.dims_z = dims.z;
     a.top_x = g->dims[0]; a.top_y = g->dims[1];
     a.top_xy = (long long)g->dims[0] * g->dims[1] < (1 << 23) ? g->dims[0] * g->dims[1] : 0;
@@ -290,19 +285,6 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // Measured with the reference step counts as the key (tools/dev_wave_timeline.py): 1024^2 0.181 -> 0.152 ms, mean occupancy 0.61 -> 0.79.
         // The kernel's own key counts an iteration with one ray per lane twice (its lists' rounds run one after the other): 1024^2 0.1455 ms with
         // plain iterations, 0.1380 / 0.1389 with that phase counted twice / three times, 0.142 with 2.5 on a key of half the resolution.
-        // "traverse.refill": a wavefront of the tail kernel owns a POOL of this many tiles, and lanes whose rays are done take the pool's next rays (trav_kernels.h
-        // REFILL).  Measured on the prototype of round 4 (tools/proto/README.md): two tiles per wavefront +6.5 % on the 8.4M-ray share of configuration 5 (bounce rays in
-        // image order over 1.6 GB of image and triangles: 70 % of a wavefront's lock-step iterations have at most 16 of 64 rays alive), larger pools worse (K = 3 / 4 / 8:
-        // -1 / -11 / -27 % against two), -1.5 % on the binned incoherent share of configuration 4 (bound by the vector-memory path), +-0 on 16M primary rays, -3 % on
-        // configuration 5's whole 64M-ray batch (seven instead of eight wavefronts per SIMD).  -1 (default): two tiles where the mailbox rule applies to a batch in image
-        // order -- a launch of at least eight rounds whose rays are fewer than the 64-byte sectors of a working set beyond 512 MB.  A refilled launch follows no learned
-        // tile order (its rule misfires on such launches anyway: -5.3 % on that share) and starts no tile with four lanes per ray.  Hits do not depend on it.
-        int refill_k = 0;
-        {
-            const bool can = ctx->opt_tail && !flags && ctx->image.uniform && narrow;
-            const bool first_touch = a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 && size_t(num_rays) * 64 < a.bin_working_set;
-            refill_k = !can ? 0 : (ctx->opt_refill < 0 ? ((!perm && first_touch) ? 2 : 0) : ctx->opt_refill);
-        }
         const int tiles = blocks;
         bool learn_order = false;
         const long long rounds100 = 100ll * blocks / std::max((long long)ctx->num_cus * 32, 1ll);        // size of the launch in rounds of the resident wavefronts, per cent
@@ -323,7 +305,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         {
             const bool shared_image = ctx->image.alive && ctx->image.alive.use_count() > 1;
             const bool rows = a.row_len_hint > 0 || a.row_len != nullptr;
-            const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && refill_k <= 1 && (perm || rows) && tiles >= 64 && tiles <= kMaxOrderTiles;
+            const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && (perm || rows) && tiles >= 64 && tiles <= kMaxOrderTiles;
             if (elig) {
                 const int rule = (perm != nullptr) ? 0 : (rounds100 <= 40 ? 100 : (rounds100 <= 65 ? 50 : (rounds100 <= 110 ? 37 : (rounds100 <= 320 ? 25 : 0))));
                 int cands[4]; int nc = 0;
@@ -390,7 +372,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             // (with the share trial the order is held against the default order by measurement -- below -- and may be TRIED on launches of any size the sort covers; the
             // limit fitted in rounds 3 - 5 -- 25 rounds -- stands where nothing is measured: "traverse.share_trial" = 0 of the test library)
             const bool measured = share_pct >= 0;
-            const int want = refill_k > 1 ? 0 : ctx->opt_tile_order < 0 ? (((measured || rounds100 <= 2500) && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
+            const int want = ctx->opt_tile_order < 0 ? (((measured || rounds100 <= 2500) && !shared_image) ? 1 : 0) : ctx->opt_tile_order;
             // (a row length the host has seen: a batch without one gets no tile packets and keeps the plain rules; while the length is looked for
             // again -- every 16th call -- the last answer counts)
             const bool rows_known = a.row_len_hint > 0 || (a.row_len && (H.rowlen_known > 0 || (H.rowlen_known < 0 && H.rowlen_seen > 0)));
@@ -465,11 +447,13 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         a.tail_dual = ctx->opt_tail_dual < 0 ? (perm ? 0 : 1) : ctx->opt_tail_dual;
         // "traverse.mailbox": every ray skips a triangle it was tested against among its last four tests (trav_kernels.h, MAILBOX; seven instead of eight
         // wavefronts per SIMD, one id per round trip).  What it saves are triangle fetches; what it costs is an LDS round trip in front of every
-        // triangle round and a resident wavefront.  Measured (profiles/NOTES.md "Round 4"), 8M triangles (image and triangles five times the Infinity
-        // Cache): +3.6 % on the 8.4M-ray share of configuration 5, where nearly every fetch is a first touch, -5 % on its whole 64M-ray batch, whose rays
-        // reuse each other's lines; -1 % on the cache-resident incoherent batch, -13 % on the 1024^2 launch.  -1 (default): for launches of at least
-        // eight rounds of wavefronts whose rays are fewer than the 64-byte sectors of a working set beyond 512 MB.
-        a.mailbox = ctx->opt_mailbox < 0 ? (a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 &&
+        // triangle round and a resident wavefront.  -1 (default): for BINNED batches of at least eight rounds of wavefronts whose rays are fewer than the 64-byte
+        // sectors of a working set beyond 512 MB -- nearly every fetch is a first touch there: 16M binned incoherent rays over the 8M-triangle soup 6.54 -> 5.98 ms
+        // (-9 %, round 6, gpurun_out/r6pad).  Not for rays in image order (the 8.4M bounce rays of configuration 5's per-GPU share: 5263 Mrays/s without, 4851 with;
+        // round 4 had measured +3.6 % there, before bands and measured orders), not for cache-resident scenes (-1 % ... -13 %).  The instantiation whose lanes took new
+        // rays as they finished (REFILL, round 4: +6.5 % on that share then) lost to the plain kernel by 2.5 - 6.7 % on the same share in round 6 and was removed
+        // (tools/proto/pruned_r6.patch).
+        a.mailbox = ctx->opt_mailbox < 0 ? (perm != nullptr && a.bin_working_set > (size_t(512) << 20) && grid_blocks(num_rays, 64) >= 8ll * std::max(ctx->num_cus, 1) * 32 &&
                                             size_t(num_rays) * 64 < a.bin_working_set)
                                          : ctx->opt_mailbox;
         if (a.mailbox) a.tail_dual = 0;
@@ -491,7 +475,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // first (a.quad_head).  The share follows the suggestion at the periodic sorts; the first suggestion gets a sort of its own.
         int want_rot = 0;
         int* suggest = ctx->mailbox + kMbxHeadSuggest + hint_slot;
-        const bool head_ok = ctx->opt_quad_head > 0 && ctx->opt_quad_tail < 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tail && !flags && narrow && refill_k <= 1 &&
+        const bool head_ok = ctx->opt_quad_head > 0 && ctx->opt_quad_tail < 0 && rounds100 > 100 && rounds100 <= 500 && !perm && ctx->opt_tail && !flags && narrow &&
                              !(ctx->image.alive && ctx->image.alive.use_count() > 1);
         // The share measures itself (the rule above is fitted on two scene families; on a soup with a density gradient it takes tiles whose lists are short and loses
         // 7 - 19 %): timed launches in the learned order without it first (three samples, the smallest counts), then with it; a share that is not 3 % faster is dropped
@@ -558,9 +542,6 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const int chunk = 8 << (a.xcd_chunk_log2 >= 0 ? a.xcd_chunk_log2 : 4);
             const int full = std::min(blocks, int((long long)blocks * (100 - quad_pct) / 100 + chunk - 1) / chunk * chunk);
             if (full < blocks) { a.quad_first_block = full; blocks = full + 4 * (blocks - full); }
-        }
-        if (refill_k > 1) {      // ("traverse.refill" above)
-            a.refill = refill_k; a.tail_dual = 0; a.mailbox = 1; a.quad_first_block = 0x7fffffff; blocks = grid_blocks(grid_blocks(num_rays, 64), refill_k);      // (the policy switches refill and mailbox on together: one instantiation)
         }
         // (a timed launch of the trial: in the learned order, in its steady state -- not the launch that learns or follows a sort)
         const bool timed = conf_sample || (a.tile_order && !learn_order && !H.trial_pending && H.lpt_age >= 2 &&

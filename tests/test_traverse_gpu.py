@@ -220,8 +220,9 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
             mem.set_option("traverse.variant", bad)
     with pytest.raises(api.HagridError):
         mem.set_option("no.such.key", 1)
-    with pytest.raises(api.HagridError):
-        mem.set_option("traverse.refill_at", 24)
+    for gone in ("traverse.refill", "traverse.tri_pad", "traverse.order_moving"):          # (round 6: measured, below the bar, removed)
+        with pytest.raises(api.HagridError):
+            mem.set_option(gone, 1)
     grid.free(); mem.free(d_tris)
 
 
@@ -891,24 +892,21 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             # for binned batches as well, where the default switches it off)
             # ... and "traverse.mailbox": a ray skips a triangle it was tested against among its last four tests (nine coincident copies of every
             # triangle in "long_lists": equal t, the first copy must win every time)
-            # ... and "traverse.refill": a wavefront owns a pool of 2 / 3 / 5 tiles and lanes whose rays are done take its next rays (with and without the
-            # mailbox; batches smaller than a pool, pools cut off by the end of the batch, rays that miss the grid in the pool)
-            for tail, quad, dual, mbox, refill in ((1, -1, -1, -1, -1), (1, 0, 1, 0, 0), (1, 0, 0, 1, 0), (1, 30, 1, 1, 0), (1, 100, 0, 1, 0), (1, -1, -1, 1, 0), (0, 0, -1, 0, 0),
-                                                   (1, -1, -1, 0, 2), (1, -1, -1, 1, 3), (1, -1, -1, 1, 5)):
+            for tail, quad, dual, mbox in ((1, -1, -1, -1), (1, 0, 1, 0), (1, 0, 0, 1), (1, 30, 1, 1), (1, 100, 0, 1), (1, -1, -1, 1), (0, 0, -1, 0)):
                 mem.set_option("traverse.tail", tail); mem.set_option("traverse.quad_tail", quad); mem.set_option("traverse.tail_dual", dual)
-                mem.set_option("traverse.mailbox", mbox); mem.set_option("traverse.refill", refill)
+                mem.set_option("traverse.mailbox", mbox)
                 for binning in (0, 1):
                     mem.set_ray_binning(binning)
                     for first, n in ((0, rays.shape[0]), (0, 64 * 48), (0, 64), (5, 1), (7, 15), (0, 16), (3, 17), (64 * 48, 4099)):
                         got = gpu_traverse(mem, grid, d_tris, rays[first:first + n])
                         w = want[first:first + n]
-                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, quad, dual, mbox, refill, binning, first, n)
+                        assert (got["id"] == w["id"]).all() and (bits(got["t"]) == bits(w["t"])).all(), (name, tail, quad, dual, mbox, binning, first, n)
             if name == "long_lists":
                 assert (want["id"] >= 0).any()
             grid.free(); mem.free(d_tris)
     finally:
         mem.set_option("traverse.tail", 1); mem.set_option("traverse.quad_tail", -1); mem.set_option("traverse.tail_dual", -1)
-        mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0); mem.set_option("traverse.mailbox", -1); mem.set_option("traverse.refill", -1)
+        mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0); mem.set_option("traverse.mailbox", -1)
         mem.set_option("traverse.image_general", 1)
 
 

@@ -1,5 +1,5 @@
 """DEV TOOL: the POLICY-REGRET table.  Scene families x image sizes x ray kinds: the default policy of hagrid_traverse_grid against every forced
-setting of the options its rules choose between -- tile order, the share of tiles that start with four lanes per ray (tail / head), the share trial, refill, mailbox,
+setting of the options its rules choose between -- tile order, the share of tiles that start with four lanes per ray (tail / head), the share trial, mailbox,
 padded triangles, two ids per round trip, band rows.  Per cell: steady-state ms (back-to-back launches, event-timed) of the default and of the best forced setting, and the
 regret (default / best - 1).  A rule whose default loses more than 3 % somewhere is a candidate for a measured trial or for removal; an option that never wins by more than
 3 % anywhere is a candidate for deletion.  Hits are checked (checksum) to be the same under every setting.
@@ -15,9 +15,9 @@ arg = lambda name, default: (sys.argv[sys.argv.index(name) + 1] if name in sys.a
 scenes = arg("--scenes", "soup,clustered,gradient,shell,stadium").split(",")
 sizes = [tuple(int(v) for v in s.split("x")) for s in arg("--sizes", "640x480,1280x720,1024x1024,1920x1080,4096x4096").split(",")]
 kinds = arg("--kinds", "primary,bounce,incoherent,aimed").split(",")
-FORCED = [("traverse.tile_order", (0, 1)), ("traverse.quad_tail", (0, 25, 50, 100)), ("traverse.quad_head", (0,)), ("traverse.share_trial", (0,)), ("traverse.refill", (0, 2)),
+FORCED = [("traverse.tile_order", (0, 1)), ("traverse.quad_tail", (0, 25, 50, 100)), ("traverse.quad_head", (0,)), ("traverse.share_trial", (0,)),
           ("traverse.mailbox", (0, 1)), ("traverse.tail_dual", (0, 1)), ("traverse.band_rows", (1, 4))]
-DEFAULTS = {"traverse.tile_order": -1, "traverse.quad_tail": -1, "traverse.quad_head": 20, "traverse.share_trial": 1, "traverse.refill": -1, "traverse.mailbox": -1,
+DEFAULTS = {"traverse.tile_order": -1, "traverse.quad_tail": -1, "traverse.quad_head": 20, "traverse.share_trial": 1, "traverse.mailbox": -1,
             "traverse.tail_dual": -1, "traverse.band_rows": 0}
 mem = api.MemManager(keep=True)
 rows = []
