@@ -1,7 +1,9 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job).  Job 49: after the second pruning (REFILL gone, the mailbox for binned batches only): traversal tests, configuration 5 (share and whole batch), the headline
-OUT=gpurun_out/r6prune2; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_traverse_gpu.py tests/test_abi.py -m gpu -q -x 2>&1 | tail -3 | cut -c1-300
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench.json
-timeout 300 python bench.py --gpus 1 --steps 10 --warmup 2 --config 5 --shard 3/8 --no-cpu-baseline > $OUT/bench_config5_shard.json 2> $OUT/bench_config5_shard.err; cut -c1-200 $OUT/bench_config5_shard.json
-timeout 300 python bench.py --gpus 1 --steps 5 --warmup 1 --config 5 --no-cpu-baseline > $OUT/bench_config5.json 2> $OUT/bench_config5.err; cut -c1-200 $OUT/bench_config5.json
+# One-off experiment script of round 6 (rewritten per job).  Job 51: the construction's own switches on three scene families (are rounds 2 - 4's settings still the best?)
+OUT=gpurun_out/r6build; mkdir -p $OUT
+for sc in "" clustered stadium; do
+  for o in "" "merge.inplace=0" "merge.inplace_div=3" "merge.inplace_div=4" "merge.inplace_div=8" "merge.inplace_div=1" "merge.narrow_cells=0" "expand.voxel_map=0" "scan.lookback=2"; do
+    r=$(SCENE=$sc OPTS=$o ITERS=8 timeout 300 python tools/dev_build_time.py 2>&1 | grep build_ms_mean | cut -c1-200)
+    echo "scene ${sc:-soup}  opts ${o:-(defaults)}  $r"
+  done
+done | tee $OUT/options.txt
