@@ -571,7 +571,7 @@ def main():
                                    + (f", rays [{first}, {first + n_rays}) = the share of rank {shard[0]} of {shard[1]}, on ONE GPU" if shard else f", sharded over {world} GPU(s)" if scaling == "strong" else f" per GPU x {world} GPU(s)")
                                    + f"; td {top_density} sd {snd_density} alpha {args.alpha} exp {expansion}" + (" compress" if compress else ""),
                        "baseline_config": args.config, "shard": args.shard, "rays_total": int(total_rays), "rays_rank0": n_rays, "triangles": n_tris, "ray_binning": bin_rays,
-                       "traversal_image": "off (construction format)" if not args.image else (lambda f: f"{record_bytes}-byte slim records, " + ("uniform layout (a record per voxel, table-free)" if f.get("uniform") else "general layout (a record per voxel-map entry: links, wide records)" if f.get("general") else "table layout (a block of records per top-level cell)") + ", built by setup_traversal")(mem.image_format(grid)),
+                       "traversal_image": "off (construction format)" if not args.image else (lambda f: f"{record_bytes}-byte slim records, " + ("uniform layout (a record per voxel, table-free)" + (" with the table layout next to it for binned batches" if f.get("two_layouts") else "") if f.get("uniform") else "general layout (a record per voxel-map entry: links, wide records)" if f.get("general") else "table layout (a block of records per top-level cell)") + ", built by setup_traversal")(mem.image_format(grid)),
                        "ray_packets": "8x8 pixel tiles, row length detected on the device (kept per ray buffer, looked for again every 16th call; buffer stays in image order); from the second launch over a buffer on the tiles are dispatched longest first, by the costs the previous launches left (`tile_order`)",
                        "eye_dist_diagonals": args.eye_dist, "parallelism": f"ray-sharded x{world} ({scaling}), grid broadcast once",
                        "grid": grid.summary(), "device": info},

@@ -159,7 +159,7 @@ class MemManager:
         f = (C.c_int32 * 4)()
         if self._L.hagrid_traversal_image_info(self._ctx, C.byref(grid.pod), f, None) != 0:
             return {}
-        return {"flat": bool(f[0]), "uniform": bool(f[1]), "general": f[0] == 2, "slim_id_bits": int(f[2]), "record_bytes": int(f[3])}
+        return {"flat": bool(f[0]), "uniform": bool(f[1] & 1), "general": f[0] == 2, "slim_id_bits": int(f[2]), "record_bytes": int(f[3]), "two_layouts": bool(f[1] & 2)}
 
     def image_record_bytes(self, grid: "Grid") -> int:
         """16 when the traversal image of `grid` holds slim records, else 32."""

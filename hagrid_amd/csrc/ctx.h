@@ -47,6 +47,10 @@ struct TravImageCache {
     const void* entries = nullptr; const void* cells = nullptr; const void* refs = nullptr;
     int num_cells = 0, num_entries = 0, num_refs = 0, shift = 0, dims[3] = {0, 0, 0}, cell_bytes = 32;
     int max_ref = -1;               // largest primitive id the grid refers to
+    // A uniform layout that costs more than a quarter more records than the table layout is built NEXT TO the table layout (trav_image.hip build_blocks): rays in image
+    // order gather from the uniform one (the record of a voxel by arithmetic: -7 ... -13 % on grids of three levels), batches without coherence -- binned ones -- from the
+    // compact one (a 977 MB image instead of 120 MB costs them a quarter more time).  alt_blocks == nullptr: one layout serves every batch.
+    void* alt_blocks = nullptr; void* alt_table = nullptr; size_t alt_block_bytes = 0, alt_table_bytes = 0; int alt_wide_records = 0, alt_slim = 0;
 };
 
 } // namespace hagrid_impl
@@ -108,7 +112,7 @@ struct hagrid_ctx {
     int opt_image_width = 0;    // tile packets: -1 off, 0 detect the row length on the device, > 0 row length given by the caller
     int opt_band_rows = 0;      // tile packets: rows of super-tiles per band; 0 = as many as make the in-flight tiles a square block of the image
     int opt_super_log2 = 3;     // tile packets: 2^k x 2^k tiles per super-tile (Z order inside); round-3 sweep: 3 (profiles/dev_r3_tile_params.txt)
-    int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 up to ~2 rounds of wavefronts, else 5)
+    int opt_xcd_chunk_log2 = -2; // tile packets: the XCDs take chunks of 2^k blocks in turn; -1 = one eighth of the block range each; -2 = by launch size (3 below twelve rounds of wavefronts, else 5)
     int opt_narrow = 1;         // v2: 32-bit offsets / 24-bit multiplies when the arrays allow it
     int opt_image_max_mb = 0;   // traversal image: size limit in MB (0 = max(1 GB, 8x the arrays it replaces)); an image beyond it is not built
     int opt_quad_head = 20;     // tail kernel: the tiles of a learned order that cost at least this many TENTHS of the median working tile -- if they are more than a twelfth of the tiles -- start with four lanes per ray, first (0: never)
@@ -120,7 +124,7 @@ struct hagrid_ctx {
     // slot is taken over by a new buffer.  Slot i owns the device word dscratch[kScrRowLen + i] and the pinned words mailbox[kMbxRowLen + i], [kMbxOrderStale + i], [kMbxHeadSuggest + i].
     struct RayHints {
         const void* key_rays = nullptr; int key_n = 0;       // the buffer the slot belongs to
-        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0;   // rowlen_known: the row length as the host has seen it (-1: not yet)
+        const void* rowlen_rays = nullptr; int rowlen_n = 0, rowlen_age = 0, rowlen_known = -1, rowlen_seen = 0; bool rows_from_origins = false /* the row length came from neighbouring origins alone: an image order without coherent directions (bounce rays) */;   // rowlen_known: the row length as the host has seen it (-1: not yet)
         hipEvent_t rowlen_evt = nullptr; bool rowlen_pending = false;
         // tile order of the tail kernel: cost | order, lpt_cap ints each; the order is valid for launches over (lpt_rays, lpt_n)
         int* lpt_buf = nullptr; int lpt_cap = 0; const void* lpt_rays = nullptr; int lpt_n = 0, lpt_blocks = 0, lpt_age = 0, lpt_period = 32, lpt_rot = 0 /* positions the stored order is rotated by: its last lpt_rot tiles are the longest */; bool rot_adopted = false /* the first suggestion of a sort was taken up by a sort of its own */;

@@ -451,12 +451,16 @@ int build_blocks(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     int table_records = 0;
     int rc = read_back(ctx, total, &table_records, sizeof(int));
     if (rc != HAGRID_OK) { release(); hagrid_mem_free(ctx, table); return rc; }
-    // An image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed; "traverse.image_max_mb" sets the limit); the uniform
-    // layout when it costs at most a quarter more records than the table layout (every top-level cell subdivided to the full depth, as in evenly
-    // filled scenes): the record of a voxel is then found by arithmetic alone.
+    // An image may not cost more than 8x the arrays it replaces (and at least 1 GB is always allowed; "traverse.image_max_mb" sets the limit).  The uniform layout
+    // (every top-level cell subdivided to the full depth: the record of a voxel is found by arithmetic alone) whenever it fits that limit; where it costs more than a
+    // quarter more records than the table layout, the table layout is built NEXT TO it for the batches without coherence (TravImageCache::alt_blocks; round 6, same
+    // box, gpurun_out/r6geo: the soup at --snd-density 3 / 4 / 5 and configuration 3's grid, three levels, 0.98 - 1.29 GB uniform against 120 - 450 MB: primary rays
+    // -7 ... -13 % with the uniform layout at 1024^2 and 4096^2, 4M binned incoherent rays +26 / +17 / -2 % -- rounds 4 - 5 took the table layout for all of them).
+    // "traverse.image_uniform" = 2: the uniform layout alone (tests), 0: never.
     const long long limit = ctx->opt_image_max_mb > 0 ? (long long)ctx->opt_image_max_mb << 20 : std::max(1ll << 30, 8 * k.source_bytes);
     const long long uniform_records = (long long)k.num_top << (3 * D);
-    const bool uniform = ctx->opt_image_uniform && (uniform_records * 4 <= (long long)table_records * 5 || ctx->opt_image_uniform == 2) && uniform_records * 16 <= limit;
+    const bool much_bigger = uniform_records * 4 > (long long)table_records * 5;
+    const bool uniform = ctx->opt_image_uniform && uniform_records * 16 <= limit;
     int rs = 1;
     uint2* own_table = nullptr;                  // (the table layout with wide records brings a table of its own: table + wide records in one buffer)
     if (uniform) rs = build_slim<D>(ctx, k, img, table, true, metas, nullptr, partials);
@@ -464,6 +468,19 @@ int build_blocks(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
     if (rs == 1 && (long long)table_records * 16 <= limit) {       // top-level cells of different depth, or a cell the uniform layout's bytes cannot hold
         rs = build_slim<D>(ctx, k, img, table, false, metas, offs, partials);
         own_table = static_cast<uint2*>(img.table);
+    }
+    if (is_uniform && much_bigger && ctx->opt_image_uniform == 1 && (long long)table_records * 16 <= limit) {          // ... and the compact layout next to it
+        uint2* table2 = pool_alloc<uint2>(ctx, size_t(k.num_top));
+        TravImageCache second;
+        const int ra = table2 ? build_slim<D>(ctx, k, second, table2, false, metas, offs, partials) : HAGRID_ENOMEM;
+        if (ra == HAGRID_OK) {
+            if (second.table) hagrid_mem_free(ctx, table2); else second.table = table2;          // (wide records: build_slim made one buffer of table + wide records)
+            img.alt_blocks = second.blocks; img.alt_block_bytes = second.block_bytes; img.alt_table = second.table; img.alt_table_bytes = second.table_bytes;
+            img.alt_wide_records = second.wide_records; img.alt_slim = second.slim;
+        } else {                                // (no room, or a cell the table layout cannot say either: the uniform layout serves every batch)
+            if (table2) hagrid_mem_free(ctx, table2);
+            if (ra < 0) { ctx->err.clear(); (void)hipGetLastError(); }
+        }
     }
     release();
     if (rs != HAGRID_OK) { hagrid_mem_free(ctx, table); return rs; }
@@ -477,10 +494,13 @@ int build_blocks(hagrid_ctx* ctx, const ImgK& k, TravImageCache& img) {
 void hagrid_impl::trav_image_drop(hagrid_ctx* ctx) {
     TravImageCache& img = ctx->image;
     void* t = img.borrowed ? nullptr : img.table; void* b = img.borrowed ? nullptr : img.blocks;
+    void* t2 = img.borrowed ? nullptr : img.alt_table; void* b2 = img.borrowed ? nullptr : img.alt_blocks;
     if (!img.borrowed && img.alive) img.alive->store(false);          // every borrower sees it before the memory is handed on
     img = TravImageCache();
     if (t) hagrid_mem_free(ctx, t);
     if (b) hagrid_mem_free(ctx, b);
+    if (t2) hagrid_mem_free(ctx, t2);
+    if (b2) hagrid_mem_free(ctx, b2);
 }
 
 bool hagrid_impl::trav_image_stale(const hagrid_ctx* ctx) {
@@ -602,7 +622,7 @@ extern "C" int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* g
     if (!ctx || !grid) return HAGRID_EINVAL;
     if (!trav_image_matches(ctx, grid)) HG_FAIL(ctx, HAGRID_EINVAL, "no traversal image for this grid");
     const TravImageCache& img = ctx->image;
-    if (format4) { format4[0] = img.general ? 2 : 1; format4[1] = img.uniform ? 1 : 0; format4[2] = img.slim; format4[3] = 16; }
-    if (image_bytes) *image_bytes = (int64_t)img.block_bytes + (int64_t)img.table_bytes;
+    if (format4) { format4[0] = img.general ? 2 : 1; format4[1] = (img.uniform ? 1 : 0) | (img.alt_blocks ? 2 : 0); format4[2] = img.slim; format4[3] = 16; }
+    if (image_bytes) *image_bytes = (int64_t)img.block_bytes + (int64_t)img.table_bytes + (int64_t)img.alt_block_bytes + (int64_t)img.alt_table_bytes;
     return HAGRID_OK;
 }

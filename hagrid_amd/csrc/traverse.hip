@@ -113,7 +113,10 @@ int hagrid_trav::make_args(hagrid_ctx* ctx, const hagrid_grid* g, const void* tr
     a.hits = static_cast<float4*>(hits);
     a.steps = nullptr; a.stats = nullptr; a.perm = nullptr; a.perm_flag = nullptr; a.wave_times = nullptr; a.tile_order = nullptr; a.tile_cost = nullptr; a.order_samples = nullptr; a.order_report = nullptr; a.order_epoch = 0;
     a.row_len = nullptr; a.row_len_hint = 0; a.super_log2 = ctx->opt_super_log2;
-    a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (4ll * grid_blocks(num_rays, 64) <= 9ll * ctx->num_cus * 32 ? 3 : 5);
+    // (the XCDs take chunks of 8 blocks in turn, of 32 in launches of at least twelve rounds of the resident wavefronts.  Round 6, same box, gpurun_out/r6geo: at 32 rounds 32
+    // blocks per chunk gain 0.5 - 1.3 % -- the soup, configuration 3's grid -- and 0.6 % at 16 -- configuration 5's share; at 8 rounds, where round 4's rule took them as well,
+    // they cost the stadium mesh 4.7 % and gain nothing anywhere; up to 4 rounds 4 ... 64 blocks are the same within a per cent on three scene families)
+    a.xcd_chunk_log2 = ctx->opt_xcd_chunk_log2 != -2 ? ctx->opt_xcd_chunk_log2 : (grid_blocks(num_rays, 64) < 12ll * ctx->num_cus * 32 ? 3 : 5);
     // Bands of four rows of super-tiles for launches of at least eight rounds of the resident wavefronts, one row below ("traverse.band_rows" > 0
     // forces it).  Measured (profiles/NOTES.md "Round 4"): the bounce rays of configuration 5 (16 rounds at its per-GPU share) +3.7 % with four rows,
     // +1.9 % with eleven (a square in-flight block), -2 % with 22; primary batches of 8 and 32 rounds +-0 with four, -1 ... -2 % with eleven; a 1024^2
@@ -170,7 +173,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
     bool publish_row_len = false;
     {   // what the batch gathers from: the traversal image (or cells and entries), the references, the triangles
         const bool img = (ctx->opt_image || ctx->image.detached) && trav_image_matches(ctx, grid);
-        a.bin_working_set = (img ? ctx->image.block_bytes : size_t(grid->num_cells) * (grid->small_cells ? 16 : 32) + size_t(grid->num_entries) * 4)
+        a.bin_working_set = (img ? ((ctx->image.alt_blocks && ctx->ray_binning) ? ctx->image.alt_block_bytes : ctx->image.block_bytes) : size_t(grid->num_cells) * (grid->small_cells ? 16 : 32) + size_t(grid->num_entries) * 4)
                             + size_t(grid->num_refs) * 4 + size_t(std::max<int64_t>(ctx->counts.num_tris, 0)) * 48;
     }
     HG_TRY(bin_rays(ctx, a, num_rays, tmp));
@@ -198,7 +201,8 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (const auto& d : ctx->hints)
                 if (&d != &N && d.key_n == num_rays && d.rowlen_seen > 0 && (!donor || d.used > donor->used)) donor = &d;
             N.share_choice = -1; N.share_last = -1; N.share_issued = N.share_done = 0; N.share_launches = 0; N.share_serial = ctx->image_serial; N.share_ncand = 0; N.share_shape_nc = 0; N.order_loses = false; N.learned_once = false;
-            if (donor) N.rowlen_seen = donor->rowlen_seen;
+            N.rows_from_origins = false;
+            if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
             if (donor && donor->share_serial == ctx->image_serial && donor->share_ncand > 0) {       // (the donor's answer, its candidates and times with it: same launch shape)
                 N.share_ncand = donor->share_ncand; N.share_shape_nc = donor->share_shape_nc; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
                 N.share_choice = donor->share_choice; N.share_last = donor->share_last; N.share_launches = donor->share_launches; N.order_loses = donor->order_loses;
@@ -233,9 +237,16 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         if (ctx->image.detached) HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: this grid was released for traversal and its slim traversal image needs the narrow kernel (arrays below 4 GB)");
         variant = 2;
     }
+    // (an image of two layouts -- trav_image.hip build_blocks: a uniform one much bigger than the table layout next to it -- serves the batches WITHOUT coherent directions
+    // from the compact one: binned batches, and rays in image order whose row length came from neighbouring origins alone -- bounce rays -- once the host has seen that:
+    // configuration 3's grid, bounce rays at 1024^2 / 2048^2 / 4096^2: +2 / +17 / +8 % with the table layout, primary rays -8 ... -13 %, gpurun_out/r6two)
+    const bool compact = variant == 4 && ctx->image.alt_blocks && (perm || H.rows_from_origins);
     if (variant == 4) {
         image_args(ctx, a);
+        if (compact) { a.img_table = static_cast<const uint2*>(ctx->image.alt_table); a.img_blocks = static_cast<const unsigned char*>(ctx->image.alt_blocks); a.img_wide = ctx->image.alt_wide_records > 0; }
     }
+    const bool img_uniform = ctx->image.uniform && !compact;
+    const int img_slim = compact ? ctx->image.alt_slim : ctx->image.slim;
     // Tile packets (v2 and the image kernel, not for binned batches): "traverse.image_width" > 0 gives the row length, 0
     // (default) looks for one on the device, -1 switches the feature off.  The kernel reads the answer from device memory,
     // nobody waits for it.
@@ -252,7 +263,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             int* row_len = ctx->dscratch + kScrRowLen + hint_slot;
             const bool same = ctx->opt_row_cache && H.rowlen_rays == rays && H.rowlen_n == num_rays;
             if (same && H.rowlen_pending) {
-                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[kMbxRowLen + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
+                if (hipEventQuery(H.rowlen_evt) == hipSuccess) { const int word = ctx->mailbox[kMbxRowLen + hint_slot]; H.rowlen_known = word & kRowLenMask; H.rows_from_origins = (word & kRowsFromOrigins) != 0; H.rowlen_pending = false; H.rowlen_seen = H.rowlen_known; }
                 else (void)hipGetLastError();                             // not ready yet: not an error
             }
             if (same && H.rowlen_known != 0 && H.rowlen_age < 15) H.rowlen_age++;
@@ -554,7 +565,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             for (auto& e : H.share_evt[H.share_issued]) if (!e) HG_HIP(ctx, hipEventCreate(&e));
             HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][0], ctx->stream));
         }
-        if (!launch_img(ctx->stream, blocks, narrow, ctx->image.uniform && narrow, ctx->image.general, ctx->image.slim, ctx->opt_tail != 0, flags, a))
+        if (!launch_img(ctx->stream, blocks, narrow, img_uniform && narrow, ctx->image.general, img_slim, ctx->opt_tail != 0, flags, a))
             HG_FAIL(ctx, HAGRID_EINVAL, "traverse_grid: the traversal image of this grid has no kernel for this call (slim records need arrays below 4 GB)");
         if (timed) { HG_HIP(ctx, hipEventRecord(H.trial_evt[1], ctx->stream)); H.trial_pending = true; H.trial_with_head = a.quad_head > 0; H.trial_kind = conf_sample ? 3 : (a.quad_head > 0 ? 1 : (all_sample ? 2 : 0)); }
         if (share_timed) { HG_HIP(ctx, hipEventRecord(H.share_evt[H.share_issued][1], ctx->stream)); H.share_issued++; }

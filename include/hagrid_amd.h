@@ -272,8 +272,8 @@ int hagrid_set_ray_binning(hagrid_ctx* ctx, int mode);
  * xcd_chunk|row_cache|lds_pad" and "merge.narrow_cells" of version 2 moved there; version 2 had moved the known-answer test hooks out of this library.) */
 int hagrid_set_option(hagrid_ctx* ctx, const char* key, int value);
 
-/* The traversal image this context holds for `grid`: format4 = { flat (1: a record per voxel; 2: the general layout, a slim record per voxel-map entry), uniform (table-free), bits per packed
- * reference id of slim 16-byte records (0: 32-byte records), bytes per record }, *image_bytes = its size (table + blocks); either
+/* The traversal image this context holds for `grid`: format4 = { flat (1: a record per voxel; 2: the general layout, a slim record per voxel-map entry), bit 0: uniform (table-free) | bit 1: the compact table layout is held next to a much bigger uniform one (binned batches gather from it), bits per packed
+ * reference id of slim 16-byte records (0: 32-byte records), bytes per record }, *image_bytes = its size (table + blocks, both layouts); either
  * pointer may be NULL.  HAGRID_EINVAL when the context holds no image of this grid. */
 int hagrid_traversal_image_info(hagrid_ctx* ctx, const hagrid_grid* grid, int32_t* format4, int64_t* image_bytes);
 

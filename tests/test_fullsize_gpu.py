@@ -128,14 +128,18 @@ def test_config3_dense_grid_16M_primary_rays(world):
     n = rays.shape[0]
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
     got = {}
-    for image, general in ((2, 1), (1, 2), (0, 1)):          # the table layout (this grid's default), the general layout forced, the construction format
-        mem.set_option("traverse.image", image); mem.set_option("traverse.image_general", general)
+    # the uniform layout with the table layout next to it (this grid's default since round 6: rays in image order gather from the uniform one), the table layout alone,
+    # the general layout forced, the construction format
+    for key, image, general, uniform in (("default", 2, 1, 1), ("table", 2, 1, 0), (1, 1, 2, 1), (0, 0, 1, 1)):
+        mem.set_option("traverse.image", image); mem.set_option("traverse.image_general", general); mem.set_option("traverse.image_uniform", uniform)
         api.setup_traversal(grid)
-        if image: assert mem.image_format(grid)["general"] == (general == 2) and not mem.image_format(grid)["uniform"]
+        f = mem.image_format(grid)
+        if image: assert f["general"] == (general == 2) and f["uniform"] == (key == "default") and f["two_layouts"] == (key == "default"), (key, f)
         api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
-        got[image] = mem.download(d_hits, api.HIT_DTYPE, n)
-    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_general", 1)
-    assert same_hits(got[2], got[1]) and same_hits(got[2], got[0])
+        got[key] = mem.download(d_hits, api.HIT_DTYPE, n)
+    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_general", 1); mem.set_option("traverse.image_uniform", 1)
+    got[2] = got["default"]
+    assert same_hits(got[2], got[1]) and same_hits(got[2], got[0]) and same_hits(got[2], got["table"])
     hits = got[2]
     assert (hits["id"] >= 0).mean() > 0.7
     sel = np.arange(7, n, 16)                                   # 1M rays spread over the whole image

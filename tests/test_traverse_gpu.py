@@ -422,8 +422,9 @@ def test_traversal_image_resolves_every_voxel_to_its_cell(mem, name, fmt_name):
     grid = upload_oracle_grid(mem, G)
     from hagrid_amd import api
     mem.set_option("traverse.image", fmt); mem.set_option("traverse.image_slim", slim); mem.set_option("traverse.image_general", general)
+    mem.set_option("traverse.image_uniform", 0 if name == "soup30k_shift3" else 1)        # (the table layout alone: by default it comes next to a uniform layout, which the records below would be read from)
     api.setup_traversal(grid)
-    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.image_general", 1)
+    mem.set_option("traverse.image", 2); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.image_general", 1); mem.set_option("traverse.image_uniform", 1)
     res = np.array(G.dims) << G.shift
     total = int(res[0]) * int(res[1]) * int(res[2])
     rng = np.random.default_rng(1)
@@ -550,7 +551,7 @@ def test_cells_too_long_for_a_byte_get_wide_records(mem):
             assert (got["id"] == want2["id"]).all() and (bits(got["t"]) == bits(want2["t"])).all(), slim
             assert mem._K.hagrid_kat_image_records(mem._ctx, C.byref(grid2.pod), None, 0, None, C.byref(nb)) == 0
             assert nb.value == 16 * total2 + 8 * int(np.prod(G2.dims)), "slim records expected"
-            assert mem.image_format(grid2) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16}
+            assert mem.image_format(grid2) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 26 if slim == 2 else 20, "record_bytes": 16, "two_layouts": False}
         grid2.free(); mem.free(d_tris2)
     finally:
         mem.set_option("traverse.image_uniform", 1); mem.set_option("traverse.image_slim", 1); mem.set_option("traverse.tail", 1); mem.set_option("traverse.image_general", 1)
@@ -868,6 +869,7 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
     scenes = {"soup": (scene.make_soup(30000, seed=42), {}),
               "long_lists": (np.concatenate([coincident, scene.make_soup(4000, seed=43)]), dict(top_density=0.3, snd_density=1.0)),
               "table_layout": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),     # three levels, top-level cells of different depth: table layout
+              "two_layouts": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),      # the same grid as the defaults hold it: the uniform layout for rays in image order, the table layout next to it for binned batches
               "general_shallow": (scene.make_soup(30000, seed=11), dict(top_density=0.15, snd_density=3.0)),  # the same grid in the general layout (forced)
               "deep": (scene.make_soup(6000, seed=12), dict(top_density=0.01, snd_density=40.0)),             # shift 5: links below the top level
               "clustered": (scene.make_clustered(3000, 3, 4000), {}),                                          # shift 5, blobs in a sparse soup: wide records between them
@@ -883,10 +885,12 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
             rays = np.concatenate([primary, scene.make_rays_incoherent(lo - 0.3, hi + 0.3, 20011, 23)]).astype(np.float32)
             want, _ = G.traverse(tris, rays, nthreads=8)
             mem.set_option("traverse.image_general", 2 if name == "general_shallow" else 1)
+            mem.set_option("traverse.image_uniform", 0 if name == "table_layout" else 1)            # (the table layout alone: forced; by default it comes next to the uniform one)
             api.setup_traversal(grid)
             info = mem.image_format(grid)
             assert info["slim_id_bits"] == (26 if slim == 2 else 20), (name, info)
-            if name != "long_lists": assert info["uniform"] == (name == "soup") and info["general"] == (name not in ("soup", "table_layout")), (name, info)      # the three slim layouts are exercised
+            if name != "long_lists": assert info["uniform"] == (name in ("soup", "two_layouts")) and info["general"] == (name not in ("soup", "table_layout", "two_layouts")), (name, info)      # the three slim layouts are exercised
+            if name != "long_lists": assert info["two_layouts"] == (name == "two_layouts"), (name, info)          # ("long_lists": two layouts as well, whatever its levels give)
             # (tail mode, per cent of the tiles that START with four lanes per ray -- "traverse.quad_tail", 16 rays per wavefront)
             # ... and "traverse.tail_dual": two ids of an inline list per round trip in phase 1, the second triangle through LDS (forced on
             # for binned batches as well, where the default switches it off)
@@ -907,7 +911,7 @@ def test_tail_mode_gives_the_oracle_hits(mem, slim):
     finally:
         mem.set_option("traverse.tail", 1); mem.set_option("traverse.quad_tail", -1); mem.set_option("traverse.tail_dual", -1)
         mem.set_option("traverse.image_slim", 1); mem.set_ray_binning(0); mem.set_option("traverse.mailbox", -1)
-        mem.set_option("traverse.image_general", 1)
+        mem.set_option("traverse.image_general", 1); mem.set_option("traverse.image_uniform", 1)
 
 
 def test_row_length_cache_never_changes_hits(mem):
@@ -958,7 +962,9 @@ def test_tile_order_never_changes_hits(mem, params):
                scene.make_rays_incoherent(lo - 0.2, hi + 0.2, n, 31), scene.make_rays_primary(lo, hi, 256, 32)]
     batches = [np.ascontiguousarray(b, np.float32) for b in batches]
     want = [G.traverse(tris, b, nthreads=8)[0] for b in batches]
+    mem.set_option("traverse.image_uniform", 0 if params else 1)          # (the table layout alone for the second grid: rays in image order would gather from the uniform layout the defaults put next to it)
     api.setup_traversal(grid)
+    mem.set_option("traverse.image_uniform", 1)
     info = mem.image_format(grid)
     assert info["slim_id_bits"] == 20 and info["uniform"] == (not params), info          # both layouts of the tail kernel
     d_rays = mem.upload(batches[0]); d_hits = mem.alloc(16 * n)
@@ -1144,7 +1150,7 @@ def test_wave_time_diagnostic_does_not_change_hits(mem):
     n = rays.shape[0]; nw = n // 64
     d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n); d_times = mem.alloc(16 * nw)
     api.setup_traversal(grid)
-    assert mem.image_format(grid) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 20, "record_bytes": 16}
+    assert mem.image_format(grid) == {"flat": True, "uniform": True, "general": False, "slim_id_bits": 20, "record_bytes": 16, "two_layouts": False}
     api.traverse_grid(grid, d_tris, d_rays, d_hits, n)
     ref = mem.download(d_hits, api.HIT_DTYPE, n)
     d_order = mem.upload(np.arange(nw, dtype=np.int32)[::-1].copy())

@@ -28,10 +28,11 @@ def other_scene(name):
 tris = other_scene(os.environ["SCENE"]) if os.environ.get("SCENE") else scene.make_soup(1_000_000); d_tris = mem.upload(tris)          # (SCENE=clustered: the non-uniform scene of bench.py --config clustered)
 grid = api.build_all(mem, d_tris, tris.shape[0], top_density=td, snd_density=sd)
 api.setup_traversal(grid)
-print(json.dumps({"grid": grid.summary(), "image": mem.image_format(grid)}), flush=True)
+print(json.dumps({"grid": grid.summary(), "image": mem.image_format(grid), "image_mb": round(mem.image_bytes(grid) / 2**20, 1)}), flush=True)
 gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
         "primary 2048^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 2048, 2048),
         "primary 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
+        "config3 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 1024, 1024),
         "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
         "incoherent 16M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 24, scene.RAY_SEED_BASE + 4),       # the per-GPU share of configuration 4
