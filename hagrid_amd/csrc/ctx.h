@@ -99,7 +99,6 @@ struct hagrid_ctx {
 
     // traversal options (hagrid_set_ray_binning, hagrid_set_option)
     int ray_binning = 0;
-    int opt_bin_bits = 0;       // ray binning: Morton bits per axis of the bin key (3 = 512 bins, 4 = 4096 bins); 0: by the size of what the batch gathers from
     int opt_variant = 0;        // 0 = the image kernel when the grid has an image, else v2; 1 / 2 / 4 = force the reference-shaped kernel / v2 / the image kernel
     int opt_lookback = 1;        // scans of the construction passes: single-pass decoupled look-back
     int opt_merge_inplace = 1;   // merge_grid: iterations in place (dirty cells only, one compaction at the end) once an iteration has merged less than half of its cells (merge.inplace_div)

@@ -282,7 +282,7 @@ extern "C" int hagrid_kat_set_option(hagrid_ctx* ctx, const char* key, int value
         {"traverse.super_tile", &ctx->opt_super_log2, 0, 8},        {"traverse.xcd_chunk", &ctx->opt_xcd_chunk_log2, -2, 16},
         {"traverse.row_cache", &ctx->opt_row_cache, 0, 1},          {"traverse.lds_pad", &ctx->opt_lds_pad, 0, 65536},
         {"merge.narrow_cells", &ctx->opt_merge_narrow, 0, 1},       {"scan.lookback", &ctx->opt_lookback, 1, 2},
-        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.share_trial", &ctx->opt_share_trial, 0, 1}, {"traverse.bin_bits", &ctx->opt_bin_bits, 0, 4}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
+        {"traverse.order_gate", &ctx->opt_order_gate, 0, 1}, {"traverse.share_trial", &ctx->opt_share_trial, 0, 1}, {"traverse.band_rows", &ctx->opt_band_rows, 0, 1 << 16}, {"traverse.mailbox", &ctx->opt_mailbox, -1, 1},
         {"merge.inplace", &ctx->opt_merge_inplace, 0, 1},           {"merge.inplace_iters", &ctx->opt_merge_inplace_iters, 0, 1 << 20}, {"merge.inplace_room", &ctx->opt_merge_inplace_room, 0, 0x7fffffff}, {"merge.inplace_div", &ctx->opt_merge_inplace_div, 0, 1 << 20},
         {"expand.voxel_map", &ctx->opt_expand_voxel_map, 0, 1},
     };

@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(kDetectBlock) detect_ray_rows(const float4* __
 //   device_scan     : exclusive scan of the table in (bin, workgroup) order = first slot of every (bin, workgroup) run
 //   ray_bin_scatter : slot = run start + rank inside the run (LDS atomic), perm[slot] = ray index
 // The order inside a bin is irrelevant.  No global atomics; one extra 4-byte word per ray.
-// BITS bits per axis: 3 (512 bins, the default: scenes whose image and triangles fit the Infinity Cache) or 4 (4096 bins: scenes far beyond
-// it, where a bin's share of the image should fit an XCD's L2 -- "traverse.bin_bits" of the test library, chosen per grid by bin_rays below)
+// BITS bits per axis: 3 (512 bins).  (Rounds 3 - 5 took 4096 bins for working sets beyond 512 MB -- a bin's share of the image in an XCD's L2; same box, round 6,
+// gpurun_out/r6geo: never faster -- the 8M-triangle soup with 16M / 64M rays +2 % with 4096 bins, scenes within the cache +4 ... +10 % -- and removed.)
 constexpr int kBinItems = 16;                       // rays per thread
 constexpr int kBinTile = kBlock * kBinItems;        // rays per workgroup
 
@@ -360,8 +360,9 @@ struct TableOut { int* t; __device__ void operator()(int i, int s) const { t[i] 
 } // namespace
 
 // row length of an image-ordered batch -> row_len[0] on the device.  The origin criterion costs ~17 us (2049 candidates x 256
-// sampled pairs) and only pays where tile packets pay for bounce rays: it runs as a second launch for batches of at least
-// kOriginMinRays rays and returns at once when the first criterion has already answered.
+// sampled pairs) behind every 16th call over a buffer: it runs as a second launch for batches of at least kOriginMinRays rays (256K; rounds 5's 4M was stale -- with
+// rows a launch gets tile packets AND its measured share of four-lane tiles: bounce rays at 1024^2 +11 % on the soup, +5 % on configuration 3's grid, +3 % clustered,
+// +10 % on the stadium mesh, 1920 x 1080 +1 %: same box, round 6, gpurun_out/r6geo/origin_rows.txt) and returns at once when the first criterion has already answered.
 void hagrid_trav::launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays) {
     detect_ray_rows<<<1, kDetectBlock, 0, ctx->stream>>>(a.rays, num_rays, row_len, nullptr, 0.0f, 0); HG_DBG(ctx);
     const vec3 ext(a.max_x - a.min_x, a.max_y - a.min_y, a.max_z - a.min_z);
@@ -436,11 +437,7 @@ int bin_rays_bits(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp
 int hagrid_trav::bin_rays(hagrid_ctx* ctx, TraverseArgs& a, int num_rays, PoolTemps& tmp) {
     a.perm = nullptr;
     if (!ctx->ray_binning || num_rays <= kBinTile) return HAGRID_OK;
-    // Bins per axis.  What a bin is for: the wavefronts an XCD has resident at a time come from one or two bins, and what they gather -- the
-    // bin's share of the traversal image and of the triangles, and a margin around it -- should stay in that XCD's 4 MB of L2.  512 bins do
-    // that for working sets up to a few hundred MB (which the Infinity Cache holds anyway); beyond, 4096 bins (BASELINE configuration 5:
-    // 1.35 GB of image and triangles).  "traverse.bin_bits" (test library) forces 3 or 4.
-    int bits = ctx->opt_bin_bits;
-    if (bits == 0) bits = a.bin_working_set > (size_t(512) << 20) ? 4 : 3;
-    return bits == 4 ? bin_rays_bits<4>(ctx, a, num_rays, tmp) : bin_rays_bits<3>(ctx, a, num_rays, tmp);
+    // 512 bins: the wavefronts an XCD has resident at a time come from one or two bins, and what they gather -- the bin's share of the traversal image and of the
+    // triangles, and a margin around it -- mostly stays in that XCD's 4 MB of L2.
+    return bin_rays_bits<3>(ctx, a, num_rays, tmp);
 }

@@ -304,7 +304,10 @@ size_t buffer_bytes_from(const void* p);
 void launch_plain(hipStream_t st, int num_rays, bool small, const TraverseArgs& a);
 void launch_v2(hipStream_t st, int blocks, bool small, bool narrow, unsigned mode, const TraverseArgs& a);
 // ray_order.hip: row length of an image-ordered batch -> row_len[0] on the device (0: none); nobody waits for it
-constexpr int kOriginMinRays = 1 << 22;
+#ifndef HG_ORIGIN_MIN_RAYS
+#define HG_ORIGIN_MIN_RAYS (1 << 18)
+#endif
+constexpr int kOriginMinRays = HG_ORIGIN_MIN_RAYS;
 void launch_detect(hagrid_ctx* ctx, const TraverseArgs& a, int num_rays, int* row_len, int origin_min_rays = kOriginMinRays);
 // ray_order.hip: the tail kernel's tile order (longest tile first): buffers of the context for `tiles` tiles; order <- the costs the
 // launches since the last call left, costs cleared

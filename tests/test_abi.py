@@ -95,7 +95,7 @@ def test_header_is_plain_c():
 
 
 def test_product_library_kernel_count(built):
-    """Variant sprawl stays pruned: at most 120 kernels in the product library's code objects (115 since round 6's pruning; tools/count_kernels.py reads the .kd symbols of every
+    """Variant sprawl stays pruned: at most 120 kernels in the product library's code objects (113 since round 6's pruning; tools/count_kernels.py reads the .kd symbols of every
     gfx950 code object in the library's fat binary), none of them a three-kernel scan form (those live in the test library)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -172,18 +172,15 @@ def test_ray_binning_gives_identical_hits(mem):
             mem.set_ray_binning(0)
             plain = gpu_traverse(mem, grid, d_tris, rays)
             mem.set_ray_binning(1)
-            for bin_bits in (0, 3, 4):                       # 512 bins, or 4096 (chosen for working sets beyond 512 MB; forced here)
-                mem.set_option("traverse.bin_bits", bin_bits)
-                binned = gpu_traverse(mem, grid, d_tris, rays)
-                assert (plain["id"] == binned["id"]).all() and (bits(plain["t"]) == bits(binned["t"])).all(), bin_bits
-            mem.set_option("traverse.bin_bits", 0)
+            binned = gpu_traverse(mem, grid, d_tris, rays)
+            assert (plain["id"] == binned["id"]).all() and (bits(plain["t"]) == bits(binned["t"])).all()
         oh, _ = G.traverse(tris, batches[0], nthreads=8)
         assert (binned["id"] == plain["id"]).all()
         mem.set_ray_binning(1)
         b0 = gpu_traverse(mem, grid, d_tris, batches[0])
         assert (b0["id"] == oh["id"]).all() and (bits(b0["t"]) == bits(oh["t"])).all()
     finally:
-        mem.set_ray_binning(0); mem.set_option("traverse.bin_bits", 0)
+        mem.set_ray_binning(0)
     with pytest.raises(api.HagridError):
         mem.set_ray_binning(7)
     grid.free(); mem.free(d_tris)
@@ -220,7 +217,7 @@ def test_every_traversal_kernel_gives_the_oracle_hits(mem, compressed):
             mem.set_option("traverse.variant", bad)
     with pytest.raises(api.HagridError):
         mem.set_option("no.such.key", 1)
-    for gone in ("traverse.refill", "traverse.tri_pad", "traverse.order_moving"):          # (round 6: measured, below the bar, removed)
+    for gone in ("traverse.refill", "traverse.tri_pad", "traverse.order_moving", "traverse.bin_bits"):          # (round 6: measured, below the bar, removed)
         with pytest.raises(api.HagridError):
             mem.set_option(gone, 1)
     grid.free(); mem.free(d_tris)

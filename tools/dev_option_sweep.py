@@ -36,6 +36,7 @@ gens = {"primary 1024^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bb
         "config3 4096^2": lambda: scene.make_rays_primary(grid.bbox_min, grid.bbox_max, 4096, 4096),
         "incoherent 4M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 22, scene.RAY_SEED_BASE + 4),
         "incoherent 16M binned": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 24, scene.RAY_SEED_BASE + 4),       # the per-GPU share of configuration 4
+        "incoherent 64M binned": lambda: scene.generate_parallel(lambda f, c: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, c, scene.RAY_SEED_BASE + 4, first=f), 0, 1 << 26, chunk=1 << 22),
         "aimed 1M": lambda: scene.make_rays_aimed(grid.bbox_min, grid.bbox_max, 1 << 20, 5),
         "incoherent 1M": lambda: scene.make_rays_incoherent(grid.bbox_min, grid.bbox_max, 1 << 20, scene.RAY_SEED_BASE + 4)}
 import re
