@@ -1,16 +1,9 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job).  Job 66: the uniform layout's tail kernel WITHOUT the cost bookkeeping for launches that keep no costs (library B) against the one instantiation for all (A)
+# One-off experiment script of round 6 (rewritten per job).  Job 67: the head share's threshold (tiles that cost N tenths of the median start with four lanes per ray, first; 20 by default)
 OUT=gpurun_out/r6geo; mkdir -p $OUT
-cp hagrid_amd/libhagrid_amd.so /tmp/libA.so
-for v in A B A B; do
-  if [ $v = A ]; then cp /tmp/libA.so hagrid_amd/libhagrid_amd.so; else cp ab/libB.so hagrid_amd/libhagrid_amd.so; fi
-  for cfg in "3" "4 --shard 3/8" "5 --shard 3/8" "5" "2 --width 4096 --height 4096"; do
-    timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --config $cfg --no-cpu-baseline --no-order-compare --inflight 1 > $OUT/b.json 2> $OUT/b.err
-    python - $v "$cfg" <<'PY'
-import json, sys
-d = json.load(open('gpurun_out/r6geo/b.json'))
-print("lib %s  config %-28s %8.1f Mrays/s  %.4f ms" % (sys.argv[1], sys.argv[2], d["value"], d["ms_per_step"]))
-PY
+for sc in clustered stadium gradient shell ""; do
+  for b in "primary 1024^2" "primary 1920x1080"; do
+    echo "== ${sc:-soup} $b"
+    SCENE=$sc timeout 300 python tools/dev_option_sweep.py traverse.quad_head 20,12,15,30,40,0 --batch "$b" --reps 1 --launches 200 2>&1 | grep "ms_median\|rror" | cut -c10-110
   done
-done | tee $OUT/uniform_nocost.txt
-cp /tmp/libA.so hagrid_amd/libhagrid_amd.so
+done | tee $OUT/quad_head.txt
