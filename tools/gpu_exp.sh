@@ -1,9 +1,14 @@
 #!/bin/bash
-# One-off experiment script of round 6 (rewritten per job).  Job 67: the head share's threshold (tiles that cost N tenths of the median start with four lanes per ray, first; 20 by default)
+# One-off experiment script of round 6 (rewritten per job).  Job 68: the general layout's instantiations at eight resident wavefronts per SIMD (library B) against seven (A)
 OUT=gpurun_out/r6geo; mkdir -p $OUT
-for sc in clustered stadium gradient shell ""; do
-  for b in "primary 1024^2" "primary 1920x1080"; do
-    echo "== ${sc:-soup} $b"
-    SCENE=$sc timeout 300 python tools/dev_option_sweep.py traverse.quad_head 20,12,15,30,40,0 --batch "$b" --reps 1 --launches 200 2>&1 | grep "ms_median\|rror" | cut -c10-110
+cp hagrid_amd/libhagrid_amd.so /tmp/libA.so
+for v in A B A B; do
+  if [ $v = A ]; then cp /tmp/libA.so hagrid_amd/libhagrid_amd.so; else cp ab/libB.so hagrid_amd/libhagrid_amd.so; fi
+  for sc in clustered stadium; do
+    for b in "primary 1024^2" "primary 4096^2" "incoherent 4M binned"; do
+      r=$(SCENE=$sc timeout 300 python tools/dev_option_sweep.py traverse.tile_order -1 --batch "$b" --reps 1 --launches 60 2>&1 | grep "ms_median" | cut -c50-110)
+      echo "lib $v  $sc  $r"
+    done
   done
-done | tee $OUT/quad_head.txt
+done | tee $OUT/general_waves.txt
+cp /tmp/libA.so hagrid_amd/libhagrid_amd.so
