@@ -136,10 +136,10 @@ struct hagrid_ctx {
         // buffer holds other rays (refilled, recycled address, a camera that moved) reports the order's epoch in the pinned word mailbox[kMbxOrderStale + i],
         // which the host polls: that launch is the only one that follows the stale order, the order is learned again.  Orders that do not last (a camera that moves fast) are not learned for a while (cooldown).
         int lpt_epoch = 1 /* never 0: the pinned report word starts as 0 and is reset to -1 */, relearn_streak = 0, cooldown = 0, cooldown_len = 64; unsigned long long relearn_clock = 0;     // (cooldown_len: doubles with every give-up in a row, up to 1024 launches)
-        // the share trial of launches in the default order (traverse.hip "traverse.share_trial"): candidates = the rule's share of tiles with four lanes per ray, a half, none, all, 37 and 25 per cent
+        // the share trial of launches in the default order (traverse.hip "traverse.share_trial"): candidates = the rule's share of tiles with four lanes per ray, a half, none, all
         // (sample k = candidate k % share_ncand, each with its own event pair: all may be in flight at once)
-        hipEvent_t share_evt[18][2] = {}; int share_issued = 0, share_done = 0, share_choice = -1 /* index into share_cands; -1: being measured */, share_ncand = 0 /* candidates of the running trial */, share_shape_nc = 0 /* ... of the launch shape's first trial */, share_cands[6] = {0, 0, 0, 0} /* per cent */,
-            share_last = -1 /* the share (per cent) the last trial chose */, share_launches = 0; float share_t[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; unsigned share_serial = 0 /* ctx->image_serial the answer belongs to */;
+        hipEvent_t share_evt[12][2] = {}; int share_issued = 0, share_done = 0, share_choice = -1 /* index into share_cands; -1: being measured */, share_ncand = 0 /* candidates of the running trial */, share_shape_nc = 0 /* ... of the launch shape's first trial */, share_cands[4] = {0, 0, 0, 0} /* per cent */,
+            share_last = -1 /* the share (per cent) the last trial chose */, share_launches = 0; float share_t[4] = {0.0f, 0.0f, 0.0f, 0.0f}; unsigned share_serial = 0 /* ctx->image_serial the answer belongs to */;
         int trial_kind = 0 /* the timed launch in flight: 0 the order alone, 1 with the head share, 2 with ALL tiles four lanes per ray */, n_all = 0, all_stage = 0 /* 0 not tried, 1 - 2 learning its own order, 3 timed, 4 decided */; float t_all = 0.0f; bool learned_all = false;
         bool learned_once = false;          // the first share trial of this launch shape has been decided and the order learned behind it
         unsigned order_serial = 0;          // ctx->image_serial the learned tile order belongs to

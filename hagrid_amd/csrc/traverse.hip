@@ -204,7 +204,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             N.rows_from_origins = false;
             if (donor) { N.rowlen_seen = donor->rowlen_seen; N.rows_from_origins = donor->rows_from_origins; }
             if (donor && donor->share_serial == ctx->image_serial && donor->share_ncand > 0) {       // (the donor's answer, its candidates and times with it: same launch shape)
-                N.share_ncand = donor->share_ncand; N.share_shape_nc = donor->share_shape_nc; for (int i = 0; i < 6; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
+                N.share_ncand = donor->share_ncand; N.share_shape_nc = donor->share_shape_nc; for (int i = 0; i < 4; i++) { N.share_cands[i] = donor->share_cands[i]; N.share_t[i] = donor->share_t[i]; }
                 N.share_choice = donor->share_choice; N.share_last = donor->share_last; N.share_launches = donor->share_launches; N.order_loses = donor->order_loses;
                 if (N.share_choice < 0) N.share_ncand = N.share_shape_nc = 0;          // (a donor still measuring: measured here from nothing, with its last answer meanwhile)
             }
@@ -306,7 +306,7 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
         // a sphere shell 0.177 -> 0.165), the soup and a density gradient do not (+17 %, +10 %), bounce rays want none where the rule says a quarter (+12 ... +14 %), a
         // binned incoherent batch of two rounds wants all where the rule says none (+21 % on the soup) -- and nothing the host knows about a grid tells them apart
         // (gpurun_out/r6c, r6e, r6m: tools/dev_policy_regret.py).  An event pair around the kernel does: the first launches over a buffer run in the default order with the
-        // candidates in turn -- the rule's share, a half, none, all, 37 and 25 per cent (the extremes up to five rounds) -- three samples each, every sample with an event pair of its own (polled by later
+        // candidates in turn -- the rule's share, a half, none, all (up to five rounds) -- three samples each, every sample with an event pair of its own (polled by later
         // calls, nobody waits; a caller that never synchronises has all of them in flight at once); the smallest time wins, the rule's share unless another is 3 % faster.
         // The answer is about the scene and the launch shape, not about the rays: it survives a camera that moves, a new buffer of the same shape starts with it, it is
         // measured again every 1024 launches.  A LEARNED tile order (below) is then held against it: an order whose steady launches (three timed ones, with the head share
@@ -319,23 +319,18 @@ extern "C" int hagrid_traverse_grid_ex(hagrid_ctx* ctx, const hagrid_grid* grid,
             const bool elig = ctx->opt_share_trial && ctx->opt_quad_tail < 0 && ctx->opt_tail && !flags && narrow && !shared_image && (perm || rows) && tiles >= 64 && tiles <= kMaxOrderTiles;
             if (elig) {
                 const int rule = (perm != nullptr) ? 0 : (rounds100 <= 40 ? 100 : (rounds100 <= 65 ? 50 : (rounds100 <= 110 ? 37 : (rounds100 <= 320 ? 25 : 0))));
-                int cands[6]; int nc = 0;
+                int cands[4]; int nc = 0;
                 cands[nc++] = rule;
                 if (rounds100 <= 1000) {                     // (beyond ten rounds four lanes per ray lose everywhere measured: the rule's share -- none -- is sampled alone, for the order's comparison)
                     if (rule != 50) cands[nc++] = 50;
                     if (rule != 0) cands[nc++] = 0;
                     if (rule != 100 && rounds100 <= 500) cands[nc++] = 100;
-                    // ... and the shares between them: WHICH tiles the last N per cent of the dispatch order are decides as much as how many -- the clustered scene at 1024^2
-                    // 0.258 ms with a quarter, 0.165 with 37 per cent, 0.179 with a half; at 1920 x 1080 0.296 with 37, 0.210 with a half; the stadium wants a half at
-                    // both sizes (0.215 / 0.303 with 37), a sphere shell 37 (-3 ... -5 % against a half): gpurun_out/r6geo/share_between.txt
-                    if (rule != 37) cands[nc++] = 37;
-                    if (rule != 25) cands[nc++] = 25;
                 }
                 // ... and, where the bands rule of make_args takes four rows of super-tiles (launches of eight rounds and more; fitted on configuration 5's bounce rays in round
                 // 4), ONE row with the rule's share (bit 8 of a candidate): the stadium at 2048^2 0.386 -> 0.361 ms, bounce rays there 0.911 -> 0.878 (the last two cells of
                 // tools/dev_policy_regret.py above 3 %).  The band decides which tile a block index means, so it is chosen here, before an order is learned, and then holds for
                 // the order as well.
-                if (!perm && ctx->opt_band_rows <= 0 && a.band_rows > 1 && nc < 6) cands[nc++] = rule | 256;
+                if (!perm && ctx->opt_band_rows <= 0 && a.band_rows > 1 && nc < 4) cands[nc++] = rule | 256;
                 if (H.share_serial != ctx->image_serial || H.share_shape_nc != nc || H.share_cands[0] != rule) {          // another grid, another launch shape: measured from nothing
                     H.share_serial = ctx->image_serial; H.share_shape_nc = H.share_ncand = nc; for (int i = 0; i < nc; i++) H.share_cands[i] = cands[i];
                     H.share_choice = -1; H.share_issued = H.share_done = 0; H.order_loses = false; H.learned_once = false;
