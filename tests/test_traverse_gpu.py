@@ -1069,6 +1069,47 @@ def test_any_hit_and_uvs_traversal(mem, compressed):
     mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
 
 
+def test_any_hit_and_uvs_on_a_grid_with_two_layouts(mem):
+    """A grid of three levels with unevenly deep top-level cells holds a uniform layout and the table layout next to it (round 6): rays in image order gather from
+    the first, binned batches from the second -- in the nearest-hit kernel and in the any-hit / barycentric variants alike; a second context that borrows the image
+    (hagrid_share_traversal) gets both.  Every combination gives the oracle's hits."""
+    from oracle import oracle as O
+    from hagrid_amd import api
+    tris = scene.make_soup(30000, seed=11)
+    G = O.Grid.full(tris, top_density=0.15, snd_density=3.0)
+    assert G.shift == 3
+    d_tris = mem.upload(tris); grid = upload_oracle_grid(mem, G)
+    rays = np.concatenate([scene.make_rays_primary(G.bbox_min, G.bbox_max, 256, 128),
+                           scene.make_rays_incoherent(G.bbox_min - 0.1, G.bbox_max + 0.1, 50001, 6)]).astype(np.float32)
+    n = rays.shape[0]
+    d_rays = mem.upload(rays); d_hits = mem.alloc(16 * n)
+    api.setup_traversal(grid)
+    info = mem.image_format(grid)
+    assert info["uniform"] and info["two_layouts"], info
+    other = api.MemManager(keep=True)
+    try:
+        grid.mem = mem
+        borrowed = api.share_traversal(other, grid)
+        o_tris = other.upload(tris); o_rays = other.upload(rays); o_hits = other.alloc(16 * n)
+        for binning in (0, 1):
+            mem.set_ray_binning(binning); other.set_ray_binning(binning)
+            for flags, oflags in ((0, 0), (api.ANY_HIT, O.ANY_HIT), (api.UVS, O.UVS), (api.ANY_HIT | api.UVS, O.ANY_HIT | O.UVS)):
+                want = G.traverse_ex(tris, rays, oflags, nthreads=8)
+                api.traverse_grid(grid, d_tris, d_rays, d_hits, n, flags)
+                got = mem.download(d_hits, api.HIT_DTYPE, n)
+                assert (got["id"] == want["id"]).all(), (binning, flags)
+                for f in ("t", "u", "v"):
+                    assert (bits(got[f]) == bits(want[f])).all(), (binning, flags, f)
+                if flags in (0, api.UVS):                       # the borrower: its own buffers, the owner's image (both layouts)
+                    api.traverse_grid(borrowed, o_tris, o_rays, o_hits, n, flags); other.synchronize()
+                    got = other.download(o_hits, api.HIT_DTYPE, n)
+                    assert (got["id"] == want["id"]).all() and (bits(got["t"]) == bits(want["t"])).all(), ("borrowed", binning, flags)
+    finally:
+        mem.set_ray_binning(0)
+        other.close()
+    mem.free(d_rays); mem.free(d_hits); grid.free(); mem.free(d_tris)
+
+
 def test_any_hit_and_uvs_on_a_deep_clustered_grid(mem):
     """The table-layout image kernels (nested blocks, lists by index, the per-ray nested-block state) in their any-hit and
     barycentric variants, with and without the binning permutation: a small clustered scene with a grid deeper than three levels."""
